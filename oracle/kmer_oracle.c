@@ -1,0 +1,454 @@
+/*
+ * kmer_oracle.c -- CPU restatement of krust's canonical k-mer counting path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see kmer_oracle.h).  Plain C11 + pthreads.
+ * Parity is pinned against the reference's own known-answer tests
+ * (tests/test_oracle_golden.py); the reference itself (Rust) cannot be built
+ * in this image, so there is no oracle/_ref binary.
+ */
+#include "kmer_oracle.h"
+
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================== */
+/* src/kmer.rs                                                              */
+/* ======================================================================== */
+
+int ko_kmer_length_ok(uint64_t k) { return (k >= 1 && k <= 32) ? 0 : -1; } /* kmer.rs:100-110 */
+
+/* PACK_TABLE, src/kmer.rs:21-32.  Anything else maps to 0 there; callers only
+ * look up validated bytes. */
+static inline uint64_t pack_code(uint8_t b) {
+    switch (b) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 0;
+    }
+}
+
+/* COMPLEMENT_TABLE, src/kmer.rs:36-47 (result is always upper case). */
+static inline uint8_t complement(uint8_t b) {
+    switch (b) {
+    case 'A': case 'a': return 'T';
+    case 'C': case 'c': return 'G';
+    case 'G': case 'g': return 'C';
+    case 'T': case 't': return 'A';
+    default: return 0;
+    }
+}
+
+int ko_from_sub(const uint8_t *sub, size_t k, uint8_t *norm, uint8_t *err_base,
+                size_t *err_pos) {
+    /* src/kmer.rs:266-286: first failing byte wins (iterator short-circuits) */
+    for (size_t i = 0; i < k; i++) {
+        uint8_t b = sub[i];
+        switch (b) {
+        case 'A': case 'C': case 'G': case 'T':
+            norm[i] = b;
+            break;
+        case 'a': case 'c': case 'g': case 't':
+            norm[i] = (uint8_t)(b - 32); /* to_ascii_uppercase */
+            break;
+        default:
+            if (err_base) *err_base = b;
+            if (err_pos) *err_pos = i;
+            return -1;
+        }
+    }
+    return 0;
+}
+
+uint64_t ko_pack_bytes(const uint8_t *bytes, size_t k) {
+    /* src/kmer.rs:467-471 */
+    uint64_t acc = 0;
+    for (size_t i = 0; i < k; i++) acc = (acc << 2) | pack_code(bytes[i]);
+    return acc;
+}
+
+uint64_t ko_canonical(const uint8_t *bytes, size_t k, int *is_rc) {
+    /* src/kmer.rs:348-390 */
+    int use_rc = 0; /* unwrap_or(false): palindrome keeps the original */
+    for (size_t i = 0; i < k; i++) {
+        uint8_t fwd = bytes[i];
+        uint8_t rc = complement(bytes[k - 1 - i]);
+        if (fwd < rc) { use_rc = 0; break; }
+        if (fwd > rc) { use_rc = 1; break; }
+    }
+    if (is_rc) *is_rc = use_rc;
+    if (!use_rc) return ko_pack_bytes(bytes, k);
+    uint8_t rcb[32];
+    for (size_t i = 0; i < k; i++) rcb[i] = complement(bytes[k - 1 - i]);
+    return ko_pack_bytes(rcb, k); /* kmer.rs:369-375 */
+}
+
+void ko_unpack(uint64_t packed, size_t k, char *out) {
+    /* src/kmer.rs:431-440 */
+    static const char UNPACK_TABLE[4] = {'A', 'C', 'G', 'T'}; /* kmer.rs:50 */
+    for (size_t i = 0; i < k; i++) {
+        unsigned shift = (unsigned)((k - 1 - i) * 2);
+        out[i] = UNPACK_TABLE[(packed >> shift) & 3u];
+    }
+    out[k] = '\0';
+}
+
+/* ======================================================================== */
+/* count map                                                                */
+/* ======================================================================== */
+
+struct ko_map {
+    uint64_t *keys;
+    uint64_t *vals;
+    uint8_t *used;
+    uint64_t cap; /* power of two */
+    uint64_t len;
+};
+
+uint64_t ko_mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xbf58476d1ce4e5b9ULL;
+    z ^= z >> 27; z *= 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return z;
+}
+
+static void map_alloc(ko_map *m, uint64_t cap) {
+    m->keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    m->vals = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    m->used = (uint8_t *)calloc(cap, 1);
+    if (!m->keys || !m->vals || !m->used) abort();
+    m->cap = cap;
+    m->len = 0;
+}
+
+ko_map *ko_map_new(void) {
+    ko_map *m = (ko_map *)malloc(sizeof(ko_map));
+    if (!m) abort();
+    map_alloc(m, 1024);
+    return m;
+}
+
+void ko_map_free(ko_map *m) {
+    if (!m) return;
+    free(m->keys); free(m->vals); free(m->used); free(m);
+}
+
+uint64_t ko_map_len(const ko_map *m) { return m->len; }
+
+static inline uint64_t sat_add(uint64_t a, uint64_t b) {
+    uint64_t s = a + b;
+    return s < a ? UINT64_MAX : s; /* saturating_add, run.rs:569 */
+}
+
+static void map_insert_raw(ko_map *m, uint64_t key, uint64_t addend) {
+    uint64_t mask = m->cap - 1;
+    uint64_t i = ko_mix64(key) & mask;
+    while (m->used[i]) {
+        if (m->keys[i] == key) { m->vals[i] = sat_add(m->vals[i], addend); return; }
+        i = (i + 1) & mask;
+    }
+    m->used[i] = 1; m->keys[i] = key; m->vals[i] = addend; m->len++;
+}
+
+static void map_grow(ko_map *m) {
+    ko_map old = *m;
+    map_alloc(m, old.cap * 2);
+    for (uint64_t i = 0; i < old.cap; i++)
+        if (old.used[i]) map_insert_raw(m, old.keys[i], old.vals[i]);
+    free(old.keys); free(old.vals); free(old.used);
+}
+
+void ko_map_add(ko_map *m, uint64_t key, uint64_t addend) {
+    if ((m->len + 1) * 10 > m->cap * 6) map_grow(m);
+    map_insert_raw(m, key, addend);
+}
+
+uint64_t ko_map_get(const ko_map *m, uint64_t key) {
+    uint64_t mask = m->cap - 1;
+    uint64_t i = ko_mix64(key) & mask;
+    while (m->used[i]) {
+        if (m->keys[i] == key) return m->vals[i];
+        i = (i + 1) & mask;
+    }
+    return 0;
+}
+
+uint64_t ko_map_dump(const ko_map *m, uint64_t *keys, uint64_t *counts, uint64_t cap) {
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < m->cap && n < cap; i++)
+        if (m->used[i]) { keys[n] = m->keys[i]; counts[n] = m->vals[i]; n++; }
+    return n;
+}
+
+uint64_t ko_map_total(const ko_map *m) {
+    uint64_t t = 0;
+    for (uint64_t i = 0; i < m->cap; i++)
+        if (m->used[i]) t = sat_add(t, m->vals[i]);
+    return t;
+}
+
+/* ======================================================================== */
+/* src/run.rs hot loop                                                      */
+/* ======================================================================== */
+
+typedef void (*emit_fn)(void *ctx, uint64_t key);
+
+static inline int qual_threshold(int min_quality) {
+    /* min_quality.map(|q| q.saturating_add(33)), run.rs:538 (u8 arithmetic) */
+    int t = min_quality + 33;
+    return t > 255 ? 255 : t;
+}
+
+/* The literal loop of src/run.rs:526-563 with an abstract upsert. */
+static uint64_t literal_loop(const uint8_t *seq, size_t len, const uint8_t *qual,
+                             size_t k, int min_quality, emit_fn emit, void *ctx) {
+    uint64_t counted = 0;
+    if (len < k) return 0; /* run.rs:533-535 */
+    int have_thr = (qual != NULL && min_quality >= 0);
+    int thr = have_thr ? qual_threshold(min_quality) : 0;
+    size_t i = 0;
+    uint8_t norm[32];
+    while (i <= len - k) { /* run.rs:541 */
+        if (have_thr) {    /* run.rs:543-548 */
+            size_t bad = k;
+            for (size_t j = 0; j < k; j++)
+                if ((int)qual[i + j] < thr) { bad = j; break; }
+            if (bad != k) { i += bad + 1; continue; }
+        }
+        uint8_t eb; size_t ep;
+        if (ko_from_sub(seq + i, k, norm, &eb, &ep) == 0) { /* run.rs:552-556 */
+            uint64_t key = ko_canonical(norm, k, NULL);     /* run.rs:566 */
+            if (emit) emit(ctx, key);
+            counted++;
+            i += 1;
+        } else {
+            i += ep + 1; /* run.rs:557-560 */
+        }
+    }
+    return counted;
+}
+
+static void emit_to_map(void *ctx, uint64_t key) { ko_map_add((ko_map *)ctx, key, 1); }
+
+void ko_process_sequence(ko_map *m, const uint8_t *seq, size_t len,
+                         const uint8_t *qual, size_t k, int min_quality) {
+    literal_loop(seq, len, qual, k, min_quality, emit_to_map, m);
+}
+
+uint64_t ko_count_valid_windows(const uint8_t *seq, size_t len, const uint8_t *qual,
+                                size_t k, int min_quality) {
+    return literal_loop(seq, len, qual, k, min_quality, NULL, NULL);
+}
+
+void ko_process_sequence_rolling(ko_map *m, const uint8_t *seq, size_t len,
+                                 const uint8_t *qual, size_t k, int min_quality) {
+    /* Equivalent formulation: a window is counted iff all of its k positions
+     * are "good" (base in ACGTacgt and, when filtering, qual >= thr); integer
+     * min(fwd, rc) equals the lexicographic choice of kmer.rs:348-365 because
+     * codes A<C<G<T are in ASCII order; on a tie both are the same bits. */
+    int have_thr = (qual != NULL && min_quality >= 0);
+    int thr = have_thr ? qual_threshold(min_quality) : 0;
+    uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    unsigned rcshift = (unsigned)(2 * (k - 1));
+    uint64_t fwd = 0, rc = 0;
+    size_t run = 0;
+    for (size_t i = 0; i < len; i++) {
+        uint8_t b = seq[i];
+        uint8_t u = (uint8_t)(b & 0xDF);
+        int good = (u == 'A' || u == 'C' || u == 'G' || u == 'T');
+        if (good && have_thr && (int)qual[i] < thr) good = 0;
+        if (!good) { run = 0; fwd = 0; rc = 0; continue; }
+        uint64_t c = pack_code(b);
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((3 - c) << rcshift);
+        if (++run >= k) ko_map_add(m, fwd < rc ? fwd : rc, 1);
+    }
+}
+
+/* ---- histogram, src/histogram.rs:110-116 + src/run.rs:447-450 ---------- */
+
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+uint64_t ko_histogram(const ko_map *m, uint64_t min_count, uint64_t *count,
+                      uint64_t *freq, uint64_t cap) {
+    uint64_t n = 0;
+    uint64_t *v = (uint64_t *)malloc((m->len ? m->len : 1) * sizeof(uint64_t));
+    if (!v) abort();
+    for (uint64_t i = 0; i < m->cap; i++)
+        if (m->used[i] && m->vals[i] >= min_count) v[n++] = m->vals[i];
+    qsort(v, n, sizeof(uint64_t), cmp_u64);
+    uint64_t nd = 0;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && v[j] == v[i]) j++;
+        if (nd < cap) { count[nd] = v[i]; freq[nd] = j - i; }
+        nd++;
+        i = j;
+    }
+    free(v);
+    return nd;
+}
+
+/* ---- crc32, src/index.rs:404-431 --------------------------------------- */
+
+uint32_t ko_crc32(const uint8_t *data, size_t n) {
+    uint32_t crc = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) {
+        crc ^= data[i];
+        for (int b = 0; b < 8; b++) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    }
+    return ~crc;
+}
+
+/* ======================================================================== */
+/* krust-equivalent threaded baseline                                       */
+/* ======================================================================== */
+
+typedef struct {
+    pthread_mutex_t lock;
+    ko_map map;
+    char pad[64];
+} shard_t;
+
+typedef struct {
+    shard_t *shards;
+    uint64_t nshards; /* power of two */
+    unsigned shift;
+} sharded_t;
+
+static void emit_to_shards(void *ctx, uint64_t key) {
+    /* DashMap: hash -> shard index from the high bits, then lock + upsert
+     * (run.rs:565-571).  FxHash is a multiplicative hash; any well-mixed hash
+     * gives the same results, only speed differs. */
+    sharded_t *s = (sharded_t *)ctx;
+    uint64_t h = key * 0x517cc1b727220a95ULL; /* Fx-style multiply */
+    shard_t *sh = &s->shards[(h >> s->shift) & (s->nshards - 1)];
+    pthread_mutex_lock(&sh->lock);
+    ko_map_add(&sh->map, key, 1);
+    pthread_mutex_unlock(&sh->lock);
+}
+
+typedef struct {
+    sharded_t *sh;
+    const uint8_t *seq, *qual;
+    const uint64_t *off;
+    const uint32_t *lens;
+    uint64_t nrec;
+    size_t k;
+    int min_quality;
+    atomic_ullong *next;
+    uint64_t counted;
+} worker_t;
+
+static void *worker_main(void *arg) {
+    worker_t *w = (worker_t *)arg;
+    const uint64_t CHUNK = 256; /* records per steal, stands in for rayon splitting */
+    uint64_t counted = 0;
+    for (;;) {
+        uint64_t b = atomic_fetch_add(w->next, CHUNK);
+        if (b >= w->nrec) break;
+        uint64_t e = b + CHUNK < w->nrec ? b + CHUNK : w->nrec;
+        for (uint64_t r = b; r < e; r++)
+            counted += literal_loop(w->seq + w->off[r], w->lens[r],
+                                    w->qual ? w->qual + w->off[r] : NULL, w->k,
+                                    w->min_quality, emit_to_shards, w->sh);
+    }
+    w->counted = counted;
+    return NULL;
+}
+
+uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
+                             const uint64_t *off, const uint32_t *lens,
+                             uint64_t nrec, size_t k, int min_quality, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    sharded_t sh;
+    uint64_t ns = 1;
+    while (ns < (uint64_t)nthreads * 4) ns <<= 1; /* DashMap default_shard_amount */
+    sh.nshards = ns;
+    unsigned bits = 0;
+    while ((1ULL << bits) < ns) bits++;
+    sh.shift = 64 - bits; /* ns >= 4, so bits >= 2 */
+    sh.shards = (shard_t *)calloc(ns, sizeof(shard_t));
+    if (!sh.shards) abort();
+    for (uint64_t i = 0; i < ns; i++) {
+        pthread_mutex_init(&sh.shards[i].lock, NULL);
+        map_alloc(&sh.shards[i].map, 1024);
+    }
+    atomic_ullong next;
+    atomic_init(&next, 0);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    worker_t *ws = (worker_t *)calloc((size_t)nthreads, sizeof(worker_t));
+    if (!th || !ws) abort();
+    for (int t = 0; t < nthreads; t++) {
+        ws[t] = (worker_t){&sh, seq, qual, off, lens, nrec, k, min_quality, &next, 0};
+        pthread_create(&th[t], NULL, worker_main, &ws[t]);
+    }
+    uint64_t counted = 0;
+    for (int t = 0; t < nthreads; t++) {
+        pthread_join(th[t], NULL);
+        counted += ws[t].counted;
+    }
+    for (uint64_t i = 0; i < ns; i++) {
+        ko_map *sm = &sh.shards[i].map;
+        for (uint64_t j = 0; j < sm->cap; j++)
+            if (sm->used[j]) ko_map_add(m, sm->keys[j], sm->vals[j]);
+        free(sm->keys); free(sm->vals); free(sm->used);
+        pthread_mutex_destroy(&sh.shards[i].lock);
+    }
+    free(sh.shards); free(th); free(ws);
+    return counted;
+}
+
+/* ======================================================================== */
+/* deterministic synthetic reads                                            */
+/* ======================================================================== */
+
+#define KO_GOLDEN 0x9E3779B97F4A7C15ULL
+
+static inline uint64_t stream_key(uint64_t seed, uint64_t s) {
+    return ko_mix64(seed + (s + 1) * KO_GOLDEN);
+}
+static inline uint64_t draw(uint64_t key, uint64_t idx) {
+    return ko_mix64(key + idx * KO_GOLDEN);
+}
+
+void ko_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t read_len,
+                    uint64_t first_read, uint64_t n_reads, uint8_t *bases,
+                    uint8_t *qual) {
+    static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+    const uint64_t kg = stream_key(seed, 0), ks = stream_key(seed, 1),
+                   kd = stream_key(seed, 2), ke = stream_key(seed, 3);
+    const uint64_t span = genome_len - read_len + 1;
+    const uint64_t stride = (uint64_t)read_len + 1;
+    for (uint64_t i = 0; i < n_reads; i++) {
+        uint64_t r = first_read + i;
+        uint64_t start = draw(ks, r) % span;
+        int strand = (int)(draw(kd, r) & 1);
+        uint8_t *bo = bases + i * stride;
+        uint8_t *qo = qual ? qual + i * stride : NULL;
+        for (uint32_t j = 0; j < read_len; j++) {
+            uint64_t c;
+            if (!strand) c = draw(kg, start + j) & 3;
+            else c = 3 - (draw(kg, start + (read_len - 1 - j)) & 3);
+            uint64_t u = draw(ke, r * read_len + j);
+            int subst = ((u & 0xFF) == 0);
+            if (subst) c = (c + 1 + ((u >> 8) % 3)) & 3;
+            int isn = (((u >> 16) & 0x3FF) == 0);
+            bo[j] = isn ? 'N' : (uint8_t)ACGT[c];
+            if (qo) {
+                unsigned v = (unsigned)((u >> 32) & 0xFF);
+                uint8_t q = v < 230 ? 'I' : (v < 250 ? '5' : '#');
+                if (subst && ((u >> 40) & 1)) q = '#';
+                qo[j] = q;
+            }
+        }
+        bo[read_len] = '\n';
+        if (qo) qo[read_len] = '\n';
+    }
+}

@@ -1,0 +1,197 @@
+"""ctypes binding of oracle/libkmer_oracle.so -- the CHECKER used by tests,
+smoke() and bench.py's cpu_baseline leg.  Never imported by krust_amd/."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "libkmer_oracle.so")
+
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _load():
+    lib = C.CDLL(_SO)
+    lib.ko_kmer_length_ok.argtypes = [C.c_uint64]
+    lib.ko_kmer_length_ok.restype = C.c_int
+    lib.ko_from_sub.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, _u8p, C.POINTER(C.c_size_t)]
+    lib.ko_from_sub.restype = C.c_int
+    lib.ko_pack_bytes.argtypes = [C.c_char_p, C.c_size_t]
+    lib.ko_pack_bytes.restype = C.c_uint64
+    lib.ko_canonical.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    lib.ko_canonical.restype = C.c_uint64
+    lib.ko_unpack.argtypes = [C.c_uint64, C.c_size_t, C.c_char_p]
+    lib.ko_unpack.restype = None
+    lib.ko_map_new.restype = C.c_void_p
+    lib.ko_map_free.argtypes = [C.c_void_p]
+    lib.ko_map_len.argtypes = [C.c_void_p]
+    lib.ko_map_len.restype = C.c_uint64
+    lib.ko_map_add.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    lib.ko_map_get.argtypes = [C.c_void_p, C.c_uint64]
+    lib.ko_map_get.restype = C.c_uint64
+    lib.ko_map_dump.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.ko_map_dump.restype = C.c_uint64
+    lib.ko_map_total.argtypes = [C.c_void_p]
+    lib.ko_map_total.restype = C.c_uint64
+    for name in ("ko_process_sequence", "ko_process_sequence_rolling"):
+        f = getattr(lib, name)
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+        f.restype = None
+    lib.ko_count_valid_windows.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    lib.ko_count_valid_windows.restype = C.c_uint64
+    lib.ko_histogram.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64]
+    lib.ko_histogram.restype = C.c_uint64
+    lib.ko_crc32.argtypes = [C.c_char_p, C.c_size_t]
+    lib.ko_crc32.restype = C.c_uint32
+    lib.ko_count_records_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_uint64, C.c_size_t, C.c_int, C.c_int]
+    lib.ko_count_records_mt.restype = C.c_uint64
+    lib.ko_mix64.argtypes = [C.c_uint64]
+    lib.ko_mix64.restype = C.c_uint64
+    lib.ko_synth_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
+                                   C.c_void_p, C.c_void_p]
+    lib.ko_synth_reads.restype = None
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def _buf(b):
+    """bytes / bytearray / np.uint8 array -> (address, length, keepalive)."""
+    if b is None:
+        return None, 0, None
+    a = np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b, dtype=np.uint8)
+    return a.ctypes.data, a.size, a
+
+
+class OracleMap:
+    """u64 -> u64 count map (stands in for krust's DashMap, src/run.rs:489)."""
+
+    def __init__(self):
+        self._m = lib().ko_map_new()
+
+    def __del__(self):
+        if getattr(self, "_m", None):
+            lib().ko_map_free(self._m)
+            self._m = None
+
+    def __len__(self):
+        return int(lib().ko_map_len(self._m))
+
+    def add(self, key, addend=1):
+        lib().ko_map_add(self._m, key, addend)
+
+    def get(self, key):
+        return int(lib().ko_map_get(self._m, key))
+
+    def total(self):
+        return int(lib().ko_map_total(self._m))
+
+    def process(self, seq, k, qual=None, min_quality=None, rolling=False):
+        sp, sn, _ks = _buf(seq)
+        qp, qn, _kq = _buf(qual)
+        if qual is not None:
+            assert qn >= sn
+        f = lib().ko_process_sequence_rolling if rolling else lib().ko_process_sequence
+        f(self._m, sp, sn, qp, k, -1 if min_quality is None else int(min_quality))
+
+    def arrays(self):
+        n = len(self)
+        keys = np.empty(n, dtype=np.uint64)
+        cnts = np.empty(n, dtype=np.uint64)
+        got = lib().ko_map_dump(self._m, keys.ctypes.data, cnts.ctypes.data, n)
+        assert got == n
+        order = np.argsort(keys, kind="stable")
+        return keys[order], cnts[order]
+
+    def as_dict(self):
+        k, c = self.arrays()
+        return dict(zip(k.tolist(), c.tolist()))
+
+    def as_str_dict(self, k):
+        return {unpack(key, k): c for key, c in self.as_dict().items()}
+
+    def histogram(self, min_count=1):
+        n = max(len(self), 1)
+        cnt = np.empty(n, dtype=np.uint64)
+        frq = np.empty(n, dtype=np.uint64)
+        nd = lib().ko_histogram(self._m, min_count, cnt.ctypes.data, frq.ctypes.data, n)
+        return list(zip(cnt[:nd].tolist(), frq[:nd].tolist()))
+
+    def count_records_mt(self, seq, offs, lens, k, qual=None, min_quality=None, nthreads=1):
+        sp, _, _ks = _buf(seq)
+        qp, _, _kq = _buf(qual)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        return int(lib().ko_count_records_mt(self._m, sp, qp, offs.ctypes.data, lens.ctypes.data,
+                                             len(offs), k, -1 if min_quality is None else int(min_quality),
+                                             nthreads))
+
+
+def count_records(records, k, quals=None, min_quality=None, rolling=False):
+    """records: list of bytes -> OracleMap (one process_sequence per record)."""
+    m = OracleMap()
+    for i, r in enumerate(records):
+        q = None if quals is None else quals[i]
+        m.process(r, k, qual=q, min_quality=min_quality, rolling=rolling)
+    return m
+
+
+def pack(seq):
+    return int(lib().ko_pack_bytes(seq, len(seq)))
+
+
+def unpack(bits, k):
+    out = C.create_string_buffer(k + 1)
+    lib().ko_unpack(bits, k, out)
+    return out.value.decode()
+
+
+def canonical(seq):
+    rc = C.c_int(0)
+    bits = lib().ko_canonical(seq, len(seq), C.byref(rc))
+    return int(bits), bool(rc.value)
+
+
+def from_sub(seq):
+    norm = C.create_string_buffer(len(seq) + 1)
+    eb = C.c_uint8(0)
+    ep = C.c_size_t(0)
+    r = lib().ko_from_sub(seq, len(seq), norm, C.byref(eb), C.byref(ep))
+    if r == 0:
+        return norm.raw[: len(seq)], None
+    return None, (chr(eb.value), int(ep.value))
+
+
+def valid_windows(seq, k, qual=None, min_quality=None):
+    sp, sn, _ks = _buf(seq)
+    qp, _, _kq = _buf(qual)
+    return int(lib().ko_count_valid_windows(sp, sn, qp, k, -1 if min_quality is None else int(min_quality)))
+
+
+def crc32(data):
+    return int(lib().ko_crc32(data, len(data)))
+
+
+def mix64(z):
+    return int(lib().ko_mix64(z & 0xFFFFFFFFFFFFFFFF))
+
+
+def synth_reads(seed, genome_len, read_len, first_read, n_reads, with_qual=True):
+    stride = read_len + 1
+    bases = np.empty(n_reads * stride, dtype=np.uint8)
+    qual = np.empty(n_reads * stride, dtype=np.uint8) if with_qual else None
+    lib().ko_synth_reads(seed, genome_len, read_len, first_read, n_reads, bases.ctypes.data,
+                         qual.ctypes.data if with_qual else None)
+    return bases, qual
