@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- canonical k-mers/s at k=21 on synthetic 150 bp reads (BASELINE.json metric).
+
+A "step" = one full pass of the counting hot path over this GPU's batch of synthetic reads,
+already resident in HBM: table reset, encode + mask + canonicalise + upsert of every window
+(kh_push_device), completion (kh_finish) and, for N>1, the key-partitioned RCCL merge of the
+per-GPU tables.  Default workload: S100M = 100 M x 150 bp per GPU (the configuration the
+metric is quoted on; it fits one MI355X: 15.1 GB reads + ~34 GB table).
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline      algorithmic HBM bytes of the count kernel / its HIP-event duration, vs 8 TB/s
+  cpu_baseline  the krust-equivalent threaded CPU port (oracle/) timed on this host's cores on a
+                bounded sample of the same reads (rank 0, N=1 only).  A reported baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20260130
+GENOME_LEN = 1 << 27
+READ_LEN = 150
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (150 bp each)")
+    ap.add_argument("--k", type=int, default=21)
+    ap.add_argument("--min-quality", type=int, default=None, help="enable the quality stream + -Q masking")
+    ap.add_argument("--capacity-hint", type=int, default=0, help="expected distinct k-mers per GPU (0 = estimate)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--verify", action="store_true", help="check a 1/1024 key sample against the CPU oracle")
+    return ap.parse_args()
+
+
+def estimate_distinct(reads, k, world):
+    """Genomic canonical k-mers + error k-mers (1/256 substitutions, ~k*(L-k+1)/L novel each)."""
+    novel_per_read = READ_LEN * (1.0 / 256.0) * k * (READ_LEN - k + 1) / READ_LEN
+    return int(GENOME_LEN * 1.05 + reads * novel_per_read * 1.12)
+
+
+def cpu_baseline(host_bases, k, target_seconds):
+    """krust-equivalent port (oracle/ko_count_records_mt: one task per record on all cores, literal
+    per-window algorithm, sharded lock-per-shard map) on a bounded sample of the same reads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    stride = READ_LEN + 1
+    avail = host_bases.size // stride
+
+    def run(n):
+        offs = np.arange(n, dtype=np.uint64) * stride
+        lens = np.full(n, READ_LEN, dtype=np.uint32)
+        m = O.OracleMap()
+        t0 = time.perf_counter()
+        cnt = m.count_records_mt(host_bases[: n * stride], offs, lens, k, nthreads=cores)
+        return cnt, time.perf_counter() - t0
+
+    probe_n = min(avail, 100_000)
+    cnt, dt = run(probe_n)
+    rate = cnt / max(dt, 1e-9)
+    n = int(min(avail, max(probe_n, target_seconds * rate / (READ_LEN - k + 1))))
+    if n > probe_n:
+        cnt, dt = run(n)
+    return {"value": cnt / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} reads of the same synthetic set ({cnt} k-mers, {dt:.1f} s); "
+                      "krust-equivalent C port (oracle/kmer_oracle.c ko_count_records_mt), not krust itself"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import krust_amd
+    from krust_amd.distributed import merge_across_ranks
+
+    k = args.k
+    reads = args.reads
+    stride = READ_LEN + 1
+    nbytes = reads * stride
+    with_qual = args.min_quality is not None
+    tb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    tq = torch.empty(nbytes, dtype=torch.uint8, device=dev) if with_qual else None
+    first = rank * reads  # weak scaling: every GPU gets its own `reads` reads of the same genome
+    krust_amd.synth_reads_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, SEED, GENOME_LEN, READ_LEN,
+                                 first, reads, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+    hint = args.capacity_hint or estimate_distinct(reads, k, world)
+    dc = krust_amd.DeviceCounter(k, min_quality=args.min_quality, capacity_hint=hint, device=local_rank,
+                                 stream=torch.cuda.current_stream().cuda_stream)
+
+    def step():
+        dc.reset()
+        dc.push_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, nbytes)
+        st = dc.finish()
+        mg = merge_across_ranks(dc) if world > 1 else None
+        return st, mg
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    launches = 0
+    st = mg = None
+    for _ in range(args.steps):
+        st, mg = step()
+        kernel_ms += st["count_kernel_ms"]
+        launches += st["launches"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        km = torch.tensor([st["kmers"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(km, op=dist.ReduceOp.SUM)
+        total_kmers = int(km.item())
+    else:
+        total_kmers = int(st["kmers"])
+
+    verify = None
+    if args.verify and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        host = tb.cpu().numpy()
+        hq = tq.cpu().numpy() if with_qual else None
+        m = O.OracleMap()
+        tot = m.scan_flat(host, k, qual=hq, min_quality=args.min_quality, sample_mask=1023, nthreads=os.cpu_count() or 1)
+        if world == 1:
+            skeys, scnts = m.arrays()
+            ok = bool(tot == st["kmers"] and np.array_equal(dc.lookup(skeys), scnts))
+        else:
+            ok = bool(tot == st["kmers"])
+        verify = {"sampled_keys": len(m), "cpu_total_kmers": tot, "ok": ok}
+        del host, hq
+
+    if rank == 0:
+        # dominant kernel: count_direct_kernel.  Algorithmic bytes:
+        # every input byte once + 24 B per valid k-mer (slot key+count read, count write-back)
+        # + 8 B per distinct key written once.
+        alg_bytes_step = nbytes * (2 if with_qual else 1) + 24 * st["kmers"] + 8 * st["distinct"]
+        launches_step = max(1, st["launches"])
+        avg_launch_ms = kernel_ms / max(1, launches)
+        achieved = (alg_bytes_step / launches_step) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):  # measured in separate rocprofv3 --pmc passes (see profiles/README.md)
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("reads_per_gpu") == reads and tj.get("k") == k:
+                    traffic = tj.get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "canonical k-mers/s at k=21, 100M x 150bp reads; bit-exact vs krust CPU",
+            "value": total_kmers * args.steps / elapsed,
+            "unit": "k-mers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": f"S{reads // 1_000_000}M: {reads} x {READ_LEN} bp reads per GPU, k={k}"
+                                   + (f", -Q {args.min_quality}" if with_qual else "")
+                                   + f", genome 2^27 bp, seed {SEED}; resident in HBM",
+                       "k": k, "reads_per_gpu": reads, "kmers_per_step_per_gpu": int(st["kmers"]),
+                       "distinct_per_gpu": int(st["distinct"]), "table_slots": int(st["table_slots"]),
+                       "table_grows": int(st["grows"]),
+                       "parallelism": f"reads sharded x{world}" + ("; RCCL all-to-all table merge" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "count_direct_kernel", "launches_per_step": int(st["launches"]),
+                         "avg_launch_ms": avg_launch_ms, "alg_bytes_per_launch": alg_bytes_step / launches_step,
+                         "kernel_kmers_per_s": st["kmers"] * args.steps / (kernel_ms * 1e-3) if kernel_ms else None},
+        }
+        if mg is not None:
+            out["config"]["merge"] = mg
+        if verify is not None:
+            out["verify"] = verify
+        if world == 1 and not args.no_cpu_baseline:
+            sample_reads = min(reads, 6_000_000)
+            host = tb[: sample_reads * stride].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(host, k, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    dc.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

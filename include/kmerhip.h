@@ -1,0 +1,164 @@
+/*
+ * kmerhip.h -- C ABI of the MI355X-native canonical k-mer counter.
+ *
+ * This is the drop-in boundary for krust's counting hot path.  The reference
+ * (Rust crate `kmerust` 0.3.1) has no FFI of its own; the seam these entry
+ * points replace is the internal call
+ *
+ *     KmerMap::new().build(seqs, k)                     src/run.rs:494-503
+ *     KmerMap::new().build_with_quality(seqs, k, minq)  src/run.rs:505-520
+ *     KmerMap::into_hashmap(k)                          src/run.rs:573-582
+ *
+ * and its public packed twin
+ *
+ *     count_kmers_from_sequences(iter<Bytes>, KmerLength) -> HashMap<u64,u64>
+ *                                                       src/streaming.rs:198-204
+ *
+ * INTEGRATION.md shows the Rust `extern "C"` binding a krust maintainer would
+ * add at those call sites.  Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary; no exception crosses it.
+ *
+ * Semantics (bit-exact with the reference):
+ *   - k-mer = k consecutive bytes all in ACGTacgt (src/kmer.rs:266-286), 2-bit
+ *     packed A=0 C=1 G=2 T=3, first base most significant (kmer.rs:21-32,467-471)
+ *   - canonical = lexicographic min of k-mer and reverse complement
+ *     (kmer.rs:348-390) == integer min of the packed forms
+ *   - optional quality mask: a window is skipped iff any of its k quality bytes
+ *     is < min_quality.saturating_add(33)          (run.rs:538,543-548)
+ *   - k-mers never span records; in a flat buffer records are separated by at
+ *     least one byte outside ACGTacgt (e.g. '\n'), which no window may contain
+ *   - count[key] += 1 per window, u64 counts          (run.rs:565-571)
+ *
+ * Threading: one producer thread per context (not re-entrant); independent
+ * contexts may be used concurrently.  All functions return KH_OK (0) or a
+ * negative kh_status; k-mers are never dropped silently.
+ */
+#ifndef KMERHIP_H
+#define KMERHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMERHIP_ABI_VERSION 1
+
+typedef enum kh_status {
+    KH_OK = 0,
+    KH_ERR_BAD_K = -1,      /* KmerLengthError, src/kmer.rs:100-110, src/error.rs:86-95 */
+    KH_ERR_BAD_ARG = -2,
+    KH_ERR_NO_DEVICE = -3,  /* no HIP device / HIP runtime unusable */
+    KH_ERR_OOM = -4,        /* device or pinned-host allocation failed */
+    KH_ERR_TABLE_FULL = -5, /* table cannot grow further */
+    KH_ERR_HIP = -6,        /* a HIP call failed; kh_last_error() has the text */
+    KH_ERR_STATE = -7,      /* call not valid in the context's current state */
+    KH_ERR_RANGE = -8       /* caller-provided output array too small */
+} kh_status;
+
+typedef struct kh_ctx kh_ctx;
+
+/* Counter configuration.  Mirrors what the reference passes across its seam:
+ * k (run.rs:500), min_quality: Option<u8> (run.rs:509). */
+typedef struct kh_config {
+    uint32_t struct_size;    /* sizeof(kh_config), for ABI evolution */
+    uint32_t k;              /* 1..32 */
+    int32_t  min_quality;    /* -1 = None; 0..255 = Some(q) (Phred, +33 applied inside) */
+    int32_t  device;         /* HIP device ordinal; -1 = current device */
+    uint64_t capacity_hint;  /* expected number of DISTINCT canonical k-mers; 0 = grow on demand */
+    void    *stream;         /* hipStream_t to launch on; NULL = context-owned stream */
+    uint32_t flags;          /* KH_FLAG_* */
+    uint32_t reserved;
+} kh_config;
+
+#define KH_FLAG_TRACE 1u     /* print phase timings to stderr (also env KMERHIP_TRACE=1) */
+
+typedef struct kh_stats {
+    uint64_t bases;          /* bytes pushed (incl. separators) */
+    uint64_t kmers;          /* valid windows counted == sum of all counts */
+    uint64_t distinct;       /* live table entries */
+    uint64_t table_slots;    /* current table capacity (16-byte slots) */
+    uint64_t grows;          /* number of table rehashes */
+    uint64_t launches;       /* count-kernel launches */
+    double   count_kernel_ms;/* sum of count-kernel durations (HIP events on the launch stream) */
+    double   h2d_ms;         /* host->device staging time for kh_push */
+} kh_stats;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int  kh_create(kh_ctx **out, const kh_config *cfg);
+void kh_destroy(kh_ctx *ctx);
+/* Forget all counts, keep the table allocation (KmerMap::new() again). */
+int  kh_reset(kh_ctx *ctx);
+
+/* ---- input: replaces KmerMap::build / build_with_quality ---------------- */
+/* Host buffers.  `bases` is a flat byte buffer of n bytes holding any number
+ * of records separated by >=1 non-ACGTacgt byte; `qual` is NULL or a parallel
+ * buffer of n bytes (same offsets).  With qual==NULL or min_quality==-1 no
+ * quality masking happens (run.rs:543: both must be Some).  Returns after the
+ * buffers have been consumed (caller may reuse them). */
+int kh_push(kh_ctx *ctx, const uint8_t *bases, const uint8_t *qual, uint64_t n);
+/* Same, for buffers already resident in this device's HBM (no copy). */
+int kh_push_device(kh_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual, uint64_t n);
+/* Wait for all pushed work; fill stats (may be NULL). */
+int kh_finish(kh_ctx *ctx, kh_stats *stats);
+
+/* ---- output: replaces KmerMap::into_hashmap ----------------------------- */
+/* Number of distinct canonical k-mers with count >= min_count
+ * (min_count filter of output_counts, run.rs:447-450). */
+int kh_result_size(kh_ctx *ctx, uint64_t min_count, uint64_t *n);
+/* Copy (packed canonical key, count) pairs with count >= min_count into
+ * caller arrays of capacity cap; order unspecified (HashMap iteration order is
+ * unspecified in the reference too).  *n receives the number written. */
+int kh_result_copy(kh_ctx *ctx, uint64_t *keys, uint64_t *counts, uint64_t cap,
+                   uint64_t min_count, uint64_t *n);
+/* Same into device arrays (for the multi-GPU exchange and device consumers). */
+int kh_result_copy_device(kh_ctx *ctx, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
+                          uint64_t min_count, uint64_t *n);
+/* Count-of-counts after the min_count filter, ascending by count
+ * (compute_histogram, src/histogram.rs:88-94 as used by run.rs:471-481). */
+int kh_histogram(kh_ctx *ctx, uint64_t min_count, uint64_t *count, uint64_t *freq,
+                 uint64_t cap, uint64_t *n);
+/* counts[i] = count of packed canonical key keys[i], 0 if absent
+ * (`kmerust query`, src/main.rs:264-280). */
+int kh_lookup(kh_ctx *ctx, const uint64_t *keys, uint64_t n, uint64_t *counts);
+
+/* ---- multi-GPU merge (no reference counterpart) ----------- */
+/* Owner shard of a key among nparts shards (same function on host and device). */
+uint32_t kh_owner(uint64_t key, uint32_t nparts);
+/* Compact all live (key,count) pairs grouped by owner shard into device arrays
+ * of capacity cap; part_counts[p] (host array, nparts entries) receives the
+ * number of pairs for shard p; pairs of shard p start at sum(part_counts[0..p)). */
+int kh_export_by_owner_device(kh_ctx *ctx, uint32_t nparts, uint64_t *d_keys,
+                              uint64_t *d_counts, uint64_t cap, uint64_t *part_counts);
+/* count[key] += counts[i] for n device-resident / host-resident pairs. */
+int kh_merge_pairs_device(kh_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_counts, uint64_t n);
+int kh_merge_pairs(kh_ctx *ctx, const uint64_t *keys, const uint64_t *counts, uint64_t n);
+
+/* ---- pure helpers (host, no device) ------------------------------------- */
+/* pack_bytes / Kmer::pack, src/kmer.rs:304-312,467-471.  KH_ERR_BAD_ARG if a
+ * byte is outside ACGTacgt (*err_pos, if given, = its position: kmer.rs:277-280). */
+int kh_pack(const uint8_t *bases, uint32_t k, uint64_t *packed, uint32_t *err_pos);
+/* unpack_to_bytes, src/kmer.rs:431-440; writes k bytes (no terminator). */
+int kh_unpack(uint64_t packed, uint32_t k, uint8_t *out);
+/* canonical form of a packed k-mer, src/kmer.rs:348-390; *is_rc optional. */
+int kh_canonical(uint64_t packed, uint32_t k, uint64_t *canonical, int *is_rc);
+
+/* ---- diagnostics -------------------------------------------------------- */
+const char *kh_strerror(int status);
+/* Text of the last failure on this context (HIP error string etc.). */
+const char *kh_last_error(const kh_ctx *ctx);
+int kh_abi_version(void);
+
+/* ---- deterministic synthetic reads (bench / tests) -------- */
+/* Writes reads [first_read, first_read+n_reads) as stride-(read_len+1) records
+ * (read_len bases then '\n') into device buffers of n_reads*(read_len+1) bytes.
+ * d_qual may be NULL.  Launches on `stream` (hipStream_t or NULL) of `device`. */
+int kh_synth_reads_device(int device, void *stream, uint64_t seed, uint64_t genome_len,
+                          uint32_t read_len, uint64_t first_read, uint64_t n_reads,
+                          uint8_t *d_bases, uint8_t *d_qual);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMERHIP_H */

@@ -1,0 +1,11 @@
+"""krust_amd -- MI355X-native canonical k-mer counting (drop-in for krust's hot path).
+
+Layout:
+  csrc/      hand-written gfx950 HIP kernels + the C ABI of include/kmerhip.h
+  native.py  ctypes binding of that C ABI (plumbing; no CPU fallback)
+"""
+from .native import (DeviceCounter, KmerHipError, KmerLengthError, canonical, lib, owner, pack,  # noqa: F401
+                     synth_reads_device, unpack)
+
+__all__ = ["DeviceCounter", "KmerHipError", "KmerLengthError", "canonical", "lib", "owner", "pack",
+           "synth_reads_device", "unpack"]

@@ -1,0 +1,477 @@
+// kernels.hip.h -- hand-written gfx950 (CDNA4, wave64) kernels of the counting path.
+//
+// Replaces the reference's per-window loop (src/run.rs:526-571) and its DashMap upsert:
+//   count_direct_kernel   a1-a7 of SURVEY.md section 8: encode + validity/quality mask +
+//                         sliding-window canonicalisation + open-addressing upsert
+//   table_* kernels       a8 (into_hashmap) as device compaction, histogram, lookup, rehash
+//   owner_* kernels       multi-GPU key-partitioned export
+//   synth_reads_kernel    deterministic synthetic reads
+//
+// All integer work; HBM/atomic bound; no MFMA (there is no contraction on this path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kmer_bits.h"
+
+namespace kh {
+
+typedef unsigned long long u64;
+
+// One table entry.  key == KH_EMPTY_KEY marks a free slot (count is then 0).
+struct alignas(16) Slot {
+    u64 key;
+    u64 count;
+};
+
+// Device-resident running counters (one instance per context).
+struct Counters {
+    u64 kmers;     // valid windows counted so far (== sum of counts added by count kernels)
+    u64 distinct;  // slots claimed so far
+    u64 failed;    // upserts that found no free slot (must stay 0)
+    u64 cursor;    // scratch cursor for compaction / counting kernels
+    u64 big;       // scratch cursor for the histogram's big-count list
+    u64 pad[3];
+};
+
+constexpr int BLOCK = 256;           // 4 waves of 64
+constexpr int CHUNK = 16;            // bases per thread per tile (one 16-byte load)
+constexpr int TILE = BLOCK * CHUNK;  // 4096 positions per workgroup iteration
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers (wave = 64 lanes on gfx950)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ uint32_t mbcnt(u64 mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+// ---------------------------------------------------------------------------------------------
+// open-addressing table: placement = fast-range of mix64(key), linear probing with wrap
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 slot_of(u64 key, u64 cap) { return __umul64hi(kh_mix64(key), cap); }
+
+__device__ __forceinline__ void count_add(Slot *s, u64 addend) {
+    // fire-and-forget device-scope add (result unused -> no-return global_atomic_add_x2)
+    (void)__hip_atomic_fetch_add(&s->count, addend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Upsert starting at slot idx whose key was observed (by a plain, possibly stale load) as `cur`.
+// A stale observation is harmless: a slot only ever goes EMPTY -> K once, so a non-empty value is
+// final, and a stale EMPTY is corrected by the value the CAS returns.
+__device__ __forceinline__ void upsert_from(Slot *table, u64 cap, u64 key, u64 idx, u64 cur, u64 addend,
+                                            uint32_t &ndistinct, uint32_t &nfailed) {
+    for (u64 probes = 0; probes < cap; ++probes) {
+        if (cur == KH_EMPTY_KEY) {
+            u64 expected = KH_EMPTY_KEY;
+            if (__hip_atomic_compare_exchange_strong(&table[idx].key, &expected, (u64)key, __ATOMIC_RELAXED,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                ++ndistinct;
+                cur = key;
+            } else {
+                cur = expected;  // someone else claimed it first; may be our key
+            }
+        }
+        if (cur == key) {
+            count_add(&table[idx], addend);
+            return;
+        }
+        if (++idx == cap) idx = 0;
+        cur = table[idx].key;
+    }
+    ++nfailed;
+}
+
+__device__ __forceinline__ void upsert(Slot *table, u64 cap, u64 key, u64 addend, uint32_t &ndistinct,
+                                       uint32_t &nfailed) {
+    u64 idx = slot_of(key, cap);
+    upsert_from(table, cap, key, idx, table[idx].key, addend, ndistinct, nfailed);
+}
+
+// ---------------------------------------------------------------------------------------------
+// G1+G2: encode + mask + canonicalise + upsert, straight into the HBM table
+// ---------------------------------------------------------------------------------------------
+// Positions are "virtual": abase is the 16-byte-aligned address at or below the caller's pointer,
+// real data occupies [vbeg, vend), and only windows ENDING at >= wlo are counted (wlo > vbeg when
+// the bytes before it are a halo that an earlier launch already counted).
+//
+// Per tile of 4096 positions a workgroup: (1) loads 16 bases (+16 quals) per lane with one
+// coalesced 16-byte load each, (2) turns them into a 32-bit 2-bit-code word and a 16-bit
+// validity word, staged in LDS so every lane can read the two words in front of its own (the
+// k-1 <= 31 base look-back), (3) extracts the 16 windows ending in its chunk by funnel shifts,
+// canonicalises them and (4) upserts them eight at a time (eight independent slot loads in
+// flight per lane before the first atomic).
+__device__ __forceinline__ uint32_t byte_of(const uint4 &w, int j) {
+    uint32_t d = (j < 4) ? w.x : (j < 8) ? w.y : (j < 12) ? w.z : w.w;
+    return (d >> (8 * (j & 3))) & 0xFFu;
+}
+
+template <bool QUAL>
+__device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase,
+                                             int qaligned, int64_t p0, u64 vbeg, u64 vend, uint32_t thr,
+                                             uint32_t &code, uint32_t &val) {
+    code = 0;
+    val = 0;
+    if (p0 < 0 || (u64)p0 >= vend) return;
+    const uint4 w = *reinterpret_cast<const uint4 *>(abase + p0);
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (QUAL) {
+        if (qaligned) {
+            q = *reinterpret_cast<const uint4 *>(qbase + p0);
+        } else {
+            uint32_t qq[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j) {
+                u64 pos = (u64)p0 + j;
+                uint32_t b = (pos >= vbeg && pos < vend) ? qbase[pos] : 0u;
+                qq[j >> 2] |= b << (8 * (j & 3));
+            }
+            q = make_uint4(qq[0], qq[1], qq[2], qq[3]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) {
+        uint32_t b = byte_of(w, j);
+        u64 pos = (u64)p0 + j;
+        uint32_t v = kh_base_valid(b) & (uint32_t)(pos >= vbeg) & (uint32_t)(pos < vend);
+        if (QUAL) v &= (uint32_t)(byte_of(q, j) >= thr);  // run.rs:545: skip iff qv < threshold
+        code = (code << 2) | kh_base_code(b);
+        val = (val << 1) | v;
+    }
+}
+
+template <bool QUAL>
+__global__ __launch_bounds__(BLOCK) void count_direct_kernel(
+    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend,
+    u64 wlo, u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, Slot *table, u64 cap,
+    Counters *ctr) {
+    __shared__ uint32_t s_code[2][BLOCK + 2];
+    __shared__ uint32_t s_val[2][BLOCK + 2];
+
+    const int tid = threadIdx.x;
+    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
+    u64 te = tb + tiles_per_block;
+    if (te > tile0 + ntiles) te = tile0 + ntiles;
+
+    const u64 kmask = kh_kmask(k);
+    const u64 vmask = (k >= 32) ? 0xFFFFFFFFull : ((1ull << k) - 1ull);
+    uint32_t nk = 0, nd = 0, nf = 0;
+
+    int buf = 0;
+    for (u64 t = tb; t < te; ++t, buf ^= 1) {
+        const int64_t p0 = (int64_t)(t * TILE + (u64)tid * CHUNK);
+        uint32_t code, val;
+        encode_chunk<QUAL>(abase, qbase, qaligned, p0, vbeg, vend, thr, code, val);
+        s_code[buf][tid + 2] = code;
+        s_val[buf][tid + 2] = val;
+        if (t == tb && tid < 2) {  // look-back words of the first tile; later tiles get them carried
+            uint32_t hc, hv;
+            encode_chunk<QUAL>(abase, qbase, qaligned, (int64_t)(t * TILE) - (int64_t)(2 - tid) * CHUNK, vbeg, vend,
+                               thr, hc, hv);
+            s_code[buf][tid] = hc;
+            s_val[buf][tid] = hv;
+        }
+        __syncthreads();
+        // Carry the last two words to the next tile's look-back slots.  Done AFTER the barrier:
+        // the other buffer's slots [0,1] were last read in the previous iteration, and every
+        // reader is past those reads once it has arrived here.
+        if (tid >= BLOCK - 2) {
+            s_code[buf ^ 1][tid - (BLOCK - 2)] = code;
+            s_val[buf ^ 1][tid - (BLOCK - 2)] = val;
+        }
+        const uint32_t hi = s_code[buf][tid];
+        const uint32_t mid = s_code[buf][tid + 1];
+        const u64 lo64 = ((u64)mid << 32) | code;
+        const u64 V = ((u64)s_val[buf][tid] << 32) | ((u64)s_val[buf][tid + 1] << 16) | (u64)val;
+
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u64 key[8];
+            u64 idx[8];
+            u64 cur[8];
+            uint32_t ok = 0;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = half * 8 + jj;
+                const int sh = 2 * (15 - j);
+                const u64 x = (sh == 0) ? lo64 : ((lo64 >> sh) | ((u64)hi << (64 - sh)));
+                const u64 fwd = x & kmask;
+                const bool good = (((V >> (15 - j)) & vmask) == vmask) && ((u64)p0 + j >= wlo);
+                key[jj] = kh_canonical_bits(fwd, k);
+                ok |= (uint32_t)good << jj;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                idx[jj] = slot_of(key[jj], cap);
+                cur[jj] = KH_EMPTY_KEY;
+                if (ok & (1u << jj)) cur[jj] = table[idx[jj]].key;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                if (ok & (1u << jj)) {
+                    ++nk;
+                    if (cur[jj] == key[jj]) count_add(&table[idx[jj]], 1ull);
+                    else upsert_from(table, cap, key[jj], idx[jj], cur[jj], 1ull, nd, nf);
+                }
+            }
+        }
+    }
+
+    // wave-aggregated statistics: one atomic per wave per counter
+    u64 s = wave_sum((u64)nk);
+    u64 d = wave_sum((u64)nd);
+    u64 f = wave_sum((u64)nf);
+    if (lane_id() == 0) {
+        if (s) atomicAdd(&ctr->kmers, s);
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (f) atomicAdd(&ctr->failed, f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// table maintenance
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void table_init_kernel(Slot *table, u64 cap) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride)
+        *reinterpret_cast<uint4 *>(&table[i]) = e;
+}
+
+// ctr->cursor += number of live slots with count >= min_count
+__global__ __launch_bounds__(BLOCK) void table_count_kernel(const Slot *table, u64 cap, u64 min_count, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    u64 n = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
+        const Slot s = table[i];
+        n += (s.key != KH_EMPTY_KEY && s.count >= min_count) ? 1 : 0;
+    }
+    n = wave_sum(n);
+    if (lane_id() == 0 && n) atomicAdd(&ctr->cursor, n);
+}
+
+// Wave-aggregated stream compaction of live slots (ballot + mbcnt prefix, one cursor atomic per
+// wave).  Pairs past out_cap are not written; ctr->cursor still counts them.
+__global__ __launch_bounds__(BLOCK) void table_compact_kernel(const Slot *table, u64 cap, u64 min_count, u64 *keys,
+                                                              u64 *counts, u64 out_cap, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    const u64 first = (u64)blockIdx.x * BLOCK + threadIdx.x;
+    const u64 rounds = (cap + stride - 1) / stride;  // uniform trip count: ballots need whole waves
+    for (u64 r = 0; r < rounds; ++r) {
+        const u64 i = first + r * stride;
+        Slot s;
+        s.key = KH_EMPTY_KEY;
+        s.count = 0;
+        if (i < cap) s = table[i];
+        const bool live = (s.key != KH_EMPTY_KEY) && (s.count >= min_count);
+        const u64 m = __ballot(live);
+        if (m == 0) continue;
+        u64 base = 0;
+        if (lane_id() == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&ctr->cursor, (u64)__builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (live) {
+            const u64 o = base + mbcnt(m);
+            if (o < out_cap) {
+                keys[o] = s.key;
+                counts[o] = s.count;
+            }
+        }
+    }
+}
+
+// count[key] += addend for n (key, addend) pairs: rehash-free merge of another table's pairs.
+__global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(Slot *table, u64 cap, const u64 *keys,
+                                                                  const u64 *counts, u64 n, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    uint32_t nd = 0, nf = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const u64 key = keys[i];
+        const u64 c = counts[i];
+        if (key != KH_EMPTY_KEY && c != 0) upsert(table, cap, key, c, nd, nf);
+    }
+    u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (f) atomicAdd(&ctr->failed, f);
+    }
+}
+
+// Move every live pair of `old` into `nt` (table growth).
+__global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, Slot *nt, u64 ncap,
+                                                             Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    uint32_t nd = 0, nf = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < oldcap; i += stride) {
+        const Slot s = old[i];
+        if (s.key != KH_EMPTY_KEY) upsert(nt, ncap, s.key, s.count, nd, nf);
+    }
+    u64 f = wave_sum((u64)nf);
+    if (lane_id() == 0 && f) atomicAdd(&ctr->failed, f);
+}
+
+__global__ __launch_bounds__(BLOCK) void table_lookup_kernel(const Slot *table, u64 cap, const u64 *keys, u64 n,
+                                                             u64 *out) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const u64 key = keys[i];
+        u64 idx = slot_of(key, cap);
+        u64 res = 0;
+        for (u64 probes = 0; probes < cap; ++probes) {
+            const Slot s = table[idx];
+            if (s.key == key) { res = s.count; break; }
+            if (s.key == KH_EMPTY_KEY) break;
+            if (++idx == cap) idx = 0;
+        }
+        out[i] = res;
+    }
+}
+
+// Count-of-counts.  Counts below HIST_LDS are binned in LDS per workgroup and flushed once;
+// counts below HIST_DENSE go to a dense global array; the (rare) rest are appended to `big`.
+constexpr uint32_t HIST_LDS = 2048;
+constexpr uint32_t HIST_DENSE = 1u << 16;
+
+__global__ __launch_bounds__(BLOCK) void table_hist_kernel(const Slot *table, u64 cap, u64 min_count, u64 *dense,
+                                                           u64 *big, u64 big_cap, Counters *ctr) {
+    __shared__ uint32_t s_bins[HIST_LDS];
+    for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) s_bins[i] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
+        const Slot s = table[i];
+        if (s.key == KH_EMPTY_KEY || s.count < min_count) continue;
+        if (s.count < HIST_LDS) {
+            atomicAdd(&s_bins[(uint32_t)s.count], 1u);
+        } else if (s.count < HIST_DENSE) {
+            atomicAdd(&dense[s.count], 1ull);
+        } else {
+            const u64 o = atomicAdd(&ctr->big, 1ull);
+            if (o < big_cap) big[o] = s.count;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) {
+        const uint32_t v = s_bins[i];
+        if (v) atomicAdd(&dense[i], (u64)v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU export: live pairs grouped by owner shard
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t MAX_PARTS = 256;
+
+__global__ __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u64 cap, uint32_t nparts,
+                                                            u64 *part_counts) {
+    __shared__ uint32_t s_cnt[MAX_PARTS];
+    for (uint32_t i = threadIdx.x; i < nparts; i += BLOCK) s_cnt[i] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
+        const Slot s = table[i];
+        if (s.key != KH_EMPTY_KEY) atomicAdd(&s_cnt[kh_owner_of(s.key, nparts)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nparts; i += BLOCK)
+        if (s_cnt[i]) atomicAdd(&part_counts[i], (u64)s_cnt[i]);
+}
+
+// cursors[p] starts at the exclusive prefix of part_counts; wave-aggregated per owner.
+__global__ __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table, u64 cap, uint32_t nparts,
+                                                              u64 *cursors, u64 *keys, u64 *counts, u64 out_cap) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    const u64 first = (u64)blockIdx.x * BLOCK + threadIdx.x;
+    const u64 rounds = (cap + stride - 1) / stride;
+    for (u64 r = 0; r < rounds; ++r) {
+        const u64 i = first + r * stride;
+        Slot s;
+        s.key = KH_EMPTY_KEY;
+        s.count = 0;
+        if (i < cap) s = table[i];
+        const bool live = (s.key != KH_EMPTY_KEY);
+        const uint32_t own = live ? kh_owner_of(s.key, nparts) : 0xFFFFFFFFu;
+        u64 todo = __ballot(live);
+        while (todo) {  // one round per distinct owner present in the wave
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t p = (uint32_t)__shfl((int)own, leader, 64);
+            const u64 m = __ballot(live && own == p);
+            u64 base = 0;
+            if ((int)lane_id() == leader) base = atomicAdd(&cursors[p], (u64)__builtin_popcountll(m));
+            base = __shfl(base, leader, 64);
+            if (live && own == p) {
+                const u64 o = base + mbcnt(m);
+                if (o < out_cap) {
+                    keys[o] = s.key;
+                    counts[o] = s.count;
+                }
+            }
+            todo &= ~m;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// deterministic synthetic reads: one lane per 16 output bytes, one 16-byte store each
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void synth_reads_kernel(u64 seed, u64 genome_len, uint32_t read_len,
+                                                            u64 first_read, u64 n_reads, uint8_t *bases,
+                                                            uint8_t *qual) {
+    const u64 kg = kh_stream_key(seed, 0), ks = kh_stream_key(seed, 1), kd = kh_stream_key(seed, 2),
+              ke = kh_stream_key(seed, 3);
+    const u64 span = genome_len - read_len + 1;
+    const u64 rstride = (u64)read_len + 1;
+    const u64 total = n_reads * rstride;
+    const u64 nchunks = (total + 15) / 16;
+    const u64 gstride = (u64)gridDim.x * BLOCK;
+    for (u64 c = (u64)blockIdx.x * BLOCK + threadIdx.x; c < nchunks; c += gstride) {
+        u64 pos = c * 16;
+        u64 i = pos / rstride;            // read index inside this buffer
+        uint32_t j = (uint32_t)(pos - i * rstride);
+        u64 r = first_read + i;
+        u64 start = kh_draw(ks, r) % span;
+        uint32_t strand = (uint32_t)(kh_draw(kd, r) & 1);
+        uint32_t ob[4] = {0, 0, 0, 0}, oq[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            uint32_t bb = '\n', qq = '\n';
+            if (pos + b < total && j < read_len) {
+                u64 cc = strand ? 3 - (kh_draw(kg, start + (read_len - 1 - j)) & 3) : (kh_draw(kg, start + j) & 3);
+                const u64 u = kh_draw(ke, r * read_len + j);
+                const bool subst = (u & 0xFF) == 0;
+                if (subst) cc = (cc + 1 + ((u >> 8) % 3)) & 3;
+                const bool isn = ((u >> 16) & 0x3FF) == 0;
+                bb = isn ? 'N' : (uint32_t)("ACGT"[cc]);
+                const uint32_t v = (uint32_t)((u >> 32) & 0xFF);
+                qq = v < 230 ? 'I' : (v < 250 ? '5' : '#');
+                if (subst && ((u >> 40) & 1)) qq = '#';
+            }
+            ob[b >> 2] |= bb << (8 * (b & 3));
+            oq[b >> 2] |= qq << (8 * (b & 3));
+            if (++j == rstride) {  // crossed into the next read
+                j = 0;
+                ++r;
+                start = kh_draw(ks, r) % span;
+                strand = (uint32_t)(kh_draw(kd, r) & 1);
+            }
+        }
+        if (pos + 16 <= total) {
+            *reinterpret_cast<uint4 *>(bases + pos) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+            if (qual) *reinterpret_cast<uint4 *>(qual + pos) = make_uint4(oq[0], oq[1], oq[2], oq[3]);
+        } else {
+            for (int b = 0; pos + b < total; ++b) {
+                bases[pos + b] = (uint8_t)(ob[b >> 2] >> (8 * (b & 3)));
+                if (qual) qual[pos + b] = (uint8_t)(oq[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+    }
+}
+
+}  // namespace kh

@@ -1,0 +1,74 @@
+"""Multi-GPU leg of the counting path: one process per GPU, reads sharded by contiguous
+read-index ranges, per-GPU tables merged by ONE key-partitioned exchange step.
+
+A hash table is not element-wise reducible, so the "reduce of per-GPU tables" is an
+all-to-all of compacted (key,count) pairs to owner = kh_owner(key, world) followed by a local
+re-insert with `count` as the addend.  On ROCm torch.distributed's "nccl"
+backend is RCCL; an all-to-all drives all 7 xGMI links of a GPU at once, where a ring
+all-reduce would be per-link bound (and semantically wrong for a hash table).  The result stays
+key-sharded across the ranks.
+
+The reference has no counterpart (it is single-process; src/run.rs:500-503 is its only
+parallelism).  torch is used for device buffers and the collective only.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [lo, hi) range of `n_items` for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def exchange_pairs(keys, counts, part_counts, group=None):
+    """All-to-all of owner-grouped pairs.
+
+    keys/counts: int64 tensors (bit views of u64) laid out as [pairs for owner 0 | owner 1 | ...];
+    part_counts: per-owner pair counts (len == world).  Returns (recv_keys, recv_counts): every
+    pair this rank owns, from all ranks (its own included)."""
+    world = dist.get_world_size(group)
+    send_sizes = [int(x) for x in part_counts]
+    assert len(send_sizes) == world and sum(send_sizes) == keys.numel() == counts.numel()
+    dev = keys.device
+    ssz = torch.tensor(send_sizes, dtype=torch.int64, device=dev)
+    rsz = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rsz, ssz, group=group)
+    recv_sizes = [int(x) for x in rsz.tolist()]
+    rk = torch.empty(sum(recv_sizes), dtype=torch.int64, device=dev)
+    rc = torch.empty(sum(recv_sizes), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rk, keys, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
+    dist.all_to_all_single(rc, counts, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
+    return rk, rc
+
+
+def merge_across_ranks(counter, group=None):
+    """Turns per-rank tables (each built from that rank's read shard) into a key-sharded global
+    table: afterwards `counter` on rank r holds exactly the keys with kh_owner(key, world) == r,
+    with counts summed over all ranks.  Returns a dict of sizes for reporting."""
+    world = dist.get_world_size(group)
+    st = counter.finish()
+    n_local = int(st["distinct"])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
+    cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
+    parts = counter.export_by_owner_device(world, keys.data_ptr(), cnts.data_ptr(), n_local)
+    rk, rc = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group)
+    counter.reset()
+    counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
+    st2 = counter.finish()
+    return {"local_distinct": n_local, "sent_pairs": int(n_local - parts[dist.get_rank(group)]),
+            "recv_pairs": int(rk.numel()), "owned_distinct": int(st2["distinct"])}
+
+
+def group_pairs_by_owner(keys, counts, world, owner_fn):
+    """Host-side twin of kh_export_by_owner_device for numpy pairs (used where the pairs are
+    already on the host, e.g. gathering a final result)."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    counts = np.asarray(counts, dtype=np.uint64)
+    own = np.fromiter((owner_fn(int(k), world) for k in keys), dtype=np.int64, count=keys.size)
+    order = np.argsort(own, kind="stable")
+    parts = np.bincount(own, minlength=world).astype(np.int64)
+    return keys[order], counts[order], parts

@@ -1,0 +1,291 @@
+"""ctypes binding of the C ABI in include/kmerhip.h (krust_amd/lib/libkmerhip.so).
+
+This is plumbing only: every call goes to the hand-written HIP path.  There is
+no CPU fallback -- if the shared library is missing, or no HIP device is usable,
+the calls fail loudly (ImportError / KmerHipError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkmerhip.so")
+
+KH_OK = 0
+KH_ERR_BAD_K = -1
+KH_ERR_BAD_ARG = -2
+KH_ERR_NO_DEVICE = -3
+KH_ERR_OOM = -4
+KH_ERR_TABLE_FULL = -5
+KH_ERR_HIP = -6
+KH_ERR_STATE = -7
+KH_ERR_RANGE = -8
+
+
+class KhConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("k", C.c_uint32), ("min_quality", C.c_int32),
+                ("device", C.c_int32), ("capacity_hint", C.c_uint64), ("stream", C.c_void_p),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class KhStats(C.Structure):
+    _fields_ = [("bases", C.c_uint64), ("kmers", C.c_uint64), ("distinct", C.c_uint64),
+                ("table_slots", C.c_uint64), ("grows", C.c_uint64), ("launches", C.c_uint64),
+                ("count_kernel_ms", C.c_double), ("h2d_ms", C.c_double)]
+
+
+# every symbol include/kmerhip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_U64 = C.c_uint64
+SYMBOLS = {
+    "kh_abi_version": (C.c_int, []),
+    "kh_create": (C.c_int, [C.POINTER(_P), C.POINTER(KhConfig)]),
+    "kh_destroy": (None, [_P]),
+    "kh_reset": (C.c_int, [_P]),
+    "kh_push": (C.c_int, [_P, _P, _P, _U64]),
+    "kh_push_device": (C.c_int, [_P, _P, _P, _U64]),
+    "kh_finish": (C.c_int, [_P, C.POINTER(KhStats)]),
+    "kh_result_size": (C.c_int, [_P, _U64, C.POINTER(_U64)]),
+    "kh_result_copy": (C.c_int, [_P, _P, _P, _U64, _U64, C.POINTER(_U64)]),
+    "kh_result_copy_device": (C.c_int, [_P, _P, _P, _U64, _U64, C.POINTER(_U64)]),
+    "kh_histogram": (C.c_int, [_P, _U64, _P, _P, _U64, C.POINTER(_U64)]),
+    "kh_lookup": (C.c_int, [_P, _P, _U64, _P]),
+    "kh_owner": (C.c_uint32, [_U64, C.c_uint32]),
+    "kh_export_by_owner_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P]),
+    "kh_merge_pairs_device": (C.c_int, [_P, _P, _P, _U64]),
+    "kh_merge_pairs": (C.c_int, [_P, _P, _P, _U64]),
+    "kh_pack": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(_U64), C.POINTER(C.c_uint32)]),
+    "kh_unpack": (C.c_int, [_U64, C.c_uint32, C.c_char_p]),
+    "kh_canonical": (C.c_int, [_U64, C.c_uint32, C.POINTER(_U64), C.POINTER(C.c_int)]),
+    "kh_strerror": (C.c_char_p, [C.c_int]),
+    "kh_last_error": (C.c_char_p, [_P]),
+    "kh_synth_reads_device": (C.c_int, [C.c_int, _P, _U64, _U64, C.c_uint32, _U64, _U64, _P, _P]),
+}
+
+
+class KmerHipError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = lib().kh_strerror(status).decode()
+        super().__init__(f"kmerhip error {status}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+class KmerLengthError(ValueError):
+    """Mirror of kmerust::error::KmerLengthError (src/error.rs:86-95)."""
+
+    def __init__(self, k):
+        self.k, self.min, self.max = k, 1, 32
+        super().__init__(f"k-mer length {k} is out of range: must be between 1 and 32")
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises ImportError (never falls back) if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C krust_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+        # torch bundles its own libamdhip64.so.7; importing it first makes the dynamic linker
+        # resolve our DT_NEEDED entry to that already-loaded copy, so the process holds ONE HIP
+        # runtime and tensor.data_ptr() addresses are valid in our kernels.  (torch is plumbing:
+        # device memory, streams, torch.distributed.)  Without torch, /opt/rocm/lib is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _addr(a):
+    """numpy array / bytes / int address / None -> (address or None, keepalive)."""
+    if a is None:
+        return None, None
+    if isinstance(a, int):
+        return a, None
+    if isinstance(a, np.ndarray):
+        a = np.ascontiguousarray(a)
+        return a.ctypes.data, a
+    arr = np.frombuffer(a, dtype=np.uint8)
+    return arr.ctypes.data, arr
+
+
+class DeviceCounter:
+    """One kh_ctx: a GPU-resident canonical k-mer count table.
+
+    Stands where the reference has `KmerMap` (src/run.rs:491-583): build()/
+    build_with_quality() -> push()/push_device(); into_hashmap() -> result()."""
+
+    def __init__(self, k, min_quality=None, capacity_hint=0, device=-1, stream=None, trace=False):
+        if not (1 <= int(k) <= 32):
+            raise KmerLengthError(int(k))
+        cfg = KhConfig(C.sizeof(KhConfig), int(k), -1 if min_quality is None else int(min_quality),
+                       int(device), int(capacity_hint), stream, 1 if trace else 0, 0)
+        h = _P()
+        rc = lib().kh_create(C.byref(h), C.byref(cfg))
+        if rc != KH_OK:
+            raise KmerHipError(rc)
+        self._h = h
+        self.k = int(k)
+        self.min_quality = min_quality
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().kh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != KH_OK:
+            raise KmerHipError(rc, lib().kh_last_error(self._h).decode())
+
+    def reset(self):
+        self._check(lib().kh_reset(self._h))
+
+    # -- input -------------------------------------------------------------
+    def push(self, bases, qual=None):
+        """Flat host buffer(s); records separated by >=1 non-ACGT byte."""
+        bp, kb = _addr(bases)
+        n = kb.size if kb is not None else 0
+        qp, kq = _addr(qual)
+        if kq is not None and kq.size != n:
+            raise ValueError("qual must have the same length as bases")
+        self._check(lib().kh_push(self._h, bp, qp, n))
+
+    def push_device(self, d_bases, d_qual, n):
+        """Device-resident flat buffers given as integer addresses (e.g. tensor.data_ptr())."""
+        self._check(lib().kh_push_device(self._h, d_bases, d_qual, int(n)))
+
+    def finish(self):
+        st = KhStats()
+        self._check(lib().kh_finish(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in KhStats._fields_}
+
+    # -- output ------------------------------------------------------------
+    def result_size(self, min_count=1):
+        n = _U64(0)
+        self._check(lib().kh_result_size(self._h, int(min_count), C.byref(n)))
+        return int(n.value)
+
+    def result(self, min_count=1, sort=True):
+        """(keys, counts) as uint64 arrays; packed canonical keys."""
+        n = self.result_size(min_count)
+        keys = np.empty(n, dtype=np.uint64)
+        cnts = np.empty(n, dtype=np.uint64)
+        got = _U64(0)
+        self._check(lib().kh_result_copy(self._h, keys.ctypes.data, cnts.ctypes.data, n, int(min_count), C.byref(got)))
+        assert got.value == n
+        if sort:
+            o = np.argsort(keys, kind="stable")
+            keys, cnts = keys[o], cnts[o]
+        return keys, cnts
+
+    def result_device(self, d_keys, d_counts, cap, min_count=1):
+        got = _U64(0)
+        self._check(lib().kh_result_copy_device(self._h, d_keys, d_counts, int(cap), int(min_count), C.byref(got)))
+        return int(got.value)
+
+    def as_dict(self, min_count=1):
+        k, c = self.result(min_count)
+        return dict(zip(k.tolist(), c.tolist()))
+
+    def as_str_dict(self, min_count=1):
+        """HashMap<String,u64> of into_hashmap (src/run.rs:573-582)."""
+        return {unpack(key, self.k): c for key, c in self.as_dict(min_count).items()}
+
+    def histogram(self, min_count=1):
+        cap = 1 << 12
+        while True:
+            cnt = np.empty(cap, dtype=np.uint64)
+            frq = np.empty(cap, dtype=np.uint64)
+            n = _U64(0)
+            rc = lib().kh_histogram(self._h, int(min_count), cnt.ctypes.data, frq.ctypes.data, cap, C.byref(n))
+            if rc == KH_ERR_RANGE:
+                cap *= 16
+                continue
+            self._check(rc)
+            return list(zip(cnt[: n.value].tolist(), frq[: n.value].tolist()))
+
+    def lookup(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(keys.size, dtype=np.uint64)
+        self._check(lib().kh_lookup(self._h, keys.ctypes.data, keys.size, out.ctypes.data))
+        return out
+
+    # -- multi-GPU merge ---------------------------------------------------
+    def export_by_owner_device(self, nparts, d_keys, d_counts, cap):
+        parts = np.zeros(nparts, dtype=np.uint64)
+        self._check(lib().kh_export_by_owner_device(self._h, int(nparts), d_keys, d_counts, int(cap), parts.ctypes.data))
+        return parts
+
+    def merge_pairs_device(self, d_keys, d_counts, n):
+        self._check(lib().kh_merge_pairs_device(self._h, d_keys, d_counts, int(n)))
+
+    def merge_pairs(self, keys, counts):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        assert keys.size == counts.size
+        self._check(lib().kh_merge_pairs(self._h, keys.ctypes.data, counts.ctypes.data, keys.size))
+
+
+# ---- pure helpers (host) ----------------------------------------------------
+
+def pack(seq):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    out = _U64(0)
+    pos = C.c_uint32(0)
+    rc = lib().kh_pack(seq, len(seq), C.byref(out), C.byref(pos))
+    if rc == KH_ERR_BAD_K:
+        raise KmerLengthError(len(seq))
+    if rc != KH_OK:
+        b = seq[pos.value]  # Display of InvalidBaseError, src/error.rs:106-122
+        if 0x20 <= b < 0x7F:
+            raise ValueError(f"invalid base '{chr(b)}' (0x{b:02x}) at position {pos.value}")
+        raise ValueError(f"invalid base 0x{b:02x} at position {pos.value}")
+    return int(out.value)
+
+
+def unpack(bits, k):
+    if not (1 <= k <= 32):
+        raise KmerLengthError(k)
+    buf = C.create_string_buffer(k)
+    lib().kh_unpack(int(bits), k, buf)
+    return buf.raw.decode()
+
+
+def canonical(bits, k):
+    out = _U64(0)
+    rc_flag = C.c_int(0)
+    rc = lib().kh_canonical(int(bits), k, C.byref(out), C.byref(rc_flag))
+    if rc == KH_ERR_BAD_K:
+        raise KmerLengthError(k)
+    return int(out.value), bool(rc_flag.value)
+
+
+def owner(key, nparts):
+    return int(lib().kh_owner(int(key), int(nparts)))
+
+
+def synth_reads_device(d_bases, d_qual, seed, genome_len, read_len, first_read, n_reads, device=-1, stream=None):
+    rc = lib().kh_synth_reads_device(int(device), stream, int(seed), int(genome_len), int(read_len),
+                                     int(first_read), int(n_reads), d_bases, d_qual)
+    if rc != KH_OK:
+        raise KmerHipError(rc)

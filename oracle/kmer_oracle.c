@@ -100,10 +100,10 @@ void ko_unpack(uint64_t packed, size_t k, char *out) {
 /* count map                                                                */
 /* ======================================================================== */
 
+typedef struct { uint64_t key, val; } ko_entry; /* val == 0 marks a free entry */
+
 struct ko_map {
-    uint64_t *keys;
-    uint64_t *vals;
-    uint8_t *used;
+    ko_entry *e;
     uint64_t cap; /* power of two */
     uint64_t len;
 };
@@ -116,10 +116,8 @@ uint64_t ko_mix64(uint64_t z) {
 }
 
 static void map_alloc(ko_map *m, uint64_t cap) {
-    m->keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
-    m->vals = (uint64_t *)malloc(cap * sizeof(uint64_t));
-    m->used = (uint8_t *)calloc(cap, 1);
-    if (!m->keys || !m->vals || !m->used) abort();
+    m->e = (ko_entry *)calloc(cap, sizeof(ko_entry));
+    if (!m->e) abort();
     m->cap = cap;
     m->len = 0;
 }
@@ -133,7 +131,7 @@ ko_map *ko_map_new(void) {
 
 void ko_map_free(ko_map *m) {
     if (!m) return;
-    free(m->keys); free(m->vals); free(m->used); free(m);
+    free(m->e); free(m);
 }
 
 uint64_t ko_map_len(const ko_map *m) { return m->len; }
@@ -146,22 +144,23 @@ static inline uint64_t sat_add(uint64_t a, uint64_t b) {
 static void map_insert_raw(ko_map *m, uint64_t key, uint64_t addend) {
     uint64_t mask = m->cap - 1;
     uint64_t i = ko_mix64(key) & mask;
-    while (m->used[i]) {
-        if (m->keys[i] == key) { m->vals[i] = sat_add(m->vals[i], addend); return; }
+    while (m->e[i].val) {
+        if (m->e[i].key == key) { m->e[i].val = sat_add(m->e[i].val, addend); return; }
         i = (i + 1) & mask;
     }
-    m->used[i] = 1; m->keys[i] = key; m->vals[i] = addend; m->len++;
+    m->e[i].key = key; m->e[i].val = addend; m->len++;
 }
 
 static void map_grow(ko_map *m) {
     ko_map old = *m;
     map_alloc(m, old.cap * 2);
     for (uint64_t i = 0; i < old.cap; i++)
-        if (old.used[i]) map_insert_raw(m, old.keys[i], old.vals[i]);
-    free(old.keys); free(old.vals); free(old.used);
+        if (old.e[i].val) map_insert_raw(m, old.e[i].key, old.e[i].val);
+    free(old.e);
 }
 
 void ko_map_add(ko_map *m, uint64_t key, uint64_t addend) {
+    if (addend == 0) return; /* counts are >= 1 on this path; 0 is the free marker */
     if ((m->len + 1) * 10 > m->cap * 6) map_grow(m);
     map_insert_raw(m, key, addend);
 }
@@ -169,8 +168,8 @@ void ko_map_add(ko_map *m, uint64_t key, uint64_t addend) {
 uint64_t ko_map_get(const ko_map *m, uint64_t key) {
     uint64_t mask = m->cap - 1;
     uint64_t i = ko_mix64(key) & mask;
-    while (m->used[i]) {
-        if (m->keys[i] == key) return m->vals[i];
+    while (m->e[i].val) {
+        if (m->e[i].key == key) return m->e[i].val;
         i = (i + 1) & mask;
     }
     return 0;
@@ -179,14 +178,14 @@ uint64_t ko_map_get(const ko_map *m, uint64_t key) {
 uint64_t ko_map_dump(const ko_map *m, uint64_t *keys, uint64_t *counts, uint64_t cap) {
     uint64_t n = 0;
     for (uint64_t i = 0; i < m->cap && n < cap; i++)
-        if (m->used[i]) { keys[n] = m->keys[i]; counts[n] = m->vals[i]; n++; }
+        if (m->e[i].val) { keys[n] = m->e[i].key; counts[n] = m->e[i].val; n++; }
     return n;
 }
 
 uint64_t ko_map_total(const ko_map *m) {
     uint64_t t = 0;
     for (uint64_t i = 0; i < m->cap; i++)
-        if (m->used[i]) t = sat_add(t, m->vals[i]);
+        if (m->e[i].val) t = sat_add(t, m->e[i].val);
     return t;
 }
 
@@ -268,6 +267,76 @@ void ko_process_sequence_rolling(ko_map *m, const uint8_t *seq, size_t len,
     }
 }
 
+/* ---- threaded sampled scan (full-size parity checks) -------------------- */
+
+typedef struct {
+    const uint8_t *seq, *qual;
+    size_t lo, hi, len; /* count windows ENDING in [lo, hi) */
+    size_t k;
+    int min_quality;
+    uint64_t sample_mask;
+    ko_map map;
+    uint64_t total;
+} scan_t;
+
+static void *scan_main(void *arg) {
+    scan_t *s = (scan_t *)arg;
+    const size_t k = s->k;
+    int have_thr = (s->qual != NULL && s->min_quality >= 0);
+    int thr = have_thr ? qual_threshold(s->min_quality) : 0;
+    uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    unsigned rcshift = (unsigned)(2 * (k - 1));
+    uint64_t fwd = 0, rc = 0, total = 0;
+    size_t run = 0;
+    size_t begin = s->lo >= k - 1 ? s->lo - (k - 1) : 0; /* warm-up overlap */
+    for (size_t i = begin; i < s->hi; i++) {
+        uint8_t b = s->seq[i];
+        uint8_t u = (uint8_t)(b & 0xDF);
+        int good = (u == 'A' || u == 'C' || u == 'G' || u == 'T');
+        if (good && have_thr && (int)s->qual[i] < thr) good = 0;
+        if (!good) { run = 0; fwd = 0; rc = 0; continue; }
+        uint64_t c = pack_code(b);
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((3 - c) << rcshift);
+        if (++run >= k && i >= s->lo) {
+            uint64_t key = fwd < rc ? fwd : rc;
+            total++;
+            if ((ko_mix64(key) & s->sample_mask) == 0) ko_map_add(&s->map, key, 1);
+        }
+    }
+    s->total = total;
+    return NULL;
+}
+
+uint64_t ko_scan_flat_sampled_mt(ko_map *m, const uint8_t *seq, size_t len,
+                                 const uint8_t *qual, size_t k, int min_quality,
+                                 uint64_t sample_mask, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    scan_t *ss = (scan_t *)calloc((size_t)nthreads, sizeof(scan_t));
+    if (!th || !ss) abort();
+    size_t per = (len + (size_t)nthreads - 1) / (size_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        size_t lo = per * (size_t)t, hi = lo + per;
+        if (lo > len) lo = len;
+        if (hi > len) hi = len;
+        ss[t] = (scan_t){seq, qual, lo, hi, len, k, min_quality, sample_mask, {0}, 0};
+        map_alloc(&ss[t].map, 1024);
+        pthread_create(&th[t], NULL, scan_main, &ss[t]);
+    }
+    uint64_t total = 0;
+    for (int t = 0; t < nthreads; t++) {
+        pthread_join(th[t], NULL);
+        total += ss[t].total;
+        ko_map *sm = &ss[t].map;
+        for (uint64_t j = 0; j < sm->cap; j++)
+            if (sm->e[j].val) ko_map_add(m, sm->e[j].key, sm->e[j].val);
+        free(sm->e);
+    }
+    free(th); free(ss);
+    return total;
+}
+
 /* ---- histogram, src/histogram.rs:110-116 + src/run.rs:447-450 ---------- */
 
 static int cmp_u64(const void *a, const void *b) {
@@ -281,7 +350,7 @@ uint64_t ko_histogram(const ko_map *m, uint64_t min_count, uint64_t *count,
     uint64_t *v = (uint64_t *)malloc((m->len ? m->len : 1) * sizeof(uint64_t));
     if (!v) abort();
     for (uint64_t i = 0; i < m->cap; i++)
-        if (m->used[i] && m->vals[i] >= min_count) v[n++] = m->vals[i];
+        if (m->e[i].val && m->e[i].val >= min_count) v[n++] = m->e[i].val;
     qsort(v, n, sizeof(uint64_t), cmp_u64);
     uint64_t nd = 0;
     for (uint64_t i = 0; i < n;) {
@@ -311,7 +380,7 @@ uint32_t ko_crc32(const uint8_t *data, size_t n) {
 /* ======================================================================== */
 
 typedef struct {
-    pthread_mutex_t lock;
+    atomic_flag lock; /* DashMap's per-shard RwLock spins before it parks; a spinlock stands in */
     ko_map map;
     char pad[64];
 } shard_t;
@@ -329,9 +398,9 @@ static void emit_to_shards(void *ctx, uint64_t key) {
     sharded_t *s = (sharded_t *)ctx;
     uint64_t h = key * 0x517cc1b727220a95ULL; /* Fx-style multiply */
     shard_t *sh = &s->shards[(h >> s->shift) & (s->nshards - 1)];
-    pthread_mutex_lock(&sh->lock);
+    while (atomic_flag_test_and_set_explicit(&sh->lock, memory_order_acquire)) __builtin_ia32_pause();
     ko_map_add(&sh->map, key, 1);
-    pthread_mutex_unlock(&sh->lock);
+    atomic_flag_clear_explicit(&sh->lock, memory_order_release);
 }
 
 typedef struct {
@@ -377,7 +446,7 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
     sh.shards = (shard_t *)calloc(ns, sizeof(shard_t));
     if (!sh.shards) abort();
     for (uint64_t i = 0; i < ns; i++) {
-        pthread_mutex_init(&sh.shards[i].lock, NULL);
+        atomic_flag_clear(&sh.shards[i].lock);
         map_alloc(&sh.shards[i].map, 1024);
     }
     atomic_ullong next;
@@ -397,9 +466,8 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
     for (uint64_t i = 0; i < ns; i++) {
         ko_map *sm = &sh.shards[i].map;
         for (uint64_t j = 0; j < sm->cap; j++)
-            if (sm->used[j]) ko_map_add(m, sm->keys[j], sm->vals[j]);
-        free(sm->keys); free(sm->vals); free(sm->used);
-        pthread_mutex_destroy(&sh.shards[i].lock);
+            if (sm->e[j].val) ko_map_add(m, sm->e[j].key, sm->e[j].val);
+        free(sm->e);
     }
     free(sh.shards); free(th); free(ws);
     return counted;

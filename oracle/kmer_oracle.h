@@ -82,6 +82,15 @@ void ko_process_sequence(ko_map *m, const uint8_t *seq, size_t len,
 void ko_process_sequence_rolling(ko_map *m, const uint8_t *seq, size_t len,
                                  const uint8_t *qual, size_t k, int min_quality);
 
+/* Rolling scan of one flat buffer on nthreads threads (segments overlap by k-1
+ * bytes so every window is seen exactly once).  Only keys with
+ * (ko_mix64(key) & sample_mask) == 0 are added to m (sample_mask 0 = all keys);
+ * returns the TOTAL number of valid windows (sampled or not).  Used by the
+ * full-size parity checks, where a complete CPU map would not finish in seconds. */
+uint64_t ko_scan_flat_sampled_mt(ko_map *m, const uint8_t *seq, size_t len,
+                                 const uint8_t *qual, size_t k, int min_quality,
+                                 uint64_t sample_mask, int nthreads);
+
 /* Number of windows the literal loop counts (sum of counts it would add). */
 uint64_t ko_count_valid_windows(const uint8_t *seq, size_t len, const uint8_t *qual,
                                 size_t k, int min_quality);

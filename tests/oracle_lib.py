@@ -49,6 +49,9 @@ def _load():
     lib.ko_count_records_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint64, C.c_size_t, C.c_int, C.c_int]
     lib.ko_count_records_mt.restype = C.c_uint64
+    lib.ko_scan_flat_sampled_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
+                                            C.c_uint64, C.c_int]
+    lib.ko_scan_flat_sampled_mt.restype = C.c_uint64
     lib.ko_mix64.argtypes = [C.c_uint64]
     lib.ko_mix64.restype = C.c_uint64
     lib.ko_synth_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
@@ -128,6 +131,13 @@ class OracleMap:
         frq = np.empty(n, dtype=np.uint64)
         nd = lib().ko_histogram(self._m, min_count, cnt.ctypes.data, frq.ctypes.data, n)
         return list(zip(cnt[:nd].tolist(), frq[:nd].tolist()))
+
+    def scan_flat(self, seq, k, qual=None, min_quality=None, sample_mask=0, nthreads=1):
+        """Threaded rolling scan of a flat buffer; returns total valid windows."""
+        sp, sn, _ks = _buf(seq)
+        qp, _, _kq = _buf(qual)
+        return int(lib().ko_scan_flat_sampled_mt(self._m, sp, sn, qp, k, -1 if min_quality is None else int(min_quality),
+                                                 sample_mask, nthreads))
 
     def count_records_mt(self, seq, offs, lens, k, qual=None, min_quality=None, nthreads=1):
         sp, _, _ks = _buf(seq)

@@ -1,0 +1,98 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/kmerhip.h declares; the pure host helpers agree with the oracle.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import pytest
+from hypothesis import given, settings, strategies as st
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def K():
+    import krust_amd
+    krust_amd.lib()
+    return krust_amd
+
+
+def _declared():
+    with open(os.path.join(ROOT, "include", "kmerhip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(kh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(K):
+    from krust_amd import native
+    declared = _declared()
+    assert declared, "header parse failed"
+    raw = C.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in kmerhip.h but not exported"
+    assert sorted(native.SYMBOLS) == declared, "native.py binding list out of sync with kmerhip.h"
+    assert K.lib().kh_abi_version() == 1
+
+
+def test_struct_layouts(K):
+    from krust_amd import native
+    assert C.sizeof(native.KhConfig) == 40
+    assert C.sizeof(native.KhStats) == 64
+
+
+def test_strerror_and_bad_k(K):
+    L = K.lib()
+    assert L.kh_strerror(0) == b"ok"
+    assert b"between 1 and 32" in L.kh_strerror(-1)      # src/error.rs:87 wording
+    for k in (0, 33, 1000):
+        with pytest.raises(K.KmerLengthError):
+            K.DeviceCounter(k)
+    from krust_amd import native
+    cfg = native.KhConfig(C.sizeof(native.KhConfig), 0, -1, -1, 0, None, 0, 0)
+    h = C.c_void_p()
+    assert L.kh_create(C.byref(h), C.byref(cfg)) == native.KH_ERR_BAD_K  # validated before any device work
+    cfg.k = 21
+    cfg.struct_size = 8
+    assert L.kh_create(C.byref(h), C.byref(cfg)) == native.KH_ERR_BAD_ARG
+
+
+def test_no_device_fails_loudly(K):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(K.KmerHipError) as e:
+        K.DeviceCounter(21)
+    assert e.value.status == -3  # KH_ERR_NO_DEVICE: there is no CPU fallback
+
+
+def test_pure_helpers_kats(K):
+    assert K.pack("ACGT") == 27 and K.unpack(27, 4) == "ACGT"        # src/kmer.rs:299-302,836-841
+    assert K.canonical(K.pack("TGTAATC"), 7) == (9156, True)          # src/kmer.rs:721-727
+    assert K.canonical(K.pack("GATTACA"), 7) == (9156, False)
+    assert K.canonical(K.pack("ACGT"), 4) == (27, False)              # palindrome keeps original
+    assert K.canonical(K.pack("T" * 32), 32) == (0, True)
+    for seq, pos in (("NACNN", 0), ("ANCNG", 1), ("AANTG", 2), ("CCCNG", 3), ("AACTN", 4)):  # kmer.rs:646-660
+        with pytest.raises(ValueError, match=f"at position {pos}"):
+            K.pack(seq)
+    assert K.pack("gattaca") == K.pack("GATTACA")
+
+
+@given(st.text(alphabet="ACGTacgt", min_size=1, max_size=32))
+@settings(max_examples=400, deadline=None)
+def test_pure_helpers_match_oracle(K, s):
+    b = s.encode()
+    k = len(b)
+    assert K.pack(b) == O.pack(b)
+    assert K.unpack(O.pack(b), k) == O.unpack(O.pack(b), k)
+    want, is_rc = O.canonical(b.upper())
+    assert K.canonical(K.pack(b), k) == (want, is_rc)
+
+
+def test_owner_is_a_partition(K):
+    for nparts in (1, 2, 3, 8, 64):
+        owners = [K.owner(O.mix64(i), nparts) for i in range(2000)]
+        assert min(owners) >= 0 and max(owners) < nparts
+        if nparts > 1:
+            assert len(set(owners)) == nparts

@@ -1,0 +1,397 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/kmerhip.h via
+krust_amd.native), against the CPU oracle on the same inputs -- bit-exact maps.
+
+Run with `pytest -m gpu` on an MI355X.  Nothing here reads /root/reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "krust_kats.json")) as f:
+    KATS = json.load(f)
+with open(os.path.join(HERE, "golden", "derived_fixture_tables.json")) as f:
+    DERIVED = json.load(f)
+
+SEED = 20260130
+NCPU = max(1, min(os.cpu_count() or 1, 16))
+
+
+@pytest.fixture(scope="module")
+def K():
+    import torch
+    assert torch.cuda.is_available(), "these tests need a GPU (run through gpurun)"
+    import krust_amd
+    krust_amd.lib()  # ImportError if the HIP extension is missing: no silent fallback
+    return krust_amd
+
+
+def flat(records, quals=None):
+    """records -> one flat buffer with '\\n' separators (the kh_push layout)."""
+    b = b"\n".join(records) + b"\n"
+    q = None
+    if quals is not None:
+        q = b"\n".join(quals) + b"\n"
+        assert len(q) == len(b)
+    return b, q
+
+
+def gpu_count(K, records, k, quals=None, min_quality=None, **kw):
+    b, q = flat(records, quals)
+    with K.DeviceCounter(k, min_quality=min_quality, **kw) as dc:
+        dc.push(b, q)
+        st = dc.finish()
+        d = dc.as_dict()
+    assert st["kmers"] == sum(d.values())
+    assert st["distinct"] == len(d)
+    return d
+
+
+def oracle_dict(records, k, quals=None, min_quality=None):
+    return O.count_records(records, k, quals=quals, min_quality=min_quality).as_dict()
+
+
+# ---------------------------------------------------------------------------
+# the reference's own known-answer tests, through the device path
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kat", KATS["count_kats"], ids=lambda k: k["name"])
+def test_count_kats(K, kat):
+    recs = [r.encode() for r in kat["records"]]
+    got = {K.unpack(key, kat["k"]): c for key, c in gpu_count(K, recs, kat["k"]).items()}
+    if kat["exact"]:
+        assert got == kat["counts"]
+    else:
+        for key, c in kat["counts"].items():
+            assert got.get(key) == c
+    for key in kat.get("absent", []):
+        assert key not in got
+    assert got == O.count_records(recs, kat["k"]).as_str_dict(kat["k"])
+
+
+@pytest.mark.parametrize("kat", KATS["quality_kats"], ids=lambda k: k["name"])
+def test_quality_kats(K, kat):
+    seq = kat["seq"].encode()
+    qual = kat["qual"].encode() if kat["qual"] is not None else None
+    got = gpu_count(K, [seq], kat["k"], quals=None if qual is None else [qual], min_quality=kat["min_quality"])
+    if "distinct" in kat:
+        assert len(got) == kat["distinct"] and list(got.values()) == [kat["only_count"]]
+    if kat.get("nonempty"):
+        assert got == oracle_dict([seq], kat["k"])
+
+
+def test_equal_map_and_histogram_kats(K):
+    for kat in KATS["equal_map_kats"]:
+        a = gpu_count(K, [r.encode() for r in kat["a"]], kat["k"])
+        b = gpu_count(K, [r.encode() for r in kat["b"]], kat["k"])
+        assert a == b and a
+    for kat in KATS["histogram_kats"]:
+        b, _ = flat([r.encode() for r in kat["records"]])
+        with K.DeviceCounter(kat["k"]) as dc:
+            dc.push(b)
+            dc.finish()
+            assert tuple(kat["contains_line"]) in dc.histogram(kat["min_count"])
+
+
+def test_bad_k(K):
+    for k in KATS["kmer_length"]["err"]:
+        with pytest.raises(K.KmerLengthError):
+            K.DeviceCounter(k)
+
+
+def _parse_fixture(path):
+    recs, quals = [], []
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    if lines and lines[0].startswith(b">"):
+        return [lines[i + 1] for i in range(0, len(lines) - 1, 2)], None
+    for i in range(0, len(lines) - 1, 4):
+        recs.append(lines[i + 1])
+        quals.append(lines[i + 3])
+    return recs, quals
+
+
+@pytest.mark.parametrize("row", DERIVED["tables"], ids=lambda r: f'{r["fixture"]}-k{r["k"]}-q{r["min_quality"]}')
+def test_fixture_tables(K, row, fixtures_dir):
+    recs, quals = _parse_fixture(os.path.join(fixtures_dir, row["fixture"]))
+    b, q = flat(recs, quals)
+    with K.DeviceCounter(row["k"], min_quality=row["min_quality"]) as dc:
+        dc.push(b, q)
+        st = dc.finish()
+        assert dc.as_str_dict() == row["counts"]
+        assert [list(x) for x in dc.histogram(1)] == row["histogram"]
+        assert st["kmers"] == row["total"] and st["distinct"] == row["distinct"]
+
+
+# ---------------------------------------------------------------------------
+# random / ragged / edge inputs vs the oracle
+# ---------------------------------------------------------------------------
+
+def _dirty(rng, n, p_bad=0.02, lower=True):
+    alpha = np.frombuffer(b"ACGTacgt" if lower else b"ACGT", dtype=np.uint8)
+    s = alpha[rng.integers(0, alpha.size, size=n)]
+    bad = rng.random(n) < p_bad
+    s = np.where(bad, np.frombuffer(b"NnRY*-", dtype=np.uint8)[rng.integers(0, 6, size=n)], s)
+    return s.astype(np.uint8).tobytes()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 5, 11, 15, 16, 17, 21, 31, 32])
+def test_random_ragged_records(K, k):
+    rng = np.random.default_rng(1000 + k)
+    recs = [_dirty(rng, int(n)) for n in rng.integers(0, 400, size=300)]
+    recs += [b"", b"A", b"N" * 50, b"A" * 200, b"ACGT" * 50, _dirty(rng, 5000, p_bad=0.0)]
+    assert gpu_count(K, recs, k) == oracle_dict(recs, k)
+
+
+@pytest.mark.parametrize("k,minq", [(4, 20), (21, 20), (31, 20), (32, 0), (21, 255), (5, 40), (21, 41)])
+def test_random_quality_masking(K, k, minq):
+    rng = np.random.default_rng(77 + k + minq)
+    recs, quals = [], []
+    for n in rng.integers(0, 500, size=200):
+        recs.append(_dirty(rng, int(n)))
+        quals.append(rng.choice(np.frombuffer(b"!#+5?IJ~\xff", dtype=np.uint8), size=int(n)).astype(np.uint8).tobytes())
+    assert gpu_count(K, recs, k, quals=quals, min_quality=minq) == oracle_dict(recs, k, quals=quals, min_quality=minq)
+    # qual present but no threshold, and threshold but no qual: nothing is filtered (run.rs:543)
+    assert gpu_count(K, recs, k, quals=quals, min_quality=None) == oracle_dict(recs, k)
+    assert gpu_count(K, recs, k, quals=None, min_quality=minq) == oracle_dict(recs, k)
+
+
+def test_empty_and_tiny_inputs(K):
+    for k in (1, 21, 32):
+        assert gpu_count(K, [], k) == {}
+        assert gpu_count(K, [b""], k) == {}
+        assert gpu_count(K, [b"ACGT"[: k - 1] if k <= 4 else b"A" * (k - 1)], k) == {}
+    with K.DeviceCounter(21) as dc:
+        dc.push(b"")
+        assert dc.finish()["kmers"] == 0 and dc.result_size() == 0 and dc.histogram() == []
+
+
+def test_one_long_record_and_tile_boundaries(K):
+    """A single 300 kb record (hg38-style long record): windows cross the 4096-position tile
+    boundaries and the workgroup range boundaries; N runs and soft-masked blocks inside."""
+    rng = np.random.default_rng(5)
+    s = bytearray(_dirty(rng, 300_000, p_bad=0.0))
+    s[50_000:50_700] = b"N" * 700
+    s[4090:4100] = b"acgtacgtac"
+    s[8191] = ord("N")
+    for k in (21, 32, 7):
+        assert gpu_count(K, [bytes(s)], k) == oracle_dict([bytes(s)], k)
+
+
+def test_device_pointer_alignment(K):
+    """kh_push_device with base/qual pointers at every 16-byte phase (aligned fast path and the
+    byte-wise quality fallback)."""
+    import torch
+    rng = np.random.default_rng(11)
+    recs, quals = [], []
+    for n in rng.integers(1, 300, size=120):
+        recs.append(_dirty(rng, int(n)))
+        quals.append(rng.choice(np.frombuffer(b"#5I", dtype=np.uint8), size=int(n)).astype(np.uint8).tobytes())
+    b, q = flat(recs, quals)
+    want = oracle_dict(recs, 21, quals=quals, min_quality=20)
+    n = len(b)
+    for boff, qoff in [(0, 0), (1, 1), (5, 5), (15, 15), (3, 0), (0, 7), (9, 12)]:
+        tb = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        tq = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+        tb[boff:boff + n] = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+        tq[qoff:qoff + n] = torch.frombuffer(bytearray(q), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        with K.DeviceCounter(21, min_quality=20) as dc:
+            dc.push_device(tb.data_ptr() + boff, tq.data_ptr() + qoff, n)
+            dc.finish()
+            assert dc.as_dict() == want, (boff, qoff)
+
+
+def test_multiple_pushes_and_reset(K):
+    rng = np.random.default_rng(3)
+    recs = [_dirty(rng, int(n)) for n in rng.integers(0, 300, size=400)]
+    want = oracle_dict(recs, 13)
+    with K.DeviceCounter(13) as dc:
+        for i in range(0, len(recs), 37):  # k-mers never span pushes: each push holds whole records
+            dc.push(flat(recs[i:i + 37])[0])
+        dc.finish()
+        assert dc.as_dict() == want
+        dc.reset()
+        assert dc.finish()["kmers"] == 0 and dc.result_size() == 0
+        dc.push(flat(recs)[0])
+        dc.finish()
+        assert dc.as_dict() == want
+
+
+def test_table_growth_from_tiny_capacity(K):
+    """No capacity hint: the table starts small and must grow (rehash) without losing counts."""
+    bases, _ = O.synth_reads(SEED, 1 << 22, 150, 0, 60_000, with_qual=False)
+    m = O.OracleMap()
+    total = m.scan_flat(bases, 21, nthreads=NCPU)
+    with K.DeviceCounter(21) as dc:
+        dc.push(bases)
+        st = dc.finish()
+        assert st["grows"] >= 1
+        assert st["kmers"] == total and st["distinct"] == len(m)
+        keys, cnts = dc.result()
+    okeys, ocnts = m.arrays()
+    assert np.array_equal(keys, okeys) and np.array_equal(cnts, ocnts)
+
+
+def test_host_staging_chunk_boundary(K):
+    """kh_push stages the host buffer in 64 MiB chunks; windows crossing a chunk boundary must
+    be counted exactly once (the k-1 halo is re-sent)."""
+    n_reads = 460_000  # 69.5 MB > one staging chunk
+    bases, qual = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads)
+    # make the chunk boundary fall inside a long N-free stretch: replace separators near it
+    bases = bases.copy()
+    bases[(64 << 20) - 500:(64 << 20) + 500] = np.frombuffer(b"ACGT" * 250, dtype=np.uint8)
+    for k, minq in ((31, None), (21, 20)):
+        m = O.OracleMap()
+        total = m.scan_flat(bases, k, qual=qual, min_quality=minq, nthreads=NCPU)
+        with K.DeviceCounter(k, min_quality=minq, capacity_hint=len(m)) as dc:
+            dc.push(bases, qual)
+            st = dc.finish()
+            assert st["kmers"] == total and st["distinct"] == len(m)
+            keys, cnts = dc.result()
+        okeys, ocnts = m.arrays()
+        assert np.array_equal(keys, okeys) and np.array_equal(cnts, ocnts)
+
+
+def test_min_count_histogram_lookup(K):
+    bases, _ = O.synth_reads(SEED, 1 << 14, 150, 0, 20_000, with_qual=False)  # high coverage: big counts
+    m = O.OracleMap()
+    m.scan_flat(bases, 15, nthreads=NCPU)
+    od = m.as_dict()
+    with K.DeviceCounter(15) as dc:
+        dc.push(bases)
+        dc.finish()
+        for mc in (1, 2, 50, 10**9):
+            want = {k: c for k, c in od.items() if c >= mc}
+            assert dc.result_size(mc) == len(want)
+            assert dc.as_dict(mc) == want
+            assert dc.histogram(mc) == m.histogram(mc)
+        probe = np.array(list(od.keys())[:1000] + [0xDEADBEEF, 5, 2**40 + 12345], dtype=np.uint64)
+        got = dc.lookup(probe)
+        assert got.tolist() == [od.get(int(k), 0) for k in probe]
+    # counts far beyond the dense histogram range (k=1: two keys with huge counts)
+    m1 = O.OracleMap()
+    m1.scan_flat(bases, 1, nthreads=NCPU)
+    with K.DeviceCounter(1) as dc:
+        dc.push(bases)
+        dc.finish()
+        assert dc.histogram(1) == m1.histogram(1)
+        assert dc.as_dict() == m1.as_dict()
+
+
+def test_synth_generator_matches_oracle(K):
+    import torch
+    for (glen, rl, first, n) in [(1 << 20, 150, 0, 3000), (1 << 27, 150, 99_999_000, 1001), (5000, 36, 7, 513)]:
+        tb = torch.empty(n * (rl + 1), dtype=torch.uint8, device="cuda")
+        tq = torch.empty(n * (rl + 1), dtype=torch.uint8, device="cuda")
+        K.synth_reads_device(tb.data_ptr(), tq.data_ptr(), SEED, glen, rl, first, n)
+        torch.cuda.synchronize()
+        ob, oq = O.synth_reads(SEED, glen, rl, first, n)
+        assert np.array_equal(tb.cpu().numpy(), ob)
+        assert np.array_equal(tq.cpu().numpy(), oq)
+
+
+def test_determinism_digest(K):
+    """Same input twice -> identical multiset (atomics race, results must not)."""
+    bases, qual = O.synth_reads(SEED, 1 << 18, 150, 0, 50_000)
+    digests = []
+    for _ in range(3):
+        with K.DeviceCounter(21, min_quality=20) as dc:
+            dc.push(bases, qual)
+            dc.finish()
+            k, c = dc.result()
+            digests.append((int(np.bitwise_xor.reduce(k * np.uint64(0x9E3779B97F4A7C15) + c)), int(c.sum()), k.size))
+    assert digests[0] == digests[1] == digests[2]
+
+
+# ---------------------------------------------------------------------------
+# multi-GPU merge, exercised as logical shards on one device
+# ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_owner_partitioned_merge_logical_shards(K, nshards):
+    import torch
+    n_reads = 24_000
+    bases, _ = O.synth_reads(SEED, 1 << 16, 150, 0, n_reads, with_qual=False)
+    m = O.OracleMap()
+    m.scan_flat(bases, 21, nthreads=NCPU)
+    want = m.as_dict()
+    per = n_reads // nshards
+    exports = []
+    for s in range(nshards):  # each "rank" counts its contiguous read range
+        lo, hi = s * per, (n_reads if s == nshards - 1 else (s + 1) * per)
+        with K.DeviceCounter(21) as dc:
+            dc.push(bases[lo * 151: hi * 151])
+            st = dc.finish()
+            cap = st["distinct"]
+            dk = torch.empty(cap, dtype=torch.int64, device="cuda")
+            dcnt = torch.empty(cap, dtype=torch.int64, device="cuda")
+            parts = dc.export_by_owner_device(nshards, dk.data_ptr(), dcnt.data_ptr(), cap)
+            assert int(parts.sum()) == cap
+            offs = np.concatenate([[0], np.cumsum(parts)]).astype(np.int64)
+            hk = dk.cpu().numpy().view(np.uint64)
+            for p in range(nshards):
+                seg = hk[offs[p]:offs[p + 1]]
+                assert all(K.owner(int(x), nshards) == p for x in seg[:50])
+            exports.append((dk, dcnt, offs))
+    merged = {}
+    for p in range(nshards):  # owner p merges the p-th segment of every shard's export
+        with K.DeviceCounter(21) as dc:
+            for dk, dcnt, offs in exports:
+                n = int(offs[p + 1] - offs[p])
+                dc.merge_pairs_device(dk.data_ptr() + 8 * int(offs[p]), dcnt.data_ptr() + 8 * int(offs[p]), n)
+            dc.finish()
+            d = dc.as_dict()
+        assert not (set(d) & set(merged))
+        assert all(K.owner(k, nshards) == p for k in list(d)[:200])
+        merged.update(d)
+    assert merged == want
+
+
+def test_merge_pairs_host(K):
+    with K.DeviceCounter(9) as dc:
+        dc.merge_pairs(np.array([1, 2, 3, 2], dtype=np.uint64), np.array([10, 20, 30, 5], dtype=np.uint64))
+        dc.push(b"AAAAAAAAA\n")  # key 0
+        dc.finish()
+        assert dc.as_dict() == {0: 1, 1: 10, 2: 25, 3: 30}
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configs[1] at full size: size-independent properties + sampled parity
+# ---------------------------------------------------------------------------
+
+def test_full_size_10M_reads_k21(K):
+    import torch
+    n_reads, rl, k = 10_000_000, 150, 21
+    nbytes = n_reads * (rl + 1)
+    tb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    K.synth_reads_device(tb.data_ptr(), None, SEED, 1 << 27, rl, 0, n_reads)
+    torch.cuda.synchronize()
+    host = tb.cpu().numpy()
+    m = O.OracleMap()
+    total = m.scan_flat(host, k, sample_mask=1023, nthreads=NCPU)  # exact counts on 1/1024 of the keys
+    skeys, scnts = m.arrays()
+    with K.DeviceCounter(k, capacity_hint=400_000_000) as dc:
+        dc.push_device(tb.data_ptr(), None, nbytes)
+        st = dc.finish()
+        assert st["kmers"] == total                                  # every valid window counted once
+        assert dc.result_size() == st["distinct"]
+        hist = dc.histogram()
+        assert sum(f for _, f in hist) == st["distinct"]             # checksum of checksums
+        assert sum(c * f for c, f in hist) == st["kmers"]
+        assert [c for c, _ in hist] == sorted(c for c, _ in hist)    # ascending (BTreeMap order)
+        assert np.array_equal(dc.lookup(skeys), scnts)               # sampled keys: exact counts
+        keys, cnts = dc.result(sort=False)
+        assert int(cnts.sum()) == total and keys.size == st["distinct"]
+        sel = (np.array([O.mix64(int(x)) for x in keys[:200000]], dtype=np.uint64) & np.uint64(1023)) == 0
+        assert set(keys[:200000][sel].tolist()) <= set(skeys.tolist())
+        # idempotence: counting the same input again doubles every count, adds no key
+        dc.push_device(tb.data_ptr(), None, nbytes)
+        st2 = dc.finish()
+        assert st2["distinct"] == st["distinct"] and st2["kmers"] == 2 * total
+        assert np.array_equal(dc.lookup(skeys), 2 * scnts)
