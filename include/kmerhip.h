@@ -72,7 +72,22 @@ typedef struct kh_config {
     uint32_t reserved;
 } kh_config;
 
-#define KH_FLAG_TRACE 1u     /* print phase timings to stderr (also env KMERHIP_TRACE=1) */
+#define KH_FLAG_TRACE 1u           /* print phase timings to stderr (also env KMERHIP_TRACE=1) */
+#define KH_FLAG_FORCE_DIRECT 2u    /* always use the direct (device-scope atomic) insert path */
+#define KH_FLAG_FORCE_PARTITION 4u /* always use the partitioned (LDS region rebuild) path;
+                                      default: chosen per push from batch and table size
+                                      (env KMERHIP_PATH=direct|partition overrides) */
+
+/* indices into kh_stats.stage_ms */
+#define KH_NUM_STAGES 8
+#define KH_STAGE_DIRECT 0      /* count_direct_kernel */
+#define KH_STAGE_P1_COUNT 1    /* part1_count_kernel */
+#define KH_STAGE_P1_SCATTER 2  /* part1_scatter_kernel */
+#define KH_STAGE_P2_COUNT 3    /* part2_count_kernel */
+#define KH_STAGE_P2_SCATTER 4  /* part2_scatter_kernel */
+#define KH_STAGE_REGION 5      /* region_count_kernel */
+#define KH_STAGE_MISC 6        /* scans, plan, bounds, memsets */
+#define KH_STAGE_GROW 7        /* table growth / rehash */
 
 typedef struct kh_stats {
     uint64_t bases;          /* bytes pushed (incl. separators) */
@@ -81,8 +96,10 @@ typedef struct kh_stats {
     uint64_t table_slots;    /* current table capacity (16-byte slots) */
     uint64_t grows;          /* number of table rehashes */
     uint64_t launches;       /* count-kernel launches */
-    double   count_kernel_ms;/* sum of count-kernel durations (HIP events on the launch stream) */
+    double   count_kernel_ms;/* sum of all counting-kernel durations (HIP events on the launch stream) */
     double   h2d_ms;         /* host->device staging time for kh_push */
+    uint64_t part_batches;   /* batches that went through the partitioned path */
+    double   stage_ms[KH_NUM_STAGES]; /* per-stage kernel time, see KH_STAGE_* */
 } kh_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */

@@ -31,7 +31,8 @@ struct Counters {
     u64 failed;    // upserts that found no free slot (must stay 0)
     u64 cursor;    // scratch cursor for compaction / counting kernels
     u64 big;       // scratch cursor for the histogram's big-count list
-    u64 pad[3];
+    u64 part_failed;  // regions that overflowed in region_count_kernel (re-inserted after growth)
+    u64 pad[2];
 };
 
 constexpr int BLOCK = 256;           // 4 waves of 64
@@ -55,24 +56,34 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// open-addressing table: placement = fast-range of mix64(key), linear probing with wrap
+// open-addressing table, laid out in REGIONS of REGION_SLOTS slots (128 KiB = one LDS image):
+//   region = fast-range(mix64(key), nregions)      (high hash bits)
+//   start  = mix64(key) & (REGION_SLOTS-1)         (low hash bits)
+// linear probing wraps INSIDE the region, so a region is self-contained: the direct path updates
+// it in HBM with device-scope atomics, the partitioned path rebuilds it in LDS with no global
+// atomics at all.  capacity = nregions * REGION_SLOTS.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 slot_of(u64 key, u64 cap) { return __umul64hi(kh_mix64(key), cap); }
+constexpr uint32_t REGION_SLOTS = 8192;
+constexpr uint32_t REGION_MASK = REGION_SLOTS - 1;
+
+__device__ __forceinline__ u64 region_of_hash(u64 h, u64 nregions) { return __umul64hi(h, nregions); }
+__device__ __forceinline__ uint32_t start_of_hash(u64 h) { return (uint32_t)h & REGION_MASK; }
 
 __device__ __forceinline__ void count_add(Slot *s, u64 addend) {
     // fire-and-forget device-scope add (result unused -> no-return global_atomic_add_x2)
     (void)__hip_atomic_fetch_add(&s->count, addend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Upsert starting at slot idx whose key was observed (by a plain, possibly stale load) as `cur`.
-// A stale observation is harmless: a slot only ever goes EMPTY -> K once, so a non-empty value is
-// final, and a stale EMPTY is corrected by the value the CAS returns.
-__device__ __forceinline__ void upsert_from(Slot *table, u64 cap, u64 key, u64 idx, u64 cur, u64 addend,
+// Upsert into region `reg` (pointer to its first slot) starting at in-region offset `off`, whose
+// key was observed (by a plain, possibly stale load) as `cur`.  A stale observation is harmless: a
+// slot only ever goes EMPTY -> K once, so a non-empty value is final, and a stale EMPTY is
+// corrected by the value the CAS returns.
+__device__ __forceinline__ void upsert_from(Slot *reg, u64 key, uint32_t off, u64 cur, u64 addend,
                                             uint32_t &ndistinct, uint32_t &nfailed) {
-    for (u64 probes = 0; probes < cap; ++probes) {
+    for (uint32_t probes = 0; probes < REGION_SLOTS; ++probes) {
         if (cur == KH_EMPTY_KEY) {
             u64 expected = KH_EMPTY_KEY;
-            if (__hip_atomic_compare_exchange_strong(&table[idx].key, &expected, (u64)key, __ATOMIC_RELAXED,
+            if (__hip_atomic_compare_exchange_strong(&reg[off].key, &expected, (u64)key, __ATOMIC_RELAXED,
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 ++ndistinct;
                 cur = key;
@@ -81,19 +92,21 @@ __device__ __forceinline__ void upsert_from(Slot *table, u64 cap, u64 key, u64 i
             }
         }
         if (cur == key) {
-            count_add(&table[idx], addend);
+            count_add(&reg[off], addend);
             return;
         }
-        if (++idx == cap) idx = 0;
-        cur = table[idx].key;
+        off = (off + 1) & REGION_MASK;
+        cur = reg[off].key;
     }
-    ++nfailed;
+    ++nfailed;  // region full: the host keeps the load factor far below this
 }
 
-__device__ __forceinline__ void upsert(Slot *table, u64 cap, u64 key, u64 addend, uint32_t &ndistinct,
+__device__ __forceinline__ void upsert(Slot *table, u64 nregions, u64 key, u64 addend, uint32_t &ndistinct,
                                        uint32_t &nfailed) {
-    u64 idx = slot_of(key, cap);
-    upsert_from(table, cap, key, idx, table[idx].key, addend, ndistinct, nfailed);
+    const u64 h = kh_mix64(key);
+    Slot *reg = table + region_of_hash(h, nregions) * REGION_SLOTS;
+    const uint32_t off = start_of_hash(h);
+    upsert_from(reg, key, off, reg[off].key, addend, ndistinct, nfailed);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -148,13 +161,71 @@ __device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ abase, 
     }
 }
 
+// One staged tile as seen by one lane: its own 16 codes (low half of lo64), the 32 codes in front
+// of them (high half of lo64, hi) and 48 validity bits (bit 15-j = own base j, older bases higher).
+struct WinCtx {
+    u64 lo64;
+    u64 V;
+    u64 p0;  // virtual position of the lane's first base
+    uint32_t hi;
+};
+
+// Stages tile t (NT*16 positions) for a workgroup of NT lanes.  s_code/s_val are [2][NT+2] LDS
+// arrays, double-buffered by `buf`; `first` = this is the workgroup's first tile (its look-back
+// words are then encoded from memory, later tiles get them carried from the previous tile).
+// Contains the tile's only barrier.
+template <bool QUAL, int NT>
+__device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_t (*s_val)[NT + 2], int buf, bool first,
+                                             int tid, const uint8_t *__restrict__ abase,
+                                             const uint8_t *__restrict__ qbase, int qaligned, u64 t, u64 vbeg, u64 vend,
+                                             uint32_t thr) {
+    constexpr int TILE_N = NT * CHUNK;
+    const int64_t p0 = (int64_t)(t * TILE_N + (u64)tid * CHUNK);
+    uint32_t code, val;
+    encode_chunk<QUAL>(abase, qbase, qaligned, p0, vbeg, vend, thr, code, val);
+    s_code[buf][tid + 2] = code;
+    s_val[buf][tid + 2] = (uint16_t)val;
+    if (first && tid < 2) {
+        uint32_t hc, hv;
+        encode_chunk<QUAL>(abase, qbase, qaligned, (int64_t)(t * TILE_N) - (int64_t)(2 - tid) * CHUNK, vbeg, vend, thr,
+                           hc, hv);
+        s_code[buf][tid] = hc;
+        s_val[buf][tid] = (uint16_t)hv;
+    }
+    __syncthreads();
+    // Carry the last two words to the next tile's look-back slots.  Done AFTER the barrier: the
+    // other buffer's slots [0,1] were last read in the previous iteration, and every reader is
+    // past those reads once it has arrived here.
+    if (tid >= NT - 2) {
+        s_code[buf ^ 1][tid - (NT - 2)] = code;
+        s_val[buf ^ 1][tid - (NT - 2)] = (uint16_t)val;
+    }
+    WinCtx w;
+    w.hi = s_code[buf][tid];
+    w.lo64 = ((u64)s_code[buf][tid + 1] << 32) | code;
+    w.V = ((u64)s_val[buf][tid] << 32) | ((u64)s_val[buf][tid + 1] << 16) | (u64)val;
+    w.p0 = (u64)p0;
+    return w;
+}
+
+// Canonical key of the window ENDING at the lane's base j (0..15); false if the window holds an
+// invalid / masked base, starts before the data, or ends before wlo.
+__device__ __forceinline__ bool window_key(const WinCtx &w, int j, u64 kmask, u64 vmask, uint32_t k, u64 wlo, u64 &key) {
+    const int sh = 2 * (15 - j);
+    const u64 x = (sh == 0) ? w.lo64 : ((w.lo64 >> sh) | ((u64)w.hi << (64 - sh)));
+    key = kh_canonical_bits(x & kmask, k);
+    return (((w.V >> (15 - j)) & vmask) == vmask) && (w.p0 + j >= wlo);
+}
+
+__device__ __forceinline__ u64 valid_mask_of(uint32_t k) { return (k >= 32) ? 0xFFFFFFFFull : ((1ull << k) - 1ull); }
+
 template <bool QUAL>
 __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend,
-    u64 wlo, u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, Slot *table, u64 cap,
+    u64 wlo, u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, Slot *table, u64 nregions,
     Counters *ctr) {
     __shared__ uint32_t s_code[2][BLOCK + 2];
-    __shared__ uint32_t s_val[2][BLOCK + 2];
+    __shared__ uint16_t s_val[2][BLOCK + 2];
 
     const int tid = threadIdx.x;
     const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
@@ -162,64 +233,35 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
     if (te > tile0 + ntiles) te = tile0 + ntiles;
 
     const u64 kmask = kh_kmask(k);
-    const u64 vmask = (k >= 32) ? 0xFFFFFFFFull : ((1ull << k) - 1ull);
+    const u64 vmask = valid_mask_of(k);
     uint32_t nk = 0, nd = 0, nf = 0;
 
     int buf = 0;
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        const int64_t p0 = (int64_t)(t * TILE + (u64)tid * CHUNK);
-        uint32_t code, val;
-        encode_chunk<QUAL>(abase, qbase, qaligned, p0, vbeg, vend, thr, code, val);
-        s_code[buf][tid + 2] = code;
-        s_val[buf][tid + 2] = val;
-        if (t == tb && tid < 2) {  // look-back words of the first tile; later tiles get them carried
-            uint32_t hc, hv;
-            encode_chunk<QUAL>(abase, qbase, qaligned, (int64_t)(t * TILE) - (int64_t)(2 - tid) * CHUNK, vbeg, vend,
-                               thr, hc, hv);
-            s_code[buf][tid] = hc;
-            s_val[buf][tid] = hv;
-        }
-        __syncthreads();
-        // Carry the last two words to the next tile's look-back slots.  Done AFTER the barrier:
-        // the other buffer's slots [0,1] were last read in the previous iteration, and every
-        // reader is past those reads once it has arrived here.
-        if (tid >= BLOCK - 2) {
-            s_code[buf ^ 1][tid - (BLOCK - 2)] = code;
-            s_val[buf ^ 1][tid - (BLOCK - 2)] = val;
-        }
-        const uint32_t hi = s_code[buf][tid];
-        const uint32_t mid = s_code[buf][tid + 1];
-        const u64 lo64 = ((u64)mid << 32) | code;
-        const u64 V = ((u64)s_val[buf][tid] << 32) | ((u64)s_val[buf][tid + 1] << 16) | (u64)val;
-
+        const WinCtx w = stage_tile<QUAL, BLOCK>(s_code, s_val, buf, t == tb, tid, abase, qbase, qaligned, t, vbeg, vend, thr);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             u64 key[8];
-            u64 idx[8];
+            Slot *reg[8];
+            uint32_t off[8];
             u64 cur[8];
             uint32_t ok = 0;
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const int j = half * 8 + jj;
-                const int sh = 2 * (15 - j);
-                const u64 x = (sh == 0) ? lo64 : ((lo64 >> sh) | ((u64)hi << (64 - sh)));
-                const u64 fwd = x & kmask;
-                const bool good = (((V >> (15 - j)) & vmask) == vmask) && ((u64)p0 + j >= wlo);
-                key[jj] = kh_canonical_bits(fwd, k);
-                ok |= (uint32_t)good << jj;
-            }
+            for (int jj = 0; jj < 8; ++jj) ok |= (uint32_t)window_key(w, half * 8 + jj, kmask, vmask, k, wlo, key[jj]) << jj;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                idx[jj] = slot_of(key[jj], cap);
+                const u64 h = kh_mix64(key[jj]);
+                reg[jj] = table + region_of_hash(h, nregions) * REGION_SLOTS;
+                off[jj] = start_of_hash(h);
                 cur[jj] = KH_EMPTY_KEY;
-                if (ok & (1u << jj)) cur[jj] = table[idx[jj]].key;
+                if (ok & (1u << jj)) cur[jj] = reg[jj][off[jj]].key;
             }
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 if (ok & (1u << jj)) {
                     ++nk;
-                    if (cur[jj] == key[jj]) count_add(&table[idx[jj]], 1ull);
-                    else upsert_from(table, cap, key[jj], idx[jj], cur[jj], 1ull, nd, nf);
+                    if (cur[jj] == key[jj]) count_add(&reg[jj][off[jj]], 1ull);
+                    else upsert_from(reg[jj], key[jj], off[jj], cur[jj], 1ull, nd, nf);
                 }
             }
         }
@@ -288,14 +330,14 @@ __global__ __launch_bounds__(BLOCK) void table_compact_kernel(const Slot *table,
 }
 
 // count[key] += addend for n (key, addend) pairs: rehash-free merge of another table's pairs.
-__global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(Slot *table, u64 cap, const u64 *keys,
+__global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(Slot *table, u64 nregions, const u64 *keys,
                                                                   const u64 *counts, u64 n, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
         const u64 c = counts[i];
-        if (key != KH_EMPTY_KEY && c != 0) upsert(table, cap, key, c, nd, nf);
+        if (key != KH_EMPTY_KEY && c != 0) upsert(table, nregions, key, c, nd, nf);
     }
     u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
     if (lane_id() == 0) {
@@ -305,30 +347,32 @@ __global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(Slot *table, u
 }
 
 // Move every live pair of `old` into `nt` (table growth).
-__global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, Slot *nt, u64 ncap,
+__global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, Slot *nt, u64 nregions,
                                                              Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < oldcap; i += stride) {
         const Slot s = old[i];
-        if (s.key != KH_EMPTY_KEY) upsert(nt, ncap, s.key, s.count, nd, nf);
+        if (s.key != KH_EMPTY_KEY) upsert(nt, nregions, s.key, s.count, nd, nf);
     }
     u64 f = wave_sum((u64)nf);
     if (lane_id() == 0 && f) atomicAdd(&ctr->failed, f);
 }
 
-__global__ __launch_bounds__(BLOCK) void table_lookup_kernel(const Slot *table, u64 cap, const u64 *keys, u64 n,
+__global__ __launch_bounds__(BLOCK) void table_lookup_kernel(const Slot *table, u64 nregions, const u64 *keys, u64 n,
                                                              u64 *out) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
-        u64 idx = slot_of(key, cap);
+        const u64 h = kh_mix64(key);
+        const Slot *reg = table + region_of_hash(h, nregions) * REGION_SLOTS;
+        uint32_t off = start_of_hash(h);
         u64 res = 0;
-        for (u64 probes = 0; probes < cap; ++probes) {
-            const Slot s = table[idx];
+        for (uint32_t probes = 0; probes < REGION_SLOTS; ++probes) {
+            const Slot s = reg[off];
             if (s.key == key) { res = s.count; break; }
             if (s.key == KH_EMPTY_KEY) break;
-            if (++idx == cap) idx = 0;
+            off = (off + 1) & REGION_MASK;
         }
         out[i] = res;
     }

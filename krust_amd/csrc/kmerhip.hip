@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "kernels.hip.h"
+#include "partition.hip.h"
 
 using kh::Counters;
 using kh::Slot;
@@ -26,13 +27,17 @@ namespace {
 
 constexpr double LOAD_HARD = 0.80;    // never let distinct exceed this fraction of capacity
 constexpr double LOAD_TARGET = 0.50;  // load right after a growth
-constexpr u64 MIN_CAP = 1ull << 16;
+constexpr u64 MIN_CAP = 8ull * kh::REGION_SLOTS;
 constexpr u64 DEFAULT_CAP = 1ull << 20;
 constexpr u64 SUB_TILES = 1ull << 16;      // tiles per count launch (2^28 positions)
 constexpr u64 SUB_TILES_MIN = 1ull << 10;  // smallest launch when squeezing under LOAD_HARD
 constexpr u64 STAGE_BYTES = 64ull << 20;   // host staging chunk for kh_push
 constexpr u64 HALO = 32;                   // >= k-1 bytes re-sent in front of every staged chunk
 constexpr int GRID_CAP = 256 * 8;          // 256 CUs x 8 resident workgroups of 256 threads
+constexpr int PART_G1 = 512;               // level-1 workgroups (fixed: count and scatter must agree)
+constexpr u64 PART_MIN_WINDOWS = 1ull << 22;   // below this the partition passes cannot pay off
+constexpr double LOAD_PART = 0.70;         // grow before the next partitioned batch above this load
+enum { ST_DIRECT = 0, ST_P1_COUNT, ST_P1_SCATTER, ST_P2_COUNT, ST_P2_SCATTER, ST_REGION, ST_MISC, ST_GROW, ST_N };
 
 }  // namespace
 
@@ -57,12 +62,38 @@ struct kh_ctx {
     u64 launches = 0;
     double kernel_ms = 0.0;
     double h2d_ms = 0.0;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 
     uint8_t *h_stage[2] = {nullptr, nullptr};  // pinned: bases then qual, each HALO+STAGE_BYTES
     uint8_t *d_stage[2] = {nullptr, nullptr};
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
+
+    // ---- partitioned path ----
+    bool table_empty = true;   // no insert since creation / reset: regions need not be read back
+    bool hinted = false;       // caller gave a capacity hint
+    int path_mode = 0;         // 0 auto, 1 force direct, 2 force partitioned
+    u64 part_budget = 0;       // bytes for the two key buffers (0 = decide at first use)
+    u64 *keysA = nullptr, *keysB = nullptr;
+    u64 key_cap = 0;           // entries per key buffer
+    uint32_t *H1 = nullptr;
+    u64 *O1 = nullptr;
+    kh::Part2Block *blocks = nullptr;
+    u64 blocks_cap = 0;
+    u64 *moff = nullptr;
+    uint32_t *nch = nullptr;
+    u64 *info = nullptr;
+    uint32_t *H2 = nullptr;
+    u64 *O2 = nullptr;
+    u64 h2_cap = 0;
+    u64 *bstart = nullptr;
+    uint8_t *rfail = nullptr;
+    u64 region_cap = 0;
+    u64 *scan_partial = nullptr;
+    u64 scan_cap = 0;
+    u64 part_batches = 0;
+    double stage_ms[ST_N] = {0};
+    struct StageEv { int stage; hipEvent_t a, b; };
+    std::vector<StageEv> stage_events;
 
     bool poisoned = false;
     std::string last_error;
@@ -128,7 +159,7 @@ int sync_counters(kh_ctx *c) {
 u64 round_cap(double want) {
     u64 cap = (u64)want;
     if (cap < MIN_CAP) cap = MIN_CAP;
-    return (cap + 4095) & ~4095ull;
+    return (cap + kh::REGION_SLOTS - 1) / kh::REGION_SLOTS * kh::REGION_SLOTS;  // whole regions
 }
 
 int grow_to(kh_ctx *c, u64 newcap) {
@@ -136,7 +167,7 @@ int grow_to(kh_ctx *c, u64 newcap) {
     int rc = alloc_table(c, newcap, &nt);
     if (rc != KH_OK) return rc;
     hipLaunchKernelGGL(kh::table_rehash_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
-                       c->cap, nt, newcap, c->d_ctr);
+                       c->cap, nt, newcap / kh::REGION_SLOTS, c->d_ctr);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipFree(c->table));
@@ -182,25 +213,249 @@ void launch_count(kh_ctx *c, const uint8_t *abase, const uint8_t *qbase, int qal
         thr = (uint32_t)(t > 255 ? 255 : t);
     }
     hipLaunchKernelGGL(kh::count_direct_kernel<QUAL>, dim3((unsigned)blocks), dim3(kh::BLOCK), 0, c->stream, abase,
-                       qbase, qaligned, vbeg, vend, wlo, tile0, ntiles, tpb, c->k, thr, c->table, c->cap, c->d_ctr);
+                       qbase, qaligned, vbeg, vend, wlo, tile0, ntiles, tpb, c->k, thr, c->table, c->cap / kh::REGION_SLOTS, c->d_ctr);
 }
 
-// Count all windows of the device buffer [d_bases, d_bases+n) that end at offset >= wlo_off.
-int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual, u64 n, u64 wlo_off) {
-    if (n == 0) return KH_OK;
-    const uintptr_t addr = (uintptr_t)d_bases;
-    const u64 lead = addr & 15;
-    const uint8_t *abase = d_bases - lead;
-    const u64 vbeg = lead, vend = lead + n, wlo = lead + wlo_off;
-    const bool use_qual = (d_qual != nullptr) && (c->minq >= 0);
-    const uint8_t *qbase = nullptr;
-    int qaligned = 0;
-    if (use_qual) {
-        qbase = d_qual - lead;  // same virtual coordinates as the bases
-        qaligned = (((uintptr_t)qbase) & 15) == 0;
+// ---- stage timing: HIP events on the launch stream, resolved lazily ---------------------------
+struct StageTimer {
+    kh_ctx *c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(kh_ctx *ctx, int st) : c(ctx), stage(st) {
+        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, c->stream);
     }
-    const u64 first_tile = wlo / kh::TILE;
-    const u64 end_tile = (vend + kh::TILE - 1) / kh::TILE;
+    void stop() {
+        if (a && b) {
+            (void)hipEventRecord(b, c->stream);
+            c->stage_events.push_back({stage, a, b});
+            a = b = nullptr;
+        }
+    }
+    ~StageTimer() { stop(); }
+};
+
+int drain_events(kh_ctx *c) {
+    for (auto &e : c->stage_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->stage_ms[e.stage] += ms;
+            c->kernel_ms += ms;
+        }
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    c->stage_events.clear();
+    return KH_OK;
+}
+
+// ---- device scratch management for the partitioned path --------------------------------------
+template <typename T>
+int ensure_buf(kh_ctx *c, T **ptr, u64 *cap, u64 need, const char *what) {
+    if (*cap >= need && *ptr) return KH_OK;
+    if (*ptr) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(*ptr);
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    hipError_t e = hipMalloc((void **)ptr, need * sizeof(T));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(c, KH_ERR_OOM, what, e);
+    }
+    *cap = need;
+    return KH_OK;
+}
+
+kh::PartGeom make_geom(u64 cap) {
+    kh::PartGeom g;
+    g.nregions = cap / kh::REGION_SLOTS;
+    uint32_t bits = 0;
+    while (bits < kh::MAX_P2_BITS && (2ull << bits) <= g.nregions) ++bits;
+    g.p2_bits = bits;
+    g.P1 = (uint32_t)((g.nregions + (1ull << bits) - 1) >> bits);
+    return g;
+}
+
+// exclusive scan of `in` (n u32 entries) into `out` (n+1 u64 entries) on the context's stream
+int device_scan(kh_ctx *c, const uint32_t *in, u64 n, u64 *out) {
+    const u64 nb = (n + kh::SCAN_CHUNK - 1) / kh::SCAN_CHUNK;
+    int rc = ensure_buf(c, &c->scan_partial, &c->scan_cap, nb + 2, "hipMalloc(scan)");
+    if (rc != KH_OK) return rc;
+    hipLaunchKernelGGL(kh::scan_partials_kernel, dim3((unsigned)nb), dim3(kh::SCAN_NT), 0, c->stream, in, n, c->scan_partial);
+    hipLaunchKernelGGL(kh::scan_spine_kernel, dim3(1), dim3(1024), 0, c->stream, c->scan_partial, nb);
+    hipLaunchKernelGGL(kh::scan_apply_kernel, dim3((unsigned)nb), dim3(kh::SCAN_NT), 0, c->stream, in, n,
+                       (const u64 *)c->scan_partial, out);
+    HIP_TRY(c, hipGetLastError());
+    return KH_OK;
+}
+
+struct RangeArgs {
+    const uint8_t *abase, *qbase;
+    int qaligned;
+    bool use_qual;
+    u64 vbeg, vend, wlo;
+};
+
+uint32_t qual_thr(const kh_ctx *c) {
+    int t = c->minq + 33;  // saturating_add(33) on u8, run.rs:538
+    return (uint32_t)(t > 255 ? 255 : t);
+}
+
+// One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
+int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
+    const kh::PartGeom g = make_geom(c->cap);
+    const u64 n_ub = ntiles * kh::PART_TILE;  // upper bound on keys
+    const u64 max_blocks = (n_ub + kh::PART2_CHUNK - 1) / kh::PART2_CHUNK + g.P1;
+    const u64 n1 = (u64)g.P1 * PART_G1;
+    const u64 n2 = max_blocks << g.p2_bits;
+    int rc;
+    if (!c->H1) {  // fixed-size scratch, allocated once
+        u64 z = 0;
+        if ((rc = ensure_buf(c, &c->H1, &z, (u64)kh::MAX_P1 * PART_G1, "hipMalloc(H1)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->O1, &z, (u64)kh::MAX_P1 * PART_G1 + 1, "hipMalloc(O1)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->moff, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(moff)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->nch, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(nch)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->info, &z, 4, "hipMalloc(info)")) != KH_OK) return rc;
+    }
+    if ((rc = ensure_buf(c, &c->blocks, &c->blocks_cap, max_blocks, "hipMalloc(blocks)")) != KH_OK) return rc;
+    if (c->h2_cap < n2) {  // H2 and O2 grow together
+        u64 z = c->h2_cap;
+        if ((rc = ensure_buf(c, &c->H2, &z, n2, "hipMalloc(H2)")) != KH_OK) return rc;
+        z = c->O2 ? c->h2_cap + 1 : 0;
+        if ((rc = ensure_buf(c, &c->O2, &z, n2 + 1, "hipMalloc(O2)")) != KH_OK) return rc;
+        c->h2_cap = n2;
+    }
+    if (c->region_cap < g.nregions) {
+        u64 z = c->bstart ? c->region_cap + 1 : 0;
+        if ((rc = ensure_buf(c, &c->bstart, &z, g.nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
+        z = c->rfail ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rfail, &z, g.nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
+        c->region_cap = g.nregions;
+    }
+    if (c->key_cap < n_ub) {
+        u64 z = c->keysA ? c->key_cap : 0;
+        if ((rc = ensure_buf(c, &c->keysA, &z, n_ub, "hipMalloc(keysA)")) != KH_OK) return rc;
+        z = c->keysB ? c->key_cap : 0;
+        if ((rc = ensure_buf(c, &c->keysB, &z, n_ub, "hipMalloc(keysB)")) != KH_OK) return rc;
+        c->key_cap = n_ub;
+    }
+
+    const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
+    const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
+    const dim3 g1(PART_G1), b1(kh::PART_NT);
+
+    {
+        StageTimer t(c, ST_P1_COUNT);
+        if (ra.use_qual)
+            hipLaunchKernelGGL(kh::part1_count_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
+                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
+        else
+            hipLaunchKernelGGL(kh::part1_count_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
+                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
+    }
+    {
+        StageTimer t(c, ST_MISC);
+        if ((rc = device_scan(c, c->H1, n1, c->O1)) != KH_OK) return rc;
+    }
+    {
+        StageTimer t(c, ST_P1_SCATTER);
+        if (ra.use_qual)
+            hipLaunchKernelGGL(kh::part1_scatter_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
+                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, c->keysA);
+        else
+            hipLaunchKernelGGL(kh::part1_scatter_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
+                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, c->keysA);
+    }
+    {
+        StageTimer t(c, ST_MISC);
+        hipLaunchKernelGGL(kh::part2_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->O1, (uint32_t)PART_G1, g, n1,
+                           c->blocks, max_blocks, c->moff, c->nch, c->info);
+        HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
+    }
+    {
+        StageTimer t(c, ST_P2_COUNT);
+        hipLaunchKernelGGL(kh::part2_count_kernel, dim3((unsigned)max_blocks), b1, 0, c->stream, (const u64 *)c->keysA,
+                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2);
+    }
+    {
+        StageTimer t(c, ST_MISC);
+        if ((rc = device_scan(c, c->H2, n2, c->O2)) != KH_OK) return rc;
+    }
+    {
+        StageTimer t(c, ST_P2_SCATTER);
+        hipLaunchKernelGGL(kh::part2_scatter_kernel, dim3((unsigned)max_blocks), b1, 0, c->stream, (const u64 *)c->keysA,
+                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, c->keysB);
+    }
+    {
+        StageTimer t(c, ST_MISC);
+        hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((g.nregions + 256) / 256)), dim3(256), 0, c->stream,
+                           (const u64 *)c->O2, (const u64 *)c->moff, (const uint32_t *)c->nch, (const u64 *)c->info, g, c->bstart);
+        HIP_TRY(c, hipMemsetAsync(c->rfail, 0, g.nregions, c->stream));
+    }
+    {
+        StageTimer t(c, ST_REGION);
+        if (c->table_empty)
+            hipLaunchKernelGGL(kh::region_count_kernel<true>, dim3((unsigned)g.nregions), dim3(kh::REGION_NT), 0, c->stream,
+                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->d_ctr);
+        else
+            hipLaunchKernelGGL(kh::region_count_kernel<false>, dim3((unsigned)g.nregions), dim3(kh::REGION_NT), 0, c->stream,
+                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->d_ctr);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->table_empty = false;
+    c->launches++;
+    c->part_batches++;
+
+    // exact bookkeeping after every batch (batches are hundreds of ms; one sync is noise)
+    rc = sync_counters(c);
+    if (rc != KH_OK) return rc;
+    if (c->h_ctr->part_failed) {
+        // some regions overflowed: they were left untouched; grow, then insert their buckets directly
+        const u64 old_regions = g.nregions;
+        // worst case every key of a failed bucket is new: size the grown table for that
+        std::vector<uint8_t> hf(old_regions);
+        std::vector<u64> hb(old_regions + 1);
+        HIP_TRY(c, hipMemcpy(hf.data(), c->rfail, old_regions, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(hb.data(), c->bstart, (old_regions + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+        u64 failed_keys = 0;
+        for (u64 r = 0; r < old_regions; ++r)
+            if (hf[r]) failed_keys += hb[r + 1] - hb[r];
+        u64 newcap = c->cap * 2;
+        while ((double)(c->distinct_known + failed_keys) > LOAD_HARD * (double)newcap ||
+               (double)c->distinct_known > LOAD_TARGET * (double)newcap)
+            newcap *= 2;
+        if (c->trace)
+            fprintf(stderr, "[kmerhip] %llu regions overflowed (%llu keys): growing and re-inserting them directly\n",
+                    (u64)c->h_ctr->part_failed, failed_keys);
+        {
+            StageTimer t(c, ST_GROW);
+            rc = grow_to(c, newcap);
+            if (rc != KH_OK) return rc;
+            hipLaunchKernelGGL(kh::failed_buckets_insert_kernel, dim3((unsigned)old_regions), dim3(kh::BLOCK), 0, c->stream,
+                               c->table, c->cap / kh::REGION_SLOTS, (const u64 *)c->keysB, (const u64 *)c->bstart,
+                               (const uint8_t *)c->rfail, c->d_ctr);
+            HIP_TRY(c, hipMemsetAsync(&c->d_ctr->part_failed, 0, sizeof(u64), c->stream));
+        }
+        HIP_TRY(c, hipGetLastError());
+        rc = sync_counters(c);
+        if (rc != KH_OK) return rc;
+    }
+    if ((double)c->distinct_known > LOAD_PART * (double)c->cap) {
+        u64 newcap = c->cap * 2;
+        while ((double)c->distinct_known > LOAD_TARGET * (double)newcap) newcap *= 2;
+        StageTimer t(c, ST_GROW);
+        rc = grow_to(c, newcap);
+        if (rc != KH_OK) return rc;
+    }
+    return KH_OK;
+}
+
+int direct_range(kh_ctx *c, const RangeArgs &ra, u64 first_tile, u64 end_tile) {
     u64 t = first_tile;
     u64 sub = SUB_TILES;
     while (t < end_tile) {
@@ -212,15 +467,13 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
             sub = std::max(SUB_TILES_MIN, nt / 4);
             continue;
         }
-        hipEvent_t e0, e1;
-        HIP_TRY(c, hipEventCreate(&e0));
-        HIP_TRY(c, hipEventCreate(&e1));
-        HIP_TRY(c, hipEventRecord(e0, c->stream));
-        if (use_qual) launch_count<true>(c, abase, qbase, qaligned, vbeg, vend, wlo, t, nt);
-        else launch_count<false>(c, abase, nullptr, 0, vbeg, vend, wlo, t, nt);
+        {
+            StageTimer tm(c, ST_DIRECT);
+            if (ra.use_qual) launch_count<true>(c, ra.abase, ra.qbase, ra.qaligned, ra.vbeg, ra.vend, ra.wlo, t, nt);
+            else launch_count<false>(c, ra.abase, nullptr, 0, ra.vbeg, ra.vend, ra.wlo, t, nt);
+        }
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(e1, c->stream));
-        c->events.emplace_back(e0, e1);
+        c->table_empty = false;
         c->launches++;
         c->pending_bound += nt * kh::TILE;
         t += nt;
@@ -228,15 +481,69 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     return KH_OK;
 }
 
-int drain_events(kh_ctx *c) {
-    for (auto &p : c->events) {
-        float ms = 0.f;
-        hipError_t e = hipEventElapsedTime(&ms, p.first, p.second);
-        if (e == hipSuccess) c->kernel_ms += ms;
-        (void)hipEventDestroy(p.first);
-        (void)hipEventDestroy(p.second);
+// Count all windows of the device buffer [d_bases, d_bases+n) that end at offset >= wlo_off.
+int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual, u64 n, u64 wlo_off) {
+    if (n == 0) return KH_OK;
+    const uintptr_t addr = (uintptr_t)d_bases;
+    const u64 lead = addr & 15;
+    RangeArgs ra;
+    ra.abase = d_bases - lead;
+    ra.vbeg = lead;
+    ra.vend = lead + n;
+    ra.wlo = lead + wlo_off;
+    ra.use_qual = (d_qual != nullptr) && (c->minq >= 0);
+    ra.qbase = nullptr;
+    ra.qaligned = 0;
+    if (ra.use_qual) {
+        ra.qbase = d_qual - lead;  // same virtual coordinates as the bases
+        ra.qaligned = (((uintptr_t)ra.qbase) & 15) == 0;
     }
-    c->events.clear();
+    const u64 windows = ra.vend - ra.wlo;  // upper bound on k-mers of this range
+
+    // Path choice.  Partitioned cost ~ 32 B per key of HBM traffic + one read and one write of the
+    // whole table (32 B per slot); direct cost ~ one memory-side atomic per key (~18.5 G/s), i.e.
+    // ~270 B per key at streaming rate.  So partition when the table is < ~7x the batch.
+    bool part = false;
+    if (c->path_mode == 2) part = true;
+    else if (c->path_mode == 0) part = windows >= PART_MIN_WINDOWS && (double)c->cap <= 7.0 * (double)windows;
+    if (part && c->table_empty && !c->hinted && c->cap < windows / 8) {
+        // no hint and an obviously undersized empty table: size it for the batch up front
+        Slot *nt = nullptr;
+        const u64 newcap = round_cap((double)windows / 8.0);
+        int rc = alloc_table(c, newcap, &nt);
+        if (rc == KH_OK) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->table);
+            c->table = nt;
+            c->cap = newcap;
+        }
+    }
+    if (part && make_geom(c->cap).P1 > kh::MAX_P1) part = false;  // table beyond 2 levels of partitioning
+
+    if (!part) return direct_range(c, ra, ra.wlo / kh::TILE, (ra.vend + kh::TILE - 1) / kh::TILE);
+
+    if (c->pending_bound) {  // exact counters before switching paths
+        int rc = sync_counters(c);
+        if (rc != KH_OK) return rc;
+    }
+    if (!c->part_budget) {
+        size_t fr = 0, tot = 0;
+        u64 budget = 96ull << 30;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap * 16) * 0.75));
+        const char *e = getenv("KMERHIP_PART_BUDGET_GB");
+        if (e && atof(e) > 0) budget = (u64)(atof(e) * (double)(1ull << 30));
+        c->part_budget = std::max<u64>(budget, 64ull << 20);
+    }
+    const u64 first_tile = ra.wlo / kh::PART_TILE;
+    const u64 end_tile = (ra.vend + kh::PART_TILE - 1) / kh::PART_TILE;
+    const u64 total_tiles = end_tile - first_tile;
+    u64 batch_tiles = std::max<u64>(1, c->part_budget / 16 / kh::PART_TILE);
+    const u64 nb = (total_tiles + batch_tiles - 1) / batch_tiles;  // equal-sized batches
+    batch_tiles = (total_tiles + nb - 1) / nb;
+    for (u64 t = first_tile; t < end_tile; t += batch_tiles) {
+        int rc = partition_batch(c, ra, t, std::min(batch_tiles, end_tile - t));
+        if (rc != KH_OK) return rc;
+    }
     return KH_OK;
 }
 
@@ -286,6 +593,12 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
     c->flags = cfg->flags;
     const char *tr = getenv("KMERHIP_TRACE");
     c->trace = (cfg->flags & KH_FLAG_TRACE) || (tr && tr[0] && tr[0] != '0');
+    c->hinted = cfg->capacity_hint != 0;
+    c->path_mode = (cfg->flags & KH_FLAG_FORCE_DIRECT) ? 1 : (cfg->flags & KH_FLAG_FORCE_PARTITION) ? 2 : 0;
+    if (const char *pm = getenv("KMERHIP_PATH")) {
+        if (!strcmp(pm, "direct")) c->path_mode = 1;
+        else if (!strcmp(pm, "partition")) c->path_mode = 2;
+    }
 
     int rc = KH_OK;
     do {
@@ -323,6 +636,10 @@ extern "C" void kh_destroy(kh_ctx *c) {
         if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
         if (c->stage_done[i]) (void)hipEventDestroy(c->stage_done[i]);
     }
+    void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
+                       c->bstart, c->rfail, c->scan_partial};
+    for (void *q : scratch)
+        if (q) (void)hipFree(q);
     if (c->table) (void)hipFree(c->table);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -342,6 +659,9 @@ extern "C" int kh_reset(kh_ctx *c) {
     c->bases_pushed = 0;
     c->launches = 0;
     c->kernel_ms = c->h2d_ms = 0.0;
+    for (double &m : c->stage_ms) m = 0.0;
+    c->table_empty = true;
+    c->part_batches = 0;
     return KH_OK;
 }
 
@@ -415,11 +735,15 @@ extern "C" int kh_finish(kh_ctx *c, kh_stats *st) {
         st->launches = c->launches;
         st->count_kernel_ms = c->kernel_ms;
         st->h2d_ms = c->h2d_ms;
+        st->part_batches = c->part_batches;
+        for (int i = 0; i < KH_NUM_STAGES; ++i) st->stage_ms[i] = i < ST_N ? c->stage_ms[i] : 0.0;
     }
     if (c->trace)
-        fprintf(stderr, "[kmerhip] bases=%llu kmers=%llu distinct=%llu slots=%llu load=%.3f launches=%llu kernel=%.3f ms h2d=%.3f ms\n",
+        fprintf(stderr, "[kmerhip] bases=%llu kmers=%llu distinct=%llu slots=%llu load=%.3f launches=%llu kernel=%.3f ms h2d=%.3f ms | direct=%.2f p1c=%.2f p1s=%.2f p2c=%.2f p2s=%.2f region=%.2f misc=%.2f grow=%.2f\n",
                 (u64)c->bases_pushed, c->h_ctr->kmers, c->h_ctr->distinct, c->cap,
-                (double)c->h_ctr->distinct / (double)c->cap, (u64)c->launches, c->kernel_ms, c->h2d_ms);
+                (double)c->h_ctr->distinct / (double)c->cap, (u64)c->launches, c->kernel_ms, c->h2d_ms,
+                c->stage_ms[0], c->stage_ms[1], c->stage_ms[2], c->stage_ms[3], c->stage_ms[4], c->stage_ms[5],
+                c->stage_ms[6], c->stage_ms[7]);
     return KH_OK;
 }
 
@@ -579,8 +903,8 @@ extern "C" int kh_lookup(kh_ctx *c, const uint64_t *keys, uint64_t n, uint64_t *
     }
     hipError_t e = hipMemcpyAsync(dk, keys, n * sizeof(u64), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kh::table_lookup_kernel, dim3(grid_for(n)), dim3(kh::BLOCK), 0, c->stream, c->table, c->cap,
-                           dk, (u64)n, dc);
+        hipLaunchKernelGGL(kh::table_lookup_kernel, dim3(grid_for(n)), dim3(kh::BLOCK), 0, c->stream, c->table,
+                           c->cap / kh::REGION_SLOTS, dk, (u64)n, dc);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(counts, dc, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
@@ -658,8 +982,9 @@ extern "C" int kh_merge_pairs_device(kh_ctx *c, const uint64_t *d_keys, const ui
         rc = ensure_room(c, m, false, &smaller);
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL(kh::table_merge_pairs_kernel, dim3(grid_for(m)), dim3(kh::BLOCK), 0, c->stream, c->table,
-                           c->cap, (const u64 *)d_keys + off, (const u64 *)d_counts + off, m, c->d_ctr);
+                           c->cap / kh::REGION_SLOTS, (const u64 *)d_keys + off, (const u64 *)d_counts + off, m, c->d_ctr);
         HIP_TRY(c, hipGetLastError());
+        c->table_empty = false;
         c->pending_bound += m;
         off += m;
     }

@@ -32,7 +32,11 @@ class KhConfig(C.Structure):
 class KhStats(C.Structure):
     _fields_ = [("bases", C.c_uint64), ("kmers", C.c_uint64), ("distinct", C.c_uint64),
                 ("table_slots", C.c_uint64), ("grows", C.c_uint64), ("launches", C.c_uint64),
-                ("count_kernel_ms", C.c_double), ("h2d_ms", C.c_double)]
+                ("count_kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("part_batches", C.c_uint64),
+                ("stage_ms", C.c_double * 8)]
+
+STAGES = ("direct", "p1_count", "p1_scatter", "p2_count", "p2_scatter", "region", "misc", "grow")
+FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION = 1, 2, 4
 
 
 # every symbol include/kmerhip.h declares: name -> (restype, argtypes)
@@ -125,11 +129,13 @@ class DeviceCounter:
     Stands where the reference has `KmerMap` (src/run.rs:491-583): build()/
     build_with_quality() -> push()/push_device(); into_hashmap() -> result()."""
 
-    def __init__(self, k, min_quality=None, capacity_hint=0, device=-1, stream=None, trace=False):
+    def __init__(self, k, min_quality=None, capacity_hint=0, device=-1, stream=None, trace=False, path=None):
         if not (1 <= int(k) <= 32):
             raise KmerLengthError(int(k))
         cfg = KhConfig(C.sizeof(KhConfig), int(k), -1 if min_quality is None else int(min_quality),
-                       int(device), int(capacity_hint), stream, 1 if trace else 0, 0)
+                       int(device), int(capacity_hint), stream,
+                       (FLAG_TRACE if trace else 0) | {None: 0, "auto": 0, "direct": FLAG_FORCE_DIRECT,
+                                                       "partition": FLAG_FORCE_PARTITION}[path], 0)
         h = _P()
         rc = lib().kh_create(C.byref(h), C.byref(cfg))
         if rc != KH_OK:
@@ -176,7 +182,9 @@ class DeviceCounter:
     def finish(self):
         st = KhStats()
         self._check(lib().kh_finish(self._h, C.byref(st)))
-        return {f: getattr(st, f) for f, _ in KhStats._fields_}
+        d = {f: getattr(st, f) for f, _ in KhStats._fields_ if f != "stage_ms"}
+        d["stage_ms"] = {name: st.stage_ms[i] for i, name in enumerate(STAGES)}
+        return d
 
     # -- output ------------------------------------------------------------
     def result_size(self, min_count=1):

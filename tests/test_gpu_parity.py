@@ -31,6 +31,13 @@ def K():
     return krust_amd
 
 
+@pytest.fixture(params=["direct", "partition"])
+def path(request):
+    """Both insert strategies must give the same table: device-scope atomics straight into HBM,
+    and the two-level partition + LDS region rebuild."""
+    return request.param
+
+
 def flat(records, quals=None):
     """records -> one flat buffer with '\\n' separators (the kh_push layout)."""
     b = b"\n".join(records) + b"\n"
@@ -41,7 +48,8 @@ def flat(records, quals=None):
     return b, q
 
 
-def gpu_count(K, records, k, quals=None, min_quality=None, **kw):
+def gpu_count(K, records, k, quals=None, min_quality=None, path=None, **kw):
+    kw["path"] = path
     b, q = flat(records, quals)
     with K.DeviceCounter(k, min_quality=min_quality, **kw) as dc:
         dc.push(b, q)
@@ -61,9 +69,9 @@ def oracle_dict(records, k, quals=None, min_quality=None):
 # ---------------------------------------------------------------------------
 
 @pytest.mark.parametrize("kat", KATS["count_kats"], ids=lambda k: k["name"])
-def test_count_kats(K, kat):
+def test_count_kats(K, kat, path):
     recs = [r.encode() for r in kat["records"]]
-    got = {K.unpack(key, kat["k"]): c for key, c in gpu_count(K, recs, kat["k"]).items()}
+    got = {K.unpack(key, kat["k"]): c for key, c in gpu_count(K, recs, kat["k"], path=path).items()}
     if kat["exact"]:
         assert got == kat["counts"]
     else:
@@ -75,10 +83,10 @@ def test_count_kats(K, kat):
 
 
 @pytest.mark.parametrize("kat", KATS["quality_kats"], ids=lambda k: k["name"])
-def test_quality_kats(K, kat):
+def test_quality_kats(K, kat, path):
     seq = kat["seq"].encode()
     qual = kat["qual"].encode() if kat["qual"] is not None else None
-    got = gpu_count(K, [seq], kat["k"], quals=None if qual is None else [qual], min_quality=kat["min_quality"])
+    got = gpu_count(K, [seq], kat["k"], quals=None if qual is None else [qual], min_quality=kat["min_quality"], path=path)
     if "distinct" in kat:
         assert len(got) == kat["distinct"] and list(got.values()) == [kat["only_count"]]
     if kat.get("nonempty"):
@@ -117,10 +125,10 @@ def _parse_fixture(path):
 
 
 @pytest.mark.parametrize("row", DERIVED["tables"], ids=lambda r: f'{r["fixture"]}-k{r["k"]}-q{r["min_quality"]}')
-def test_fixture_tables(K, row, fixtures_dir):
+def test_fixture_tables(K, row, fixtures_dir, path):
     recs, quals = _parse_fixture(os.path.join(fixtures_dir, row["fixture"]))
     b, q = flat(recs, quals)
-    with K.DeviceCounter(row["k"], min_quality=row["min_quality"]) as dc:
+    with K.DeviceCounter(row["k"], min_quality=row["min_quality"], path=path) as dc:
         dc.push(b, q)
         st = dc.finish()
         assert dc.as_str_dict() == row["counts"]
@@ -141,37 +149,37 @@ def _dirty(rng, n, p_bad=0.02, lower=True):
 
 
 @pytest.mark.parametrize("k", [1, 2, 3, 5, 11, 15, 16, 17, 21, 31, 32])
-def test_random_ragged_records(K, k):
+def test_random_ragged_records(K, k, path):
     rng = np.random.default_rng(1000 + k)
     recs = [_dirty(rng, int(n)) for n in rng.integers(0, 400, size=300)]
     recs += [b"", b"A", b"N" * 50, b"A" * 200, b"ACGT" * 50, _dirty(rng, 5000, p_bad=0.0)]
-    assert gpu_count(K, recs, k) == oracle_dict(recs, k)
+    assert gpu_count(K, recs, k, path=path) == oracle_dict(recs, k)
 
 
 @pytest.mark.parametrize("k,minq", [(4, 20), (21, 20), (31, 20), (32, 0), (21, 255), (5, 40), (21, 41)])
-def test_random_quality_masking(K, k, minq):
+def test_random_quality_masking(K, k, minq, path):
     rng = np.random.default_rng(77 + k + minq)
     recs, quals = [], []
     for n in rng.integers(0, 500, size=200):
         recs.append(_dirty(rng, int(n)))
         quals.append(rng.choice(np.frombuffer(b"!#+5?IJ~\xff", dtype=np.uint8), size=int(n)).astype(np.uint8).tobytes())
-    assert gpu_count(K, recs, k, quals=quals, min_quality=minq) == oracle_dict(recs, k, quals=quals, min_quality=minq)
+    assert gpu_count(K, recs, k, quals=quals, min_quality=minq, path=path) == oracle_dict(recs, k, quals=quals, min_quality=minq)
     # qual present but no threshold, and threshold but no qual: nothing is filtered (run.rs:543)
-    assert gpu_count(K, recs, k, quals=quals, min_quality=None) == oracle_dict(recs, k)
-    assert gpu_count(K, recs, k, quals=None, min_quality=minq) == oracle_dict(recs, k)
+    assert gpu_count(K, recs, k, quals=quals, min_quality=None, path=path) == oracle_dict(recs, k)
+    assert gpu_count(K, recs, k, quals=None, min_quality=minq, path=path) == oracle_dict(recs, k)
 
 
-def test_empty_and_tiny_inputs(K):
+def test_empty_and_tiny_inputs(K, path):
     for k in (1, 21, 32):
-        assert gpu_count(K, [], k) == {}
-        assert gpu_count(K, [b""], k) == {}
-        assert gpu_count(K, [b"ACGT"[: k - 1] if k <= 4 else b"A" * (k - 1)], k) == {}
-    with K.DeviceCounter(21) as dc:
+        assert gpu_count(K, [], k, path=path) == {}
+        assert gpu_count(K, [b""], k, path=path) == {}
+        assert gpu_count(K, [b"ACGT"[: k - 1] if k <= 4 else b"A" * (k - 1)], k, path=path) == {}
+    with K.DeviceCounter(21, path=path) as dc:
         dc.push(b"")
         assert dc.finish()["kmers"] == 0 and dc.result_size() == 0 and dc.histogram() == []
 
 
-def test_one_long_record_and_tile_boundaries(K):
+def test_one_long_record_and_tile_boundaries(K, path):
     """A single 300 kb record (hg38-style long record): windows cross the 4096-position tile
     boundaries and the workgroup range boundaries; N runs and soft-masked blocks inside."""
     rng = np.random.default_rng(5)
@@ -180,10 +188,10 @@ def test_one_long_record_and_tile_boundaries(K):
     s[4090:4100] = b"acgtacgtac"
     s[8191] = ord("N")
     for k in (21, 32, 7):
-        assert gpu_count(K, [bytes(s)], k) == oracle_dict([bytes(s)], k)
+        assert gpu_count(K, [bytes(s)], k, path=path) == oracle_dict([bytes(s)], k)
 
 
-def test_device_pointer_alignment(K):
+def test_device_pointer_alignment(K, path):
     """kh_push_device with base/qual pointers at every 16-byte phase (aligned fast path and the
     byte-wise quality fallback)."""
     import torch
@@ -201,17 +209,17 @@ def test_device_pointer_alignment(K):
         tb[boff:boff + n] = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
         tq[qoff:qoff + n] = torch.frombuffer(bytearray(q), dtype=torch.uint8).cuda()
         torch.cuda.synchronize()
-        with K.DeviceCounter(21, min_quality=20) as dc:
+        with K.DeviceCounter(21, min_quality=20, path=path) as dc:
             dc.push_device(tb.data_ptr() + boff, tq.data_ptr() + qoff, n)
             dc.finish()
             assert dc.as_dict() == want, (boff, qoff)
 
 
-def test_multiple_pushes_and_reset(K):
+def test_multiple_pushes_and_reset(K, path):
     rng = np.random.default_rng(3)
     recs = [_dirty(rng, int(n)) for n in rng.integers(0, 300, size=400)]
     want = oracle_dict(recs, 13)
-    with K.DeviceCounter(13) as dc:
+    with K.DeviceCounter(13, path=path) as dc:
         for i in range(0, len(recs), 37):  # k-mers never span pushes: each push holds whole records
             dc.push(flat(recs[i:i + 37])[0])
         dc.finish()
@@ -223,22 +231,22 @@ def test_multiple_pushes_and_reset(K):
         assert dc.as_dict() == want
 
 
-def test_table_growth_from_tiny_capacity(K):
+def test_table_growth_from_tiny_capacity(K, path):
     """No capacity hint: the table starts small and must grow (rehash) without losing counts."""
     bases, _ = O.synth_reads(SEED, 1 << 22, 150, 0, 60_000, with_qual=False)
     m = O.OracleMap()
     total = m.scan_flat(bases, 21, nthreads=NCPU)
-    with K.DeviceCounter(21) as dc:
+    with K.DeviceCounter(21, path=path) as dc:
         dc.push(bases)
         st = dc.finish()
-        assert st["grows"] >= 1
+        assert st["grows"] >= 1 or path == "partition"
         assert st["kmers"] == total and st["distinct"] == len(m)
         keys, cnts = dc.result()
     okeys, ocnts = m.arrays()
     assert np.array_equal(keys, okeys) and np.array_equal(cnts, ocnts)
 
 
-def test_host_staging_chunk_boundary(K):
+def test_host_staging_chunk_boundary(K, path):
     """kh_push stages the host buffer in 64 MiB chunks; windows crossing a chunk boundary must
     be counted exactly once (the k-1 halo is re-sent)."""
     n_reads = 460_000  # 69.5 MB > one staging chunk
@@ -249,7 +257,7 @@ def test_host_staging_chunk_boundary(K):
     for k, minq in ((31, None), (21, 20)):
         m = O.OracleMap()
         total = m.scan_flat(bases, k, qual=qual, min_quality=minq, nthreads=NCPU)
-        with K.DeviceCounter(k, min_quality=minq, capacity_hint=len(m)) as dc:
+        with K.DeviceCounter(k, min_quality=minq, capacity_hint=len(m), path=path) as dc:
             dc.push(bases, qual)
             st = dc.finish()
             assert st["kmers"] == total and st["distinct"] == len(m)
@@ -258,12 +266,12 @@ def test_host_staging_chunk_boundary(K):
         assert np.array_equal(keys, okeys) and np.array_equal(cnts, ocnts)
 
 
-def test_min_count_histogram_lookup(K):
+def test_min_count_histogram_lookup(K, path):
     bases, _ = O.synth_reads(SEED, 1 << 14, 150, 0, 20_000, with_qual=False)  # high coverage: big counts
     m = O.OracleMap()
     m.scan_flat(bases, 15, nthreads=NCPU)
     od = m.as_dict()
-    with K.DeviceCounter(15) as dc:
+    with K.DeviceCounter(15, path=path) as dc:
         dc.push(bases)
         dc.finish()
         for mc in (1, 2, 50, 10**9):
@@ -277,7 +285,7 @@ def test_min_count_histogram_lookup(K):
     # counts far beyond the dense histogram range (k=1: two keys with huge counts)
     m1 = O.OracleMap()
     m1.scan_flat(bases, 1, nthreads=NCPU)
-    with K.DeviceCounter(1) as dc:
+    with K.DeviceCounter(1, path=path) as dc:
         dc.push(bases)
         dc.finish()
         assert dc.histogram(1) == m1.histogram(1)
@@ -296,12 +304,12 @@ def test_synth_generator_matches_oracle(K):
         assert np.array_equal(tq.cpu().numpy(), oq)
 
 
-def test_determinism_digest(K):
+def test_determinism_digest(K, path):
     """Same input twice -> identical multiset (atomics race, results must not)."""
     bases, qual = O.synth_reads(SEED, 1 << 18, 150, 0, 50_000)
     digests = []
     for _ in range(3):
-        with K.DeviceCounter(21, min_quality=20) as dc:
+        with K.DeviceCounter(21, min_quality=20, path=path) as dc:
             dc.push(bases, qual)
             dc.finish()
             k, c = dc.result()
@@ -365,7 +373,7 @@ def test_merge_pairs_host(K):
 # BASELINE.json configs[1] at full size: size-independent properties + sampled parity
 # ---------------------------------------------------------------------------
 
-def test_full_size_10M_reads_k21(K):
+def test_full_size_10M_reads_k21(K, path):
     import torch
     n_reads, rl, k = 10_000_000, 150, 21
     nbytes = n_reads * (rl + 1)
@@ -376,7 +384,7 @@ def test_full_size_10M_reads_k21(K):
     m = O.OracleMap()
     total = m.scan_flat(host, k, sample_mask=1023, nthreads=NCPU)  # exact counts on 1/1024 of the keys
     skeys, scnts = m.arrays()
-    with K.DeviceCounter(k, capacity_hint=400_000_000) as dc:
+    with K.DeviceCounter(k, capacity_hint=400_000_000, path=path) as dc:
         dc.push_device(tb.data_ptr(), None, nbytes)
         st = dc.finish()
         assert st["kmers"] == total                                  # every valid window counted once
