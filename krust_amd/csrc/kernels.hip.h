@@ -56,14 +56,17 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// open-addressing table, laid out in REGIONS of REGION_SLOTS slots (128 KiB = one LDS image):
+// open-addressing table, laid out in REGIONS of REGION_SLOTS slots (64 KiB = one LDS image):
 //   region = fast-range(mix64(key), nregions)      (high hash bits)
 //   start  = mix64(key) & (REGION_SLOTS-1)         (low hash bits)
 // linear probing wraps INSIDE the region, so a region is self-contained: the direct path updates
 // it in HBM with device-scope atomics, the partitioned path rebuilds it in LDS with no global
 // atomics at all.  capacity = nregions * REGION_SLOTS.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t REGION_SLOTS = 8192;
+#ifndef KH_REGION_SLOTS
+#define KH_REGION_SLOTS 4096
+#endif
+constexpr uint32_t REGION_SLOTS = KH_REGION_SLOTS;
 constexpr uint32_t REGION_MASK = REGION_SLOTS - 1;
 
 __device__ __forceinline__ u64 region_of_hash(u64 h, u64 nregions) { return __umul64hi(h, nregions); }
@@ -127,18 +130,26 @@ __device__ __forceinline__ uint32_t byte_of(const uint4 &w, int j) {
     return (d >> (8 * (j & 3))) & 0xFFu;
 }
 
+// Raw 16-byte chunk(s) of one lane, as loaded from HBM (zeros outside the data).
+struct RawChunk {
+    uint4 w, q;
+    int64_t p0;
+    bool live;
+};
+
 template <bool QUAL>
-__device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase,
-                                             int qaligned, int64_t p0, u64 vbeg, u64 vend, uint32_t thr,
-                                             uint32_t &code, uint32_t &val) {
-    code = 0;
-    val = 0;
-    if (p0 < 0 || (u64)p0 >= vend) return;
-    const uint4 w = *reinterpret_cast<const uint4 *>(abase + p0);
-    uint4 q = make_uint4(0, 0, 0, 0);
+__device__ __forceinline__ RawChunk load_raw(const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase,
+                                             int qaligned, int64_t p0, u64 vbeg, u64 vend) {
+    RawChunk r;
+    r.p0 = p0;
+    r.w = make_uint4(0, 0, 0, 0);
+    r.q = make_uint4(0, 0, 0, 0);
+    r.live = !(p0 < 0 || (u64)p0 >= vend);
+    if (!r.live) return r;
+    r.w = *reinterpret_cast<const uint4 *>(abase + p0);
     if (QUAL) {
         if (qaligned) {
-            q = *reinterpret_cast<const uint4 *>(qbase + p0);
+            r.q = *reinterpret_cast<const uint4 *>(qbase + p0);
         } else {
             uint32_t qq[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -147,18 +158,35 @@ __device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ abase, 
                 uint32_t b = (pos >= vbeg && pos < vend) ? qbase[pos] : 0u;
                 qq[j >> 2] |= b << (8 * (j & 3));
             }
-            q = make_uint4(qq[0], qq[1], qq[2], qq[3]);
+            r.q = make_uint4(qq[0], qq[1], qq[2], qq[3]);
         }
     }
+    return r;
+}
+
+template <bool QUAL>
+__device__ __forceinline__ void encode_raw(const RawChunk &r, u64 vbeg, u64 vend, uint32_t thr, uint32_t &code,
+                                           uint32_t &val) {
+    code = 0;
+    val = 0;
+    if (!r.live) return;
 #pragma unroll
     for (int j = 0; j < CHUNK; ++j) {
-        uint32_t b = byte_of(w, j);
-        u64 pos = (u64)p0 + j;
+        uint32_t b = byte_of(r.w, j);
+        u64 pos = (u64)r.p0 + j;
         uint32_t v = kh_base_valid(b) & (uint32_t)(pos >= vbeg) & (uint32_t)(pos < vend);
-        if (QUAL) v &= (uint32_t)(byte_of(q, j) >= thr);  // run.rs:545: skip iff qv < threshold
+        if (QUAL) v &= (uint32_t)(byte_of(r.q, j) >= thr);  // run.rs:545: skip iff qv < threshold
         code = (code << 2) | kh_base_code(b);
         val = (val << 1) | v;
     }
+}
+
+template <bool QUAL>
+__device__ __forceinline__ void encode_chunk(const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase,
+                                             int qaligned, int64_t p0, u64 vbeg, u64 vend, uint32_t thr,
+                                             uint32_t &code, uint32_t &val) {
+    const RawChunk r = load_raw<QUAL>(abase, qbase, qaligned, p0, vbeg, vend);
+    encode_raw<QUAL>(r, vbeg, vend, thr, code, val);
 }
 
 // One staged tile as seen by one lane: its own 16 codes (low half of lo64), the 32 codes in front
@@ -174,15 +202,19 @@ struct WinCtx {
 // arrays, double-buffered by `buf`; `first` = this is the workgroup's first tile (its look-back
 // words are then encoded from memory, later tiles get them carried from the previous tile).
 // Contains the tile's only barrier.
+// Position of lane tid's chunk in tile t.
+template <int NT>
+__device__ __forceinline__ int64_t chunk_pos(u64 t, int tid) { return (int64_t)(t * (u64)(NT * CHUNK) + (u64)tid * CHUNK); }
+
 template <bool QUAL, int NT>
-__device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_t (*s_val)[NT + 2], int buf, bool first,
-                                             int tid, const uint8_t *__restrict__ abase,
-                                             const uint8_t *__restrict__ qbase, int qaligned, u64 t, u64 vbeg, u64 vend,
-                                             uint32_t thr) {
+__device__ __forceinline__ WinCtx stage_tile_raw(uint32_t (*s_code)[NT + 2], uint16_t (*s_val)[NT + 2], int buf, bool first,
+                                                 int tid, const RawChunk &raw, const uint8_t *__restrict__ abase,
+                                                 const uint8_t *__restrict__ qbase, int qaligned, u64 t, u64 vbeg,
+                                                 u64 vend, uint32_t thr) {
     constexpr int TILE_N = NT * CHUNK;
-    const int64_t p0 = (int64_t)(t * TILE_N + (u64)tid * CHUNK);
+    const int64_t p0 = raw.p0;
     uint32_t code, val;
-    encode_chunk<QUAL>(abase, qbase, qaligned, p0, vbeg, vend, thr, code, val);
+    encode_raw<QUAL>(raw, vbeg, vend, thr, code, val);
     s_code[buf][tid + 2] = code;
     s_val[buf][tid + 2] = (uint16_t)val;
     if (first && tid < 2) {
@@ -206,6 +238,15 @@ __device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_
     w.V = ((u64)s_val[buf][tid] << 32) | ((u64)s_val[buf][tid + 1] << 16) | (u64)val;
     w.p0 = (u64)p0;
     return w;
+}
+
+template <bool QUAL, int NT>
+__device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_t (*s_val)[NT + 2], int buf, bool first,
+                                             int tid, const uint8_t *__restrict__ abase,
+                                             const uint8_t *__restrict__ qbase, int qaligned, u64 t, u64 vbeg, u64 vend,
+                                             uint32_t thr) {
+    const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<NT>(t, tid), vbeg, vend);
+    return stage_tile_raw<QUAL, NT>(s_code, s_val, buf, first, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
 }
 
 // Canonical key of the window ENDING at the lane's base j (0..15); false if the window holds an

@@ -87,6 +87,7 @@ struct kh_ctx {
     u64 h2_cap = 0;
     u64 *bstart = nullptr;
     uint8_t *rfail = nullptr;
+    uint32_t *rnew = nullptr;
     u64 region_cap = 0;
     u64 *scan_partial = nullptr;
     u64 scan_cap = 0;
@@ -335,6 +336,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
         if ((rc = ensure_buf(c, &c->bstart, &z, g.nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
         z = c->rfail ? c->region_cap : 0;
         if ((rc = ensure_buf(c, &c->rfail, &z, g.nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
+        z = c->rnew ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rnew, &z, g.nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
         c->region_cap = g.nregions;
     }
     if (c->key_cap < n_ub) {
@@ -401,10 +404,15 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
         StageTimer t(c, ST_REGION);
         if (c->table_empty)
             hipLaunchKernelGGL(kh::region_count_kernel<true>, dim3((unsigned)g.nregions), dim3(kh::REGION_NT), 0, c->stream,
-                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->d_ctr);
+                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
         else
             hipLaunchKernelGGL(kh::region_count_kernel<false>, dim3((unsigned)g.nregions), dim3(kh::REGION_NT), 0, c->stream,
-                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->d_ctr);
+                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+    }
+    {
+        StageTimer t(c, ST_MISC);
+        hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(g.nregions)), dim3(kh::BLOCK), 0, c->stream,
+                           (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)g.nregions, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
@@ -528,7 +536,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     }
     if (!c->part_budget) {
         size_t fr = 0, tot = 0;
-        u64 budget = 96ull << 30;
+        u64 budget = 160ull << 30;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap * 16) * 0.75));
         const char *e = getenv("KMERHIP_PART_BUDGET_GB");
         if (e && atof(e) > 0) budget = (u64)(atof(e) * (double)(1ull << 30));
@@ -637,7 +645,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
         if (c->stage_done[i]) (void)hipEventDestroy(c->stage_done[i]);
     }
     void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->rfail, c->scan_partial};
+                       c->bstart, c->rfail, c->rnew, c->scan_partial};
     for (void *q : scratch)
         if (q) (void)hipFree(q);
     if (c->table) (void)hipFree(c->table);

@@ -3,9 +3,9 @@
 // The direct path (count_direct_kernel) issues one memory-side atomic per k-mer and saturates the
 // chip's atomic request rate (~18.5 G/s measured, profiles/r01a).  This path issues NO global
 // atomics per k-mer: canonical keys are radix-partitioned by the high bits of their table hash in
-// two levels (level 1: P1 <= 1024 partitions straight from the bases; level 2: P2 <= 512 buckets
+// two levels (level 1: P1 <= 1024 partitions straight from the bases; level 2: P2 <= 1024 buckets
 // inside each level-1 partition), so that every bucket holds exactly the keys of ONE table region
-// (kernels.hip.h: 8192 slots = 128 KiB).  One workgroup then rebuilds each region in LDS with LDS
+// (kernels.hip.h: 4096 slots = 64 KiB).  One workgroup then rebuilds each region in LDS with LDS
 // atomics and writes it back with coalesced 16-byte stores.
 //
 // Both partition levels are "count, scan, scatter" with deterministic offsets (no global cursor
@@ -24,9 +24,10 @@ namespace kh {
 constexpr int PART_NT = 1024;                    // lanes per workgroup in the partition kernels
 constexpr int PART_TILE = PART_NT * CHUNK;       // 16384 positions / keys per batch
 constexpr uint32_t MAX_P1 = 1024;
-constexpr uint32_t MAX_P2_BITS = 9;              // P2 <= 512 regions per level-1 partition
+constexpr uint32_t MAX_P2_BITS = 10;             // P2 <= 1024 regions per level-1 partition
 constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // keys per level-2 workgroup (262144)
 constexpr int REGION_NT = 1024;                  // lanes per workgroup in region_count_kernel
+constexpr int REGION_RK = 8;                     // keys prefetched per lane per round
 
 struct PartGeom {
     u64 nregions;      // R
@@ -127,8 +128,9 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
     const u64 kmask = kh_kmask(k), vmask = valid_mask_of(k);
     int buf = 0;
     __syncthreads();
+    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        const WinCtx w = stage_tile<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, abase, qbase, qaligned, t, vbeg, vend, thr);
+        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
         u64 key[CHUNK];
         uint32_t tag[CHUNK];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
 #pragma unroll
@@ -145,6 +147,8 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
         for (int j = 0; j < CHUNK; ++j)
             if (tag[j] != 0xFFFFFFFFu) s_stage[s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = key[j];
         __syncthreads();
+        // next tile's bases are fetched while this tile's runs are written out
+        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
         const uint32_t total = s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
         for (uint32_t i = tid; i < total; i += PART_NT) {
             const u64 kk = s_stage[i];
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const u64 *__restr
     if ((u64)blockIdx.x >= info[0]) return;
     const Part2Block pb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
-    if (tid < (1 << MAX_P2_BITS)) s_hist[tid] = 0;
+    s_hist[tid] = 0;  // PART_NT == 1 << MAX_P2_BITS
     __syncthreads();
     for (u64 i = pb.lo + tid; i < pb.hi; i += PART_NT) atomicAdd(&s_hist[p2_of_key(keys[i], g)], 1u);
     __syncthreads();
@@ -332,15 +336,18 @@ __global__ __launch_bounds__(PART_NT) void part2_scatter_kernel(const u64 *__res
     s_cnt[tid] = 0;
     if ((uint32_t)tid < P2) s_gcur[tid] = O2[pb.mbase + (u64)tid * pb.mstride];
     __syncthreads();
+    u64 key[CHUNK];
+#pragma unroll
+    for (int j = 0; j < CHUNK; ++j) {  // lane-contiguous: coalesced 8-byte loads
+        const u64 i = pb.lo + (u64)j * PART_NT + tid;
+        key[j] = i < pb.hi ? keys[i] : KH_EMPTY_KEY;
+    }
     for (u64 base = pb.lo; base < pb.hi; base += PART_TILE) {
-        u64 key[CHUNK];
         uint32_t tag[CHUNK];
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
-            const u64 i = base + (u64)j * PART_NT + tid;  // lane-contiguous: coalesced 8-byte loads
             tag[j] = 0xFFFFFFFFu;
-            if (i < pb.hi) {
-                key[j] = keys[i];
+            if (key[j] != KH_EMPTY_KEY) {
                 const uint32_t p = p2_of_key(key[j], g);
                 tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);
             }
@@ -351,6 +358,12 @@ __global__ __launch_bounds__(PART_NT) void part2_scatter_kernel(const u64 *__res
         for (int j = 0; j < CHUNK; ++j)
             if (tag[j] != 0xFFFFFFFFu) s_stage[s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = key[j];
         __syncthreads();
+        // next batch's keys are fetched while this batch's runs are written out
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            const u64 i = base + PART_TILE + (u64)j * PART_NT + tid;
+            key[j] = i < pb.hi ? keys[i] : KH_EMPTY_KEY;
+        }
         const uint32_t total = s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
         for (uint32_t i = tid; i < total; i += PART_NT) {
             const u64 kk = s_stage[i];
@@ -388,59 +401,121 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restric
 template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT) void region_count_kernel(Slot *__restrict__ table, const u64 *__restrict__ keys,
                                                                  const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
-                                                                 Counters *ctr) {
-    __shared__ Slot s_tab[REGION_SLOTS];  // 128 KiB
+                                                                 uint32_t *__restrict__ rnew) {
+    // LDS image is structure-of-arrays: 8-byte key probes then spread over all 64 banks instead of
+    // the 16 bank pairs a 16-byte-slot layout would hit.
+    __shared__ u64 s_key[REGION_SLOTS];  // 32 KiB
+    __shared__ u64 s_cnt[REGION_SLOTS];  // 32 KiB
     __shared__ uint32_t s_fail;
+    __shared__ uint32_t s_new;
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bstart[r + 1];
-    if (lo == hi) return;  // nothing new for this region
-    Slot *reg = table + r * REGION_SLOTS;
-    uint4 *s4 = reinterpret_cast<uint4 *>(s_tab);
-    const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
-    if (FRESH) {
-        const uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
-        for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) s4[i] = e;
-    } else {
-        for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) s4[i] = g4[i];
+    if (lo == hi) {  // nothing new for this region
+        if (tid == 0) rnew[r] = 0;
+        return;
     }
-    if (tid == 0) s_fail = 0;
+    Slot *reg = table + r * REGION_SLOTS;
+    u64 kbuf[REGION_RK];  // first round of keys: in flight while the region image is loaded
+#pragma unroll
+    for (int j = 0; j < REGION_RK; ++j) {
+        const u64 i = lo + (u64)j * REGION_NT + tid;
+        kbuf[j] = i < hi ? keys[i] : KH_EMPTY_KEY;
+    }
+    const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
+#pragma unroll
+    for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) {
+        if (FRESH) {
+            s_key[i] = KH_EMPTY_KEY;
+            s_cnt[i] = 0;
+        } else {
+            const uint4 v = g4[i];
+            s_key[i] = ((u64)v.y << 32) | v.x;
+            s_cnt[i] = ((u64)v.w << 32) | v.z;
+        }
+    }
+    if (tid == 0) {
+        s_fail = 0;
+        s_new = 0;
+    }
     __syncthreads();
     uint32_t nd = 0;
-    for (u64 i = lo + tid; i < hi; i += REGION_NT) {
-        const u64 key = keys[i];
-        uint32_t off = start_of_hash(kh_mix64(key));
-        uint32_t probes = 0;
-        for (; probes < REGION_SLOTS; ++probes) {
-            u64 cur = s_tab[off].key;
-            if (cur == KH_EMPTY_KEY) {
-                cur = atomicCAS(&s_tab[off].key, (u64)KH_EMPTY_KEY, key);  // ds_cmpst_rtn_b64
-                if (cur == KH_EMPTY_KEY) {
-                    ++nd;
-                    cur = key;
-                }
-            }
-            if (cur == key) {
-                atomicAdd(&s_tab[off].count, 1ull);  // ds_add_u64
-                break;
-            }
-            off = (off + 1) & REGION_MASK;
+    for (u64 base = lo; base < hi; base += (u64)REGION_RK * REGION_NT) {
+        u64 nbuf[REGION_RK];
+#pragma unroll
+        for (int j = 0; j < REGION_RK; ++j) {  // next round's keys in flight while this round is inserted
+            const u64 i = base + (u64)(REGION_RK + j) * REGION_NT + tid;
+            nbuf[j] = i < hi ? keys[i] : KH_EMPTY_KEY;
         }
-        if (probes == REGION_SLOTS) s_fail = 1;
+#pragma unroll
+        for (int j = 0; j < REGION_RK; ++j) {
+            const u64 key = kbuf[j];
+            if (key == KH_EMPTY_KEY) continue;
+            uint32_t off = start_of_hash(kh_mix64(key));
+            uint32_t probes = 0;
+            for (; probes < REGION_SLOTS; ++probes) {
+                u64 cur = s_key[off];
+                if (cur == KH_EMPTY_KEY) {
+                    cur = atomicCAS(&s_key[off], (u64)KH_EMPTY_KEY, key);  // ds_cmpst_rtn_b64
+                    if (cur == KH_EMPTY_KEY) {
+                        ++nd;
+                        cur = key;
+                    }
+                }
+                if (cur == key) {
+                    atomicAdd(&s_cnt[off], 1ull);  // ds_add_u64
+                    break;
+                }
+                off = (off + 1) & REGION_MASK;
+            }
+            if (probes == REGION_SLOTS) s_fail = 1;
+        }
+#pragma unroll
+        for (int j = 0; j < REGION_RK; ++j) kbuf[j] = nbuf[j];
     }
+    // No global atomics here: a million workgroups adding to one counter word serialise at the
+    // memory side (measured: ~6 ns per same-address atomic, i.e. >100 ms per pass).  Per-region
+    // results go to rnew[]/rfail[] and region_reduce_kernel folds them afterwards.
+    const uint32_t dw = (uint32_t)wave_sum((u64)nd);
+    if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);  // LDS
     __syncthreads();
     if (s_fail) {
         if (tid == 0) {
             rfail[r] = 1;
-            atomicAdd(&ctr->part_failed, 1ull);
+            rnew[r] = 0;
         }
         return;
     }
     uint4 *o4 = reinterpret_cast<uint4 *>(reg);
-    for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) o4[i] = s4[i];
-    const u64 d = wave_sum((u64)nd);
-    if ((tid & 63) == 0 && d) atomicAdd(&ctr->distinct, d);
-    if (tid == 0) atomicAdd(&ctr->kmers, hi - lo);
+#pragma unroll
+    for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) {
+        const u64 kk = s_key[i], cc = s_cnt[i];
+        o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
+    }
+    if (tid == 0) rnew[r] = s_new;
+}
+
+// Folds the per-region results of one region_count pass into the context counters.
+__global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restrict__ bstart, const uint8_t *__restrict__ rfail,
+                                                              const uint32_t *__restrict__ rnew, u64 nregions, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    u64 d = 0, km = 0, nf = 0;
+    for (u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x; r < nregions; r += stride) {
+        if (rfail[r]) {
+            ++nf;
+        } else {
+            d += rnew[r];
+            km += bstart[r + 1] - bstart[r];
+        }
+    }
+    d = wave_sum(d);
+    km = wave_sum(km);
+    nf = wave_sum(nf);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (km) atomicAdd(&ctr->kmers, km);
+        if (nf) atomicAdd(&ctr->part_failed, nf);
+    }
 }
 
 // Direct (atomic) insertion of the buckets whose region overflowed, after the table was grown.
@@ -455,7 +530,7 @@ __global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(Slot *tabl
     uint32_t nd = 0, nf = 0;
     for (u64 i = lo + threadIdx.x; i < hi; i += BLOCK) upsert(table, nregions, keys[i], 1ull, nd, nf);
     const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
-    if (lane_id() == 0) {
+    if (lane_id() == 0) {  // rare path (only regions that overflowed): plain counter atomics are fine
         if (d) atomicAdd(&ctr->distinct, d);
         if (f) atomicAdd(&ctr->failed, f);
     }

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkmerhip.so")
+LIB_PATH = os.path.join(_HERE, "lib", os.environ.get("KMERHIP_LIB", "libkmerhip.so"))  # KMERHIP_LIB: A/B builds
 
 KH_OK = 0
 KH_ERR_BAD_K = -1
