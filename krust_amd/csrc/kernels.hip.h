@@ -56,21 +56,31 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// open-addressing table, laid out in REGIONS of REGION_SLOTS slots (64 KiB = one LDS image):
-//   region = fast-range(mix64(key), nregions)      (high hash bits)
-//   start  = mix64(key) & (REGION_SLOTS-1)         (low hash bits)
-// linear probing wraps INSIDE the region, so a region is self-contained: the direct path updates
+// open-addressing table, laid out in 2^rbits REGIONS of REGION_SLOTS slots (64 KiB each):
+//   H      = kh_table_hash(key, k)             (bijective 2k-bit hash, left-aligned in 64 bits)
+//   region = H >> (64 - rbits)                  (top bits)
+//   start  = next REGION_BITS bits of H
+// Linear probing wraps INSIDE the region, so a region is self-contained: the direct path updates
 // it in HBM with device-scope atomics, the partitioned path rebuilds it in LDS with no global
-// atomics at all.  capacity = nregions * REGION_SLOTS.
+// atomics at all.  capacity = REGION_SLOTS << rbits.
 // ---------------------------------------------------------------------------------------------
-#ifndef KH_REGION_SLOTS
-#define KH_REGION_SLOTS 4096
+#ifndef KH_REGION_BITS
+#define KH_REGION_BITS 12
 #endif
-constexpr uint32_t REGION_SLOTS = KH_REGION_SLOTS;
+constexpr uint32_t REGION_BITS = KH_REGION_BITS;
+constexpr uint32_t REGION_SLOTS = 1u << REGION_BITS;
 constexpr uint32_t REGION_MASK = REGION_SLOTS - 1;
 
-__device__ __forceinline__ u64 region_of_hash(u64 h, u64 nregions) { return __umul64hi(h, nregions); }
-__device__ __forceinline__ uint32_t start_of_hash(u64 h) { return (uint32_t)h & REGION_MASK; }
+struct TableGeom {
+    Slot *table;
+    uint32_t rbits;  // log2(number of regions)
+    uint32_t k;
+};
+
+__device__ __forceinline__ u64 region_of(const TableGeom &tg, u64 H) { return H >> (64 - tg.rbits); }
+__device__ __forceinline__ uint32_t start_of(const TableGeom &tg, u64 H) {
+    return (uint32_t)(H >> (64 - tg.rbits - REGION_BITS)) & REGION_MASK;
+}
 
 __device__ __forceinline__ void count_add(Slot *s, u64 addend) {
     // fire-and-forget device-scope add (result unused -> no-return global_atomic_add_x2)
@@ -104,11 +114,11 @@ __device__ __forceinline__ void upsert_from(Slot *reg, u64 key, uint32_t off, u6
     ++nfailed;  // region full: the host keeps the load factor far below this
 }
 
-__device__ __forceinline__ void upsert(Slot *table, u64 nregions, u64 key, u64 addend, uint32_t &ndistinct,
+__device__ __forceinline__ void upsert(const TableGeom &tg, u64 key, u64 addend, uint32_t &ndistinct,
                                        uint32_t &nfailed) {
-    const u64 h = kh_mix64(key);
-    Slot *reg = table + region_of_hash(h, nregions) * REGION_SLOTS;
-    const uint32_t off = start_of_hash(h);
+    const u64 H = kh_table_hash(key, tg.k);
+    Slot *reg = tg.table + region_of(tg, H) * REGION_SLOTS;
+    const uint32_t off = start_of(tg, H);
     upsert_from(reg, key, off, reg[off].key, addend, ndistinct, nfailed);
 }
 
@@ -164,20 +174,54 @@ __device__ __forceinline__ RawChunk load_raw(const uint8_t *__restrict__ abase, 
     return r;
 }
 
+// ---- SWAR helpers: four bases per 32-bit word -------------------------------------------------
+// 0x80 in every byte of x that is zero (exact: the per-byte add cannot carry into its neighbour)
+__device__ __forceinline__ uint32_t swar_zero_bytes(uint32_t x) {
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+}
+// 0x80 in every byte where x >= y (unsigned bytes)
+__device__ __forceinline__ uint32_t swar_ge_bytes(uint32_t x, uint32_t y) {
+    const uint32_t z = (x | 0x80808080u) - (y & 0x7F7F7F7Fu);  // bit 7: low 7 bits of x >= low 7 bits of y
+    return ((x & ~y) | (~(x ^ y) & z)) & 0x80808080u;
+}
+// bytes b0..b3 (b0 = lowest address = FIRST base) -> 8 bits, first base most significant
+__device__ __forceinline__ uint32_t swar_codes4(uint32_t w) {
+    const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;  // A,C,G,T -> 0,1,2,3 in every byte (either case)
+    return ((t >> 24) | (t >> 14) | (t >> 4) | (t << 6)) & 0xFFu;
+}
+// 0x80-per-byte flags -> 4 bits, first base most significant
+__device__ __forceinline__ uint32_t swar_flags4(uint32_t m) {
+    return ((m >> 4) & 8u) | ((m >> 13) & 4u) | ((m >> 22) & 2u) | (m >> 31);
+}
+__device__ __forceinline__ uint32_t swar_valid4(uint32_t w, uint32_t q, uint32_t thr4, bool qual) {
+    const uint32_t u = w & 0xDFDFDFDFu;  // fold case: accepted bytes are exactly ACGTacgt (src/kmer.rs:271-273)
+    uint32_t m = swar_zero_bytes(u ^ 0x41414141u) | swar_zero_bytes(u ^ 0x43434343u) | swar_zero_bytes(u ^ 0x47474747u) |
+                 swar_zero_bytes(u ^ 0x54545454u);
+    if (qual) m &= swar_ge_bytes(q, thr4);  // run.rs:545: skip iff qv < threshold
+    return swar_flags4(m);
+}
+
+// 16 bases -> 32-bit code word (first base in the top two bits) + 16-bit validity word (bit 15-j =
+// base j is countable: in ACGTacgt, inside [vbeg, vend), quality >= thr).
 template <bool QUAL>
 __device__ __forceinline__ void encode_raw(const RawChunk &r, u64 vbeg, u64 vend, uint32_t thr, uint32_t &code,
                                            uint32_t &val) {
     code = 0;
     val = 0;
     if (!r.live) return;
-#pragma unroll
-    for (int j = 0; j < CHUNK; ++j) {
-        uint32_t b = byte_of(r.w, j);
-        u64 pos = (u64)r.p0 + j;
-        uint32_t v = kh_base_valid(b) & (uint32_t)(pos >= vbeg) & (uint32_t)(pos < vend);
-        if (QUAL) v &= (uint32_t)(byte_of(r.q, j) >= thr);  // run.rs:545: skip iff qv < threshold
-        code = (code << 2) | kh_base_code(b);
-        val = (val << 1) | v;
+    const uint32_t thr4 = thr * 0x01010101u;
+    code = (swar_codes4(r.w.x) << 24) | (swar_codes4(r.w.y) << 16) | (swar_codes4(r.w.z) << 8) | swar_codes4(r.w.w);
+    val = (swar_valid4(r.w.x, r.q.x, thr4, QUAL) << 12) | (swar_valid4(r.w.y, r.q.y, thr4, QUAL) << 8) |
+          (swar_valid4(r.w.z, r.q.z, thr4, QUAL) << 4) | swar_valid4(r.w.w, r.q.w, thr4, QUAL);
+    // data bounds, once per chunk instead of two 64-bit compares per base
+    const u64 p0 = (u64)r.p0;
+    if (p0 < vbeg) {
+        const u64 d = vbeg - p0;  // first d bases lie before the data
+        val = d >= 16 ? 0u : (val & (0xFFFFu >> d));
+    }
+    if (p0 + CHUNK > vend) {
+        const u64 e = p0 + CHUNK - vend;  // last e bases lie past the data (1..15 here: the chunk is live)
+        val &= ~((1u << e) - 1u);
     }
 }
 
@@ -249,22 +293,65 @@ __device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_
     return stage_tile_raw<QUAL, NT>(s_code, s_val, buf, first, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
 }
 
-// Canonical key of the window ENDING at the lane's base j (0..15); false if the window holds an
-// invalid / masked base, starts before the data, or ends before wlo.
-__device__ __forceinline__ bool window_key(const WinCtx &w, int j, u64 kmask, u64 vmask, uint32_t k, u64 wlo, u64 &key) {
-    const int sh = 2 * (15 - j);
-    const u64 x = (sh == 0) ? w.lo64 : ((w.lo64 >> sh) | ((u64)w.hi << (64 - sh)));
-    key = kh_canonical_bits(x & kmask, k);
-    return (((w.V >> (15 - j)) & vmask) == vmask) && (w.p0 + j >= wlo);
-}
+// Rolling canonical-window state of one lane over its 16 bases.  All 32-bit arithmetic:
+//   f  = the last 32 bases as a 64-bit shift register (two words), newest base in the low bits
+//   rc = reverse complement of the last k bases in the low 2k bits
+//   good = bit (15-j): the window ENDING at own base j is countable (k valid bases, inside the
+//          data, ending at or after wlo) -- computed once per lane by eroding the 48 validity bits
+// next(j) must be called for j = 0, 1, ..., 15 in order.
+struct Roller {
+    uint32_t flo, fhi, rlo, rhi, code, good;
+    uint32_t kmlo, kmhi;  // kh_kmask(k)
+    uint32_t ins_sh;      // 2k-2: where the complemented new base enters rc
 
-__device__ __forceinline__ u64 valid_mask_of(uint32_t k) { return (k >= 32) ? 0xFFFFFFFFull : ((1ull << k) - 1ull); }
+    __device__ __forceinline__ void init(const WinCtx &w, uint32_t k, u64 wlo) {
+        const u64 km = kh_kmask(k);
+        kmlo = (uint32_t)km;
+        kmhi = (uint32_t)(km >> 32);
+        ins_sh = 2 * k - 2;
+        code = (uint32_t)w.lo64;
+        flo = (uint32_t)(w.lo64 >> 32);  // chunk t-1: bases -16..-1
+        fhi = w.hi;                      // chunk t-2: bases -32..-17
+        const u64 rc = kh_revcomp((((u64)fhi << 32) | flo) & km, k);
+        rlo = (uint32_t)rc;
+        rhi = (uint32_t)(rc >> 32);
+        // G = AND_{i<k} (V >> i): bit (15-j) set iff bases j-k+1..j are all countable
+        u64 g = w.V;
+        uint32_t L = 1;
+#pragma unroll
+        for (uint32_t sft = 1; sft <= 16; sft <<= 1)
+            if (2 * sft <= k) {
+                g &= g >> sft;
+                L = 2 * sft;
+            }
+        if (k > L) g &= g >> (k - L);
+        good = (uint32_t)g & 0xFFFFu;
+        if (w.p0 < wlo) {  // windows ending before wlo belong to an earlier launch
+            const u64 d = wlo - w.p0;
+            good = d >= 16 ? 0u : (good & (0xFFFFu >> d));
+        }
+    }
+
+    __device__ __forceinline__ bool next(int j, u64 &key) {
+        const uint32_t c = (code >> (30 - 2 * j)) & 3u;
+        fhi = __builtin_amdgcn_alignbit(fhi, flo, 30);  // (f << 2) high word
+        flo = (flo << 2) | c;
+        rlo = __builtin_amdgcn_alignbit(rhi, rlo, 2);   // rc >> 2
+        rhi >>= 2;
+        const u64 ins = (u64)(c ^ 3u) << ins_sh;         // complement enters at the top of the 2k bits
+        rlo |= (uint32_t)ins;
+        rhi |= (uint32_t)(ins >> 32);
+        const u64 fwd = ((u64)(fhi & kmhi) << 32) | (flo & kmlo);
+        const u64 rc = ((u64)rhi << 32) | rlo;
+        key = fwd < rc ? fwd : rc;  // integer min == the reference's lexicographic choice (kmer.rs:348-365)
+        return (good >> (15 - j)) & 1u;
+    }
+};
 
 template <bool QUAL>
 __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend,
-    u64 wlo, u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, Slot *table, u64 nregions,
-    Counters *ctr) {
+    u64 wlo, u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, TableGeom tg, Counters *ctr) {
     __shared__ uint32_t s_code[2][BLOCK + 2];
     __shared__ uint16_t s_val[2][BLOCK + 2];
 
@@ -273,13 +360,13 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
     u64 te = tb + tiles_per_block;
     if (te > tile0 + ntiles) te = tile0 + ntiles;
 
-    const u64 kmask = kh_kmask(k);
-    const u64 vmask = valid_mask_of(k);
     uint32_t nk = 0, nd = 0, nf = 0;
 
     int buf = 0;
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
         const WinCtx w = stage_tile<QUAL, BLOCK>(s_code, s_val, buf, t == tb, tid, abase, qbase, qaligned, t, vbeg, vend, thr);
+        Roller roll;
+        roll.init(w, k, wlo);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             u64 key[8];
@@ -288,12 +375,12 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
             u64 cur[8];
             uint32_t ok = 0;
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) ok |= (uint32_t)window_key(w, half * 8 + jj, kmask, vmask, k, wlo, key[jj]) << jj;
+            for (int jj = 0; jj < 8; ++jj) ok |= (uint32_t)roll.next(half * 8 + jj, key[jj]) << jj;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const u64 h = kh_mix64(key[jj]);
-                reg[jj] = table + region_of_hash(h, nregions) * REGION_SLOTS;
-                off[jj] = start_of_hash(h);
+                const u64 H = kh_table_hash(key[jj], k);
+                reg[jj] = tg.table + region_of(tg, H) * REGION_SLOTS;
+                off[jj] = start_of(tg, H);
                 cur[jj] = KH_EMPTY_KEY;
                 if (ok & (1u << jj)) cur[jj] = reg[jj][off[jj]].key;
             }
@@ -371,14 +458,14 @@ __global__ __launch_bounds__(BLOCK) void table_compact_kernel(const Slot *table,
 }
 
 // count[key] += addend for n (key, addend) pairs: rehash-free merge of another table's pairs.
-__global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(Slot *table, u64 nregions, const u64 *keys,
+__global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(TableGeom tg, const u64 *keys,
                                                                   const u64 *counts, u64 n, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
         const u64 c = counts[i];
-        if (key != KH_EMPTY_KEY && c != 0) upsert(table, nregions, key, c, nd, nf);
+        if (key != KH_EMPTY_KEY && c != 0) upsert(tg, key, c, nd, nf);
     }
     u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
     if (lane_id() == 0) {
@@ -388,26 +475,25 @@ __global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(Slot *table, u
 }
 
 // Move every live pair of `old` into `nt` (table growth).
-__global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, Slot *nt, u64 nregions,
+__global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, TableGeom tg,
                                                              Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < oldcap; i += stride) {
         const Slot s = old[i];
-        if (s.key != KH_EMPTY_KEY) upsert(nt, nregions, s.key, s.count, nd, nf);
+        if (s.key != KH_EMPTY_KEY) upsert(tg, s.key, s.count, nd, nf);
     }
     u64 f = wave_sum((u64)nf);
     if (lane_id() == 0 && f) atomicAdd(&ctr->failed, f);
 }
 
-__global__ __launch_bounds__(BLOCK) void table_lookup_kernel(const Slot *table, u64 nregions, const u64 *keys, u64 n,
-                                                             u64 *out) {
+__global__ __launch_bounds__(BLOCK) void table_lookup_kernel(TableGeom tg, const u64 *keys, u64 n, u64 *out) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
-        const u64 h = kh_mix64(key);
-        const Slot *reg = table + region_of_hash(h, nregions) * REGION_SLOTS;
-        uint32_t off = start_of_hash(h);
+        const u64 H = kh_table_hash(key, tg.k);
+        const Slot *reg = tg.table + region_of(tg, H) * REGION_SLOTS;
+        uint32_t off = start_of(tg, H);
         u64 res = 0;
         for (uint32_t probes = 0; probes < REGION_SLOTS; ++probes) {
             const Slot s = reg[off];

@@ -65,6 +65,50 @@ KH_HD uint64_t kh_canonical_bits(uint64_t fwd, uint32_t k) {
     return fwd < rc ? fwd : rc;
 }
 
+// ---- table hash: a BIJECTION on the 2k-bit key space, left-aligned in 64 bits -----------------
+// Four Feistel rounds over the two k-bit halves of the packed k-mer; the round function is a
+// 32-bit multiply + xorshift, keeping its top k bits.  Everything is 32-bit arithmetic (a 64-bit
+// multiply costs four quarter-rate 32-bit multiplies on gfx950, this costs four in total), and
+// being a bijection it lets the partitioned path carry 32-bit payloads instead of 64-bit keys
+// whenever 2k minus the level-1 partition bits fits in 32 (k <= 21 at the headline table size):
+// the bits of H that a partition level has consumed are implied by where the payload is stored,
+// and the key is recovered with kh_unhash_n().  Quality (chi-square of region / in-region start
+// occupancy on genomic, sequential, low-complexity and strided keys) matches splitmix64.
+KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
+    uint32_t t = r * c;
+    t ^= t >> 15;
+    return k < 32 ? (t >> (32 - k)) : t;
+}
+#define KH_FC0 0x9E3779B1u
+#define KH_FC1 0x85EBCA77u
+#define KH_FC2 0xC2B2AE3Du
+#define KH_FC3 0x27D4EB2Fu
+
+KH_HD uint64_t kh_hash_n(uint64_t key, uint32_t k) {
+    const uint32_t mask = k < 32 ? ((1u << k) - 1u) : 0xFFFFFFFFu;
+    uint32_t L = (uint32_t)(k < 32 ? (key >> k) : (key >> 32)) & mask, R = (uint32_t)key & mask, t;
+    t = (L ^ kh_feistel_f(R, KH_FC0, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f(R, KH_FC1, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f(R, KH_FC2, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f(R, KH_FC3, k)) & mask; L = R; R = t;
+    return k < 32 ? (((uint64_t)L << k) | R) : (((uint64_t)L << 32) | R);
+}
+
+KH_HD uint64_t kh_unhash_n(uint64_t h, uint32_t k) {
+    const uint32_t mask = k < 32 ? ((1u << k) - 1u) : 0xFFFFFFFFu;
+    uint32_t L = (uint32_t)(k < 32 ? (h >> k) : (h >> 32)) & mask, R = (uint32_t)h & mask, t;
+    t = (R ^ kh_feistel_f(L, KH_FC3, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_f(L, KH_FC2, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_f(L, KH_FC1, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_f(L, KH_FC0, k)) & mask; R = L; L = t;
+    return k < 32 ? (((uint64_t)L << k) | R) : (((uint64_t)L << 32) | R);
+}
+
+// H: the 2k hash bits left-aligned in 64 bits.  Table placement reads it from the top:
+//   region = H >> (64 - rbits), in-region start = the next REGION_BITS bits.
+KH_HD uint64_t kh_table_hash(uint64_t key, uint32_t k) { return kh_hash_n(key, k) << (64 - 2 * k); }
+KH_HD uint64_t kh_table_unhash(uint64_t H, uint32_t k) { return kh_unhash_n(H >> (64 - 2 * k), k); }
+
 // Owner shard for the multi-GPU key-partitioned merge.  Uses the high half of a re-mixed
 // hash so that it is independent of the table placement bits.
 KH_HD uint32_t kh_owner_of(uint64_t key, uint32_t nparts) {

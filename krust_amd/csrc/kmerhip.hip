@@ -72,9 +72,10 @@ struct kh_ctx {
     bool table_empty = true;   // no insert since creation / reset: regions need not be read back
     bool hinted = false;       // caller gave a capacity hint
     int path_mode = 0;         // 0 auto, 1 force direct, 2 force partitioned
+    int pay_mode = 0;          // 0 auto, 64 = always 64-bit payloads (env KMERHIP_PAYLOAD=64, for A/B)
     u64 part_budget = 0;       // bytes for the two key buffers (0 = decide at first use)
-    u64 *keysA = nullptr, *keysB = nullptr;
-    u64 key_cap = 0;           // entries per key buffer
+    uint8_t *keysA = nullptr, *keysB = nullptr;  // partition ping-pong buffers
+    u64 key_cap = 0;           // bytes per buffer
     uint32_t *H1 = nullptr;
     u64 *O1 = nullptr;
     kh::Part2Block *blocks = nullptr;
@@ -157,10 +158,26 @@ int sync_counters(kh_ctx *c) {
     return KH_OK;
 }
 
-u64 round_cap(double want) {
-    u64 cap = (u64)want;
-    if (cap < MIN_CAP) cap = MIN_CAP;
-    return (cap + kh::REGION_SLOTS - 1) / kh::REGION_SLOTS * kh::REGION_SLOTS;  // whole regions
+u64 round_cap(double want) {  // a power-of-two number of regions (placement takes hash bits from the top)
+    u64 cap = MIN_CAP;
+    while ((double)cap < want) cap *= 2;
+    return cap;
+}
+
+uint32_t region_bits(u64 cap) {
+    uint32_t b = 0;
+    while (((u64)kh::REGION_SLOTS << (b + 1)) <= cap) ++b;  // 64-bit: a 2^32-slot table is legal
+    return b;
+}
+
+kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap);
+
+kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap) {
+    kh::TableGeom tg;
+    tg.table = table;
+    tg.rbits = region_bits(cap);
+    tg.k = c->k;
+    return tg;
 }
 
 int grow_to(kh_ctx *c, u64 newcap) {
@@ -168,7 +185,7 @@ int grow_to(kh_ctx *c, u64 newcap) {
     int rc = alloc_table(c, newcap, &nt);
     if (rc != KH_OK) return rc;
     hipLaunchKernelGGL(kh::table_rehash_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
-                       c->cap, nt, newcap / kh::REGION_SLOTS, c->d_ctr);
+                       c->cap, table_geom(c, nt, newcap), c->d_ctr);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipFree(c->table));
@@ -214,7 +231,7 @@ void launch_count(kh_ctx *c, const uint8_t *abase, const uint8_t *qbase, int qal
         thr = (uint32_t)(t > 255 ? 255 : t);
     }
     hipLaunchKernelGGL(kh::count_direct_kernel<QUAL>, dim3((unsigned)blocks), dim3(kh::BLOCK), 0, c->stream, abase,
-                       qbase, qaligned, vbeg, vend, wlo, tile0, ntiles, tpb, c->k, thr, c->table, c->cap / kh::REGION_SLOTS, c->d_ctr);
+                       qbase, qaligned, vbeg, vend, wlo, tile0, ntiles, tpb, c->k, thr, table_geom(c, c->table, c->cap), c->d_ctr);
 }
 
 // ---- stage timing: HIP events on the launch stream, resolved lazily ---------------------------
@@ -268,14 +285,31 @@ int ensure_buf(kh_ctx *c, T **ptr, u64 *cap, u64 need, const char *what) {
     return KH_OK;
 }
 
-kh::PartGeom make_geom(u64 cap) {
+// Two-level split of the region index.  use32 = the 32-bit payload format applies (the hash bits
+// left after level 1 fit in 32).  ok = false when the table is too large for two levels.
+struct GeomChoice {
     kh::PartGeom g;
-    g.nregions = cap / kh::REGION_SLOTS;
-    uint32_t bits = 0;
-    while (bits < kh::MAX_P2_BITS && (2ull << bits) <= g.nregions) ++bits;
-    g.p2_bits = bits;
-    g.P1 = (uint32_t)((g.nregions + (1ull << bits) - 1) >> bits);
-    return g;
+    bool use32;
+    bool ok;
+};
+
+GeomChoice make_geom(const kh_ctx *c, u64 cap) {
+    GeomChoice gc;
+    const uint32_t rbits = region_bits(cap);
+    uint32_t p2 = std::min<uint32_t>(rbits, kh::MAX_P2_BITS);
+    uint32_t p1 = rbits - p2;
+    const int need = 2 * (int)c->k - 32;  // level-1 bits needed for 32-bit payloads
+    if (need > (int)p1 && need <= (int)kh::MAX_P1_BITS && need <= (int)rbits) {
+        p1 = (uint32_t)need;
+        p2 = rbits - p1;
+    }
+    gc.g.rbits = rbits;
+    gc.g.p1_bits = p1;
+    gc.g.p2_bits = p2;
+    gc.g.k = c->k;
+    gc.ok = p1 <= kh::MAX_P1_BITS && p2 <= kh::MAX_P2_BITS;
+    gc.use32 = (2 * (int)c->k - (int)p1) <= 32 && c->pay_mode != 64;
+    return gc;
 }
 
 // exclusive scan of `in` (n u32 entries) into `out` (n+1 u64 entries) on the context's stream
@@ -303,12 +337,39 @@ uint32_t qual_thr(const kh_ctx *c) {
     return (uint32_t)(t > 255 ? 255 : t);
 }
 
+// region rebuild launch, by payload type
+template <typename PT>
+void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions);
+template <>
+void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions) {
+    const kh::TableGeom tg = table_geom(c, c->table, c->cap);
+    if (c->table_empty)
+        hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+    else
+        hipLaunchKernelGGL(kh::region_count_kernel64<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+}
+template <>
+void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions) {
+    const kh::TableGeom tg = table_geom(c, c->table, c->cap);
+    if (c->table_empty)
+        hipLaunchKernelGGL(kh::region_count_kernel32<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+    else
+        hipLaunchKernelGGL(kh::region_count_kernel32<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+}
+
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
-int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
-    const kh::PartGeom g = make_geom(c->cap);
+// PT = payload type carried through the partition buffers (partition.hip.h).
+template <typename PT>
+int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 tile0, u64 ntiles) {
+    const u64 nregions = 1ull << g.rbits;
+    const u64 P1 = 1ull << g.p1_bits;
     const u64 n_ub = ntiles * kh::PART_TILE;  // upper bound on keys
-    const u64 max_blocks = (n_ub + kh::PART2_CHUNK - 1) / kh::PART2_CHUNK + g.P1;
-    const u64 n1 = (u64)g.P1 * PART_G1;
+    const u64 max_blocks = (n_ub + kh::PART2_CHUNK - 1) / kh::PART2_CHUNK + P1;
+    const u64 n1 = P1 * PART_G1;
     const u64 n2 = max_blocks << g.p2_bits;
     int rc;
     if (!c->H1) {  // fixed-size scratch, allocated once
@@ -331,22 +392,24 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
         if ((rc = ensure_buf(c, &c->O2, &z, n2 + 1, "hipMalloc(O2)")) != KH_OK) return rc;
         c->h2_cap = n2;
     }
-    if (c->region_cap < g.nregions) {
+    if (c->region_cap < nregions) {
         u64 z = c->bstart ? c->region_cap + 1 : 0;
-        if ((rc = ensure_buf(c, &c->bstart, &z, g.nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
+        if ((rc = ensure_buf(c, &c->bstart, &z, nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
         z = c->rfail ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rfail, &z, g.nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
+        if ((rc = ensure_buf(c, &c->rfail, &z, nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
         z = c->rnew ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rnew, &z, g.nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
-        c->region_cap = g.nregions;
+        if ((rc = ensure_buf(c, &c->rnew, &z, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
+        c->region_cap = nregions;
     }
-    if (c->key_cap < n_ub) {
+    const u64 key_bytes = n_ub * sizeof(PT);
+    if (c->key_cap < key_bytes) {  // key_cap is in BYTES per buffer
         u64 z = c->keysA ? c->key_cap : 0;
-        if ((rc = ensure_buf(c, &c->keysA, &z, n_ub, "hipMalloc(keysA)")) != KH_OK) return rc;
+        if ((rc = ensure_buf(c, &c->keysA, &z, key_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
         z = c->keysB ? c->key_cap : 0;
-        if ((rc = ensure_buf(c, &c->keysB, &z, n_ub, "hipMalloc(keysB)")) != KH_OK) return rc;
-        c->key_cap = n_ub;
+        if ((rc = ensure_buf(c, &c->keysB, &z, key_bytes, "hipMalloc(keysB)")) != KH_OK) return rc;
+        c->key_cap = key_bytes;
     }
+    PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);
 
     const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
     const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
@@ -368,11 +431,11 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
     {
         StageTimer t(c, ST_P1_SCATTER);
         if (ra.use_qual)
-            hipLaunchKernelGGL(kh::part1_scatter_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
-                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, c->keysA);
+            hipLaunchKernelGGL((kh::part1_scatter_kernel<true, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
+                               ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
         else
-            hipLaunchKernelGGL(kh::part1_scatter_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
-                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, c->keysA);
+            hipLaunchKernelGGL((kh::part1_scatter_kernel<false, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
+                               ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
     }
     {
         StageTimer t(c, ST_MISC);
@@ -382,7 +445,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
     }
     {
         StageTimer t(c, ST_P2_COUNT);
-        hipLaunchKernelGGL(kh::part2_count_kernel, dim3((unsigned)max_blocks), b1, 0, c->stream, (const u64 *)c->keysA,
+        hipLaunchKernelGGL(kh::part2_count_kernel<PT>, dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA,
                            (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2);
     }
     {
@@ -391,28 +454,23 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
     }
     {
         StageTimer t(c, ST_P2_SCATTER);
-        hipLaunchKernelGGL(kh::part2_scatter_kernel, dim3((unsigned)max_blocks), b1, 0, c->stream, (const u64 *)c->keysA,
-                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, c->keysB);
+        hipLaunchKernelGGL(kh::part2_scatter_kernel<PT>, dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream, (const PT *)bufA,
+                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
     }
     {
         StageTimer t(c, ST_MISC);
-        hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((g.nregions + 256) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((nregions + 256) / 256)), dim3(256), 0, c->stream,
                            (const u64 *)c->O2, (const u64 *)c->moff, (const uint32_t *)c->nch, (const u64 *)c->info, g, c->bstart);
-        HIP_TRY(c, hipMemsetAsync(c->rfail, 0, g.nregions, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
     }
     {
         StageTimer t(c, ST_REGION);
-        if (c->table_empty)
-            hipLaunchKernelGGL(kh::region_count_kernel<true>, dim3((unsigned)g.nregions), dim3(kh::REGION_NT), 0, c->stream,
-                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
-        else
-            hipLaunchKernelGGL(kh::region_count_kernel<false>, dim3((unsigned)g.nregions), dim3(kh::REGION_NT), 0, c->stream,
-                               c->table, (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+        launch_region<PT>(c, g, nregions);
     }
     {
         StageTimer t(c, ST_MISC);
-        hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(g.nregions)), dim3(kh::BLOCK), 0, c->stream,
-                           (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)g.nregions, c->d_ctr);
+        hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
+                           (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)nregions, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
@@ -423,15 +481,14 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
     if (c->h_ctr->part_failed) {
-        // some regions overflowed: they were left untouched; grow, then insert their buckets directly
-        const u64 old_regions = g.nregions;
-        // worst case every key of a failed bucket is new: size the grown table for that
-        std::vector<uint8_t> hf(old_regions);
-        std::vector<u64> hb(old_regions + 1);
-        HIP_TRY(c, hipMemcpy(hf.data(), c->rfail, old_regions, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(hb.data(), c->bstart, (old_regions + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+        // some regions overflowed: they were left untouched; grow, then insert their buckets directly.
+        // Worst case every key of a failed bucket is new: size the grown table for that.
+        std::vector<uint8_t> hf(nregions);
+        std::vector<u64> hb(nregions + 1);
+        HIP_TRY(c, hipMemcpy(hf.data(), c->rfail, nregions, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(hb.data(), c->bstart, (nregions + 1) * sizeof(u64), hipMemcpyDeviceToHost));
         u64 failed_keys = 0;
-        for (u64 r = 0; r < old_regions; ++r)
+        for (u64 r = 0; r < nregions; ++r)
             if (hf[r]) failed_keys += hb[r + 1] - hb[r];
         u64 newcap = c->cap * 2;
         while ((double)(c->distinct_known + failed_keys) > LOAD_HARD * (double)newcap ||
@@ -444,8 +501,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, u64 tile0, u64 ntiles) {
             StageTimer t(c, ST_GROW);
             rc = grow_to(c, newcap);
             if (rc != KH_OK) return rc;
-            hipLaunchKernelGGL(kh::failed_buckets_insert_kernel, dim3((unsigned)old_regions), dim3(kh::BLOCK), 0, c->stream,
-                               c->table, c->cap / kh::REGION_SLOTS, (const u64 *)c->keysB, (const u64 *)c->bstart,
+            hipLaunchKernelGGL(kh::failed_buckets_insert_kernel<PT>, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                               table_geom(c, c->table, c->cap), g, (const PT *)bufB, (const u64 *)c->bstart,
                                (const uint8_t *)c->rfail, c->d_ctr);
             HIP_TRY(c, hipMemsetAsync(&c->d_ctr->part_failed, 0, sizeof(u64), c->stream));
         }
@@ -526,7 +583,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
             c->cap = newcap;
         }
     }
-    if (part && make_geom(c->cap).P1 > kh::MAX_P1) part = false;  // table beyond 2 levels of partitioning
+    if (part && !make_geom(c, c->cap).ok) part = false;  // table beyond 2 levels of partitioning
 
     if (!part) return direct_range(c, ra, ra.wlo / kh::TILE, (ra.vend + kh::TILE - 1) / kh::TILE);
 
@@ -537,20 +594,25 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     if (!c->part_budget) {
         size_t fr = 0, tot = 0;
         u64 budget = 160ull << 30;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap * 16) * 0.75));
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap * 2) * 0.75));
         const char *e = getenv("KMERHIP_PART_BUDGET_GB");
         if (e && atof(e) > 0) budget = (u64)(atof(e) * (double)(1ull << 30));
         c->part_budget = std::max<u64>(budget, 64ull << 20);
     }
     const u64 first_tile = ra.wlo / kh::PART_TILE;
     const u64 end_tile = (ra.vend + kh::PART_TILE - 1) / kh::PART_TILE;
-    const u64 total_tiles = end_tile - first_tile;
-    u64 batch_tiles = std::max<u64>(1, c->part_budget / 16 / kh::PART_TILE);
-    const u64 nb = (total_tiles + batch_tiles - 1) / batch_tiles;  // equal-sized batches
-    batch_tiles = (total_tiles + nb - 1) / nb;
-    for (u64 t = first_tile; t < end_tile; t += batch_tiles) {
-        int rc = partition_batch(c, ra, t, std::min(batch_tiles, end_tile - t));
+    for (u64 t = first_tile; t < end_tile;) {
+        const GeomChoice gc = make_geom(c, c->cap);  // re-evaluated per batch: the table may have grown
+        if (!gc.ok) return direct_range(c, ra, t * (kh::PART_TILE / kh::TILE), (ra.vend + kh::TILE - 1) / kh::TILE);
+        const u64 per_key = gc.use32 ? 8 : 16;  // two buffers
+        u64 batch_tiles = std::max<u64>(1, c->part_budget / per_key / kh::PART_TILE);
+        const u64 left = end_tile - t;
+        const u64 nb = (left + batch_tiles - 1) / batch_tiles;  // equal-sized batches
+        batch_tiles = (left + nb - 1) / nb;
+        const u64 nt = std::min(batch_tiles, left);
+        int rc = gc.use32 ? partition_batch<uint32_t>(c, ra, gc.g, t, nt) : partition_batch<u64>(c, ra, gc.g, t, nt);
         if (rc != KH_OK) return rc;
+        t += nt;
     }
     return KH_OK;
 }
@@ -607,6 +669,7 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
         if (!strcmp(pm, "direct")) c->path_mode = 1;
         else if (!strcmp(pm, "partition")) c->path_mode = 2;
     }
+    if (const char *py = getenv("KMERHIP_PAYLOAD")) c->pay_mode = atoi(py);
 
     int rc = KH_OK;
     do {
@@ -620,7 +683,7 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
         if (hipMalloc((void **)&c->d_ctr, sizeof(Counters)) != hipSuccess) { rc = KH_ERR_OOM; break; }
         if (hipHostMalloc((void **)&c->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) { rc = KH_ERR_OOM; break; }
         if (hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream) != hipSuccess) { rc = KH_ERR_HIP; break; }
-        u64 cap = cfg->capacity_hint ? round_cap((double)cfg->capacity_hint / 0.6) : DEFAULT_CAP;
+        u64 cap = cfg->capacity_hint ? round_cap((double)cfg->capacity_hint / 0.65) : DEFAULT_CAP;
         rc = alloc_table(c, cap, &c->table);
         if (rc != KH_OK) break;
         c->cap = cap;
@@ -911,8 +974,8 @@ extern "C" int kh_lookup(kh_ctx *c, const uint64_t *keys, uint64_t n, uint64_t *
     }
     hipError_t e = hipMemcpyAsync(dk, keys, n * sizeof(u64), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(kh::table_lookup_kernel, dim3(grid_for(n)), dim3(kh::BLOCK), 0, c->stream, c->table,
-                           c->cap / kh::REGION_SLOTS, dk, (u64)n, dc);
+        hipLaunchKernelGGL(kh::table_lookup_kernel, dim3(grid_for(n)), dim3(kh::BLOCK), 0, c->stream,
+                           table_geom(c, c->table, c->cap), dk, (u64)n, dc);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(counts, dc, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
@@ -989,8 +1052,8 @@ extern "C" int kh_merge_pairs_device(kh_ctx *c, const uint64_t *d_keys, const ui
         bool smaller = false;
         rc = ensure_room(c, m, false, &smaller);
         if (rc != KH_OK) return rc;
-        hipLaunchKernelGGL(kh::table_merge_pairs_kernel, dim3(grid_for(m)), dim3(kh::BLOCK), 0, c->stream, c->table,
-                           c->cap / kh::REGION_SLOTS, (const u64 *)d_keys + off, (const u64 *)d_counts + off, m, c->d_ctr);
+        hipLaunchKernelGGL(kh::table_merge_pairs_kernel, dim3(grid_for(m)), dim3(kh::BLOCK), 0, c->stream,
+                           table_geom(c, c->table, c->cap), (const u64 *)d_keys + off, (const u64 *)d_counts + off, m, c->d_ctr);
         HIP_TRY(c, hipGetLastError());
         c->table_empty = false;
         c->pending_bound += m;

@@ -2,11 +2,18 @@
 //
 // The direct path (count_direct_kernel) issues one memory-side atomic per k-mer and saturates the
 // chip's atomic request rate (~18.5 G/s measured, profiles/r01a).  This path issues NO global
-// atomics per k-mer: canonical keys are radix-partitioned by the high bits of their table hash in
-// two levels (level 1: P1 <= 1024 partitions straight from the bases; level 2: P2 <= 1024 buckets
-// inside each level-1 partition), so that every bucket holds exactly the keys of ONE table region
-// (kernels.hip.h: 4096 slots = 64 KiB).  One workgroup then rebuilds each region in LDS with LDS
-// atomics and writes it back with coalesced 16-byte stores.
+// atomics per k-mer: canonical keys are radix-partitioned by the top bits of their table hash H in
+// two levels (level 1: 2^p1_bits <= 1024 partitions straight from the bases; level 2: 2^p2_bits
+// <= 1024 buckets inside each level-1 partition), so that every bucket holds exactly the keys of
+// ONE table region (kernels.hip.h: 4096 slots = 64 KiB).  One workgroup then rebuilds each region
+// in LDS with LDS atomics and writes it back with coalesced 16-byte stores.
+//
+// Two payload formats travel through the partition buffers (template parameter PT):
+//   u64       the canonical key itself; partition digits are recomputed from its hash.  Any k.
+//   uint32_t  bits [p1_bits, p1_bits+32) of H.  Because the table hash is a bijection on 2k bits
+//             and level 1 has already consumed the top p1_bits, these 32 bits identify the key
+//             whenever 2k - p1_bits <= 32 (k <= 21 with 1024 level-1 partitions).  Halves the
+//             HBM traffic of every stage after the extraction.
 //
 // Both partition levels are "count, scan, scatter" with deterministic offsets (no global cursor
 // atomics): workgroup b owns a fixed contiguous range of its input, the count pass writes its
@@ -24,27 +31,56 @@ namespace kh {
 constexpr int PART_NT = 1024;                    // lanes per workgroup in the partition kernels
 constexpr int PART_TILE = PART_NT * CHUNK;       // 16384 positions / keys per batch
 constexpr uint32_t MAX_P1 = 1024;
-constexpr uint32_t MAX_P2_BITS = 10;             // P2 <= 1024 regions per level-1 partition
-constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // keys per level-2 workgroup (262144)
+constexpr uint32_t MAX_P1_BITS = 10;
+constexpr uint32_t MAX_P2_BITS = 10;             // <= 1024 regions per level-1 partition
+constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // payloads per level-2 workgroup (262144)
 constexpr int REGION_NT = 1024;                  // lanes per workgroup in region_count_kernel
 constexpr int REGION_RK = 8;                     // keys prefetched per lane per round
 
 struct PartGeom {
-    u64 nregions;      // R
-    uint32_t p2_bits;  // P2 = 1 << p2_bits
-    uint32_t P1;       // ceil(R / P2)
+    uint32_t rbits;    // log2(regions) = p1_bits + p2_bits
+    uint32_t p1_bits;  // level-1 partitions = 1 << p1_bits
+    uint32_t p2_bits;  // buckets per level-1 partition = 1 << p2_bits
+    uint32_t k;
 };
 
-__device__ __forceinline__ uint32_t p1_of_key(u64 key, const PartGeom &g) {
-    return (uint32_t)(region_of_hash(kh_mix64(key), g.nregions) >> g.p2_bits);
-}
-__device__ __forceinline__ uint32_t p2_of_key(u64 key, const PartGeom &g) {
-    return (uint32_t)region_of_hash(kh_mix64(key), g.nregions) & ((1u << g.p2_bits) - 1u);
+// ---- payload traits ---------------------------------------------------------------------------
+template <typename PT>
+struct Pay;
+
+template <>
+struct Pay<u64> {  // the key itself
+    __device__ static __forceinline__ u64 make(u64 key, u64 H, const PartGeom &g) { return key; }
+    __device__ static __forceinline__ uint32_t p2(u64 pay, const PartGeom &g) {
+        const u64 H = kh_table_hash(pay, g.k);
+        return g.p2_bits ? (uint32_t)((H << g.p1_bits) >> (64 - g.p2_bits)) : 0u;
+    }
+    __device__ static __forceinline__ u64 key(u64 pay, uint32_t p1, const PartGeom &g) { return pay; }
+};
+
+template <>
+struct Pay<uint32_t> {  // bits [p1_bits, p1_bits+32) of H
+    __device__ static __forceinline__ uint32_t make(u64 key, u64 H, const PartGeom &g) { return (uint32_t)((H << g.p1_bits) >> 32); }
+    __device__ static __forceinline__ uint32_t p2(uint32_t pay, const PartGeom &g) {
+        return g.p2_bits ? (pay >> (32 - g.p2_bits)) : 0u;
+    }
+    __device__ static __forceinline__ u64 hash(uint32_t pay, uint32_t p1, const PartGeom &g) {
+        const u64 top = g.p1_bits ? ((u64)p1 << (64 - g.p1_bits)) : 0ull;
+        return top | ((u64)pay << (32 - g.p1_bits));
+    }
+    __device__ static __forceinline__ u64 key(uint32_t pay, uint32_t p1, const PartGeom &g) {
+        return kh_table_unhash(hash(pay, p1, g), g.k);
+    }
+};
+
+__device__ __forceinline__ uint32_t p1_of_hash(u64 H, const PartGeom &g) {
+    return g.p1_bits ? (uint32_t)(H >> (64 - g.p1_bits)) : 0u;
 }
 
 // Exclusive scan of s_cnt[0..1024) into s_lofs[0..1024) by a workgroup of >= 256 lanes.
 // s_wsum: 4 words of scratch.  Ends with a barrier.
-__device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt, uint32_t *s_lofs, uint32_t *s_wsum,
+template <typename LT>
+__device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt, LT *s_lofs, uint32_t *s_wsum,
                                                           int tid) {
     uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, incl = 0;
     if (tid < 256) {
@@ -65,10 +101,10 @@ __device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt,
         uint32_t base = 0;
         for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
         const uint32_t excl = base + incl - (v0 + v1 + v2 + v3);
-        s_lofs[4 * tid] = excl;
-        s_lofs[4 * tid + 1] = excl + v0;
-        s_lofs[4 * tid + 2] = excl + v0 + v1;
-        s_lofs[4 * tid + 3] = excl + v0 + v1 + v2;
+        s_lofs[4 * tid] = (LT)excl;
+        s_lofs[4 * tid + 1] = (LT)(excl + v0);
+        s_lofs[4 * tid + 2] = (LT)(excl + v0 + v1);
+        s_lofs[4 * tid + 3] = (LT)(excl + v0 + v1 + v2);
     }
     __syncthreads();
 }
@@ -89,55 +125,64 @@ __global__ __launch_bounds__(PART_NT) void part1_count_kernel(
     const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
     u64 te = tb + tiles_per_block;
     if (te > tile0 + ntiles) te = tile0 + ntiles;
-    const u64 kmask = kh_kmask(k), vmask = valid_mask_of(k);
     int buf = 0;
     __syncthreads();
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
         const WinCtx w = stage_tile<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, abase, qbase, qaligned, t, vbeg, vend, thr);
+        Roller roll;
+        roll.init(w, k, wlo);
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
             u64 key;
-            if (window_key(w, j, kmask, vmask, k, wlo, key)) atomicAdd(&s_hist[p1_of_key(key, g)], 1u);
+            if (roll.next(j, key)) atomicAdd(&s_hist[p1_of_hash(kh_table_hash(key, k), g)], 1u);
         }
     }
     __syncthreads();
-    if ((uint32_t)tid < g.P1) H1[(u64)tid * gridDim.x + blockIdx.x] = s_hist[tid];
+    if (tid < (1 << g.p1_bits)) H1[(u64)tid * gridDim.x + blockIdx.x] = s_hist[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 1, pass B: scatter keys into level-1 partitions.  O1 = exclusive scan of H1 (flattened).
+// level 1, pass B: scatter payloads into level-1 partitions.  O1 = exclusive scan of H1.
 // ---------------------------------------------------------------------------------------------
-template <bool QUAL>
+template <bool QUAL, typename PT>
 __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
     u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g,
-    const u64 *__restrict__ O1, u64 *__restrict__ out) {
+    const u64 *__restrict__ O1, PT *__restrict__ out) {
+    // u64: 8 KiB + 4 KiB + 128 KiB + 4 + 4 + 8 KiB; the partition id of a staged u64 payload (= key)
+    // is recomputed from its hash, a staged u32 payload has lost those bits and carries a 2-byte id.
+    constexpr bool WITH_PID = sizeof(PT) == 4;
     __shared__ uint32_t s_code[2][PART_NT + 2];
     __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ u64 s_stage[PART_TILE];  // 128 KiB
+    __shared__ PT s_stage[PART_TILE];
+    __shared__ uint16_t s_pid[WITH_PID ? PART_TILE : 1];
     __shared__ uint32_t s_cnt[MAX_P1];
     __shared__ uint32_t s_lofs[MAX_P1];
     __shared__ u64 s_gcur[MAX_P1];
     __shared__ uint32_t s_wsum[4];
     const int tid = threadIdx.x;
     s_cnt[tid] = 0;
-    s_gcur[tid] = ((uint32_t)tid < g.P1) ? O1[(u64)tid * gridDim.x + blockIdx.x] : 0;
+    s_gcur[tid] = (tid < (1 << g.p1_bits)) ? O1[(u64)tid * gridDim.x + blockIdx.x] : 0;
     const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
     u64 te = tb + tiles_per_block;
     if (te > tile0 + ntiles) te = tile0 + ntiles;
-    const u64 kmask = kh_kmask(k), vmask = valid_mask_of(k);
     int buf = 0;
     __syncthreads();
     RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
         const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
-        u64 key[CHUNK];
+        PT pay[CHUNK];
         uint32_t tag[CHUNK];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
+        Roller roll;
+        roll.init(w, k, wlo);
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
             tag[j] = 0xFFFFFFFFu;
-            if (window_key(w, j, kmask, vmask, k, wlo, key[j])) {
-                const uint32_t p = p1_of_key(key[j], g);
+            u64 key;
+            if (roll.next(j, key)) {
+                const u64 H = kh_table_hash(key, k);
+                const uint32_t p = p1_of_hash(H, g);
+                pay[j] = Pay<PT>::make(key, H, g);
                 tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);  // rank < 16384 fits 16 bits
             }
         }
@@ -145,15 +190,22 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) s_stage[s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = key[j];
+            if (tag[j] != 0xFFFFFFFFu) {
+                const uint32_t slot = s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu);
+                s_stage[slot] = pay[j];
+                if (WITH_PID) s_pid[slot] = (uint16_t)(tag[j] >> 16);
+            }
         __syncthreads();
         // next tile's bases are fetched while this tile's runs are written out
         raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
         const uint32_t total = s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
+#pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART_NT) {
-            const u64 kk = s_stage[i];
-            const uint32_t p = p1_of_key(kk, g);
-            out[s_gcur[p] + (i - s_lofs[p])] = kk;  // consecutive lanes -> consecutive addresses inside a run
+            const PT v = s_stage[i];
+            uint32_t p;
+            if (WITH_PID) p = s_pid[i];
+            else p = p1_of_hash(kh_table_hash((u64)v, k), g);
+            out[s_gcur[p] + (i - s_lofs[p])] = v;  // consecutive lanes -> consecutive addresses inside a run
         }
         __syncthreads();
         s_gcur[tid] += s_cnt[tid];
@@ -166,12 +218,11 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
 // level 2 work list: one workgroup per PART2_CHUNK keys of a level-1 partition
 // ---------------------------------------------------------------------------------------------
 struct Part2Block {
-    u64 lo, hi;        // key range in the level-1 output
+    u64 lo, hi;        // payload range in the level-1 output
     u64 mbase;         // H2/O2 index of (p2 = 0, this chunk)
     uint32_t mstride;  // chunks in this partition: H2 index of p2 is mbase + p2 * mstride
     uint32_t p1;
 };
-
 
 // ---------------------------------------------------------------------------------------------
 // generic exclusive scan u32 -> u64 (three small kernels)
@@ -267,22 +318,23 @@ __global__ __launch_bounds__(1024) void part2_plan_kernel(const u64 *__restrict_
     __shared__ u64 s_seg[MAX_P1 + 1];
     __shared__ u64 s_bbase[MAX_P1 + 1];
     const int tid = threadIdx.x;
-    if ((uint32_t)tid < g.P1) s_seg[tid] = O1[(u64)tid * o1_stride];
-    if (tid == 0) s_seg[g.P1] = O1[o1_total_index];
+    const int P1 = 1 << g.p1_bits;
+    if (tid < P1) s_seg[tid] = O1[(u64)tid * o1_stride];
+    if (tid == 0) s_seg[P1] = O1[o1_total_index];
     __syncthreads();
     if (tid == 0) {  // P1 <= 1024: a serial prefix is cheap
         u64 b = 0;
-        for (uint32_t p = 0; p < g.P1; ++p) {
+        for (int p = 0; p < P1; ++p) {
             s_bbase[p] = b;
             b += (s_seg[p + 1] - s_seg[p] + PART2_CHUNK - 1) / PART2_CHUNK;
         }
-        s_bbase[g.P1] = b;
+        s_bbase[P1] = b;
         info[0] = b;
         info[1] = b << g.p2_bits;
-        info[2] = s_seg[g.P1];
+        info[2] = s_seg[P1];
     }
     __syncthreads();
-    if ((uint32_t)tid < g.P1) {
+    if (tid < P1) {
         const u64 lo = s_seg[tid], hi = s_seg[tid + 1];
         const u64 b0 = s_bbase[tid];
         const uint32_t n = (uint32_t)(s_bbase[tid + 1] - b0);
@@ -304,7 +356,8 @@ __global__ __launch_bounds__(1024) void part2_plan_kernel(const u64 *__restrict_
 // ---------------------------------------------------------------------------------------------
 // level 2, pass A: histogram of bucket ids (p2) per workgroup.  H2 must be zero-filled.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PART_NT) void part2_count_kernel(const u64 *__restrict__ keys, const Part2Block *__restrict__ blocks,
+template <typename PT>
+__global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restrict__ pays, const Part2Block *__restrict__ blocks,
                                                               const u64 *__restrict__ info, PartGeom g,
                                                               uint32_t *__restrict__ H2) {
     __shared__ uint32_t s_hist[1u << MAX_P2_BITS];
@@ -313,42 +366,60 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const u64 *__restr
     const int tid = threadIdx.x;
     s_hist[tid] = 0;  // PART_NT == 1 << MAX_P2_BITS
     __syncthreads();
-    for (u64 i = pb.lo + tid; i < pb.hi; i += PART_NT) atomicAdd(&s_hist[p2_of_key(keys[i], g)], 1u);
+    for (u64 i = pb.lo + tid; i < pb.hi; i += PART_NT) atomicAdd(&s_hist[Pay<PT>::p2(pays[i], g)], 1u);
     __syncthreads();
-    if ((uint32_t)tid < (1u << g.p2_bits)) H2[pb.mbase + (u64)tid * pb.mstride] = s_hist[tid];
+    if (tid < (1 << g.p2_bits)) H2[pb.mbase + (u64)tid * pb.mstride] = s_hist[tid];
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 2, pass B: scatter into buckets (one bucket == one table region)
+// level 2, pass B: scatter into buckets (one bucket == one table region).
+// 512 lanes x 16 payloads = 8192 per batch: LDS 44 KiB (u32) / 78 KiB (u64) so that two or three
+// workgroups share a CU and one's write-out overlaps another's counting sort; 512-lane workgroups
+// also lift the 128-VGPR ceiling of 1024-lane ones (the 1024-lane version spilled).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PART_NT) void part2_scatter_kernel(const u64 *__restrict__ keys, const Part2Block *__restrict__ blocks,
-                                                                const u64 *__restrict__ info, PartGeom g,
-                                                                const u64 *__restrict__ O2, u64 *__restrict__ out) {
-    __shared__ u64 s_stage[PART_TILE];  // 128 KiB
-    __shared__ uint32_t s_cnt[MAX_P1];  // only the first P2 entries are used; sized for the shared scan
-    __shared__ uint32_t s_lofs[MAX_P1];
-    __shared__ u64 s_gcur[1u << MAX_P2_BITS];
+constexpr int PART2_NT = 512;
+constexpr int PART2_TILE = PART2_NT * CHUNK;  // 8192
+
+template <typename PT>
+__global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__restrict__ pays, const Part2Block *__restrict__ blocks,
+                                                                 const u64 *__restrict__ info, PartGeom g,
+                                                                 const u64 *__restrict__ O2, PT *__restrict__ out) {
+    __shared__ PT s_stage[PART2_TILE];   // 32 KiB (u32) / 64 KiB (u64)
+    __shared__ uint32_t s_cnt[MAX_P1];   // sized for the shared 1024-entry scan
+    __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< 8192)
+    __shared__ u64 s_dst[1u << MAX_P2_BITS];  // global position of run p minus its batch-local start
     __shared__ uint32_t s_wsum[4];
     if ((u64)blockIdx.x >= info[0]) return;
     const Part2Block pb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
-    const uint32_t P2 = 1u << g.p2_bits;
+    const int P2 = 1 << g.p2_bits;
+    // lane tid owns buckets tid and tid + 512: their running output cursors live in registers
+    u64 gcur0 = 0, gcur1 = 0;
     s_cnt[tid] = 0;
-    if ((uint32_t)tid < P2) s_gcur[tid] = O2[pb.mbase + (u64)tid * pb.mstride];
+    s_cnt[tid + PART2_NT] = 0;
+    if (tid < P2) gcur0 = O2[pb.mbase + (u64)tid * pb.mstride];
+    if (tid + PART2_NT < P2) gcur1 = O2[pb.mbase + (u64)(tid + PART2_NT) * pb.mstride];
     __syncthreads();
-    u64 key[CHUNK];
+    // Branch-free loads: indices are block-relative 32-bit, clamped to the last valid payload (the
+    // block is never empty), validity is a bit mask.  (Conditional loads made the compiler carry
+    // sixteen 64-bit addresses and their phi copies through the loop: 219 VGPRs.)
+    const PT *__restrict__ src = pays + pb.lo;
+    const uint32_t n = (uint32_t)(pb.hi - pb.lo);
+    PT pay[CHUNK];
+    uint32_t have = 0;  // bit j: pay[j] holds a payload
 #pragma unroll
-    for (int j = 0; j < CHUNK; ++j) {  // lane-contiguous: coalesced 8-byte loads
-        const u64 i = pb.lo + (u64)j * PART_NT + tid;
-        key[j] = i < pb.hi ? keys[i] : KH_EMPTY_KEY;
+    for (int j = 0; j < CHUNK; ++j) {  // lane-contiguous: coalesced loads
+        const uint32_t i = (uint32_t)j * PART2_NT + tid;
+        pay[j] = src[i < n ? i : n - 1];
+        have |= (uint32_t)(i < n) << j;
     }
-    for (u64 base = pb.lo; base < pb.hi; base += PART_TILE) {
+    for (uint32_t base = 0; base < n; base += PART2_TILE) {
         uint32_t tag[CHUNK];
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
             tag[j] = 0xFFFFFFFFu;
-            if (key[j] != KH_EMPTY_KEY) {
-                const uint32_t p = p2_of_key(key[j], g);
+            if (have & (1u << j)) {
+                const uint32_t p = Pay<PT>::p2(pay[j], g);
                 tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);
             }
         }
@@ -356,34 +427,43 @@ __global__ __launch_bounds__(PART_NT) void part2_scatter_kernel(const u64 *__res
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) s_stage[s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = key[j];
+            if (tag[j] != 0xFFFFFFFFu) s_stage[(uint32_t)s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = pay[j];
+        {  // publish run destinations, advance the cursors
+            const uint32_t c0 = s_cnt[tid], c1 = s_cnt[tid + PART2_NT];
+            s_dst[tid] = gcur0 - s_lofs[tid];
+            s_dst[tid + PART2_NT] = gcur1 - s_lofs[tid + PART2_NT];
+            gcur0 += c0;
+            gcur1 += c1;
+        }
+        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
         __syncthreads();
-        // next batch's keys are fetched while this batch's runs are written out
+        s_cnt[tid] = 0;
+        s_cnt[tid + PART2_NT] = 0;
+        // next batch's payloads are fetched while this batch's runs are written out
+        have = 0;
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
-            const u64 i = base + PART_TILE + (u64)j * PART_NT + tid;
-            key[j] = i < pb.hi ? keys[i] : KH_EMPTY_KEY;
+            const uint32_t i = base + PART2_TILE + (uint32_t)j * PART2_NT + tid;
+            pay[j] = src[i < n ? i : n - 1];
+            have |= (uint32_t)(i < n) << j;
         }
-        const uint32_t total = s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
-        for (uint32_t i = tid; i < total; i += PART_NT) {
-            const u64 kk = s_stage[i];
-            const uint32_t p = p2_of_key(kk, g);
-            out[s_gcur[p] + (i - s_lofs[p])] = kk;
+#pragma unroll 2
+        for (uint32_t i = tid; i < total; i += PART2_NT) {
+            const PT v = s_stage[i];
+            out[s_dst[Pay<PT>::p2(v, g)] + i] = v;  // consecutive lanes -> consecutive addresses inside a run
         }
-        __syncthreads();
-        if ((uint32_t)tid < P2) s_gcur[tid] += s_cnt[tid];
-        s_cnt[tid] = 0;
         __syncthreads();
     }
 }
 
-// bstart[r] = first key of region r's bucket in the level-2 output, r in [0, R]; bstart[R] = total
+// bstart[r] = first payload of region r's bucket in the level-2 output, r in [0, R]; bstart[R] = total
 __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restrict__ O2, const u64 *__restrict__ moff,
                                                             const uint32_t *__restrict__ nch, const u64 *__restrict__ info,
                                                             PartGeom g, u64 *__restrict__ bstart) {
+    const u64 nregions = 1ull << g.rbits;
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (r > g.nregions) return;
-    if (r == g.nregions) {
+    if (r > nregions) return;
+    if (r == nregions) {
         bstart[r] = info[2];
         return;
     }
@@ -396,16 +476,20 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restric
 // ---------------------------------------------------------------------------------------------
 // region rebuild: one workgroup per table region, table image in LDS, no global atomics
 // ---------------------------------------------------------------------------------------------
-// FRESH: the table is known to be empty (skip the 128 KiB read).  A region that overflows is left
+// FRESH: the table is known to be empty (skip the 64 KiB read).  A region that overflows is left
 // untouched in HBM and flagged; the host re-inserts its bucket after growing the table.
+// No global atomics here: a million workgroups adding to one counter word serialise at the memory
+// side (measured: ~6 ns per same-address atomic, >100 ms per pass).  Per-region results go to
+// rnew[]/rfail[] and region_reduce_kernel folds them afterwards.
+//
+// u64 payloads (= keys): LDS image is structure-of-arrays {key[], count[]}, 64 KiB, so that 8-byte
+// key probes spread over all 64 banks.
 template <bool FRESH>
-__global__ __launch_bounds__(REGION_NT) void region_count_kernel(Slot *__restrict__ table, const u64 *__restrict__ keys,
-                                                                 const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
-                                                                 uint32_t *__restrict__ rnew) {
-    // LDS image is structure-of-arrays: 8-byte key probes then spread over all 64 banks instead of
-    // the 16 bank pairs a 16-byte-slot layout would hit.
-    __shared__ u64 s_key[REGION_SLOTS];  // 32 KiB
-    __shared__ u64 s_cnt[REGION_SLOTS];  // 32 KiB
+__global__ __launch_bounds__(REGION_NT) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys,
+                                                                   const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
+                                                                   uint32_t *__restrict__ rnew) {
+    __shared__ u64 s_key[REGION_SLOTS];
+    __shared__ u64 s_cnt[REGION_SLOTS];
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
     const int tid = threadIdx.x;
@@ -415,12 +499,17 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel(Slot *__restric
         if (tid == 0) rnew[r] = 0;
         return;
     }
-    Slot *reg = table + r * REGION_SLOTS;
+    Slot *reg = tg.table + r * REGION_SLOTS;
+    // branch-free loads: bucket-relative index clamped to the last valid key, validity folded into the
+    // EMPTY marker (buckets of >= 2^32 keys take the 64-bit index path below through `n` saturation)
+    const u64 *__restrict__ src = keys + lo;
+    const u64 n = hi - lo;
     u64 kbuf[REGION_RK];  // first round of keys: in flight while the region image is loaded
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {
-        const u64 i = lo + (u64)j * REGION_NT + tid;
-        kbuf[j] = i < hi ? keys[i] : KH_EMPTY_KEY;
+        const u64 i = (u64)j * REGION_NT + tid;
+        const u64 v = src[i < n ? i : n - 1];
+        kbuf[j] = i < n ? v : KH_EMPTY_KEY;
     }
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
 #pragma unroll
@@ -440,18 +529,19 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel(Slot *__restric
     }
     __syncthreads();
     uint32_t nd = 0;
-    for (u64 base = lo; base < hi; base += (u64)REGION_RK * REGION_NT) {
+    for (u64 base = 0; base < n; base += (u64)REGION_RK * REGION_NT) {
         u64 nbuf[REGION_RK];
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) {  // next round's keys in flight while this round is inserted
             const u64 i = base + (u64)(REGION_RK + j) * REGION_NT + tid;
-            nbuf[j] = i < hi ? keys[i] : KH_EMPTY_KEY;
+            const u64 v = src[i < n ? i : n - 1];
+            nbuf[j] = i < n ? v : KH_EMPTY_KEY;
         }
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) {
             const u64 key = kbuf[j];
             if (key == KH_EMPTY_KEY) continue;
-            uint32_t off = start_of_hash(kh_mix64(key));
+            uint32_t off = start_of(tg, kh_table_hash(key, tg.k));
             uint32_t probes = 0;
             for (; probes < REGION_SLOTS; ++probes) {
                 u64 cur = s_key[off];
@@ -473,9 +563,6 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel(Slot *__restric
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) kbuf[j] = nbuf[j];
     }
-    // No global atomics here: a million workgroups adding to one counter word serialise at the
-    // memory side (measured: ~6 ns per same-address atomic, i.e. >100 ms per pass).  Per-region
-    // results go to rnew[]/rfail[] and region_reduce_kernel folds them afterwards.
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);  // LDS
     __syncthreads();
@@ -490,6 +577,196 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel(Slot *__restric
 #pragma unroll
     for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) {
         const u64 kk = s_key[i], cc = s_cnt[i];
+        o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
+    }
+    if (tid == 0) rnew[r] = s_new;
+}
+
+// uint32_t payloads: the LDS image is two 32-bit arrays, s_pay[] (0xFFFFFFFF = free) and s_add[] (count
+// added by this batch), 32 KiB per region.  Probing reads FOUR consecutive payload slots with one
+// ds_read_b128 (linear probing order is kept: the group is scanned from the start offset on), so
+// most keys resolve in one LDS round; the count update is a no-return ds_add_u32.  Slots that were
+// already occupied keep their 64-bit key and count in the registers of the lane that owns them; at
+// write-back the batch's delta is added, and new slots get their key back through the inverse hash.
+//   * a bucket of >= 2^32 payloads could wrap a 32-bit delta: such a region is failed up front;
+//   * the one payload that collides with the free marker (0xFFFFFFFF) is counted in s_special and
+//     inserted by a single lane at write-back.
+// A failed region is left untouched in HBM; its bucket then goes through the direct path.
+constexpr int R32_SLOTS_PER_LANE = REGION_SLOTS / REGION_NT;
+constexpr uint32_t R32_FREE = 0xFFFFFFFFu;
+
+template <bool FRESH>
+__global__ __launch_bounds__(REGION_NT) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays,
+                                                                   const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
+                                                                   uint32_t *__restrict__ rnew) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
+    __shared__ uint32_t s_add[REGION_SLOTS];
+    __shared__ uint32_t s_fail;
+    __shared__ uint32_t s_new;
+    __shared__ uint32_t s_special, s_sp_off, s_sp_new;
+    const int tid = threadIdx.x;
+    const u64 r = blockIdx.x;
+    const u64 lo = bstart[r], hi = bstart[r + 1];
+    if (lo == hi) {
+        if (tid == 0) rnew[r] = 0;
+        return;
+    }
+    if (hi - lo >= 0xFFFFFFFFull) {  // a 32-bit delta could wrap
+        if (tid == 0) {
+            rfail[r] = 1;
+            rnew[r] = 0;
+        }
+        return;
+    }
+    const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
+    // H = [p1 | payload << (32 - p1_bits) ...]: the in-region start is the REGION_BITS bits that
+    // follow the p2 digit at the top of the payload
+    const uint32_t sshift = 32 - g.p2_bits - REGION_BITS;
+    Slot *reg = tg.table + r * REGION_SLOTS;
+    const uint32_t *__restrict__ src = pays + lo;
+    const uint32_t n = (uint32_t)(hi - lo);  // < 2^32 - 1 (checked above)
+    uint32_t kbuf[REGION_RK];
+    uint32_t khave = 0;
+#pragma unroll
+    for (int j = 0; j < REGION_RK; ++j) {  // branch-free: clamped index + validity bit
+        const uint32_t i = (uint32_t)j * REGION_NT + tid;
+        kbuf[j] = src[i < n ? i : n - 1];
+        khave |= (uint32_t)(i < n) << j;
+    }
+    Slot old[R32_SLOTS_PER_LANE];
+    const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
+#pragma unroll
+    for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
+        const uint32_t i = (uint32_t)q * REGION_NT + tid;
+        uint32_t w = R32_FREE;
+        if (FRESH) {
+            old[q].key = KH_EMPTY_KEY;
+            old[q].count = 0;
+        } else {
+            const uint4 v = g4[i];
+            old[q].key = ((u64)v.y << 32) | v.x;
+            old[q].count = ((u64)v.w << 32) | v.z;
+            if (old[q].key != KH_EMPTY_KEY) w = Pay<uint32_t>::make(old[q].key, kh_table_hash(old[q].key, tg.k), g);
+            // an old key whose payload equals the free marker keeps w == FREE: new arrivals of that
+            // payload are counted in s_special and merged below
+        }
+        s_pay[i] = w;
+        s_add[i] = 0;
+    }
+    if (tid == 0) {
+        s_fail = 0;
+        s_new = 0;
+        s_special = 0;
+    }
+    __syncthreads();
+    uint32_t nd = 0;
+    const uint4 *s_pay4 = reinterpret_cast<const uint4 *>(s_pay);
+    for (u64 base = 0; base < n; base += (u64)REGION_RK * REGION_NT) {
+        uint32_t nbuf[REGION_RK];
+        uint32_t nhave = 0;
+#pragma unroll
+        for (int j = 0; j < REGION_RK; ++j) {
+            const u64 i64 = base + (u64)(REGION_RK + j) * REGION_NT + tid;
+            const uint32_t i = i64 < n ? (uint32_t)i64 : n - 1;
+            nbuf[j] = src[i];
+            nhave |= (uint32_t)(i64 < n) << j;
+        }
+#pragma unroll
+        for (int j = 0; j < REGION_RK; ++j) {
+            if (!(khave & (1u << j))) continue;
+            const uint32_t pay = kbuf[j];
+#ifdef KH_EXP_NO_INSERT  // timing experiment only: consume the payload, skip the LDS work
+            if (pay == 0x12345678u && lo == 77) s_fail = 1;
+            continue;
+#endif
+            if (pay == R32_FREE) {
+                atomicAdd(&s_special, 1u);
+                continue;
+            }
+            uint32_t off = (pay >> sshift) & REGION_MASK;
+            uint32_t scanned = 0;
+            bool done = false;
+            while (!done && scanned < REGION_SLOTS) {
+                const uint32_t gbase = off & ~3u;
+                const uint4 grp = s_pay4[gbase >> 2];
+                const uint32_t e[4] = {grp.x, grp.y, grp.z, grp.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (done || gbase + q < off) continue;  // keep linear-probing order from `off`
+                    uint32_t cur = e[q];
+                    if (cur == R32_FREE) {
+                        cur = atomicCAS(&s_pay[gbase + q], R32_FREE, pay);
+                        if (cur == R32_FREE) {
+                            ++nd;
+                            cur = pay;
+                        }
+                    }
+                    if (cur == pay) {
+                        atomicAdd(&s_add[gbase + q], 1u);  // no-return ds_add_u32
+                        done = true;
+                    }
+                }
+                scanned += 4 - (off & 3u);
+                off = (gbase + 4) & REGION_MASK;
+            }
+            if (!done) s_fail = 1;
+        }
+        khave = nhave;
+#pragma unroll
+        for (int j = 0; j < REGION_RK; ++j) kbuf[j] = nbuf[j];
+    }
+    const uint32_t dw = (uint32_t)wave_sum((u64)nd);
+    if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
+    __syncthreads();
+    if (s_special && tid == 0 && !s_fail) {
+        // The payload equal to the free marker was only counted.  One lane places it now by plain
+        // linear probing over the combined image (old keys from HBM, new claims from s_pay).
+        const u64 key = Pay<uint32_t>::key(R32_FREE, p1, g);
+        uint32_t off = (R32_FREE >> sshift) & REGION_MASK;
+        uint32_t probes = 0;
+        bool is_new = false;
+        for (; probes < REGION_SLOTS; ++probes, off = (off + 1) & REGION_MASK) {
+            const u64 o = FRESH ? (u64)KH_EMPTY_KEY : reg[off].key;
+            if (o == key) break;
+            if (o == KH_EMPTY_KEY && s_pay[off] == R32_FREE) {
+                is_new = true;
+                break;
+            }
+        }
+        if (probes == REGION_SLOTS) {
+            s_fail = 1;
+        } else {
+            s_sp_off = off;
+            s_sp_new = is_new ? 1u : 0u;
+            if (is_new) s_new += 1;
+        }
+    }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) {
+            rfail[r] = 1;
+            rnew[r] = 0;
+        }
+        return;
+    }
+    const uint32_t sp_off = s_special ? s_sp_off : 0xFFFFFFFFu;
+    uint4 *o4 = reinterpret_cast<uint4 *>(reg);
+#ifdef KH_EXP_NO_WRITEBACK  // timing experiment only
+    if (s_new != 0xFFFFFFF0u) { if (tid == 0) rnew[r] = s_new; return; }
+#endif
+#pragma unroll
+    for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
+        const uint32_t i = (uint32_t)q * REGION_NT + tid;
+        u64 kk = old[q].key, cc = old[q].count;
+        const uint32_t delta = s_add[i];
+        if (delta) {
+            if (kk == KH_EMPTY_KEY) kk = Pay<uint32_t>::key(s_pay[i], p1, g);  // new key: invert the hash
+            cc += delta;
+        }
+        if (i == sp_off) {
+            if (s_sp_new) kk = Pay<uint32_t>::key(R32_FREE, p1, g);
+            cc += s_special;
+        }
         o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
     }
     if (tid == 0) rnew[r] = s_new;
@@ -519,16 +796,18 @@ __global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restr
 }
 
 // Direct (atomic) insertion of the buckets whose region overflowed, after the table was grown.
-// One workgroup per ORIGINAL region index; rfail/bstart refer to the geometry the buckets were
-// built with, `table`/`nregions` to the grown table.
-__global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(Slot *table, u64 nregions, const u64 *__restrict__ keys,
+// One workgroup per ORIGINAL region index; rfail/bstart/g refer to the geometry the buckets were
+// built with, `tg` to the grown table.
+template <typename PT>
+__global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(TableGeom tg, PartGeom g, const PT *__restrict__ pays,
                                                                       const u64 *__restrict__ bstart,
                                                                       const uint8_t *__restrict__ rfail, Counters *ctr) {
     const u64 r = blockIdx.x;
     if (!rfail[r]) return;
     const u64 lo = bstart[r], hi = bstart[r + 1];
+    const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
     uint32_t nd = 0, nf = 0;
-    for (u64 i = lo + threadIdx.x; i < hi; i += BLOCK) upsert(table, nregions, keys[i], 1ull, nd, nf);
+    for (u64 i = lo + threadIdx.x; i < hi; i += BLOCK) upsert(tg, Pay<PT>::key(pays[i], p1, g), 1ull, nd, nf);
     const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
     if (lane_id() == 0) {  // rare path (only regions that overflowed): plain counter atomics are fine
         if (d) atomicAdd(&ctr->distinct, d);
