@@ -149,20 +149,20 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
     u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g,
     const u64 *__restrict__ O1, PT *__restrict__ out) {
-    // u64: 8 KiB + 4 KiB + 128 KiB + 4 + 4 + 8 KiB; the partition id of a staged u64 payload (= key)
-    // is recomputed from its hash, a staged u32 payload has lost those bits and carries a 2-byte id.
-    constexpr bool WITH_PID = sizeof(PT) == 4;
+    // Staged element = one 8-byte LDS word: a u64 payload is the key itself (its partition is
+    // recomputed from the hash); a u32 payload has lost its partition bits, so the word carries
+    // (partition << 32 | payload).  One LDS write + one LDS read per key either way.
+    constexpr bool P32 = sizeof(PT) == 4;
     __shared__ uint32_t s_code[2][PART_NT + 2];
     __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ PT s_stage[PART_TILE];
-    __shared__ uint16_t s_pid[WITH_PID ? PART_TILE : 1];
+    __shared__ u64 s_stage[PART_TILE];   // 128 KiB
     __shared__ uint32_t s_cnt[MAX_P1];
-    __shared__ uint32_t s_lofs[MAX_P1];
-    __shared__ u64 s_gcur[MAX_P1];
+    __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< 16384)
+    __shared__ u64 s_dst[MAX_P1];        // global position of run p minus its batch-local start
     __shared__ uint32_t s_wsum[4];
     const int tid = threadIdx.x;
     s_cnt[tid] = 0;
-    s_gcur[tid] = (tid < (1 << g.p1_bits)) ? O1[(u64)tid * gridDim.x + blockIdx.x] : 0;
+    u64 gcur = (tid < (1 << g.p1_bits)) ? O1[(u64)tid * gridDim.x + blockIdx.x] : 0;  // lane tid owns partition tid
     const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
     u64 te = tb + tiles_per_block;
     if (te > tile0 + ntiles) te = tile0 + ntiles;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
     RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
         const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
-        PT pay[CHUNK];
+        u64 item[CHUNK];
         uint32_t tag[CHUNK];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
         Roller roll;
         roll.init(w, k, wlo);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
             if (roll.next(j, key)) {
                 const u64 H = kh_table_hash(key, k);
                 const uint32_t p = p1_of_hash(H, g);
-                pay[j] = Pay<PT>::make(key, H, g);
+                item[j] = P32 ? (((u64)p << 32) | (u64)Pay<uint32_t>::make(key, H, g)) : key;
                 tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);  // rank < 16384 fits 16 bits
             }
         }
@@ -190,27 +190,22 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) {
-                const uint32_t slot = s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu);
-                s_stage[slot] = pay[j];
-                if (WITH_PID) s_pid[slot] = (uint16_t)(tag[j] >> 16);
-            }
+            if (tag[j] != 0xFFFFFFFFu) s_stage[(uint32_t)s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = item[j];
+        const uint32_t mycnt = s_cnt[tid];
+        s_dst[tid] = gcur - s_lofs[tid];
+        gcur += mycnt;
+        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
         __syncthreads();
+        s_cnt[tid] = 0;  // the next tile's stage_tile() barrier orders this before its atomics
         // next tile's bases are fetched while this tile's runs are written out
         raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        const uint32_t total = s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
 #pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART_NT) {
-            const PT v = s_stage[i];
-            uint32_t p;
-            if (WITH_PID) p = s_pid[i];
-            else p = p1_of_hash(kh_table_hash((u64)v, k), g);
-            out[s_gcur[p] + (i - s_lofs[p])] = v;  // consecutive lanes -> consecutive addresses inside a run
+            const u64 v = s_stage[i];
+            const uint32_t p = P32 ? (uint32_t)(v >> 32) : p1_of_hash(kh_table_hash(v, k), g);
+            out[s_dst[p] + i] = (PT)v;  // consecutive lanes -> consecutive addresses inside a run
         }
-        __syncthreads();
-        s_gcur[tid] += s_cnt[tid];
-        s_cnt[tid] = 0;
-        // the next tile's stage_tile() barrier orders these updates before its atomics
+        // s_stage / s_dst are rewritten only after the next tile's barriers
     }
 }
 
@@ -366,7 +361,20 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restri
     const int tid = threadIdx.x;
     s_hist[tid] = 0;  // PART_NT == 1 << MAX_P2_BITS
     __syncthreads();
-    for (u64 i = pb.lo + tid; i < pb.hi; i += PART_NT) atomicAdd(&s_hist[Pay<PT>::p2(pays[i], g)], 1u);
+    // eight independent loads in flight per lane (a one-load-per-iteration loop is latency bound)
+    const PT *__restrict__ src = pays + pb.lo;
+    const uint32_t n = (uint32_t)(pb.hi - pb.lo);
+    for (uint32_t base = 0; base < n; base += 8 * PART_NT) {
+        PT v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t i = base + (uint32_t)j * PART_NT + tid;
+            v[j] = src[i < n ? i : n - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (base + (uint32_t)j * PART_NT + tid < n) atomicAdd(&s_hist[Pay<PT>::p2(v[j], g)], 1u);
+    }
     __syncthreads();
     if (tid < (1 << g.p2_bits)) H2[pb.mbase + (u64)tid * pb.mstride] = s_hist[tid];
 }
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restric
 // u64 payloads (= keys): LDS image is structure-of-arrays {key[], count[]}, 64 KiB, so that 8-byte
 // key probes spread over all 64 banks.
 template <bool FRESH>
-__global__ __launch_bounds__(REGION_NT) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys,
+__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew) {
     __shared__ u64 s_key[REGION_SLOTS];
@@ -583,9 +591,8 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel64(TableGeom tg,
 }
 
 // uint32_t payloads: the LDS image is two 32-bit arrays, s_pay[] (0xFFFFFFFF = free) and s_add[] (count
-// added by this batch), 32 KiB per region.  Probing reads FOUR consecutive payload slots with one
-// ds_read_b128 (linear probing order is kept: the group is scanned from the start offset on), so
-// most keys resolve in one LDS round; the count update is a no-return ds_add_u32.  Slots that were
+// added by this batch), 32 KiB per region, plus 32 KiB of per-lane payload queues (see the probing
+// loop); the count update is a no-return ds_add_u32.  Slots that were
 // already occupied keep their 64-bit key and count in the registers of the lane that owns them; at
 // write-back the batch's delta is added, and new slots get their key back through the inverse hash.
 //   * a bucket of >= 2^32 payloads could wrap a 32-bit delta: such a region is failed up front;
@@ -596,7 +603,7 @@ constexpr int R32_SLOTS_PER_LANE = REGION_SLOTS / REGION_NT;
 constexpr uint32_t R32_FREE = 0xFFFFFFFFu;
 
 template <bool FRESH>
-__global__ __launch_bounds__(REGION_NT) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays,
+__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel32(TableGeom tg,
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
     __shared__ uint32_t s_special, s_sp_off, s_sp_new;
+    __shared__ uint32_t s_q[REGION_RK][REGION_NT];  // per-lane payload queues (32 KiB)
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bstart[r + 1];
@@ -626,12 +634,10 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel32(TableGeom tg,
     const uint32_t *__restrict__ src = pays + lo;
     const uint32_t n = (uint32_t)(hi - lo);  // < 2^32 - 1 (checked above)
     uint32_t kbuf[REGION_RK];
-    uint32_t khave = 0;
 #pragma unroll
-    for (int j = 0; j < REGION_RK; ++j) {  // branch-free: clamped index + validity bit
+    for (int j = 0; j < REGION_RK; ++j) {  // branch-free: clamped index
         const uint32_t i = (uint32_t)j * REGION_NT + tid;
         kbuf[j] = src[i < n ? i : n - 1];
-        khave |= (uint32_t)(i < n) << j;
     }
     Slot old[R32_SLOTS_PER_LANE];
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
@@ -660,60 +666,71 @@ __global__ __launch_bounds__(REGION_NT) void region_count_kernel32(TableGeom tg,
     }
     __syncthreads();
     uint32_t nd = 0;
-    const uint4 *s_pay4 = reinterpret_cast<const uint4 *>(s_pay);
+    // Lane-decoupled probing.  A wave that walks key j of all 64 lanes together pays, for every
+    // key, the LONGEST probe sequence among its lanes (~6 at load 0.5).  Here each lane keeps its own
+    // cursor into a private queue of REGION_RK payloads (LDS, [slot][lane]: conflict-free) and takes
+    // its next payload as soon as its current one is placed, so a round costs the largest SUM of
+    // probe lengths of one lane (~1.5 per key) instead of the sum of the per-key maxima.
     for (u64 base = 0; base < n; base += (u64)REGION_RK * REGION_NT) {
-        uint32_t nbuf[REGION_RK];
-        uint32_t nhave = 0;
+        // payloads of this round -> the lane's queue; how many of them are real
+        const u64 rem = n - base;  // > 0
+        uint32_t nk = 0;
+        if ((u64)tid < rem) nk = (uint32_t)((rem - tid + REGION_NT - 1) / REGION_NT);
+        if (nk > REGION_RK) nk = REGION_RK;
 #pragma unroll
-        for (int j = 0; j < REGION_RK; ++j) {
+        for (int j = 0; j < REGION_RK; ++j) s_q[j][tid] = kbuf[j];
+#pragma unroll
+        for (int j = 0; j < REGION_RK; ++j) {  // next round's payloads in flight during the probing
             const u64 i64 = base + (u64)(REGION_RK + j) * REGION_NT + tid;
-            const uint32_t i = i64 < n ? (uint32_t)i64 : n - 1;
-            nbuf[j] = src[i];
-            nhave |= (uint32_t)(i64 < n) << j;
+            kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
         }
-#pragma unroll
-        for (int j = 0; j < REGION_RK; ++j) {
-            if (!(khave & (1u << j))) continue;
-            const uint32_t pay = kbuf[j];
-#ifdef KH_EXP_NO_INSERT  // timing experiment only: consume the payload, skip the LDS work
-            if (pay == 0x12345678u && lo == 77) s_fail = 1;
-            continue;
+#ifdef KH_EXP_NO_INSERT  // timing experiment only
+        if (s_q[0][tid] == 0x12345678u && lo == 77) s_fail = 1;
+        continue;
 #endif
-            if (pay == R32_FREE) {
-                atomicAdd(&s_special, 1u);
-                continue;
-            }
-            uint32_t off = (pay >> sshift) & REGION_MASK;
-            uint32_t scanned = 0;
-            bool done = false;
-            while (!done && scanned < REGION_SLOTS) {
-                const uint32_t gbase = off & ~3u;
-                const uint4 grp = s_pay4[gbase >> 2];
-                const uint32_t e[4] = {grp.x, grp.y, grp.z, grp.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (done || gbase + q < off) continue;  // keep linear-probing order from `off`
-                    uint32_t cur = e[q];
+        uint32_t idx = 0, pay = 0, off = 0, probes = 0;
+        bool active = nk > 0;
+        if (active) {
+            pay = s_q[0][tid];
+            off = (pay >> sshift) & REGION_MASK;
+        }
+        while (__any(active)) {
+            if (active) {
+                bool placed = false;
+                if (pay == R32_FREE) {  // collides with the free marker: counted, placed at write-back
+                    atomicAdd(&s_special, 1u);
+                    placed = true;
+                } else {
+                    uint32_t cur = s_pay[off];
                     if (cur == R32_FREE) {
-                        cur = atomicCAS(&s_pay[gbase + q], R32_FREE, pay);
+                        cur = atomicCAS(&s_pay[off], R32_FREE, pay);
                         if (cur == R32_FREE) {
                             ++nd;
                             cur = pay;
                         }
                     }
                     if (cur == pay) {
-                        atomicAdd(&s_add[gbase + q], 1u);  // no-return ds_add_u32
-                        done = true;
+                        atomicAdd(&s_add[off], 1u);  // no-return ds_add_u32
+                        placed = true;
+                    } else {
+                        off = (off + 1) & REGION_MASK;
+                        if (++probes >= REGION_SLOTS) {  // region full
+                            s_fail = 1;
+                            placed = true;
+                        }
                     }
                 }
-                scanned += 4 - (off & 3u);
-                off = (gbase + 4) & REGION_MASK;
+                if (placed) {
+                    ++idx;
+                    active = idx < nk;
+                    if (active) {
+                        pay = s_q[idx][tid];
+                        off = (pay >> sshift) & REGION_MASK;
+                        probes = 0;
+                    }
+                }
             }
-            if (!done) s_fail = 1;
         }
-        khave = nhave;
-#pragma unroll
-        for (int j = 0; j < REGION_RK; ++j) kbuf[j] = nbuf[j];
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
