@@ -1,0 +1,469 @@
+// kmerust_host.cpp -- reader, builder, writers and KMIX index above the C ABI.  See kmerust_host.h
+// for the reference lines each piece mirrors.  Counting is always the HIP path (kh_*).
+#include "kmerust_host.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cerrno>
+#include <cstring>
+#include <memory>
+
+namespace kmerust {
+
+// =============================================================================================
+// format / input
+// =============================================================================================
+static std::string lower_ext(const std::string &name) {
+    const size_t slash = name.find_last_of('/');
+    const std::string base = slash == std::string::npos ? name : name.substr(slash + 1);
+    const size_t dot = base.find_last_of('.');
+    if (dot == std::string::npos || dot == 0) return "";
+    std::string e = base.substr(dot + 1);
+    for (char &c : e) c = (char)std::tolower((unsigned char)c);
+    return e;
+}
+
+static std::string strip_ext(const std::string &name) {
+    const size_t slash = name.find_last_of('/');
+    const size_t dot = name.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return name;
+    return name.substr(0, dot);
+}
+
+SequenceFormat format_from_extension(const std::string &path) {
+    std::string ext = lower_ext(path);
+    if (ext == "gz") ext = lower_ext(strip_ext(path));  // strip .gz, look at the real extension
+    if (ext == "fq" || ext == "fastq") return SequenceFormat::Fastq;
+    return SequenceFormat::Fasta;  // known FASTA extensions and anything unknown
+}
+
+SequenceFormat resolve_format(SequenceFormat f, const std::string *path) {
+    if (f != SequenceFormat::Auto) return f;
+    return path ? format_from_extension(*path) : SequenceFormat::Fasta;
+}
+
+const char *format_name(SequenceFormat f) {
+    switch (f) {
+    case SequenceFormat::Auto: return "auto";
+    case SequenceFormat::Fasta: return "fasta";
+    default: return "fastq";
+    }
+}
+
+// =============================================================================================
+// reader
+// =============================================================================================
+namespace {
+
+// Buffered line reader over zlib (reads plain files transparently) or stdin.
+class LineSource {
+public:
+    explicit LineSource(const std::string &path) : path_(path) {
+        if (is_stdin_path(path)) {
+            gz_ = gzdopen(0, "rb");
+        } else {
+            gz_ = gzopen(path.c_str(), "rb");
+        }
+        if (!gz_) throw Error("failed to read sequence file '" + path + "': " + std::strerror(errno));
+        gzbuffer(gz_, 1u << 20);
+        buf_.resize(1u << 22);
+    }
+    ~LineSource() {
+        if (gz_) gzclose(gz_);
+    }
+    // Next line without its terminator ('\n', optional '\r' and trailing blanks removed).
+    bool next(std::string &line) {
+        line.clear();
+        bool any = false;
+        for (;;) {
+            if (pos_ == len_) {
+                const int n = gzread(gz_, buf_.data(), (unsigned)buf_.size());
+                if (n < 0) {
+                    int en = 0;
+                    const char *msg = gzerror(gz_, &en);
+                    throw Error("failed to decompress gzip file '" + path_ + "': " + (msg ? msg : "read error"));
+                }
+                if (n == 0) break;
+                pos_ = 0;
+                len_ = (size_t)n;
+            }
+            const char *p = buf_.data() + pos_;
+            const char *nl = (const char *)memchr(p, '\n', len_ - pos_);
+            any = true;
+            if (nl) {
+                line.append(p, (size_t)(nl - p));
+                pos_ = (size_t)(nl - buf_.data()) + 1;
+                break;
+            }
+            line.append(p, len_ - pos_);
+            pos_ = len_;
+        }
+        if (!any) return false;
+        while (!line.empty() && (line.back() == '\r' || line.back() == ' ' || line.back() == '\t')) line.pop_back();
+        return true;
+    }
+
+private:
+    std::string path_;
+    gzFile gz_ = nullptr;
+    std::vector<char> buf_;
+    size_t pos_ = 0, len_ = 0;
+};
+
+struct BatchBuilder {
+    Batch b;
+    bool want_qual;
+    size_t limit;
+    const BatchSink &sink;
+    uint64_t total_records = 0;
+    BatchBuilder(bool wq, size_t lim, const BatchSink &s) : want_qual(wq), limit(lim), sink(s) {}
+    void end_record() {
+        b.bases.push_back('\n');
+        if (want_qual) b.qual.push_back('\n');
+        b.records++;
+        total_records++;
+        if (b.bases.size() >= limit) flush();
+    }
+    void flush() {
+        if (b.records) sink(b);
+        b.bases.clear();
+        b.qual.clear();
+        b.records = 0;
+    }
+};
+
+}  // namespace
+
+uint64_t read_sequences(const std::string &path, SequenceFormat fmt, bool want_qual, size_t batch_bytes,
+                        const BatchSink &sink) {
+    const SequenceFormat f = resolve_format(fmt, is_stdin_path(path) ? nullptr : &path);
+    LineSource src(path);
+    const bool fastq = f == SequenceFormat::Fastq;
+    if (!fastq) want_qual = false;  // FASTA carries no qualities (reader.rs:68-79)
+    BatchBuilder bb(want_qual, batch_bytes, sink);
+    std::string line;
+    if (!fastq) {
+        bool in_record = false;
+        while (src.next(line)) {
+            if (!line.empty() && line[0] == '>') {
+                if (in_record) bb.end_record();
+                in_record = true;
+            } else if (!in_record) {
+                if (line.empty()) continue;
+                throw Error("failed to parse sequence record: expected '>' at record start");
+            } else {
+                bb.b.bases.insert(bb.b.bases.end(), line.begin(), line.end());
+            }
+        }
+        if (in_record) bb.end_record();
+    } else {
+        bool have = src.next(line);
+        while (have) {
+            if (line.empty()) {  // blank lines between records
+                have = src.next(line);
+                continue;
+            }
+            if (line[0] != '@') throw Error("failed to parse sequence record: expected '@' at record start");
+            const size_t seq_start = bb.b.bases.size();
+            bool plus = false;
+            while ((have = src.next(line))) {
+                if (!line.empty() && line[0] == '+') {
+                    plus = true;
+                    break;
+                }
+                bb.b.bases.insert(bb.b.bases.end(), line.begin(), line.end());
+            }
+            if (!plus) throw Error("failed to parse sequence record: incomplete FASTQ record (no '+' line)");
+            const size_t seq_len = bb.b.bases.size() - seq_start;
+            size_t got = 0;
+            while (got < seq_len && (have = src.next(line))) {
+                if (want_qual) bb.b.qual.insert(bb.b.qual.end(), line.begin(), line.end());
+                got += line.size();
+            }
+            if (got != seq_len)
+                throw Error("failed to parse sequence record: unequal length of sequence and qualities");
+            bb.end_record();
+            have = src.next(line);
+        }
+    }
+    bb.flush();
+    return bb.total_records;
+}
+
+// =============================================================================================
+// counting session over the C ABI
+// =============================================================================================
+struct Session {
+    kh_ctx *ctx = nullptr;
+    uint32_t k;
+    Session(const KmerCounter &kc, bool use_qual) : k((uint32_t)kc.k_) {
+        if (!kc.k_set_) throw Error("k-mer length not set");
+        kh_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.struct_size = sizeof(cfg);
+        cfg.k = (uint32_t)kc.k_;
+        cfg.min_quality = use_qual ? kc.min_quality_ : -1;
+        cfg.device = kc.device_;
+        cfg.capacity_hint = kc.capacity_hint_;
+        check(kh_create(&ctx, &cfg), "kh_create");
+    }
+    ~Session() { kh_destroy(ctx); }
+    void check(int rc, const char *what) const {
+        if (rc == KH_OK) return;
+        std::string msg = std::string(what) + ": " + kh_strerror(rc);
+        if (ctx && kh_last_error(ctx)[0]) msg += std::string(" (") + kh_last_error(ctx) + ")";
+        throw Error(msg);
+    }
+    void count_file(const std::string &path, SequenceFormat fmt, bool want_qual) {
+        read_sequences(path, fmt, want_qual, 512u << 20, [&](const Batch &b) {
+            check(kh_push(ctx, b.bases.data(), want_qual && !b.qual.empty() ? b.qual.data() : nullptr, b.bases.size()),
+                  "kh_push");
+        });
+        check(kh_finish(ctx, nullptr), "kh_finish");
+    }
+    PackedCounts result(uint64_t min_count) {
+        PackedCounts pc;
+        pc.k = k;
+        uint64_t n = 0;
+        check(kh_result_size(ctx, min_count, &n), "kh_result_size");
+        pc.keys.resize(n);
+        pc.counts.resize(n);
+        uint64_t got = 0;
+        check(kh_result_copy(ctx, pc.keys.data(), pc.counts.data(), n, min_count, &got), "kh_result_copy");
+        pc.keys.resize(got);
+        pc.counts.resize(got);
+        return pc;
+    }
+    std::vector<std::pair<uint64_t, uint64_t>> histogram(uint64_t min_count) {
+        uint64_t cap = 1u << 16;
+        for (;;) {
+            std::vector<uint64_t> c(cap), f(cap);
+            uint64_t n = 0;
+            const int rc = kh_histogram(ctx, min_count, c.data(), f.data(), cap, &n);
+            if (rc == KH_ERR_RANGE) {
+                cap *= 16;
+                continue;
+            }
+            check(rc, "kh_histogram");
+            std::vector<std::pair<uint64_t, uint64_t>> h(n);
+            for (uint64_t i = 0; i < n; ++i) h[i] = {c[i], f[i]};
+            return h;
+        }
+    }
+};
+
+KmerCounter &KmerCounter::k(size_t kk) {
+    if (kk < 1 || kk > 32) throw KmerLengthError(kk);  // KmerLength::new, src/kmer.rs:100-110
+    k_ = kk;
+    k_set_ = true;
+    return *this;
+}
+
+static bool wants_quality(const KmerCounter &, SequenceFormat resolved, int min_quality, const std::string &path) {
+    // run.rs:543: both Some; the CLI path for stdin ignores -Q (src/main.rs:145-152, run.rs:195-197)
+    return min_quality >= 0 && resolved == SequenceFormat::Fastq && !is_stdin_path(path);
+}
+
+PackedCounts KmerCounter::count_packed(const std::string &path, bool apply_min_count) const {
+    const SequenceFormat f = resolve_format(input_format_, is_stdin_path(path) ? nullptr : &path);
+    const bool q = wants_quality(*this, f, min_quality_, path);
+    Session s(*this, q);
+    s.count_file(path, f, q);
+    return s.result(apply_min_count ? min_count_ : 1);
+}
+
+std::unordered_map<std::string, uint64_t> KmerCounter::count(const std::string &path) const {
+    const PackedCounts pc = count_packed(path, true);
+    std::unordered_map<std::string, uint64_t> m;
+    m.reserve(pc.keys.size());
+    for (size_t i = 0; i < pc.keys.size(); ++i) m.emplace(unpack_to_string(pc.keys[i], pc.k), pc.counts[i]);
+    return m;
+}
+
+std::vector<std::pair<uint64_t, uint64_t>> KmerCounter::histogram(const std::string &path) const {
+    const SequenceFormat f = resolve_format(input_format_, is_stdin_path(path) ? nullptr : &path);
+    const bool q = wants_quality(*this, f, min_quality_, path);
+    Session s(*this, q);
+    s.count_file(path, f, q);
+    return s.histogram(min_count_);  // computed on the device, after the min_count filter (run.rs:447-450)
+}
+
+void KmerCounter::count_to_writer(const std::string &path, FILE *out) const {
+    if (format_ == OutputFormat::Histogram) {
+        write_histogram(out, histogram(path));
+        return;
+    }
+    write_counts(out, count_packed(path, true), format_, 1);
+}
+
+void KmerCounter::run(const std::string &path) const { count_to_writer(path, stdout); }
+
+// =============================================================================================
+// output
+// =============================================================================================
+std::string unpack_to_string(uint64_t bits, uint32_t k) {
+    std::string s(k, 'A');
+    kh_unpack(bits, k, reinterpret_cast<uint8_t *>(&s[0]));
+    return s;
+}
+
+void write_histogram(FILE *out, const std::vector<std::pair<uint64_t, uint64_t>> &hist) {
+    for (const auto &cf : hist) fprintf(out, "%llu\t%llu\n", (unsigned long long)cf.first, (unsigned long long)cf.second);
+    fflush(out);
+}
+
+void write_counts(FILE *out, const PackedCounts &pc, OutputFormat fmt, uint64_t min_count) {
+    std::vector<char> buf(1u << 20);
+    setvbuf(out, buf.data(), _IOFBF, buf.size());  // BufWriter (run.rs:446)
+    char kmer[33];
+    auto each = [&](const std::function<void(const char *, unsigned long long, bool)> &fn) {
+        bool first = true;
+        for (size_t i = 0; i < pc.keys.size(); ++i) {
+            if (pc.counts[i] < min_count) continue;
+            kh_unpack(pc.keys[i], pc.k, reinterpret_cast<uint8_t *>(kmer));
+            kmer[pc.k] = 0;
+            fn(kmer, (unsigned long long)pc.counts[i], first);
+            first = false;
+        }
+        return first;  // true if nothing was written
+    };
+    switch (fmt) {
+    case OutputFormat::Fasta:  // ">{count}\n{kmer}\n"  (run.rs:453-456)
+        each([&](const char *km, unsigned long long c, bool) { fprintf(out, ">%llu\n%s\n", c, km); });
+        break;
+    case OutputFormat::Tsv:  // "{kmer}\t{count}\n"  (run.rs:458-461)
+        each([&](const char *km, unsigned long long c, bool) { fprintf(out, "%s\t%llu\n", km, c); });
+        break;
+    case OutputFormat::Json: {  // serde_json::to_writer_pretty of Vec<{kmer,count}> + newline (run.rs:463-470)
+        bool any = false;
+        each([&](const char *km, unsigned long long c, bool first) {
+            fputs(first ? "[\n" : ",\n", out);
+            fprintf(out, "  {\n    \"kmer\": \"%s\",\n    \"count\": %llu\n  }", km, c);
+            any = true;
+        });
+        fputs(any ? "\n]\n" : "[]\n", out);
+        break;
+    }
+    case OutputFormat::Histogram: {  // host fallback: count-of-counts after the filter (run.rs:471-481)
+        std::map<uint64_t, uint64_t> h;
+        for (size_t i = 0; i < pc.keys.size(); ++i)
+            if (pc.counts[i] >= min_count) h[pc.counts[i]]++;
+        for (const auto &cf : h) fprintf(out, "%llu\t%llu\n", (unsigned long long)cf.first, (unsigned long long)cf.second);
+        break;
+    }
+    }
+    fflush(out);
+    setvbuf(out, nullptr, _IOLBF, 0);
+}
+
+// =============================================================================================
+// KMIX index
+// =============================================================================================
+uint32_t crc32_ieee(const uint8_t *data, size_t n, uint32_t crc) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+            table[i] = c;
+        }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ data[i]) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
+
+static bool ends_with_gz(const std::string &p) { return lower_ext(p) == "gz"; }
+
+static void put_le64(std::vector<uint8_t> &v, uint64_t x) {
+    for (int i = 0; i < 8; ++i) v.push_back((uint8_t)(x >> (8 * i)));
+}
+static uint64_t get_le64(const uint8_t *p) {
+    uint64_t x = 0;
+    for (int i = 0; i < 8; ++i) x |= (uint64_t)p[i] << (8 * i);
+    return x;
+}
+
+void save_index(const PackedCounts &pc, const std::string &path) {
+    std::vector<uint8_t> v;
+    v.reserve(18 + pc.keys.size() * 16);
+    v.insert(v.end(), {'K', 'M', 'I', 'X'});  // MAGIC
+    v.push_back(1);                           // VERSION
+    v.push_back((uint8_t)pc.k);
+    put_le64(v, pc.keys.size());
+    for (size_t i = 0; i < pc.keys.size(); ++i) {
+        put_le64(v, pc.keys[i]);
+        put_le64(v, pc.counts[i]);
+    }
+    const uint32_t crc = crc32_ieee(v.data(), v.size());  // of everything before it
+    for (int i = 0; i < 4; ++i) v.push_back((uint8_t)(crc >> (8 * i)));
+    bool ok;
+    if (ends_with_gz(path)) {
+        gzFile g = gzopen(path.c_str(), "wb");
+        ok = g != nullptr;
+        size_t off = 0;
+        while (ok && off < v.size()) {
+            const unsigned chunk = (unsigned)std::min<size_t>(v.size() - off, 1u << 30);
+            ok = gzwrite(g, v.data() + off, chunk) == (int)chunk;
+            off += chunk;
+        }
+        if (g) ok = (gzclose(g) == Z_OK) && ok;
+    } else {
+        FILE *f = fopen(path.c_str(), "wb");
+        ok = f && fwrite(v.data(), 1, v.size(), f) == v.size();
+        if (f) ok = (fclose(f) == 0) && ok;
+    }
+    if (!ok) throw Error("failed to write index file '" + path + "': " + std::strerror(errno));
+}
+
+PackedCounts load_index(const std::string &path) {
+    auto bad = [&](const std::string &details) { return Error("invalid index file '" + path + "': " + details); };
+    gzFile g = gzopen(path.c_str(), "rb");  // reads plain files transparently
+    if (!g) throw Error("failed to read index file '" + path + "': " + std::strerror(errno));
+    std::vector<uint8_t> data;
+    std::vector<uint8_t> buf(1u << 20);
+    for (;;) {
+        const int n = gzread(g, buf.data(), (unsigned)buf.size());
+        if (n < 0) {
+            gzclose(g);
+            throw Error("failed to read index file '" + path + "': decompression error");
+        }
+        if (n == 0) break;
+        data.insert(data.end(), buf.begin(), buf.begin() + n);
+    }
+    gzclose(g);
+    if (data.size() < 18) throw bad("file too small");
+    if (memcmp(data.data(), "KMIX", 4) != 0) throw bad("invalid magic bytes (not a kmerust index file)");
+    const size_t body = data.size() - 4;
+    uint32_t stored = 0;
+    for (int i = 0; i < 4; ++i) stored |= (uint32_t)data[body + i] << (8 * i);
+    const uint32_t computed = crc32_ieee(data.data(), body);
+    if (computed != stored) {
+        char m[96];
+        snprintf(m, sizeof m, "checksum mismatch (expected 0x%x, got 0x%x)", stored, computed);  // {:#x}
+        throw bad(m);
+    }
+    if (data[4] != 1) throw bad("unsupported version " + std::to_string(data[4]));
+    const uint32_t k = data[5];
+    if (k < 1 || k > 32)
+        throw bad("invalid k-mer length: k-mer length " + std::to_string(k) + " is out of range: must be between 1 and 32");
+    const uint64_t count = get_le64(&data[6]);
+    const size_t have = body - 14;
+    if (count > (SIZE_MAX >> 5) || have != count * 16)
+        throw bad("data size mismatch (expected " + std::to_string(count * 16) + " bytes, got " + std::to_string(have) + " bytes)");
+    PackedCounts pc;
+    pc.k = k;
+    pc.keys.resize(count);
+    pc.counts.resize(count);
+    for (uint64_t i = 0; i < count; ++i) {
+        pc.keys[i] = get_le64(&data[14 + 16 * i]);
+        pc.counts[i] = get_le64(&data[14 + 16 * i + 8]);
+    }
+    return pc;
+}
+
+}  // namespace kmerust

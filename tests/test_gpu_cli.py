@@ -1,0 +1,126 @@
+"""GPU tests of the `kmerust` command line (krust_amd/host) -- the reference's
+tests/integration_tests.rs restated against our binary; expected values from tests/golden."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "krust_amd", "host", "kmerust")
+with open(os.path.join(ROOT, "tests", "golden", "derived_fixture_tables.json")) as f:
+    DERIVED = {(r["fixture"], r["k"], r["min_quality"]): r for r in json.load(f)["tables"]}
+
+
+def run(*args, stdin=None):
+    return subprocess.run([BIN, *args], input=stdin, capture_output=True, timeout=300)
+
+
+def tsv(out):
+    return {l.split(b"\t")[0].decode(): int(l.split(b"\t")[1]) for l in out.splitlines()}
+
+
+def fx(name):
+    return os.path.join(ROOT, "tests", "fixtures", name)
+
+
+def test_default_fasta_output():
+    r = run("3", fx("simple.fa"), "--quiet")
+    assert r.returncode == 0 and r.stderr == b""                         # integration_tests.rs:233-261: quiet => empty stderr
+    lines = r.stdout.splitlines()
+    got = {lines[i + 1].decode(): int(lines[i][1:]) for i in range(0, len(lines), 2)}
+    assert all(l.startswith(b">") for l in lines[::2])                   # ">{count}\n{kmer}" (run.rs:453-456)
+    assert got == DERIVED[("simple.fa", 3, None)]["counts"]
+
+
+def test_banner_goes_to_stderr():
+    r = run("3", fx("simple.fa"))
+    assert r.returncode == 0
+    for needle in (b"k-length: 3", b"data: ", b"input-format: fasta (auto-detected)", b"output-format: fasta"):
+        assert needle in r.stderr                                        # src/main.rs:75-134
+
+
+@pytest.mark.parametrize("key", sorted(DERIVED, key=str), ids=lambda k: f"{k[0]}-k{k[1]}-q{k[2]}")
+def test_tsv_matches_golden_tables(key):
+    fixture, k, q = key
+    args = [str(k), fx(fixture), "--format", "tsv", "-q"] + (["-Q", str(q)] if q is not None else [])
+    r = run(*args)
+    assert r.returncode == 0, r.stderr
+    assert tsv(r.stdout) == DERIVED[key]["counts"]
+
+
+def test_json_format():
+    r = run("4", fx("simple.fa"), "-f", "json", "-q")                    # integration_tests.rs:176-188, 611-661
+    data = json.loads(r.stdout)
+    assert {d["kmer"]: d["count"] for d in data} == DERIVED[("simple.fa", 4, None)]["counts"]
+    assert r.stdout.startswith(b"[\n  {\n    \"kmer\": ") and r.stdout.endswith(b"\n]\n")  # serde pretty, 2-space indent
+    assert all(list(d) == ["kmer", "count"] for d in data)
+    assert run("9", fx("simple.fa"), "-f", "json", "-q").stdout == b"[]\n"
+
+
+def test_histogram_format_and_min_count():
+    r = run("3", fx("simple.fa"), "-f", "histogram", "-q")               # integration_tests.rs:664-765
+    rows = [tuple(map(int, l.split(b"\t"))) for l in r.stdout.splitlines()]
+    assert rows == [tuple(x) for x in DERIVED[("simple.fa", 3, None)]["histogram"]]
+    assert rows == sorted(rows)
+    r = run("3", fx("simple.fa"), "-f", "histogram", "-q", "--min-count", "3")
+    assert [tuple(map(int, l.split(b"\t"))) for l in r.stdout.splitlines()] == [(3, 1), (4, 1)]  # filter first (run.rs:447-450)
+    r = run("3", "-", "--format", "histogram", "--quiet", stdin=b">seq1\nAAAAAAAA\n")
+    assert b"6\t1" in r.stdout                                            # integration_tests.rs:768-799
+
+
+def test_min_count_filters_output():
+    r = run("3", fx("simple.fa"), "-f", "tsv", "-q", "-m", "2")          # integration_tests.rs:191-230
+    assert tsv(r.stdout) == {"ACG": 4, "GTA": 3}
+
+
+def test_soft_masked_and_n():
+    assert b"AAA\t2" in run("3", fx("soft_masked.fa"), "-f", "tsv", "-q").stdout   # integration_tests.rs:264-281
+    out = run("3", fx("with_n.fa"), "-f", "tsv", "-q").stdout
+    assert b"N" not in out and tsv(out) == DERIVED[("with_n.fa", 3, None)]["counts"]
+
+
+def test_stdin_default_and_dash():
+    data = open(fx("simple.fa"), "rb").read()
+    a = run("3", "-f", "tsv", "-q", stdin=data)                          # integration_tests.rs:47-75, 284-407
+    b = run("3", "-", "-f", "tsv", "-q", stdin=data)
+    assert a.returncode == 0 and tsv(a.stdout) == tsv(b.stdout) == DERIVED[("simple.fa", 3, None)]["counts"]
+    fq = open(fx("simple.fq"), "rb").read()
+    c = run("3", "-", "-i", "fastq", "-f", "tsv", "-q", stdin=fq)
+    assert tsv(c.stdout) == tsv(a.stdout)
+
+
+def test_fastq_equals_fasta_and_gzip_equals_plain():
+    fa = tsv(run("4", fx("simple.fa"), "-f", "tsv", "-q").stdout)
+    assert tsv(run("4", fx("simple.fq"), "-f", "tsv", "-q").stdout) == fa           # integration_tests.rs:487-523
+    assert tsv(run("4", fx("simple.fa.gz"), "-f", "tsv", "-q").stdout) == fa        # integration_tests.rs:556-594
+    assert tsv(run("4", fx("simple.fq.gz"), "-f", "tsv", "-q").stdout) == fa
+
+
+def test_quality_flag_and_warnings():
+    lq = tsv(run("4", fx("low_quality.fq"), "-f", "tsv", "-q", "-Q", "20").stdout)
+    assert lq == DERIVED[("low_quality.fq", 4, 20)]["counts"]
+    r = run("4", fx("simple.fa"), "-f", "tsv", "-Q", "20")               # FASTA ignores -Q (tests/quality_tests.rs:94-114)
+    assert b"--min-quality is ignored for FASTA input" in r.stderr
+    assert tsv(r.stdout) == DERIVED[("simple.fa", 4, None)]["counts"]
+    r = run("4", "-", "-i", "fastq", "-f", "tsv", "-Q", "20", stdin=open(fx("low_quality.fq"), "rb").read())
+    assert b"--min-quality is not yet supported for stdin input" in r.stderr   # src/main.rs:145-152
+    assert tsv(r.stdout) == DERIVED[("low_quality.fq", 4, None)]["counts"]
+
+
+def test_save_and_query(tmp_path):
+    idx = str(tmp_path / "simple.kmix")                                   # integration_tests.rs:806-1083
+    r = run("3", fx("simple.fa"), "-f", "tsv", "--save", idx, "-m", "4")
+    assert r.returncode == 0 and b"saved: " in r.stderr and b"(6 k-mers)" in r.stderr
+    assert tsv(r.stdout) == {"ACG": 4}                                    # stdout honours --min-count ...
+    for kmer, cnt in DERIVED[("simple.fa", 3, None)]["counts"].items():  # ... the index holds everything (main.rs:182-205)
+        assert run("query", idx, kmer).stdout == f"{cnt}\n".encode()
+    assert run("query", idx, "CGT").stdout == b"4\n"                      # RC of ACG
+    assert run("query", idx, "CCC").stdout == b"0\n"
+    gz = str(tmp_path / "simple.kmix.gz")
+    assert run("5", fx("simple.fa"), "-q", "--save", gz).returncode == 0
+    assert gzip.open(gz).read()[:4] == b"KMIX"
+    assert run("query", gz, "ACGTA").stdout == b"2\n"
