@@ -35,7 +35,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             name = r["Kernel_Name"].split("(")[0]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for name, ctrs in acc.items():
-            if kernel not in name and "part" not in name and "region" not in name:
+            if not any(t in name for t in (kernel, "part1", "part2", "region_count", "scan_", "table_init")):
                 continue
             for c, v in ctrs.items():
                 summary["pmc"].setdefault(name, {})[c] = {"launches": len(v), "mean_per_launch": sum(v) / len(v),
@@ -52,6 +52,16 @@ for name, ctrs in summary["pmc"].items():
     if "TCC_HIT_sum" in ctrs and "TCC_MISS_sum" in ctrs:
         h, m = ctrs["TCC_HIT_sum"]["sum"], ctrs["TCC_MISS_sum"]["sum"]
         ctrs["l2_hit_rate"] = h / (h + m) if h + m else None
+# HBM bytes of one bench step = sum over the counting kernels (the profiled command runs warmup 1 + steps 1,
+# i.e. every per-step kernel is launched twice).  Wide streaming reads: FETCH_SIZE x 2 (gfx950).
+steps_profiled = 2
+tot_raw = tot_x2 = 0.0
+for name, ctrs in summary["pmc"].items():
+    if "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs and "table_init" not in name:
+        tot_raw += (ctrs["FETCH_SIZE"]["sum"] + ctrs["WRITE_SIZE"]["sum"]) * 1024 / steps_profiled
+        tot_x2 += (2 * ctrs["FETCH_SIZE"]["sum"] + ctrs["WRITE_SIZE"]["sum"]) * 1024 / steps_profiled
+summary["hbm_bytes_per_step_raw"] = tot_raw
+summary["hbm_bytes_per_step_fetch_x2"] = tot_x2
 with open(os.path.join(dst, f"{tag}_summary.json"), "w") as f:
     json.dump(summary, f, indent=1)
 print(json.dumps(summary, indent=1)[:3000])
