@@ -52,6 +52,21 @@ def estimate_distinct(reads, k, world):
     return int(GENOME_LEN * 1.05 + reads * novel_per_read * 1.12)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (the GPU
+    box shows 256 logical CPUs but grants 16 CPUs' worth of time; more threads than that only
+    add lock contention)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(host_bases, k, target_seconds):
     """krust-equivalent port (oracle/ko_count_records_mt: one task per record, literal per-window
     algorithm, sharded lock-per-shard map, 4 x threads shards) on a bounded sample of the same
@@ -60,7 +75,7 @@ def cpu_baseline(host_bases, k, target_seconds):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cpus()
     stride = READ_LEN + 1
     avail = host_bases.size // stride
 
@@ -74,25 +89,26 @@ def cpu_baseline(host_bases, k, target_seconds):
 
     probe_n = min(avail, 60_000)
     best = None
-    for threads in sorted({min(ncpu, 8), min(ncpu, 32), min(ncpu, 96), ncpu}):
+    for threads in sorted({max(1, ncpu // 2), ncpu, min(2 * ncpu, os.cpu_count() or ncpu)}):
         cnt, dt = run(probe_n, threads)
         if best is None or cnt / dt > best[0]:
             best = (cnt / dt, threads)
     rate, threads = best
-    n = int(min(avail, max(probe_n, target_seconds * rate / (READ_LEN - k + 1))))
+    # the map grows while it fills, so the rate drops with sample size: aim below the target
+    n = int(min(avail, max(probe_n, 0.5 * target_seconds * rate / (READ_LEN - k + 1))))
     cnt, dt = run(n, threads)
     out = {"value": cnt / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
-           "sample": f"first {n} reads of the same synthetic set ({cnt} k-mers, {dt:.1f} s) on {threads} of {ncpu} host "
-                     "threads; krust-equivalent C port (oracle/kmer_oracle.c ko_count_records_mt), not krust itself"}
+           "sample": f"first {n} reads of the same synthetic set ({cnt} k-mers, {dt:.1f} s) on {threads} threads "
+                     f"({ncpu} usable CPUs by cgroup quota, {os.cpu_count()} visible); krust-equivalent C port (oracle/kmer_oracle.c ko_count_records_mt), not krust itself"}
     # an optimised CPU formulation beside it, so the GPU figure is not flattered by the port's
-    # allocations and locks: rolling registers + per-thread tables merged at the end
-    n2 = min(avail, 2_000_000)
-    m = O.OracleMap()
+    # allocations and locks: rolling registers + two-phase radix count (no locks, no merge)
+    n2 = min(avail, 3_000_000)
     t0 = time.perf_counter()
-    tot = m.scan_flat(host_bases[: n2 * stride], k, nthreads=ncpu)
+    tot, distinct, _ = O.count_flat_radix(host_bases[: n2 * stride], k, nthreads=ncpu)
     dt2 = time.perf_counter() - t0
     out["optimised_cpu"] = {"value": tot / dt2, "unit": "k-mers/s", "cores": ncpu,
-                            "sample": f"first {n2} reads, rolling scan + per-thread tables (oracle ko_scan_flat_sampled_mt)"}
+                            "sample": f"first {n2} reads ({tot} k-mers, {distinct} distinct, {dt2:.1f} s): rolling scan + "
+                                      "two-phase radix count (oracle ko_count_flat_radix_mt)"}
     return out
 
 
@@ -178,7 +194,7 @@ def main():
         host = tb.cpu().numpy()
         hq = tq.cpu().numpy() if with_qual else None
         m = O.OracleMap()
-        tot = m.scan_flat(host, k, qual=hq, min_quality=args.min_quality, sample_mask=1023, nthreads=os.cpu_count() or 1)
+        tot = m.scan_flat(host, k, qual=hq, min_quality=args.min_quality, sample_mask=1023, nthreads=2 * usable_cpus())
         if world == 1:
             skeys, scnts = m.arrays()
             ok = bool(tot == st["kmers"] and np.array_equal(dc.lookup(skeys), scnts))

@@ -474,6 +474,135 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
 }
 
 /* ======================================================================== */
+/* optimised CPU formulation: rolling scan + two-phase radix count          */
+/* ======================================================================== */
+
+#define KO_RADIX_P 256
+
+typedef struct { uint64_t *v; uint64_t n, cap; } kvec_t;
+
+typedef struct {
+    const uint8_t *seq, *qual;
+    size_t lo, hi;
+    size_t k;
+    int min_quality;
+    kvec_t part[KO_RADIX_P];
+    uint64_t total;
+} rscan_t;
+
+static inline void kvec_push(kvec_t *a, uint64_t x) {
+    if (a->n == a->cap) {
+        a->cap = a->cap ? a->cap * 2 : 4096;
+        a->v = (uint64_t *)realloc(a->v, a->cap * sizeof(uint64_t));
+        if (!a->v) abort();
+    }
+    a->v[a->n++] = x;
+}
+
+static void *rscan_main(void *arg) {
+    rscan_t *s = (rscan_t *)arg;
+    const size_t k = s->k;
+    int have_thr = (s->qual != NULL && s->min_quality >= 0);
+    int thr = have_thr ? qual_threshold(s->min_quality) : 0;
+    uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    unsigned rcshift = (unsigned)(2 * (k - 1));
+    uint64_t fwd = 0, rc = 0, total = 0;
+    size_t run = 0;
+    size_t begin = s->lo >= k - 1 ? s->lo - (k - 1) : 0;
+    for (size_t i = begin; i < s->hi; i++) {
+        uint8_t b = s->seq[i];
+        uint8_t u = (uint8_t)(b & 0xDF);
+        int good = (u == 'A' || u == 'C' || u == 'G' || u == 'T');
+        if (good && have_thr && (int)s->qual[i] < thr) good = 0;
+        if (!good) { run = 0; fwd = 0; rc = 0; continue; }
+        uint64_t c = pack_code(b);
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((3 - c) << rcshift);
+        if (++run >= k && i >= s->lo) {
+            uint64_t key = fwd < rc ? fwd : rc;
+            total++;
+            kvec_push(&s->part[ko_mix64(key) >> 56], key);
+        }
+    }
+    s->total = total;
+    return NULL;
+}
+
+typedef struct {
+    rscan_t *scans;
+    int nscan;
+    atomic_ullong *next;
+    uint64_t distinct, digest;
+} rcount_t;
+
+uint64_t ko_map_digest(const ko_map *m) {
+    uint64_t d = 0;
+    for (uint64_t i = 0; i < m->cap; i++)
+        if (m->e[i].val) d += ko_mix64(m->e[i].key ^ ko_mix64(m->e[i].val));
+    return d;
+}
+
+static void *rcount_main(void *arg) {
+    rcount_t *c = (rcount_t *)arg;
+    uint64_t distinct = 0, digest = 0;
+    for (;;) {
+        uint64_t p = atomic_fetch_add(c->next, 1);
+        if (p >= KO_RADIX_P) break;
+        uint64_t n = 0;
+        for (int t = 0; t < c->nscan; t++) n += c->scans[t].part[p].n;
+        if (!n) continue;
+        uint64_t cap = 1024;
+        while (cap < n * 2) cap <<= 1; /* sized once: no growth, no rehash */
+        ko_map m;
+        map_alloc(&m, cap);
+        for (int t = 0; t < c->nscan; t++) {
+            const kvec_t *a = &c->scans[t].part[p];
+            for (uint64_t i = 0; i < a->n; i++) map_insert_raw(&m, a->v[i], 1);
+        }
+        distinct += m.len;
+        digest += ko_map_digest(&m);
+        free(m.e);
+    }
+    c->distinct = distinct;
+    c->digest = digest;
+    return NULL;
+}
+
+uint64_t ko_count_flat_radix_mt(const uint8_t *seq, size_t len, const uint8_t *qual, size_t k,
+                                int min_quality, int nthreads, uint64_t *distinct, uint64_t *digest) {
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    rscan_t *ss = (rscan_t *)calloc((size_t)nthreads, sizeof(rscan_t));
+    rcount_t *cs = (rcount_t *)calloc((size_t)nthreads, sizeof(rcount_t));
+    if (!th || !ss || !cs) abort();
+    size_t per = (len + (size_t)nthreads - 1) / (size_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        size_t lo = per * (size_t)t, hi = lo + per;
+        if (lo > len) lo = len;
+        if (hi > len) hi = len;
+        ss[t].seq = seq; ss[t].qual = qual; ss[t].lo = lo; ss[t].hi = hi; ss[t].k = k;
+        ss[t].min_quality = min_quality;
+        pthread_create(&th[t], NULL, rscan_main, &ss[t]);
+    }
+    uint64_t total = 0;
+    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); total += ss[t].total; }
+    atomic_ullong next;
+    atomic_init(&next, 0);
+    for (int t = 0; t < nthreads; t++) {
+        cs[t].scans = ss; cs[t].nscan = nthreads; cs[t].next = &next;
+        pthread_create(&th[t], NULL, rcount_main, &cs[t]);
+    }
+    uint64_t d = 0, g = 0;
+    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); d += cs[t].distinct; g += cs[t].digest; }
+    for (int t = 0; t < nthreads; t++)
+        for (int p = 0; p < KO_RADIX_P; p++) free(ss[t].part[p].v);
+    free(th); free(ss); free(cs);
+    if (distinct) *distinct = d;
+    if (digest) *digest = g;
+    return total;
+}
+
+/* ======================================================================== */
 /* deterministic synthetic reads                                            */
 /* ======================================================================== */
 

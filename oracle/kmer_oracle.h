@@ -118,6 +118,18 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
                              const uint64_t *off, const uint32_t *lens,
                              uint64_t nrec, size_t k, int min_quality, int nthreads);
 
+/* Optimised CPU formulation, reported beside the krust-equivalent port so that the GPU figure is
+ * not flattered by the port's allocations and locks (implementation B): rolling
+ * forward / reverse-complement registers, then a two-phase radix count -- every thread scatters
+ * the keys of its slice of the flat buffer into 256 partitions by hash, then the partitions are
+ * counted independently in private open-addressing tables (no locks, no merge).  Returns the
+ * number of k-mers; *distinct and *digest (order-independent: sum of mix64(key ^ mix64(count)))
+ * describe the result without materialising one big map. */
+uint64_t ko_count_flat_radix_mt(const uint8_t *seq, size_t len, const uint8_t *qual, size_t k,
+                                int min_quality, int nthreads, uint64_t *distinct, uint64_t *digest);
+/* the same digest of an existing map (to cross-check the two CPU formulations and the GPU) */
+uint64_t ko_map_digest(const ko_map *m);
+
 /* ---- deterministic synthetic reads --------------- */
 
 /* Counter-based generator shared (bit-exactly) with the device generator in

@@ -52,6 +52,11 @@ def _load():
     lib.ko_scan_flat_sampled_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
                                             C.c_uint64, C.c_int]
     lib.ko_scan_flat_sampled_mt.restype = C.c_uint64
+    lib.ko_count_flat_radix_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.ko_count_flat_radix_mt.restype = C.c_uint64
+    lib.ko_map_digest.argtypes = [C.c_void_p]
+    lib.ko_map_digest.restype = C.c_uint64
     lib.ko_mix64.argtypes = [C.c_uint64]
     lib.ko_mix64.restype = C.c_uint64
     lib.ko_synth_reads.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
@@ -139,6 +144,9 @@ class OracleMap:
         return int(lib().ko_scan_flat_sampled_mt(self._m, sp, sn, qp, k, -1 if min_quality is None else int(min_quality),
                                                  sample_mask, nthreads))
 
+    def digest(self):
+        return int(lib().ko_map_digest(self._m))
+
     def count_records_mt(self, seq, offs, lens, k, qual=None, min_quality=None, nthreads=1):
         sp, _, _ks = _buf(seq)
         qp, _, _kq = _buf(qual)
@@ -156,6 +164,17 @@ def count_records(records, k, quals=None, min_quality=None, rolling=False):
         q = None if quals is None else quals[i]
         m.process(r, k, qual=q, min_quality=min_quality, rolling=rolling)
     return m
+
+
+def count_flat_radix(seq, k, qual=None, min_quality=None, nthreads=1):
+    """Optimised CPU formulation (rolling scan + two-phase radix count): (kmers, distinct, digest)."""
+    sp, sn, _ks = _buf(seq)
+    qp, _, _kq = _buf(qual)
+    d = C.c_uint64(0)
+    g = C.c_uint64(0)
+    tot = lib().ko_count_flat_radix_mt(sp, sn, qp, k, -1 if min_quality is None else int(min_quality), nthreads,
+                                       C.byref(d), C.byref(g))
+    return int(tot), int(d.value), int(g.value)
 
 
 def pack(seq):

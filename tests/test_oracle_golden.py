@@ -231,6 +231,15 @@ def test_threaded_baseline_equals_serial():
         assert n == ser.total()
 
 
+def test_radix_formulation_equals_map():
+    bases, qual = O.synth_reads(20260130, 1 << 16, 150, 0, 3000)
+    for k, minq in ((21, None), (31, 20), (5, None)):
+        m = O.OracleMap()
+        m.process(bases, k, qual=qual, min_quality=minq)
+        tot, distinct, digest = O.count_flat_radix(bases, k, qual=qual, min_quality=minq, nthreads=3)
+        assert (tot, distinct, digest) == (m.total(), len(m), m.digest())
+
+
 def test_synth_reads_shape_and_rates():
     bases, qual = O.synth_reads(20260130, 1 << 20, 150, 0, 4000)
     b = bases.reshape(4000, 151)
