@@ -386,10 +386,26 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
             }
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                if (ok & (1u << jj)) {
-                    ++nk;
-                    if (cur[jj] == key[jj]) count_add(&reg[jj][off[jj]], 1ull);
-                    else upsert_from(reg[jj], key[jj], off[jj], cur[jj], 1ull, nd, nf);
+                // Skew guard (all lanes): a same-address device atomic costs ~6-17 ns, so a homopolymer
+                // run (every window of every lane the same key) would serialise the whole wave.  Lanes
+                // holding the first valid lane's key hand it their increment.
+                bool mine = ok & (1u << jj);
+                nk += mine;
+                u64 weight = 1;
+                const u64 vmask = __ballot(mine);
+                if (vmask) {
+                    const int first = __builtin_ctzll(vmask);
+                    const u64 lead = __shfl(key[jj], first, 64);
+                    const bool same = mine && key[jj] == lead;
+                    const u64 smask = __ballot(same);
+                    if (__builtin_popcountll(smask) > 1) {
+                        if ((int)lane_id() == first) weight = (u64)__builtin_popcountll(smask);
+                        else if (same) mine = false;
+                    }
+                }
+                if (mine) {
+                    if (cur[jj] == key[jj]) count_add(&reg[jj][off[jj]], weight);
+                    else upsert_from(reg[jj], key[jj], off[jj], cur[jj], weight, nd, nf);
                 }
             }
         }

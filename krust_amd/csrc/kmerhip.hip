@@ -339,26 +339,26 @@ uint32_t qual_thr(const kh_ctx *c) {
 
 // region rebuild launch, by payload type
 template <typename PT>
-void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions);
+void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot);
 template <>
-void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions) {
+void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
     else
         hipLaunchKernelGGL(kh::region_count_kernel64<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
 }
 template <>
-void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions) {
+void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel32<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
     else
         hipLaunchKernelGGL(kh::region_count_kernel32<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew);
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
 }
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
@@ -465,7 +465,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     }
     {
         StageTimer t(c, ST_REGION);
-        launch_region<PT>(c, g, nregions);
+        // buckets more than 4x the mean (upper bound) take the skew-guarded probing loop
+        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096);
     }
     {
         StageTimer t(c, ST_MISC);

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restric
 template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
-                                                                   uint32_t *__restrict__ rnew) {
+                                                                   uint32_t *__restrict__ rnew, u64 hot_threshold) {
     __shared__ u64 s_key[REGION_SLOTS];
     __shared__ u64 s_cnt[REGION_SLOTS];
     __shared__ uint32_t s_fail;
@@ -512,6 +512,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     // EMPTY marker (buckets of >= 2^32 keys take the 64-bit index path below through `n` saturation)
     const u64 *__restrict__ src = keys + lo;
     const u64 n = hi - lo;
+    const bool hot = n > hot_threshold;  // far above the mean bucket: skewed keys likely (see region32_probe_round)
     u64 kbuf[REGION_RK];  // first round of keys: in flight while the region image is loaded
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {
@@ -547,7 +548,20 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
         }
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) {
-            const u64 key = kbuf[j];
+            u64 key = kbuf[j];
+            // skew guard for hot buckets (all lanes): lanes holding the first valid lane's key hand it their increment
+            u64 weight = 1;
+            const u64 vmask = hot ? __ballot(key != KH_EMPTY_KEY) : 0ull;
+            if (vmask) {
+                const int first = __builtin_ctzll(vmask);
+                const u64 lead = __shfl(key, first, 64);
+                const bool same = key == lead;  // lead is a real key, so EMPTY lanes never match
+                const u64 smask = __ballot(same);
+                if (__builtin_popcountll(smask) > 1) {
+                    if ((int)lane_id() == first) weight = (u64)__builtin_popcountll(smask);
+                    else if (same) key = KH_EMPTY_KEY;
+                }
+            }
             if (key == KH_EMPTY_KEY) continue;
             uint32_t off = start_of(tg, kh_table_hash(key, tg.k));
             uint32_t probes = 0;
@@ -561,7 +575,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
                     }
                 }
                 if (cur == key) {
-                    atomicAdd(&s_cnt[off], 1ull);  // ds_add_u64
+                    atomicAdd(&s_cnt[off], weight);  // ds_add_u64
                     break;
                 }
                 off = (off + 1) & REGION_MASK;
@@ -590,6 +604,79 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     if (tid == 0) rnew[r] = s_new;
 }
 
+constexpr int R32_SLOTS_PER_LANE = REGION_SLOTS / REGION_NT;
+constexpr uint32_t R32_FREE = 0xFFFFFFFFu;  // free marker of the 32-bit LDS image
+
+// One round of lane-decoupled probing over the lanes' private payload queues (see
+// region_count_kernel32).  GUARD = skew guard for buckets far above the mean size: a bucket
+// dominated by one key (poly-A, satellites) would send every lane's increment to one LDS word, so
+// lanes whose current payload equals the first active lane's hand their weight to that lane and
+// move on.  It costs a shuffle and two ballots per iteration, hence only for hot buckets.
+template <bool GUARD>
+__device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t (*s_q)[REGION_NT], uint32_t *s_pay,
+                                                     uint32_t *s_add, uint32_t *s_special, uint32_t *s_fail, int tid,
+                                                     uint32_t sshift, uint32_t &nd) {
+    uint32_t idx = 0, pay = 0, off = 0, probes = 0, weight = 1;
+    bool active = nk > 0;
+    if (active) {
+        pay = s_q[0][tid];
+        off = (pay >> sshift) & REGION_MASK;
+    }
+    for (;;) {
+        const u64 amask = __ballot(active);
+        if (amask == 0) break;
+        bool placed = false;
+        if (GUARD) {  // all lanes take part
+            const int first = __builtin_ctzll(amask);
+            const uint32_t lead = (uint32_t)__shfl((int)pay, first, 64);
+            const bool same = active && pay == lead;
+            const u64 smask = __ballot(same);
+            if (__builtin_popcountll(smask) > 1) {
+                uint32_t wsum = same ? weight : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, o, 64);
+                if ((int)lane_id() == first) weight = wsum;
+                else if (same) placed = true;  // absorbed: nothing left to insert for this item
+            }
+        }
+        if (active && !placed) {
+            if (pay == R32_FREE) {  // collides with the free marker: counted, placed at write-back
+                atomicAdd(s_special, weight);
+                placed = true;
+            } else {
+                uint32_t cur = s_pay[off];
+                if (cur == R32_FREE) {
+                    cur = atomicCAS(&s_pay[off], R32_FREE, pay);
+                    if (cur == R32_FREE) {
+                        ++nd;
+                        cur = pay;
+                    }
+                }
+                if (cur == pay) {
+                    atomicAdd(&s_add[off], weight);  // no-return ds_add_u32
+                    placed = true;
+                } else {
+                    off = (off + 1) & REGION_MASK;
+                    if (++probes >= REGION_SLOTS) {  // region full
+                        *s_fail = 1;
+                        placed = true;
+                    }
+                }
+            }
+        }
+        if (active && placed) {
+            ++idx;
+            active = idx < nk;
+            weight = 1;
+            if (active) {
+                pay = s_q[idx][tid];
+                off = (pay >> sshift) & REGION_MASK;
+                probes = 0;
+            }
+        }
+    }
+}
+
 // uint32_t payloads: the LDS image is two 32-bit arrays, s_pay[] (0xFFFFFFFF = free) and s_add[] (count
 // added by this batch), 32 KiB per region, plus 32 KiB of per-lane payload queues (see the probing
 // loop); the count update is a no-return ds_add_u32.  Slots that were
@@ -599,13 +686,11 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
 //   * the one payload that collides with the free marker (0xFFFFFFFF) is counted in s_special and
 //     inserted by a single lane at write-back.
 // A failed region is left untouched in HBM; its bucket then goes through the direct path.
-constexpr int R32_SLOTS_PER_LANE = REGION_SLOTS / REGION_NT;
-constexpr uint32_t R32_FREE = 0xFFFFFFFFu;
 
 template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
-                                                                   uint32_t *__restrict__ rnew) {
+                                                                   uint32_t *__restrict__ rnew, u64 hot_threshold) {
     __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
     __shared__ uint32_t s_add[REGION_SLOTS];
     __shared__ uint32_t s_fail;
@@ -633,6 +718,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     Slot *reg = tg.table + r * REGION_SLOTS;
     const uint32_t *__restrict__ src = pays + lo;
     const uint32_t n = (uint32_t)(hi - lo);  // < 2^32 - 1 (checked above)
+    const bool hot = (hi - lo) > hot_threshold;  // far above the mean bucket: skewed keys likely
     uint32_t kbuf[REGION_RK];
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {  // branch-free: clamped index
@@ -688,49 +774,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         if (s_q[0][tid] == 0x12345678u && lo == 77) s_fail = 1;
         continue;
 #endif
-        uint32_t idx = 0, pay = 0, off = 0, probes = 0;
-        bool active = nk > 0;
-        if (active) {
-            pay = s_q[0][tid];
-            off = (pay >> sshift) & REGION_MASK;
-        }
-        while (__any(active)) {
-            if (active) {
-                bool placed = false;
-                if (pay == R32_FREE) {  // collides with the free marker: counted, placed at write-back
-                    atomicAdd(&s_special, 1u);
-                    placed = true;
-                } else {
-                    uint32_t cur = s_pay[off];
-                    if (cur == R32_FREE) {
-                        cur = atomicCAS(&s_pay[off], R32_FREE, pay);
-                        if (cur == R32_FREE) {
-                            ++nd;
-                            cur = pay;
-                        }
-                    }
-                    if (cur == pay) {
-                        atomicAdd(&s_add[off], 1u);  // no-return ds_add_u32
-                        placed = true;
-                    } else {
-                        off = (off + 1) & REGION_MASK;
-                        if (++probes >= REGION_SLOTS) {  // region full
-                            s_fail = 1;
-                            placed = true;
-                        }
-                    }
-                }
-                if (placed) {
-                    ++idx;
-                    active = idx < nk;
-                    if (active) {
-                        pay = s_q[idx][tid];
-                        off = (pay >> sshift) & REGION_MASK;
-                        probes = 0;
-                    }
-                }
-            }
-        }
+        if (hot) region32_probe_round<true>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
+        else region32_probe_round<false>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
