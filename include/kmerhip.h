@@ -141,9 +141,34 @@ int kh_histogram(kh_ctx *ctx, uint64_t min_count, uint64_t *count, uint64_t *fre
 int kh_lookup(kh_ctx *ctx, const uint64_t *keys, uint64_t n, uint64_t *counts);
 
 /* ---- multi-GPU merge (no reference counterpart) ----------- */
-/* Owner shard of a key among nparts shards (same function on host and device). */
-uint32_t kh_owner(uint64_t key, uint32_t nparts);
-/* Compact all live (key,count) pairs grouped by owner shard into device arrays
+/* Owner shard of a packed canonical k-mer among nparts shards: a fast-range of the top bits of
+ * the table hash, so a shard is a contiguous range of table regions (same function on host and
+ * device). */
+uint32_t kh_owner(uint64_t key, uint32_t k, uint32_t nparts);
+
+/* Fast path for a power-of-two number of ranks whose tables have the same size:
+ *   sender:   kh_export_regions_device -- live pairs in REGION order (hence grouped by owner) plus the
+ *             live count of every region; part_counts[p] (host) = pairs owned by shard p.
+ *   exchange: all-to-all of the pair segments and of each owner's slice of the region counts.
+ *   receiver: kh_reset, kh_set_shard(rank, nranks), kh_merge_regions_device -- the shard table is
+ *             rebuilt region by region in LDS from the senders' segments (no global atomics).
+ * *table_regions receives the sender's region count (must be equal on all ranks).
+ * A shard table holds only keys of its hash range: it accepts kh_merge_* but not kh_push*
+ * (KH_ERR_STATE); kh_reset turns it back into a full table. */
+int kh_set_shard(kh_ctx *ctx, uint32_t index, uint32_t count);
+int kh_export_regions_device(kh_ctx *ctx, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
+                             uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
+                             uint64_t *table_regions);
+/* d_keys[s], d_counts[s]: sender s's pairs for THIS shard (device pointers, host arrays of nsenders
+ * entries); d_region_counts[s]: sender s's live counts of the sender_regions / shard_count regions of
+ * this shard's range. */
+int kh_merge_regions_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sender_regions,
+                            const uint64_t *const *d_keys, const uint64_t *const *d_counts,
+                            const uint32_t *const *d_region_counts);
+
+/* Generic path (any number of shards, tables of any size): pairs grouped by owner, then
+ * kh_merge_pairs_device re-inserts them with device atomics. */
+/* kh_export_by_owner_device: compact all live (key,count) pairs grouped by owner shard into device arrays
  * of capacity cap; part_counts[p] (host array, nparts entries) receives the
  * number of pairs for shard p; pairs of shard p start at sum(part_counts[0..p)). */
 int kh_export_by_owner_device(kh_ctx *ctx, uint32_t nparts, uint64_t *d_keys,

@@ -73,10 +73,14 @@ constexpr uint32_t REGION_MASK = REGION_SLOTS - 1;
 
 struct TableGeom {
     Slot *table;
-    uint32_t rbits;  // log2(number of regions)
+    uint32_t rbits;        // log2(number of regions)
     uint32_t k;
+    uint32_t shard_shift;  // 0 = the table covers the whole hash space; n = it is shard `shard_index` of 2^n:
+    uint32_t shard_index;  //     every key it holds has shard_index in the top n hash bits, placement uses H << n
 };
 
+// placement hash of a key in this table
+__device__ __forceinline__ u64 table_hash(const TableGeom &tg, u64 key) { return kh_table_hash(key, tg.k) << tg.shard_shift; }
 __device__ __forceinline__ u64 region_of(const TableGeom &tg, u64 H) { return H >> (64 - tg.rbits); }
 __device__ __forceinline__ uint32_t start_of(const TableGeom &tg, u64 H) {
     return (uint32_t)(H >> (64 - tg.rbits - REGION_BITS)) & REGION_MASK;
@@ -116,7 +120,7 @@ __device__ __forceinline__ void upsert_from(Slot *reg, u64 key, uint32_t off, u6
 
 __device__ __forceinline__ void upsert(const TableGeom &tg, u64 key, u64 addend, uint32_t &ndistinct,
                                        uint32_t &nfailed) {
-    const u64 H = kh_table_hash(key, tg.k);
+    const u64 H = table_hash(tg, key);
     Slot *reg = tg.table + region_of(tg, H) * REGION_SLOTS;
     const uint32_t off = start_of(tg, H);
     upsert_from(reg, key, off, reg[off].key, addend, ndistinct, nfailed);
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
             for (int jj = 0; jj < 8; ++jj) ok |= (uint32_t)roll.next(half * 8 + jj, key[jj]) << jj;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const u64 H = kh_table_hash(key[jj], k);
+                const u64 H = table_hash(tg, key[jj]);
                 reg[jj] = tg.table + region_of(tg, H) * REGION_SLOTS;
                 off[jj] = start_of(tg, H);
                 cur[jj] = KH_EMPTY_KEY;
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void table_lookup_kernel(TableGeom tg, const
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
-        const u64 H = kh_table_hash(key, tg.k);
+        const u64 H = table_hash(tg, key);
         const Slot *reg = tg.table + region_of(tg, H) * REGION_SLOTS;
         uint32_t off = start_of(tg, H);
         u64 res = 0;
@@ -556,7 +560,7 @@ __global__ __launch_bounds__(BLOCK) void table_hist_kernel(const Slot *table, u6
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t MAX_PARTS = 256;
 
-__global__ __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u64 cap, uint32_t nparts,
+__global__ __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u64 cap, uint32_t k, uint32_t nparts,
                                                             u64 *part_counts) {
     __shared__ uint32_t s_cnt[MAX_PARTS];
     for (uint32_t i = threadIdx.x; i < nparts; i += BLOCK) s_cnt[i] = 0;
@@ -564,7 +568,7 @@ __global__ __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
         const Slot s = table[i];
-        if (s.key != KH_EMPTY_KEY) atomicAdd(&s_cnt[kh_owner_of(s.key, nparts)], 1u);
+        if (s.key != KH_EMPTY_KEY) atomicAdd(&s_cnt[kh_owner_of(s.key, k, nparts)], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nparts; i += BLOCK)
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u
 }
 
 // cursors[p] starts at the exclusive prefix of part_counts; wave-aggregated per owner.
-__global__ __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table, u64 cap, uint32_t nparts,
+__global__ __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table, u64 cap, uint32_t k, uint32_t nparts,
                                                               u64 *cursors, u64 *keys, u64 *counts, u64 out_cap) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     const u64 first = (u64)blockIdx.x * BLOCK + threadIdx.x;
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table,
         s.count = 0;
         if (i < cap) s = table[i];
         const bool live = (s.key != KH_EMPTY_KEY);
-        const uint32_t own = live ? kh_owner_of(s.key, nparts) : 0xFFFFFFFFu;
+        const uint32_t own = live ? kh_owner_of(s.key, k, nparts) : 0xFFFFFFFFu;
         u64 todo = __ballot(live);
         while (todo) {  // one round per distinct owner present in the wave
             const int leader = __builtin_ctzll(todo);

@@ -109,11 +109,15 @@ KH_HD uint64_t kh_unhash_n(uint64_t h, uint32_t k) {
 KH_HD uint64_t kh_table_hash(uint64_t key, uint32_t k) { return kh_hash_n(key, k) << (64 - 2 * k); }
 KH_HD uint64_t kh_table_unhash(uint64_t H, uint32_t k) { return kh_unhash_n(H >> (64 - 2 * k), k); }
 
-// Owner shard for the multi-GPU key-partitioned merge.  Uses the high half of a re-mixed
-// hash so that it is independent of the table placement bits.
-KH_HD uint32_t kh_owner_of(uint64_t key, uint32_t nparts) {
-    uint64_t h = kh_mix64(key ^ 0x6a09e667f3bcc909ull);
-    return (uint32_t)(((h >> 32) * (uint64_t)nparts) >> 32);
+// Owner shard for the multi-GPU merge: a fast-range of the TOP bits of the table hash, so that
+// ownership is a contiguous range of table regions (for a power-of-two shard count it is simply the
+// top log2(n) bits).  A rank's table can therefore be exported region by region already grouped by
+// owner, and an owner's shard is itself a table over the remaining hash bits (H << log2 n).
+KH_HD uint32_t kh_owner_of_hash(uint64_t H, uint32_t nparts) {
+    return (uint32_t)(((H >> 32) * (uint64_t)nparts) >> 32);
+}
+KH_HD uint32_t kh_owner_of(uint64_t key, uint32_t k, uint32_t nparts) {
+    return kh_owner_of_hash(kh_table_hash(key, k), nparts);
 }
 
 // ---- synthetic reads (counter based; bit-identical to oracle/kmer_oracle.c ko_synth_reads) ----

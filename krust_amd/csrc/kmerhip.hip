@@ -18,6 +18,7 @@
 
 #include "kernels.hip.h"
 #include "partition.hip.h"
+#include "shard.hip.h"
 
 using kh::Counters;
 using kh::Slot;
@@ -73,6 +74,10 @@ struct kh_ctx {
     bool hinted = false;       // caller gave a capacity hint
     int path_mode = 0;         // 0 auto, 1 force direct, 2 force partitioned
     int pay_mode = 0;          // 0 auto, 64 = always 64-bit payloads (env KMERHIP_PAYLOAD=64, for A/B)
+    uint32_t shard_shift = 0;  // table holds shard `shard_index` of 2^shard_shift (kh_set_shard)
+    uint32_t shard_index = 0;
+    u64 *merge_off = nullptr;  // scans of the senders' region counts (kh_merge_regions_device)
+    u64 merge_off_cap = 0;
     u64 part_budget = 0;       // bytes for the two key buffers (0 = decide at first use)
     uint8_t *keysA = nullptr, *keysB = nullptr;  // partition ping-pong buffers
     u64 key_cap = 0;           // bytes per buffer
@@ -177,6 +182,8 @@ kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap) {
     tg.table = table;
     tg.rbits = region_bits(cap);
     tg.k = c->k;
+    tg.shard_shift = c->shard_shift;
+    tg.shard_index = c->shard_index;
     return tg;
 }
 
@@ -298,7 +305,8 @@ GeomChoice make_geom(const kh_ctx *c, u64 cap) {
     const uint32_t rbits = region_bits(cap);
     uint32_t p2 = std::min<uint32_t>(rbits, kh::MAX_P2_BITS);
     uint32_t p1 = rbits - p2;
-    const int need = 2 * (int)c->k - 32;  // level-1 bits needed for 32-bit payloads
+    const int hbits = 2 * (int)c->k - (int)c->shard_shift;  // significant bits of the placement hash
+    const int need = hbits - 32;  // level-1 bits needed for 32-bit payloads
     if (need > (int)p1 && need <= (int)kh::MAX_P1_BITS && need <= (int)rbits) {
         p1 = (uint32_t)need;
         p2 = rbits - p1;
@@ -307,8 +315,10 @@ GeomChoice make_geom(const kh_ctx *c, u64 cap) {
     gc.g.p1_bits = p1;
     gc.g.p2_bits = p2;
     gc.g.k = c->k;
+    gc.g.shard_shift = c->shard_shift;
+    gc.g.shard_index = c->shard_index;
     gc.ok = p1 <= kh::MAX_P1_BITS && p2 <= kh::MAX_P2_BITS;
-    gc.use32 = (2 * (int)c->k - (int)p1) <= 32 && c->pay_mode != 64;
+    gc.use32 = (hbits - (int)p1) <= 32 && c->pay_mode != 64;
     return gc;
 }
 
@@ -709,7 +719,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
         if (c->stage_done[i]) (void)hipEventDestroy(c->stage_done[i]);
     }
     void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->rfail, c->rnew, c->scan_partial};
+                       c->bstart, c->rfail, c->rnew, c->scan_partial, c->merge_off};
     for (void *q : scratch)
         if (q) (void)hipFree(q);
     if (c->table) (void)hipFree(c->table);
@@ -734,6 +744,7 @@ extern "C" int kh_reset(kh_ctx *c) {
     for (double &m : c->stage_ms) m = 0.0;
     c->table_empty = true;
     c->part_batches = 0;
+    c->shard_shift = c->shard_index = 0;  // KmerMap::new() again: an unsharded, empty table
     return KH_OK;
 }
 
@@ -744,6 +755,7 @@ extern "C" int kh_push_device(kh_ctx *c, const uint8_t *d_bases, const uint8_t *
     int rc = enter(c);
     if (rc != KH_OK) return rc;
     if (n && !d_bases) return fail(c, KH_ERR_BAD_ARG, "d_bases is NULL");
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
     rc = count_device_range(c, d_bases, d_qual, n, 0);
     if (rc == KH_OK) c->bases_pushed += n;
     return rc;
@@ -753,6 +765,7 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
     int rc = enter(c);
     if (rc != KH_OK) return rc;
     if (n && !bases) return fail(c, KH_ERR_BAD_ARG, "bases is NULL");
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
     if (n == 0) return KH_OK;
     const bool with_qual = (qual != nullptr) && (c->minq >= 0);
     rc = ensure_stage(c, with_qual);
@@ -990,7 +1003,9 @@ extern "C" int kh_lookup(kh_ctx *c, const uint64_t *keys, uint64_t n, uint64_t *
 // =============================================================================================
 // multi-GPU merge support
 // =============================================================================================
-extern "C" uint32_t kh_owner(uint64_t key, uint32_t nparts) { return nparts ? kh_owner_of(key, nparts) : 0; }
+extern "C" uint32_t kh_owner(uint64_t key, uint32_t k, uint32_t nparts) {
+    return (nparts && k >= 1 && k <= 32) ? kh_owner_of(key, k, nparts) : 0;
+}
 
 extern "C" int kh_export_by_owner_device(kh_ctx *c, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts,
                                          uint64_t cap, uint64_t *part_counts) {
@@ -1008,7 +1023,7 @@ extern "C" int kh_export_by_owner_device(kh_ctx *c, uint32_t nparts, uint64_t *d
     hipError_t e = hipMemsetAsync(d_parts, 0, nparts * sizeof(u64), c->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(kh::owner_count_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
-                           c->cap, nparts, d_parts);
+                           c->cap, c->k, nparts, d_parts);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_parts, nparts * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
@@ -1032,7 +1047,7 @@ extern "C" int kh_export_by_owner_device(kh_ctx *c, uint32_t nparts, uint64_t *d
         e = hipMemcpyAsync(d_parts, offs.data(), nparts * sizeof(u64), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(kh::owner_scatter_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream,
-                               c->table, c->cap, nparts, d_parts, (u64 *)d_keys, (u64 *)d_counts, (u64)cap);
+                               c->table, c->cap, c->k, nparts, d_parts, (u64 *)d_keys, (u64 *)d_counts, (u64)cap);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1082,6 +1097,161 @@ extern "C" int kh_merge_pairs(kh_ctx *c, const uint64_t *keys, const uint64_t *c
     (void)hipFree(dc);
     if (e != hipSuccess || e2 != hipSuccess) return fail(c, KH_ERR_HIP, "kh_merge_pairs", e != hipSuccess ? e : e2);
     return rc;
+}
+
+// ---- hash-range sharding: region-ordered export and LDS merge ------------------------------------
+extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    if (count == 0 || (count & (count - 1)) || index >= count || count > (uint32_t)kh::MAX_SENDERS)
+        return fail(c, KH_ERR_BAD_ARG, "shard count must be a power of two (<= 64) and index < count");
+    if (!c->table_empty) return fail(c, KH_ERR_STATE, "kh_set_shard needs an empty table (call kh_reset first)");
+    uint32_t sh = 0;
+    while ((1u << sh) < count) ++sh;
+    if (sh >= 2 * c->k) return fail(c, KH_ERR_BAD_ARG, "more shards than k-mers");
+    c->shard_shift = sh;
+    c->shard_index = index;
+    return KH_OK;
+}
+
+extern "C" int kh_export_regions_device(kh_ctx *c, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
+                                        uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
+                                        uint64_t *table_regions) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    const u64 nregions = c->cap / kh::REGION_SLOTS;
+    if (table_regions) *table_regions = nregions;
+    if (nparts < 1 || nparts > (uint32_t)kh::MAX_SENDERS || (nparts & (nparts - 1)) || nparts > nregions || !part_counts ||
+        !d_region_counts)
+        return fail(c, KH_ERR_BAD_ARG, "bad nparts / NULL argument");
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, "table is already a shard");
+    if (region_cap < nregions) return fail(c, KH_ERR_RANGE, "region count array too small");
+    rc = sync_counters(c);
+    if (rc != KH_OK) return rc;
+    hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                       (const Slot *)c->table, d_region_counts);
+    HIP_TRY(c, hipGetLastError());
+    // offsets of every region in the export (device scan), and the per-owner totals (host)
+    u64 z = c->merge_off_cap;
+    rc = ensure_buf(c, &c->merge_off, &z, nregions + 1, "hipMalloc(merge_off)");
+    c->merge_off_cap = z;
+    if (rc != KH_OK) return rc;
+    rc = device_scan(c, d_region_counts, nregions, c->merge_off);
+    if (rc != KH_OK) return rc;
+    std::vector<u64> bounds(nparts + 1);
+    const u64 per = nregions / nparts;
+    for (uint32_t p = 0; p <= nparts; ++p)
+        HIP_TRY(c, hipMemcpyAsync(&bounds[p], c->merge_off + (u64)p * per, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t p = 0; p < nparts; ++p) part_counts[p] = bounds[p + 1] - bounds[p];
+    const u64 total = bounds[nparts];
+    if (total > cap) return fail(c, KH_ERR_RANGE, "export arrays too small");
+    if (total) {
+        if (!d_keys || !d_counts) return fail(c, KH_ERR_BAD_ARG, "NULL output");
+        hipLaunchKernelGGL(kh::region_compact_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                           (const Slot *)c->table, (const u64 *)c->merge_off, (u64 *)d_keys, (u64 *)d_counts);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return KH_OK;
+}
+
+extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
+                                       const uint64_t *const *d_keys, const uint64_t *const *d_counts,
+                                       const uint32_t *const *d_region_counts) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || !d_counts || !d_region_counts)
+        return fail(c, KH_ERR_BAD_ARG, "bad nsenders / NULL argument");
+    if (sender_regions == 0 || (sender_regions & (sender_regions - 1)) || (sender_regions >> c->shard_shift) == 0)
+        return fail(c, KH_ERR_BAD_ARG, "sender_regions must be a power of two >= the shard count");
+    const u64 nr = sender_regions >> c->shard_shift;  // sender regions inside this shard's hash range
+    // per-sender offsets of every region segment (device scans), and the incoming total (host)
+    u64 z = c->merge_off_cap;
+    rc = ensure_buf(c, &c->merge_off, &z, (u64)nsenders * (nr + 1), "hipMalloc(merge_off)");
+    c->merge_off_cap = z;
+    if (rc != KH_OK) return rc;
+    std::vector<u64> totals(nsenders);
+    for (uint32_t s = 0; s < nsenders; ++s) {
+        rc = device_scan(c, d_region_counts[s], nr, c->merge_off + (u64)s * (nr + 1));
+        if (rc != KH_OK) return rc;
+        HIP_TRY(c, hipMemcpyAsync(&totals[s], c->merge_off + (u64)s * (nr + 1) + nr, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    u64 incoming = 0;
+    for (u64 t : totals) incoming += t;
+    if (incoming == 0) return KH_OK;
+    // every incoming pair may be a new key: make room up front (an empty table is simply re-allocated)
+    if (c->pending_bound) {
+        rc = sync_counters(c);
+        if (rc != KH_OK) return rc;
+    }
+    if ((double)(c->distinct_known + incoming) > LOAD_HARD * (double)c->cap) {
+        u64 newcap = c->cap;
+        while ((double)(c->distinct_known + incoming) > LOAD_HARD * (double)newcap) newcap *= 2;
+        if (c->table_empty) {
+            Slot *nt = nullptr;
+            rc = alloc_table(c, newcap, &nt);
+            if (rc != KH_OK) return rc;
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->table);
+            c->table = nt;
+            c->cap = newcap;
+        } else {
+            rc = grow_to(c, newcap);
+            if (rc != KH_OK) return rc;
+        }
+    }
+    const kh::TableGeom tg = table_geom(c, c->table, c->cap);
+    const u64 nregions = c->cap / kh::REGION_SLOTS;
+    if (c->region_cap < nregions) {
+        u64 zz = c->bstart ? c->region_cap + 1 : 0;
+        if ((rc = ensure_buf(c, &c->bstart, &zz, nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
+        zz = c->rfail ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rfail, &zz, nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
+        zz = c->rnew ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rnew, &zz, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
+        c->region_cap = nregions;
+    }
+    kh::MergeArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nsenders = nsenders;
+    uint32_t nr_bits = 0;
+    while ((1ull << nr_bits) < nr) ++nr_bits;
+    a.dshift = (int32_t)tg.rbits - (int32_t)nr_bits;  // target t <-> sender-local region t >> dshift
+    for (uint32_t s = 0; s < nsenders; ++s) {
+        a.src[s].keys = (const u64 *)d_keys[s];
+        a.src[s].counts = (const u64 *)d_counts[s];
+        a.src[s].off = c->merge_off + (u64)s * (nr + 1);
+    }
+    {
+        StageTimer t(c, ST_REGION);
+        if (c->table_empty)
+            hipLaunchKernelGGL((kh::shard_merge_kernel<true, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, tg, a,
+                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr);
+        else
+            hipLaunchKernelGGL((kh::shard_merge_kernel<false, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, tg, a,
+                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr);
+        hipLaunchKernelGGL(kh::shard_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
+                           (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)nregions, c->d_ctr);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->table_empty = false;
+    rc = sync_counters(c);
+    if (rc != KH_OK) return rc;
+    if (c->h_ctr->part_failed) {  // some target regions overflowed: grow, then insert their pairs directly
+        const uint32_t old_rbits = tg.rbits;
+        StageTimer t(c, ST_GROW);
+        rc = grow_to(c, c->cap * 2);
+        if (rc != KH_OK) return rc;
+        hipLaunchKernelGGL((kh::shard_merge_kernel<false, true>), dim3((unsigned)nregions), dim3(1024), 0, c->stream,
+                           table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr);
+        HIP_TRY(c, hipMemsetAsync(&c->d_ctr->part_failed, 0, sizeof(u64), c->stream));
+        HIP_TRY(c, hipGetLastError());
+        rc = sync_counters(c);
+        if (rc != KH_OK) return rc;
+    }
+    return KH_OK;
 }
 
 // =============================================================================================

@@ -38,11 +38,20 @@ constexpr int REGION_NT = 1024;                  // lanes per workgroup in regio
 constexpr int REGION_RK = 8;                     // keys prefetched per lane per round
 
 struct PartGeom {
-    uint32_t rbits;    // log2(regions) = p1_bits + p2_bits
-    uint32_t p1_bits;  // level-1 partitions = 1 << p1_bits
-    uint32_t p2_bits;  // buckets per level-1 partition = 1 << p2_bits
+    uint32_t rbits;        // log2(regions) = p1_bits + p2_bits
+    uint32_t p1_bits;      // level-1 partitions = 1 << p1_bits
+    uint32_t p2_bits;      // buckets per level-1 partition = 1 << p2_bits
     uint32_t k;
+    uint32_t shard_shift;  // as TableGeom: placement hash = kh_table_hash << shard_shift
+    uint32_t shard_index;
 };
+
+__device__ __forceinline__ u64 part_hash(const PartGeom &g, u64 key) { return kh_table_hash(key, g.k) << g.shard_shift; }
+// key of a placement hash of this (possibly sharded) table
+__device__ __forceinline__ u64 part_unhash(const PartGeom &g, u64 Hs) {
+    const u64 H = g.shard_shift ? ((Hs >> g.shard_shift) | ((u64)g.shard_index << (64 - g.shard_shift))) : Hs;
+    return kh_table_unhash(H, g.k);
+}
 
 // ---- payload traits ---------------------------------------------------------------------------
 template <typename PT>
@@ -52,7 +61,7 @@ template <>
 struct Pay<u64> {  // the key itself
     __device__ static __forceinline__ u64 make(u64 key, u64 H, const PartGeom &g) { return key; }
     __device__ static __forceinline__ uint32_t p2(u64 pay, const PartGeom &g) {
-        const u64 H = kh_table_hash(pay, g.k);
+        const u64 H = part_hash(g, pay);
         return g.p2_bits ? (uint32_t)((H << g.p1_bits) >> (64 - g.p2_bits)) : 0u;
     }
     __device__ static __forceinline__ u64 key(u64 pay, uint32_t p1, const PartGeom &g) { return pay; }
@@ -69,7 +78,7 @@ struct Pay<uint32_t> {  // bits [p1_bits, p1_bits+32) of H
         return top | ((u64)pay << (32 - g.p1_bits));
     }
     __device__ static __forceinline__ u64 key(uint32_t pay, uint32_t p1, const PartGeom &g) {
-        return kh_table_unhash(hash(pay, p1, g), g.k);
+        return part_unhash(g, hash(pay, p1, g));
     }
 };
 
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(PART_NT) void part1_count_kernel(
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
             u64 key;
-            if (roll.next(j, key)) atomicAdd(&s_hist[p1_of_hash(kh_table_hash(key, k), g)], 1u);
+            if (roll.next(j, key)) atomicAdd(&s_hist[p1_of_hash(part_hash(g, key), g)], 1u);
         }
     }
     __syncthreads();
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
             tag[j] = 0xFFFFFFFFu;
             u64 key;
             if (roll.next(j, key)) {
-                const u64 H = kh_table_hash(key, k);
+                const u64 H = part_hash(g, key);
                 const uint32_t p = p1_of_hash(H, g);
                 item[j] = P32 ? (((u64)p << 32) | (u64)Pay<uint32_t>::make(key, H, g)) : key;
                 tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);  // rank < 16384 fits 16 bits
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
 #pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART_NT) {
             const u64 v = s_stage[i];
-            const uint32_t p = P32 ? (uint32_t)(v >> 32) : p1_of_hash(kh_table_hash(v, k), g);
+            const uint32_t p = P32 ? (uint32_t)(v >> 32) : p1_of_hash(part_hash(g, v), g);
             out[s_dst[p] + i] = (PT)v;  // consecutive lanes -> consecutive addresses inside a run
         }
         // s_stage / s_dst are rewritten only after the next tile's barriers
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
                 }
             }
             if (key == KH_EMPTY_KEY) continue;
-            uint32_t off = start_of(tg, kh_table_hash(key, tg.k));
+            uint32_t off = start_of(tg, table_hash(tg, key));
             uint32_t probes = 0;
             for (; probes < REGION_SLOTS; ++probes) {
                 u64 cur = s_key[off];
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             const uint4 v = g4[i];
             old[q].key = ((u64)v.y << 32) | v.x;
             old[q].count = ((u64)v.w << 32) | v.z;
-            if (old[q].key != KH_EMPTY_KEY) w = Pay<uint32_t>::make(old[q].key, kh_table_hash(old[q].key, tg.k), g);
+            if (old[q].key != KH_EMPTY_KEY) w = Pay<uint32_t>::make(old[q].key, table_hash(tg, old[q].key), g);
             // an old key whose payload equals the free marker keeps w == FREE: new arrivals of that
             // payload are counted in s_special and merged below
         }

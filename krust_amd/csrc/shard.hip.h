@@ -1,0 +1,184 @@
+// shard.hip.h -- multi-GPU merge of per-GPU tables by hash range (no reference
+// counterpart: the reference is single-process, src/run.rs:500-503 is its only parallelism).
+//
+// Ownership = the top bits of the table hash, i.e. a contiguous range of table regions.  A rank's
+// table can therefore be exported region by region, already grouped by owner and ordered by
+// region, with two streaming kernels and no scatter; and the owner's shard is itself a table over
+// the remaining hash bits (TableGeom::shard_shift), rebuilt region by region in LDS from the
+// senders' region segments -- no partition passes and no global atomics on the merge either.
+#pragma once
+#include "kernels.hip.h"
+
+namespace kh {
+
+// rcount[r] = live slots of region r.  One workgroup per region.
+__global__ __launch_bounds__(BLOCK) void region_live_count_kernel(const Slot *__restrict__ table, uint32_t *__restrict__ rcount) {
+    __shared__ uint32_t s_n;
+    const u64 r = blockIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const Slot *reg = table + r * REGION_SLOTS;
+    uint32_t n = 0;
+    for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) n += reg[i].key != KH_EMPTY_KEY;
+    n = (uint32_t)wave_sum((u64)n);
+    if (lane_id() == 0 && n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) rcount[r] = s_n;
+}
+
+// Live pairs of region r go to [roff[r], roff[r+1]) (any order inside the region).
+__global__ __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__restrict__ table, const u64 *__restrict__ roff,
+                                                               u64 *__restrict__ keys, u64 *__restrict__ counts) {
+    __shared__ uint32_t s_cur;
+    const u64 r = blockIdx.x;
+    const u64 base = roff[r];
+    if (roff[r + 1] == base) return;
+    if (threadIdx.x == 0) s_cur = 0;
+    __syncthreads();
+    const Slot *reg = table + r * REGION_SLOTS;
+    for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {  // uniform trip count (4096 / 256)
+        const Slot s = reg[i];
+        const bool live = s.key != KH_EMPTY_KEY;
+        const u64 m = __ballot(live);
+        if (m == 0) continue;
+        uint32_t wbase = 0;
+        if ((int)lane_id() == __builtin_ctzll(m)) wbase = atomicAdd(&s_cur, (uint32_t)__builtin_popcountll(m));
+        wbase = (uint32_t)__shfl((int)wbase, __builtin_ctzll(m), 64);
+        if (live) {
+            const u64 o = base + wbase + mbcnt(m);
+            keys[o] = s.key;
+            counts[o] = s.count;
+        }
+    }
+}
+
+// ---- receiver side -----------------------------------------------------------------------------
+constexpr int MAX_SENDERS = 64;
+struct MergeSrc {
+    const u64 *keys;    // the sender's pairs for this shard, ordered by the sender's region index
+    const u64 *counts;
+    const u64 *off;     // exclusive scan of the sender's per-region counts over this shard's region range (nr + 1)
+};
+struct MergeArgs {
+    MergeSrc src[MAX_SENDERS];
+    uint32_t nsenders;
+    int32_t dshift;  // target region t reads sender-local region t >> dshift (dshift >= 0), or the
+                     // 2^-dshift sender-local regions starting at t << -dshift (dshift < 0)
+};
+
+// One workgroup per target region of the (sharded) receiver table.  FRESH: the table is empty.
+// DIRECT: instead of rebuilding the region in LDS, upsert straight into HBM with device atomics --
+// used only for the regions a first pass flagged as overflowing, after the table was grown.
+template <bool FRESH, bool DIRECT>
+__global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, MergeArgs a, uint8_t *__restrict__ rfail,
+                                                              uint32_t *__restrict__ rnew, const uint8_t *__restrict__ only_failed,
+                                                              uint32_t old_rbits, Counters *ctr) {
+    __shared__ u64 s_key[DIRECT ? 1 : REGION_SLOTS];
+    __shared__ u64 s_cnt[DIRECT ? 1 : REGION_SLOTS];
+    __shared__ uint32_t s_fail, s_new;
+    const int tid = threadIdx.x;
+    // In DIRECT mode the grid still walks the ORIGINAL target regions (old_rbits); tg is the grown table.
+    const u64 t = blockIdx.x;
+    if (DIRECT && !only_failed[t]) return;
+    const uint32_t match_bits = DIRECT ? old_rbits : tg.rbits;
+    Slot *reg = tg.table + t * REGION_SLOTS;
+    if (!DIRECT) {
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
+        for (uint32_t i = tid; i < REGION_SLOTS; i += 1024) {
+            if (FRESH) {
+                s_key[i] = KH_EMPTY_KEY;
+                s_cnt[i] = 0;
+            } else {
+                const uint4 v = g4[i];
+                s_key[i] = ((u64)v.y << 32) | v.x;
+                s_cnt[i] = ((u64)v.w << 32) | v.z;
+            }
+        }
+    }
+    if (tid == 0) {
+        s_fail = 0;
+        s_new = 0;
+    }
+    __syncthreads();
+    uint32_t nd = 0, nf = 0;
+    const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
+    const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
+    for (uint32_t s = 0; s < a.nsenders; ++s) {
+        const MergeSrc src = a.src[s];
+        const u64 lo = src.off[rl0], hi = src.off[rl0 + nrl];
+        for (u64 i = lo + tid; i < hi; i += 1024) {
+            const u64 key = src.keys[i];
+            const u64 H = table_hash(tg, key);
+            if ((H >> (64 - match_bits)) != t) continue;  // the segment also feeds the sibling targets
+            const u64 addend = src.counts[i];
+            if (DIRECT) {
+                upsert(tg, key, addend, nd, nf);
+                continue;
+            }
+            uint32_t off = start_of(tg, H);
+            uint32_t probes = 0;
+            for (; probes < REGION_SLOTS; ++probes) {
+                u64 cur = s_key[off];
+                if (cur == KH_EMPTY_KEY) {
+                    cur = atomicCAS(&s_key[off], (u64)KH_EMPTY_KEY, key);
+                    if (cur == KH_EMPTY_KEY) {
+                        ++nd;
+                        cur = key;
+                    }
+                }
+                if (cur == key) {
+                    atomicAdd(&s_cnt[off], addend);
+                    break;
+                }
+                off = (off + 1) & REGION_MASK;
+            }
+            if (probes == REGION_SLOTS) s_fail = 1;
+        }
+    }
+    if (DIRECT) {
+        const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+        if (lane_id() == 0) {
+            if (d) atomicAdd(&ctr->distinct, d);
+            if (f) atomicAdd(&ctr->failed, f);
+        }
+        return;
+    }
+    const uint32_t dw = (uint32_t)wave_sum((u64)nd);
+    if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) {
+            rfail[t] = 1;
+            rnew[t] = 0;
+        }
+        return;
+    }
+    uint4 *o4 = reinterpret_cast<uint4 *>(reg);
+    for (uint32_t i = tid; i < REGION_SLOTS; i += 1024) {
+        const u64 kk = s_key[i], cc = s_cnt[i];
+        o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
+    }
+    if (tid == 0) {
+        rfail[t] = 0;
+        rnew[t] = s_new;
+    }
+}
+
+// distinct += sum(rnew), part_failed += number of failed target regions
+__global__ __launch_bounds__(BLOCK) void shard_reduce_kernel(const uint8_t *__restrict__ rfail, const uint32_t *__restrict__ rnew,
+                                                             u64 nregions, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    u64 d = 0, nf = 0;
+    for (u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x; r < nregions; r += stride) {
+        if (rfail[r]) ++nf;
+        else d += rnew[r];
+    }
+    d = wave_sum(d);
+    nf = wave_sum(nf);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (nf) atomicAdd(&ctr->part_failed, nf);
+    }
+}
+
+}  // namespace kh

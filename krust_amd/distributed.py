@@ -23,12 +23,13 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def exchange_pairs(keys, counts, part_counts, group=None):
+def exchange_pairs(keys, counts, part_counts, group=None, return_sizes=False):
     """All-to-all of owner-grouped pairs.
 
     keys/counts: int64 tensors (bit views of u64) laid out as [pairs for owner 0 | owner 1 | ...];
     part_counts: per-owner pair counts (len == world).  Returns (recv_keys, recv_counts): every
-    pair this rank owns, from all ranks (its own included)."""
+    pair this rank owns, from all ranks (its own included), sender by sender; with return_sizes
+    also the per-sender counts."""
     world = dist.get_world_size(group)
     send_sizes = [int(x) for x in part_counts]
     assert len(send_sizes) == world and sum(send_sizes) == keys.numel() == counts.numel()
@@ -41,31 +42,68 @@ def exchange_pairs(keys, counts, part_counts, group=None):
     rc = torch.empty(sum(recv_sizes), dtype=torch.int64, device=dev)
     dist.all_to_all_single(rk, keys, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
     dist.all_to_all_single(rc, counts, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
+    if return_sizes:
+        return rk, rc, recv_sizes
     return rk, rc
+
+
+def _same_everywhere(value, group=None):
+    """True iff every rank holds the same integer."""
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    allv = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    return all(int(v.item()) == int(value) for v in allv)
 
 
 def merge_across_ranks(counter, group=None):
     """Turns per-rank tables (each built from that rank's read shard) into a key-sharded global
-    table: afterwards `counter` on rank r holds exactly the keys with kh_owner(key, world) == r,
-    with counts summed over all ranks.  Returns a dict of sizes for reporting."""
+    table: afterwards `counter` on rank r holds exactly the keys with kh_owner(key, k, world) == r,
+    with counts summed over all ranks.  Returns a dict of sizes for reporting.
+
+    Power-of-two world and equal table sizes: the region-ordered fast path (export in region order,
+    one all-to-all of pairs + one of region counts, LDS rebuild of the shard: no scatter kernel, no
+    global atomics).  Otherwise: pairs grouped by owner and re-inserted with device atomics."""
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     st = counter.finish()
     n_local = int(st["distinct"])
+    nreg = int(st["table_slots"]) // 4096
     dev = torch.device("cuda", torch.cuda.current_device())
     keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
     cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
-    parts = counter.export_by_owner_device(world, keys.data_ptr(), cnts.data_ptr(), n_local)
-    rk, rc = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group)
-    counter.reset()
-    counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
+    pow2 = world & (world - 1) == 0
+    if pow2 and world <= 64 and nreg >= world and _same_everywhere(nreg, group):
+        rcnt = torch.empty(nreg, dtype=torch.int32, device=dev)
+        parts, nreg2 = counter.export_regions_device(world, keys.data_ptr(), cnts.data_ptr(), n_local, rcnt.data_ptr(), nreg)
+        assert nreg2 == nreg
+        rk, rc, recv_sizes = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group, return_sizes=True)
+        rrc = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices of nreg / world region counts
+        dist.all_to_all_single(rrc, rcnt, group=group)
+        counter.reset()
+        counter.set_shard(rank, world)
+        offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
+        per = nreg // world
+        counter.merge_regions_device(nreg,
+                                     [rk.data_ptr() + 8 * int(offs[s]) for s in range(world)],
+                                     [rc.data_ptr() + 8 * int(offs[s]) for s in range(world)],
+                                     [rrc.data_ptr() + 4 * per * s for s in range(world)])
+        path = "regions"
+    else:
+        parts = counter.export_by_owner_device(world, keys.data_ptr(), cnts.data_ptr(), n_local)
+        rk, rc = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group)
+        counter.reset()
+        counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
+        path = "pairs"
     st2 = counter.finish()
-    return {"local_distinct": n_local, "sent_pairs": int(n_local - parts[dist.get_rank(group)]),
+    return {"path": path, "local_distinct": n_local, "sent_pairs": int(n_local - parts[rank]),
             "recv_pairs": int(rk.numel()), "owned_distinct": int(st2["distinct"])}
 
 
 def group_pairs_by_owner(keys, counts, world, owner_fn):
     """Host-side twin of kh_export_by_owner_device for numpy pairs (used where the pairs are
-    already on the host, e.g. gathering a final result)."""
+    already on the host, e.g. gathering a final result).  owner_fn(key, world) -> shard."""
     keys = np.asarray(keys, dtype=np.uint64)
     counts = np.asarray(counts, dtype=np.uint64)
     own = np.fromiter((owner_fn(int(k), world) for k in keys), dtype=np.int64, count=keys.size)

@@ -55,7 +55,10 @@ SYMBOLS = {
     "kh_result_copy_device": (C.c_int, [_P, _P, _P, _U64, _U64, C.POINTER(_U64)]),
     "kh_histogram": (C.c_int, [_P, _U64, _P, _P, _U64, C.POINTER(_U64)]),
     "kh_lookup": (C.c_int, [_P, _P, _U64, _P]),
-    "kh_owner": (C.c_uint32, [_U64, C.c_uint32]),
+    "kh_owner": (C.c_uint32, [_U64, C.c_uint32, C.c_uint32]),
+    "kh_set_shard": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "kh_export_regions_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
+    "kh_merge_regions_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P, _P]),
     "kh_export_by_owner_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P]),
     "kh_merge_pairs_device": (C.c_int, [_P, _P, _P, _U64]),
     "kh_merge_pairs": (C.c_int, [_P, _P, _P, _U64]),
@@ -243,6 +246,27 @@ class DeviceCounter:
         self._check(lib().kh_export_by_owner_device(self._h, int(nparts), d_keys, d_counts, int(cap), parts.ctypes.data))
         return parts
 
+    def set_shard(self, index, count):
+        """Make the (empty) table shard `index` of `count` (power of two) by hash range."""
+        self._check(lib().kh_set_shard(self._h, int(index), int(count)))
+
+    def export_regions_device(self, nparts, d_keys, d_counts, cap, d_region_counts, region_cap):
+        """Live pairs in region order (grouped by owner) + per-region live counts.
+        Returns (pairs per owner as uint64 array, number of table regions)."""
+        parts = np.zeros(nparts, dtype=np.uint64)
+        nreg = _U64(0)
+        self._check(lib().kh_export_regions_device(self._h, int(nparts), d_keys, d_counts, int(cap), d_region_counts,
+                                                   int(region_cap), parts.ctypes.data, C.byref(nreg)))
+        return parts, int(nreg.value)
+
+    def merge_regions_device(self, sender_regions, d_keys, d_counts, d_region_counts):
+        """d_keys / d_counts / d_region_counts: one device address per sender."""
+        n = len(d_keys)
+        assert len(d_counts) == n and len(d_region_counts) == n
+        arr = lambda xs: (_P * n)(*[_P(int(x)) for x in xs])
+        ak, ac, ar = arr(d_keys), arr(d_counts), arr(d_region_counts)
+        self._check(lib().kh_merge_regions_device(self._h, n, int(sender_regions), ak, ac, ar))
+
     def merge_pairs_device(self, d_keys, d_counts, n):
         self._check(lib().kh_merge_pairs_device(self._h, d_keys, d_counts, int(n)))
 
@@ -288,8 +312,9 @@ def canonical(bits, k):
     return int(out.value), bool(rc_flag.value)
 
 
-def owner(key, nparts):
-    return int(lib().kh_owner(int(key), int(nparts)))
+def owner(key, k, nparts):
+    """Owner shard of a packed canonical k-mer (fast-range of the top bits of the table hash)."""
+    return int(lib().kh_owner(int(key), int(k), int(nparts)))
 
 
 def synth_reads_device(d_bases, d_qual, seed, genome_len, read_len, first_read, n_reads, device=-1, stream=None):

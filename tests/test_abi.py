@@ -91,8 +91,15 @@ def test_pure_helpers_match_oracle(K, s):
 
 
 def test_owner_is_a_partition(K):
+    # power-of-two shard counts: the owner is the top bits of the (bijective) table hash, so shards are balanced
+    keys = list(range(1 << 10))
+    for n in (2, 4, 8):
+        cnt = [0] * n
+        for key in keys:
+            cnt[K.owner(key, 5, n)] += 1
+        assert cnt == [len(keys) // n] * n  # k=5: all 4^5 keys, a bijection splits them evenly
     for nparts in (1, 2, 3, 8, 64):
-        owners = [K.owner(O.mix64(i), nparts) for i in range(2000)]
+        owners = [K.owner(O.mix64(i) & ((1 << 42) - 1), 21, nparts) for i in range(2000)]
         assert min(owners) >= 0 and max(owners) < nparts
         if nparts > 1:
             assert len(set(owners)) == nparts

@@ -26,11 +26,11 @@ lo, hi = shard_range(N_READS, rank, world)
 bases, _ = O.synth_reads(SEED, 1 << 15, 150, lo, hi - lo, with_qual=False)
 m = O.OracleMap(); m.scan_flat(bases, K)
 keys, cnts = m.arrays()
-gk, gc, parts = group_pairs_by_owner(keys, cnts, world, krust_amd.owner)
+gk, gc, parts = group_pairs_by_owner(keys, cnts, world, lambda key, w: krust_amd.owner(key, K, w))
 rk, rc = exchange_pairs(torch.from_numpy(gk.view(np.int64).copy()), torch.from_numpy(gc.view(np.int64).copy()), parts.tolist())
 owned = O.OracleMap()
 for k_, c_ in zip(rk.numpy().view(np.uint64).tolist(), rc.numpy().view(np.uint64).tolist()):
-    assert krust_amd.owner(k_, world) == rank
+    assert krust_amd.owner(k_, K, world) == rank
     owned.add(k_, c_)
 ok, oc = owned.arrays()
 gathered = [None] * world

@@ -345,7 +345,7 @@ def test_owner_partitioned_merge_logical_shards(K, nshards):
             hk = dk.cpu().numpy().view(np.uint64)
             for p in range(nshards):
                 seg = hk[offs[p]:offs[p + 1]]
-                assert all(K.owner(int(x), nshards) == p for x in seg[:50])
+                assert all(K.owner(int(x), 21, nshards) == p for x in seg[:50])
             exports.append((dk, dcnt, offs))
     merged = {}
     for p in range(nshards):  # owner p merges the p-th segment of every shard's export
@@ -356,9 +356,81 @@ def test_owner_partitioned_merge_logical_shards(K, nshards):
             dc.finish()
             d = dc.as_dict()
         assert not (set(d) & set(merged))
-        assert all(K.owner(k, nshards) == p for k in list(d)[:200])
+        assert all(K.owner(k, 21, nshards) == p for k in list(d)[:200])
         merged.update(d)
     assert merged == want
+
+
+@pytest.mark.parametrize("nshards,k,minq", [(2, 21, None), (4, 21, None), (8, 21, None), (4, 31, 20), (8, 9, None)])
+def test_region_ordered_merge_logical_shards(K, nshards, k, minq):
+    """The power-of-two fast path of the multi-GPU merge, as logical shards on one device:
+    region-ordered export from every 'rank', then each owner rebuilds its hash-range shard in LDS
+    from the senders' region segments.  Union of the shards == single-table result."""
+    import torch
+    n_reads = 40_000
+    bases, qual = O.synth_reads(SEED, 1 << 17, 150, 0, n_reads)
+    m = O.OracleMap()
+    m.scan_flat(bases, k, qual=qual, min_quality=minq, nthreads=NCPU)
+    want = m.as_dict()
+    per = n_reads // nshards
+    exports = []
+    nreg = None
+    for s in range(nshards):
+        lo, hi = s * per, (n_reads if s == nshards - 1 else (s + 1) * per)
+        with K.DeviceCounter(k, min_quality=minq, capacity_hint=3_000_000) as dc:  # same hint -> same table size
+            dc.push(bases[lo * 151: hi * 151], qual[lo * 151: hi * 151])
+            st = dc.finish()
+            R = st["table_slots"] // 4096
+            dk = torch.empty(max(st["distinct"], 1), dtype=torch.int64, device="cuda")
+            dcnt = torch.empty(max(st["distinct"], 1), dtype=torch.int64, device="cuda")
+            rc = torch.empty(R, dtype=torch.int32, device="cuda")
+            parts, R2 = dc.export_regions_device(nshards, dk.data_ptr(), dcnt.data_ptr(), st["distinct"], rc.data_ptr(), R)
+            assert R2 == R and int(parts.sum()) == st["distinct"] and int(rc.sum().item()) == st["distinct"]
+            nreg = R if nreg is None else nreg
+            assert R == nreg
+            offs = np.concatenate([[0], np.cumsum(parts)]).astype(np.int64)
+            exports.append((dk, dcnt, rc, offs))
+    merged = {}
+    per_r = nreg // nshards
+    for o in range(nshards):
+        with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+            dc.set_shard(o, nshards)
+            dc.merge_regions_device(nreg,
+                                    [e[0].data_ptr() + 8 * int(e[3][o]) for e in exports],
+                                    [e[1].data_ptr() + 8 * int(e[3][o]) for e in exports],
+                                    [e[2].data_ptr() + 4 * per_r * o for e in exports])
+            st = dc.finish()
+            d = dc.as_dict()
+            assert st["distinct"] == len(d)
+            probe = np.array(list(d)[:500] + [12345], dtype=np.uint64)  # lookups use the sharded placement
+            assert dc.lookup(probe).tolist() == [d.get(int(x), 0) for x in probe]
+        assert not (set(d) & set(merged))
+        assert all(K.owner(key, k, nshards) == o for key in list(d)[:300])
+        merged.update(d)
+    assert merged == want
+
+
+def test_shard_table_rejects_reads_until_reset(K):
+    """A shard table holds only keys of its hash range: reads cannot be pushed into it (state
+    error, nothing counted); kh_reset turns it back into a full table."""
+    bases, _ = O.synth_reads(SEED, 1 << 16, 150, 0, 5_000, with_qual=False)
+    m = O.OracleMap()
+    m.scan_flat(bases, 21, nthreads=NCPU)
+    with K.DeviceCounter(21) as dc:
+        dc.set_shard(3, 4)
+        with pytest.raises(K.KmerHipError) as e:
+            dc.push(bases)
+        assert e.value.status == -7
+        dc.reset()
+        dc.push(bases)
+        dc.finish()
+        assert dc.as_dict() == m.as_dict()
+        with pytest.raises(K.KmerHipError):   # not empty any more
+            dc.set_shard(0, 2)
+        for bad in ((0, 3), (4, 4), (0, 0)):
+            dc.reset()
+            with pytest.raises(K.KmerHipError):
+                dc.set_shard(*bad)
 
 
 def test_merge_pairs_host(K):
