@@ -124,3 +124,48 @@ def test_save_and_query(tmp_path):
     assert run("5", fx("simple.fa"), "-q", "--save", gz).returncode == 0
     assert gzip.open(gz).read()[:4] == b"KMIX"
     assert run("query", gz, "ACGTA").stdout == b"2\n"
+
+
+def test_hg_like_fasta_histogram(tmp_path):
+    """BASELINE.json configs[4] in miniature (hg38 itself is not on the box): a generated 'hg-like'
+    FASTA -- 12 records of very different lengths up to 16 Mbp, 60-column lines, ~50 % soft-masked
+    (lowercase) blocks, runs of N, a poly-A tract and a tandem repeat -- counted by the CLI with
+    `--format histogram` and compared line by line with the oracle's histogram, then `tsv` on a
+    1/64 key sample.  Exercises long records (k-mers across tile / workgroup / staging-chunk
+    boundaries), soft-masking and N handling through the real reader."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    rng = np.random.default_rng(38)
+    lens = [16_000_000, 9_000_000, 5_000_000, 3_000_000, 2_000_000, 1_000_000, 500_000, 200_000, 50_000, 3_000, 40, 7]
+    path = tmp_path / "hg_like.fa"
+    seqs = []
+    with open(path, "wb") as f:
+        for i, n in enumerate(lens):
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+            if n >= 50_000:
+                for _ in range(max(1, n // 200_000)):            # N runs
+                    a = int(rng.integers(0, n - 5_000)); s[a:a + int(rng.integers(1, 5_000))] = ord("N")
+                for _ in range(max(1, n // 100_000)):            # soft-masked blocks (~half the record)
+                    a = int(rng.integers(0, n - 50_000)); b = a + int(rng.integers(1_000, 50_000)); s[a:b] |= 0x20
+                a = int(rng.integers(0, n - 30_000)); s[a:a + 20_000] = ord("A")          # poly-A tract
+                a = int(rng.integers(0, n - 30_000)); s[a:a + 12_000] = np.frombuffer(b"ACGGTT" * 2_000, dtype=np.uint8)
+            seqs.append(s.tobytes())
+            f.write(b">chr%d some description\n" % (i + 1))
+            for off in range(0, n, 60):
+                f.write(seqs[-1][off:off + 60] + b"\n")
+    m = O.OracleMap()
+    for s in seqs:
+        m.scan_flat(s, 21, nthreads=8)
+    r = run("21", str(path), "--format", "histogram", "--quiet")
+    assert r.returncode == 0, r.stderr
+    got = [tuple(map(int, l.split(b"\t"))) for l in r.stdout.splitlines()]
+    assert got == m.histogram(1)                                   # ascending, bit-exact
+    assert sum(c * f for c, f in got) == m.total()
+    r = run("21", str(path), "--format", "tsv", "--quiet", "--min-count", "3")
+    want = {k: c for k, c in m.as_dict().items() if c >= 3}
+    got_tsv = tsv(r.stdout)
+    assert len(got_tsv) == len(want)
+    import krust_amd
+    assert all(want[krust_amd.pack(kmer)] == c for kmer, c in list(got_tsv.items())[:20000])
