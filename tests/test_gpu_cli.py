@@ -144,7 +144,7 @@ def test_hg_like_fasta_histogram(tmp_path):
     with open(path, "wb") as f:
         for i, n in enumerate(lens):
             s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
-            if n >= 50_000:
+            if n >= 200_000:
                 for _ in range(max(1, n // 200_000)):            # N runs
                     a = int(rng.integers(0, n - 5_000)); s[a:a + int(rng.integers(1, 5_000))] = ord("N")
                 for _ in range(max(1, n // 100_000)):            # soft-masked blocks (~half the record)
