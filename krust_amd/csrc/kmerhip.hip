@@ -33,6 +33,8 @@ constexpr u64 DEFAULT_CAP = 1ull << 20;
 constexpr u64 SUB_TILES = 1ull << 16;      // tiles per count launch (2^28 positions)
 constexpr u64 SUB_TILES_MIN = 1ull << 10;  // smallest launch when squeezing under LOAD_HARD
 constexpr u64 STAGE_BYTES = 64ull << 20;   // host staging chunk for kh_push
+constexpr u64 ACC_MAX = 2ull << 30;        // device accumulation buffer of kh_push (x2, x2 with qualities)
+constexpr u64 ACC_MIN = 1ull << 20;
 constexpr u64 HALO = 32;                   // >= k-1 bytes re-sent in front of every staged chunk
 constexpr int GRID_CAP = 256 * 8;          // 256 CUs x 8 resident workgroups of 256 threads
 constexpr int PART_G1 = 512;               // level-1 workgroups (fixed: count and scatter must agree)
@@ -64,10 +66,21 @@ struct kh_ctx {
     double kernel_ms = 0.0;
     double h2d_ms = 0.0;
 
-    uint8_t *h_stage[2] = {nullptr, nullptr};  // pinned: bases then qual, each HALO+STAGE_BYTES
-    uint8_t *d_stage[2] = {nullptr, nullptr};
+    // ---- kh_push: pinned staging -> device accumulation buffers -> one count per filled buffer ----
+    hipStream_t cstream = nullptr;             // copy stream (H2D overlaps counting on `stream`)
+    uint8_t *h_stage[2] = {nullptr, nullptr};  // pinned: bases then qual, each STAGE_BYTES
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
+    int stage_next = 0;
+    uint8_t *acc[2] = {nullptr, nullptr};      // device: [HALO | bases acc_cap | pad][HALO | qual acc_cap | pad]
+    u64 acc_cap = 0;                           // bytes of bases one accumulation buffer holds
+    int acc_cur = 0;
+    u64 acc_len = 0;                           // bytes accumulated in acc[acc_cur] (after the HALO head)
+    u64 acc_carry = 0;                         // HALO bytes at the head are the tail of the previous buffer
+    bool acc_qual = false;
+    hipEvent_t acc_free[2] = {nullptr, nullptr};
+    bool acc_busy[2] = {false, false};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> h2d_events;
 
     // ---- partitioned path ----
     bool table_empty = true;   // no insert since creation / reset: regions need not be read back
@@ -133,10 +146,15 @@ int grid_for(u64 items) {
     return (int)b;
 }
 
-int enter(kh_ctx *c) {
+int flush_acc(kh_ctx *c, bool carry);
+
+// Every entry point starts here.  Host pushes are accumulated on the device and counted lazily;
+// anything that looks at the table first counts what is pending.
+int enter(kh_ctx *c, bool flush_pending = true) {
     if (!c) return KH_ERR_BAD_ARG;
     if (c->poisoned) return fail(c, KH_ERR_STATE, "context is poisoned by an earlier error");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (flush_pending && c->acc_len) return flush_acc(c, false);
     return KH_OK;
 }
 
@@ -270,6 +288,13 @@ int drain_events(kh_ctx *c) {
         (void)hipEventDestroy(e.b);
     }
     c->stage_events.clear();
+    for (auto &p : c->h2d_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) c->h2d_ms += ms;
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    c->h2d_events.clear();
     return KH_OK;
 }
 
@@ -628,19 +653,74 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     return KH_OK;
 }
 
-int ensure_stage(kh_ctx *c, bool with_qual) {
-    const u64 per = HALO + STAGE_BYTES;
-    const u64 bytes = per * 2;  // bases + qual halves
-    (void)with_qual;
+int ensure_stage(kh_ctx *c) {
+    if (!c->cstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
         if (!c->h_stage[i]) {
-            hipError_t e = hipHostMalloc((void **)&c->h_stage[i], bytes, hipHostMallocDefault);
+            hipError_t e = hipHostMalloc((void **)&c->h_stage[i], 2 * STAGE_BYTES, hipHostMallocDefault);
             if (e != hipSuccess) return fail(c, KH_ERR_OOM, "hipHostMalloc(stage)", e);
-            e = hipMalloc((void **)&c->d_stage[i], bytes);
-            if (e != hipSuccess) return fail(c, KH_ERR_OOM, "hipMalloc(stage)", e);
             HIP_TRY(c, hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->acc_free[i], hipEventDisableTiming));
         }
     }
+    return KH_OK;
+}
+
+u64 acc_stride(u64 cap) { return HALO + cap + 64; }  // one of the two halves (bases / qual) of a buffer
+
+// (Re)allocates the two accumulation buffers for `cap` bytes of bases each.  Only when empty.
+int alloc_acc(kh_ctx *c, u64 cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->cstream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i) {
+        if (c->acc[i]) (void)hipFree(c->acc[i]);
+        c->acc[i] = nullptr;
+        c->acc_busy[i] = false;
+        hipError_t e = hipMalloc((void **)&c->acc[i], 2 * acc_stride(cap));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            c->acc_cap = 0;
+            return fail(c, KH_ERR_OOM, "hipMalloc(accumulation buffer)", e);
+        }
+    }
+    c->acc_cap = cap;
+    c->acc_cur = 0;
+    return KH_OK;
+}
+
+// Counts what the current accumulation buffer holds and switches to the other one.  carry: the
+// flush falls inside a push, so the last HALO bytes are re-presented at the head of the next buffer
+// (windows that straddle the seam are counted there, once).
+int flush_acc(kh_ctx *c, bool carry) {
+    if (c->acc_len == 0 && !carry) return KH_OK;
+    const int cur = c->acc_cur, nxt = cur ^ 1;
+    const u64 stride = acc_stride(c->acc_cap);
+    hipEvent_t ready;
+    HIP_TRY(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(ready, c->cstream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
+    (void)hipEventDestroy(ready);
+    const u64 head = HALO - c->acc_carry;
+    const u64 len = c->acc_carry + c->acc_len;
+    const u64 acc_len = c->acc_len;
+    c->acc_len = 0;  // (count_device_range re-enters nothing, but keep the state consistent on errors)
+    int rc = count_device_range(c, c->acc[cur] + head, c->acc_qual ? c->acc[cur] + stride + head : nullptr, len, c->acc_carry);
+    if (rc != KH_OK) return rc;
+    if (carry) {  // tail -> head of the next buffer, on the compute stream (ordered after the count)
+        if (c->acc_busy[nxt]) HIP_TRY(c, hipEventSynchronize(c->acc_free[nxt]));
+        HIP_TRY(c, hipMemcpyAsync(c->acc[nxt], c->acc[cur] + HALO + acc_len - HALO, HALO, hipMemcpyDeviceToDevice, c->stream));
+        if (c->acc_qual)
+            HIP_TRY(c, hipMemcpyAsync(c->acc[nxt] + stride, c->acc[cur] + stride + HALO + acc_len - HALO, HALO,
+                                      hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->acc_free[cur], c->stream));
+    c->acc_busy[cur] = true;
+    if (c->acc_busy[nxt]) {  // the copy stream may not overwrite a buffer that is still being counted
+        HIP_TRY(c, hipStreamWaitEvent(c->cstream, c->acc_free[nxt], 0));
+        c->acc_busy[nxt] = false;
+    }
+    c->acc_cur = nxt;
+    c->acc_carry = carry ? HALO : 0;
     return KH_OK;
 }
 
@@ -713,11 +793,14 @@ extern "C" void kh_destroy(kh_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drain_events(c);
+    if (c->cstream) (void)hipStreamSynchronize(c->cstream);
     for (int i = 0; i < 2; ++i) {
         if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
-        if (c->d_stage[i]) (void)hipFree(c->d_stage[i]);
+        if (c->acc[i]) (void)hipFree(c->acc[i]);
         if (c->stage_done[i]) (void)hipEventDestroy(c->stage_done[i]);
+        if (c->acc_free[i]) (void)hipEventDestroy(c->acc_free[i]);
     }
+    if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
                        c->bstart, c->rfail, c->rnew, c->scan_partial, c->merge_off};
     for (void *q : scratch)
@@ -730,8 +813,10 @@ extern "C" void kh_destroy(kh_ctx *c) {
 }
 
 extern "C" int kh_reset(kh_ctx *c) {
-    int rc = enter(c);
+    int rc = enter(c, false);
     if (rc != KH_OK) return rc;
+    if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
+    c->acc_len = c->acc_carry = 0;  // pushes not yet counted are forgotten with everything else
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
     hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table, c->cap);
@@ -762,45 +847,56 @@ extern "C" int kh_push_device(kh_ctx *c, const uint8_t *d_bases, const uint8_t *
 }
 
 extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uint64_t n) {
-    int rc = enter(c);
+    int rc = enter(c, false);
     if (rc != KH_OK) return rc;
     if (n && !bases) return fail(c, KH_ERR_BAD_ARG, "bases is NULL");
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
     if (n == 0) return KH_OK;
     const bool with_qual = (qual != nullptr) && (c->minq >= 0);
-    rc = ensure_stage(c, with_qual);
+    rc = ensure_stage(c);
     if (rc != KH_OK) return rc;
-    const u64 per = HALO + STAGE_BYTES;
-    int p = 0;
-    for (u64 off = 0; off < n; off += STAGE_BYTES, p ^= 1) {
+    if (c->acc_len && c->acc_qual != with_qual) {  // a buffer is counted with or without qualities, not both
+        rc = flush_acc(c, false);
+        if (rc != KH_OK) return rc;
+    }
+    // size the accumulation buffers for this push (grow-only, 1 MiB .. 2 GiB)
+    u64 want = ACC_MIN;
+    while (want < n + 1 && want < ACC_MAX) want *= 2;
+    if (want > c->acc_cap) {
+        rc = flush_acc(c, false);
+        if (rc == KH_OK) rc = alloc_acc(c, want);
+        if (rc != KH_OK) return rc;
+    }
+    c->acc_qual = with_qual;
+    const u64 stride = acc_stride(c->acc_cap);
+    for (u64 off = 0; off < n; off += STAGE_BYTES) {
         const u64 len = std::min(STAGE_BYTES, n - off);
-        const u64 halo = off ? HALO : 0;  // re-send the k-1 look-back in front of every later chunk
+        if (c->acc_len + len + 1 > c->acc_cap) {  // +1: the separator appended after the push
+            rc = flush_acc(c, off != 0);          // inside a push the seam needs the k-1 look-back
+            if (rc != KH_OK) return rc;
+        }
+        const int p = c->stage_next;
+        c->stage_next ^= 1;
         if (c->stage_used[p]) HIP_TRY(c, hipEventSynchronize(c->stage_done[p]));
+        memcpy(c->h_stage[p], bases + off, len);
+        if (with_qual) memcpy(c->h_stage[p] + STAGE_BYTES, qual + off, len);
         hipEvent_t t0, t1;
         HIP_TRY(c, hipEventCreate(&t0));
         HIP_TRY(c, hipEventCreate(&t1));
-        memcpy(c->h_stage[p] + (HALO - halo), bases + off - halo, halo + len);
-        if (with_qual) memcpy(c->h_stage[p] + per + (HALO - halo), qual + off - halo, halo + len);
-        HIP_TRY(c, hipEventRecord(t0, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_stage[p] + (HALO - halo), c->h_stage[p] + (HALO - halo), halo + len,
-                                  hipMemcpyHostToDevice, c->stream));
-        if (with_qual)
-            HIP_TRY(c, hipMemcpyAsync(c->d_stage[p] + per + (HALO - halo), c->h_stage[p] + per + (HALO - halo),
-                                      halo + len, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipEventRecord(t1, c->stream));
-        HIP_TRY(c, hipEventRecord(c->stage_done[p], c->stream));
+        HIP_TRY(c, hipEventRecord(t0, c->cstream));
+        uint8_t *dst = c->acc[c->acc_cur] + HALO + c->acc_len;
+        HIP_TRY(c, hipMemcpyAsync(dst, c->h_stage[p], len, hipMemcpyHostToDevice, c->cstream));
+        if (with_qual) HIP_TRY(c, hipMemcpyAsync(dst + stride, c->h_stage[p] + STAGE_BYTES, len, hipMemcpyHostToDevice, c->cstream));
+        HIP_TRY(c, hipEventRecord(t1, c->cstream));
+        HIP_TRY(c, hipEventRecord(c->stage_done[p], c->cstream));
         c->stage_used[p] = true;
-        rc = count_device_range(c, c->d_stage[p] + (HALO - halo), with_qual ? c->d_stage[p] + per + (HALO - halo) : nullptr,
-                                halo + len, halo);
-        if (rc != KH_OK) return rc;
-        // the device staging buffer is reused two chunks later on the same stream (ordered);
-        // the pinned one is guarded by stage_done.  H2D time is accounted lazily.
-        HIP_TRY(c, hipEventSynchronize(t1));
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t0, t1) == hipSuccess) c->h2d_ms += ms;
-        (void)hipEventDestroy(t0);
-        (void)hipEventDestroy(t1);
+        c->h2d_events.emplace_back(t0, t1);
+        c->acc_len += len;
     }
+    // k-mers never span pushes: a separator byte follows the last record of every push
+    HIP_TRY(c, hipMemsetAsync(c->acc[c->acc_cur] + HALO + c->acc_len, '\n', 1, c->cstream));
+    if (with_qual) HIP_TRY(c, hipMemsetAsync(c->acc[c->acc_cur] + stride + HALO + c->acc_len, '\n', 1, c->cstream));
+    c->acc_len += 1;
     c->bases_pushed += n;
     return KH_OK;
 }
@@ -810,6 +906,7 @@ extern "C" int kh_finish(kh_ctx *c, kh_stats *st) {
     if (rc != KH_OK) return rc;
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
+    if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
     drain_events(c);
     if (st) {
         st->bases = c->bases_pushed;
