@@ -107,6 +107,13 @@ struct kh_ctx {
     u64 *bstart = nullptr;
     uint8_t *rfail = nullptr;
     uint32_t *rnew = nullptr;
+    uint16_t *chunk_part = nullptr;  // chunk pool metadata (32-bit payload path)
+    uint8_t *fill8 = nullptr;
+    uint32_t *plist = nullptr;
+    u64 pool_cap = 0;                // chunks the metadata arrays hold
+    uint32_t *pcount = nullptr;      // [MAX_P1] chunks per partition, then cursors
+    u64 *pstart = nullptr;           // [MAX_P1 + 1]
+    u64 *pool_next = nullptr;
     u64 region_cap = 0;
     u64 *scan_partial = nullptr;
     u64 scan_cap = 0;
@@ -400,10 +407,16 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
 // PT = payload type carried through the partition buffers (partition.hip.h).
 template <typename PT>
 int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 tile0, u64 ntiles) {
+    constexpr bool CHUNKED = sizeof(PT) == 4;  // 32-bit payloads: single-pass level 1 into a chunk pool
     const u64 nregions = 1ull << g.rbits;
     const u64 P1 = 1ull << g.p1_bits;
     const u64 n_ub = ntiles * kh::PART_TILE;  // upper bound on keys
-    const u64 max_blocks = (n_ub + kh::PART2_CHUNK - 1) / kh::PART2_CHUNK + P1;
+    // chunk pool: every payload + one partial chunk per (workgroup, partition) + the unused tail of
+    // every workgroup's private ranges
+    const u64 pool_chunks = CHUNKED ? (n_ub / kh::CHUNK_PAY) + (n_ub / kh::CHUNK_PAY) / 24 +
+                                          (u64)PART_G1 * (P1 + kh::POOL_GRAB) + 1024
+                                    : 0;
+    const u64 max_blocks = CHUNKED ? pool_chunks / kh::CPB + P1 + 1 : (n_ub + kh::PART2_CHUNK - 1) / kh::PART2_CHUNK + P1;
     const u64 n1 = P1 * PART_G1;
     const u64 n2 = max_blocks << g.p2_bits;
     int rc;
@@ -418,6 +431,12 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->nch, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(nch)")) != KH_OK) return rc;
         z = 0;
         if ((rc = ensure_buf(c, &c->info, &z, 4, "hipMalloc(info)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pcount, &z, (u64)kh::MAX_P1, "hipMalloc(pcount)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pstart, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(pstart)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pool_next, &z, 1, "hipMalloc(pool_next)")) != KH_OK) return rc;
     }
     if ((rc = ensure_buf(c, &c->blocks, &c->blocks_cap, max_blocks, "hipMalloc(blocks)")) != KH_OK) return rc;
     if (c->h2_cap < n2) {  // H2 and O2 grow together
@@ -436,7 +455,17 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->rnew, &z, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
         c->region_cap = nregions;
     }
-    const u64 key_bytes = n_ub * sizeof(PT);
+    if (CHUNKED && c->pool_cap < pool_chunks) {
+        u64 z = c->chunk_part ? c->pool_cap : 0;
+        if ((rc = ensure_buf(c, &c->chunk_part, &z, pool_chunks, "hipMalloc(chunk_part)")) != KH_OK) return rc;
+        z = c->fill8 ? c->pool_cap : 0;
+        if ((rc = ensure_buf(c, &c->fill8, &z, pool_chunks, "hipMalloc(fill8)")) != KH_OK) return rc;
+        z = c->plist ? c->pool_cap : 0;
+        if ((rc = ensure_buf(c, &c->plist, &z, pool_chunks, "hipMalloc(plist)")) != KH_OK) return rc;
+        c->pool_cap = pool_chunks;
+    }
+    const u64 a_bytes = CHUNKED ? pool_chunks * kh::CHUNK_PAY * sizeof(PT) : n_ub * sizeof(PT);
+    const u64 key_bytes = std::max(a_bytes, n_ub * (u64)sizeof(PT));
     if (c->key_cap < key_bytes) {  // key_cap is in BYTES per buffer
         u64 z = c->keysA ? c->key_cap : 0;
         if ((rc = ensure_buf(c, &c->keysA, &z, key_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
@@ -449,38 +478,74 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
     const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
     const dim3 g1(PART_G1), b1(kh::PART_NT);
+    kh::ChunkSrc cs;
+    cs.pay = reinterpret_cast<const uint32_t *>(c->keysA);
+    cs.plist = c->plist;
+    cs.fill8 = c->fill8;
 
-    {
-        StageTimer t(c, ST_P1_COUNT);
-        if (ra.use_qual)
-            hipLaunchKernelGGL(kh::part1_count_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
-                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
-        else
-            hipLaunchKernelGGL(kh::part1_count_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
-                               ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
-    }
-    {
-        StageTimer t(c, ST_MISC);
-        if ((rc = device_scan(c, c->H1, n1, c->O1)) != KH_OK) return rc;
-    }
-    {
-        StageTimer t(c, ST_P1_SCATTER);
-        if (ra.use_qual)
-            hipLaunchKernelGGL((kh::part1_scatter_kernel<true, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
-                               ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
-        else
-            hipLaunchKernelGGL((kh::part1_scatter_kernel<false, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
-                               ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
-    }
-    {
-        StageTimer t(c, ST_MISC);
-        hipLaunchKernelGGL(kh::part2_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->O1, (uint32_t)PART_G1, g, n1,
-                           c->blocks, max_blocks, c->moff, c->nch, c->info);
-        HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
+    if (CHUNKED) {
+        {
+            StageTimer t(c, ST_MISC);
+            HIP_TRY(c, hipMemsetAsync(c->chunk_part, 0xFF, pool_chunks * sizeof(uint16_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->fill8, 0xFF, pool_chunks, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->pcount, 0, kh::MAX_P1 * sizeof(uint32_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->pool_next, 0, sizeof(u64), c->stream));
+        }
+        {
+            StageTimer t(c, ST_P1_SCATTER);
+            if (ra.use_qual)
+                hipLaunchKernelGGL(kh::part1_scatter_chunked_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
+                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA,
+                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr);
+            else
+                hipLaunchKernelGGL(kh::part1_scatter_chunked_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
+                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA,
+                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr);
+        }
+        {
+            StageTimer t(c, ST_MISC);
+            hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
+                               (const u64 *)c->pool_next, pool_chunks, c->pcount);
+            if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
+            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
+                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount);
+            hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
+                               (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
+            HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
+        }
+    } else {
+        {
+            StageTimer t(c, ST_P1_COUNT);
+            if (ra.use_qual)
+                hipLaunchKernelGGL(kh::part1_count_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
+                                   ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
+            else
+                hipLaunchKernelGGL(kh::part1_count_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
+                                   ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
+        }
+        {
+            StageTimer t(c, ST_MISC);
+            if ((rc = device_scan(c, c->H1, n1, c->O1)) != KH_OK) return rc;
+        }
+        {
+            StageTimer t(c, ST_P1_SCATTER);
+            if (ra.use_qual)
+                hipLaunchKernelGGL((kh::part1_scatter_kernel<true, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
+                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
+            else
+                hipLaunchKernelGGL((kh::part1_scatter_kernel<false, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
+                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
+        }
+        {
+            StageTimer t(c, ST_MISC);
+            hipLaunchKernelGGL(kh::part2_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->O1, (uint32_t)PART_G1, g,
+                               n1, c->blocks, max_blocks, c->moff, c->nch, c->info);
+            HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
+        }
     }
     {
         StageTimer t(c, ST_P2_COUNT);
-        hipLaunchKernelGGL(kh::part2_count_kernel<PT>, dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA,
+        hipLaunchKernelGGL((kh::part2_count_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA, cs,
                            (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2);
     }
     {
@@ -489,13 +554,13 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     }
     {
         StageTimer t(c, ST_P2_SCATTER);
-        hipLaunchKernelGGL(kh::part2_scatter_kernel<PT>, dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream, (const PT *)bufA,
-                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
+        hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
+                           (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
     }
     {
         StageTimer t(c, ST_MISC);
         hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((nregions + 256) / 256)), dim3(256), 0, c->stream,
-                           (const u64 *)c->O2, (const u64 *)c->moff, (const uint32_t *)c->nch, (const u64 *)c->info, g, c->bstart);
+                           (const u64 *)c->O2, (u64)n2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, c->bstart);
         HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
     }
     {
@@ -802,7 +867,8 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->rfail, c->rnew, c->scan_partial, c->merge_off};
+                       c->bstart, c->rfail, c->rnew, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->pcount, c->pstart, c->pool_next};
     for (void *q : scratch)
         if (q) (void)hipFree(q);
     if (c->table) (void)hipFree(c->table);

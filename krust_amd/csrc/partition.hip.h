@@ -86,6 +86,67 @@ __device__ __forceinline__ uint32_t p1_of_hash(u64 H, const PartGeom &g) {
     return g.p1_bits ? (uint32_t)(H >> (64 - g.p1_bits)) : 0u;
 }
 
+// ---- level-2 work unit and the two level-1 output layouts it can read -----------------------------
+struct Part2Block {
+    u64 lo, hi;        // dense source: payload range in the level-1 output;
+                       // chunked source: range of the partition's chunk list (plist indices)
+    u64 mbase;         // H2/O2 index of (p2 = 0, this chunk)
+    uint32_t mstride;  // chunks in this partition: H2 index of p2 is mbase + p2 * mstride
+    uint32_t p1;
+};
+
+// ---- level-1 output as a pool of fixed-size chunks (32-bit payload path) -------------------------
+// Level 1 can then run in ONE pass: no counting pass is needed to know where a partition's data
+// goes, a workgroup just takes the next free chunk when a partition's current chunk fills up.
+// Chunks are handed out in per-workgroup ranges (one global atomic per POOL_GRAB chunks; a lone
+// pool counter hit once per chunk would serialise at ~6-17 ns per same-address atomic).
+constexpr uint32_t CHUNK_PAY = 256;     // payloads per pool chunk (1 KiB)
+constexpr uint32_t POOL_GRAB = 4096;    // chunks per workgroup grab (4 MiB of payloads)
+constexpr uint32_t POOL_LOW = 72;       // refill the private range below this many free chunks
+constexpr uint32_t CPB = 1024;          // chunks per level-2 workgroup (262144 payloads)
+constexpr uint16_t PART_NONE = 0xFFFFu; // chunk_part[] of a chunk nobody owns
+
+struct ChunkSrc {                 // how level 2 reads a chunked level-1 output
+    const uint32_t *pay;          // pool
+    const uint32_t *plist;        // chunk ids ordered by partition
+    const uint8_t *fill8;         // payloads in the chunk minus one
+};
+
+// A level-2 workgroup first copies its slice of the chunk list (ids and fill levels) into LDS, so
+// that fetching element e is ONE global load again (plist -> fill8 -> payload would be a chain of
+// three dependent loads per element).
+template <bool CHUNKED>
+__device__ __forceinline__ void p2_stage_chunks(const ChunkSrc &cs, const Part2Block &pb, uint32_t *s_chk, uint16_t *s_cfill,
+                                                int tid, int nthreads) {
+    if (!CHUNKED) return;
+    const uint32_t nc = (uint32_t)(pb.hi - pb.lo);
+    for (uint32_t i = tid; i < nc; i += nthreads) {
+        const uint32_t chunk = cs.plist[pb.lo + i];
+        s_chk[i] = chunk;
+        s_cfill[i] = (uint16_t)((uint32_t)cs.fill8[chunk] + 1u);
+    }
+}
+
+// element e of a level-2 workgroup's input; returns false past the data
+template <bool CHUNKED, typename PT>
+__device__ __forceinline__ bool p2_load(const PT *__restrict__ dense, const ChunkSrc &cs, const Part2Block &pb,
+                                        const uint32_t *s_chk, const uint16_t *s_cfill, uint32_t e, uint32_t n, PT &out) {
+    if (!CHUNKED) {
+        out = dense[pb.lo + (e < n ? e : n - 1)];
+        return e < n;
+    }
+    const uint32_t ec = e < n ? e : n - 1;
+    const uint32_t chunk = s_chk[ec >> 8];
+    const uint32_t off = ec & (CHUNK_PAY - 1);
+    const uint32_t have = s_cfill[ec >> 8];
+    out = (PT)cs.pay[(u64)chunk * CHUNK_PAY + (off < have ? off : 0)];
+    return e < n && off < have;
+}
+template <bool CHUNKED>
+__device__ __forceinline__ uint32_t p2_count_of(const Part2Block &pb) {
+    return CHUNKED ? (uint32_t)(pb.hi - pb.lo) * CHUNK_PAY : (uint32_t)(pb.hi - pb.lo);
+}
+
 // Exclusive scan of s_cnt[0..1024) into s_lofs[0..1024) by a workgroup of >= 256 lanes.
 // s_wsum: 4 words of scratch.  Ends with a barrier.
 template <typename LT>
@@ -219,14 +280,220 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// level 1, single pass (32-bit payloads): scatter into pool chunks, no counting pass
+// ---------------------------------------------------------------------------------------------
+struct ChunkDst {  // per partition, per batch: where staged element i (local index e = i - lofs) goes
+    u64 a;         // e <  split: pool index = a + i   (the partition's current chunk)
+    u64 b;         // e >= split: pool index = b + i   (freshly taken, consecutive chunks)
+};
+
+template <bool QUAL>
+__global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
+    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
+    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
+    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
+    Counters *ctr) {
+    __shared__ uint32_t s_code[2][PART_NT + 2];
+    __shared__ uint16_t s_val[2][PART_NT + 2];
+    __shared__ uint32_t s_stage[PART_TILE];   // 64 KiB
+    __shared__ uint16_t s_pid[PART_TILE];     // 32 KiB
+    __shared__ uint32_t s_cnt[MAX_P1];
+    __shared__ uint32_t s_meta[MAX_P1];       // lofs | split << 16
+    __shared__ ChunkDst s_dst[MAX_P1];        // 16 KiB
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint16_t s_lofs[MAX_P1];
+    __shared__ u64 s_priv_next, s_priv_end;   // the workgroup's private range of chunk ids
+    const int tid = threadIdx.x;
+    s_cnt[tid] = 0;
+    if (tid == 0) {
+        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+        s_priv_end = s_priv_next + POOL_GRAB;
+    }
+    // lane tid owns partition tid: its current chunk and how full it is
+    u64 cur = 0;
+    uint32_t fill = CHUNK_PAY;  // "full": the first payload takes a chunk
+    bool have_chunk = false;
+    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
+    u64 te = tb + tiles_per_block;
+    if (te > tile0 + ntiles) te = tile0 + ntiles;
+    int buf = 0;
+    uint32_t lost = 0;
+    __syncthreads();
+    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
+    for (u64 t = tb; t < te; ++t, buf ^= 1) {
+        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
+        uint32_t pay[CHUNK];
+        uint32_t tag[CHUNK];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
+        Roller roll;
+        roll.init(w, k, wlo);
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            tag[j] = 0xFFFFFFFFu;
+            u64 key;
+            if (roll.next(j, key)) {
+                const u64 H = part_hash(g, key);
+                const uint32_t p = p1_of_hash(H, g);
+                pay[j] = Pay<uint32_t>::make(key, H, g);
+                tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);
+            }
+        }
+        __syncthreads();
+        block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j)
+            if (tag[j] != 0xFFFFFFFFu) {
+                const uint32_t slot = (uint32_t)s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu);
+                s_stage[slot] = pay[j];
+                s_pid[slot] = (uint16_t)(tag[j] >> 16);
+            }
+        {  // lane tid places partition tid's run: the rest of its current chunk, then fresh chunks
+            const uint32_t c = s_cnt[tid], lo = s_lofs[tid];
+            const uint32_t space = CHUNK_PAY - fill;
+            ChunkDst d;
+            d.a = cur * CHUNK_PAY + fill - lo;
+            d.b = 0;
+            if (c > space) {
+                const uint32_t r = c - space;
+                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
+                u64 first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
+                if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
+                if (first + nnew > pool_chunks) {  // cannot happen with the host's pool sizing; never write past it
+                    lost += r;
+                    first = 0;
+                    d.b = ~0ull;  // marks "drop" for the write-out
+                } else {
+                    for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
+                    d.b = first * CHUNK_PAY - space - lo;
+                    cur = first + nnew - 1;
+                    fill = r - (nnew - 1) * CHUNK_PAY;
+                    have_chunk = true;
+                }
+            } else {
+                fill += c;
+            }
+            s_dst[tid] = d;
+            s_meta[tid] = lo | (space << 16);
+        }
+        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
+        __syncthreads();
+        s_cnt[tid] = 0;  // the next tile's stage_tile() barrier orders this before its atomics
+        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next tile
+            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+            s_priv_end = s_priv_next + POOL_GRAB;
+        }
+        // next tile's bases are fetched while this tile's runs are written out
+        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+#pragma unroll 2
+        for (uint32_t i = tid; i < total; i += PART_NT) {
+            const uint32_t p = s_pid[i];
+            const uint32_t meta = s_meta[p];
+            const ChunkDst d = s_dst[p];
+            const uint32_t e = i - (meta & 0xFFFFu);
+            if (e < (meta >> 16)) pool[d.a + i] = s_stage[i];
+            else if (d.b != ~0ull) pool[d.b + i] = s_stage[i];
+        }
+        // s_stage / s_dst / s_meta are rewritten only after the next tile's barriers
+    }
+    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
+    const u64 l = wave_sum((u64)lost);
+    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
+}
+
+// ---- chunk list: chunk ids ordered by partition ---------------------------------------------------
+// pcount[p] += chunks owned by partition p among ids [0, nchunks)
+__global__ __launch_bounds__(1024) void chunk_hist_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
+                                                          u64 pool_chunks, uint32_t *__restrict__ pcount) {
+    __shared__ uint32_t s_h[MAX_P1];
+    const int tid = threadIdx.x;
+    s_h[tid] = 0;
+    __syncthreads();
+    u64 n = *pool_next;
+    if (n > pool_chunks) n = pool_chunks;
+    const u64 stride = (u64)gridDim.x * 1024;
+    for (u64 i = (u64)blockIdx.x * 1024 + tid; i < n; i += stride) {
+        const uint16_t p = chunk_part[i];
+        if (p != PART_NONE) atomicAdd(&s_h[p], 1u);
+    }
+    __syncthreads();
+    if (s_h[tid]) atomicAdd(&pcount[tid], s_h[tid]);
+}
+
+// plist[pstart[p] + rank] = chunk id.  cursors[] starts as a copy of pstart[] (low 32 bits suffice:
+// a pool holds far fewer than 2^32 chunks).  One workgroup per 16384 chunk ids.
+__global__ __launch_bounds__(1024) void chunk_list_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
+                                                          u64 pool_chunks, uint32_t *__restrict__ cursors,
+                                                          uint32_t *__restrict__ plist) {
+    __shared__ uint32_t s_h[MAX_P1];
+    __shared__ uint32_t s_base[MAX_P1];
+    const int tid = threadIdx.x;
+    u64 n = *pool_next;
+    if (n > pool_chunks) n = pool_chunks;
+    const u64 lo = (u64)blockIdx.x * 16384;
+    if (lo >= n) return;
+    s_h[tid] = 0;
+    __syncthreads();
+    uint32_t tag[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const u64 i = lo + (u64)j * 1024 + tid;
+        tag[j] = 0xFFFFFFFFu;
+        if (i < n) {
+            const uint16_t p = chunk_part[i];
+            if (p != PART_NONE) tag[j] = ((uint32_t)p << 16) | atomicAdd(&s_h[p], 1u);
+        }
+    }
+    __syncthreads();
+    s_base[tid] = s_h[tid] ? atomicAdd(&cursors[tid], s_h[tid]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (tag[j] != 0xFFFFFFFFu) plist[s_base[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = (uint32_t)(lo + (u64)j * 1024 + tid);
+}
+
+// Level-2 plan over chunk lists.  pstart = exclusive scan of pcount (P1 + 1 entries).  Same outputs as
+// part2_plan_kernel; info[2] is left to the level-2 scan (the grand total is not known yet).
+__global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__restrict__ pstart, PartGeom g,
+                                                                  Part2Block *__restrict__ blocks, u64 max_blocks,
+                                                                  u64 *__restrict__ moff, uint32_t *__restrict__ nch,
+                                                                  u64 *__restrict__ info, uint32_t *__restrict__ cursors) {
+    __shared__ u64 s_bbase[MAX_P1 + 1];
+    const int tid = threadIdx.x;
+    const int P1 = 1 << g.p1_bits;
+    if (tid < P1) cursors[tid] = (uint32_t)pstart[tid];
+    if (tid == 0) {
+        u64 b = 0;
+        for (int p = 0; p < P1; ++p) {
+            s_bbase[p] = b;
+            b += (pstart[p + 1] - pstart[p] + CPB - 1) / CPB;
+        }
+        s_bbase[P1] = b;
+        info[0] = b;
+        info[1] = b << g.p2_bits;
+        info[2] = 0;
+    }
+    __syncthreads();
+    if (tid < P1) {
+        const u64 lo = pstart[tid], hi = pstart[tid + 1];
+        const u64 b0 = s_bbase[tid];
+        const uint32_t n = (uint32_t)(s_bbase[tid + 1] - b0);
+        moff[tid] = b0 << g.p2_bits;
+        nch[tid] = n;
+        for (uint32_t c = 0; c < n; ++c) {
+            if (b0 + c >= max_blocks) break;
+            Part2Block pb;
+            pb.lo = lo + (u64)c * CPB;
+            pb.hi = pb.lo + CPB < hi ? pb.lo + CPB : hi;
+            pb.mbase = (b0 << g.p2_bits) + c;
+            pb.mstride = n;
+            pb.p1 = (uint32_t)tid;
+            blocks[b0 + c] = pb;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // level 2 work list: one workgroup per PART2_CHUNK keys of a level-1 partition
 // ---------------------------------------------------------------------------------------------
-struct Part2Block {
-    u64 lo, hi;        // payload range in the level-1 output
-    u64 mbase;         // H2/O2 index of (p2 = 0, this chunk)
-    uint32_t mstride;  // chunks in this partition: H2 index of p2 is mbase + p2 * mstride
-    uint32_t p1;
-};
 
 // ---------------------------------------------------------------------------------------------
 // generic exclusive scan u32 -> u64 (three small kernels)
@@ -360,29 +627,31 @@ __global__ __launch_bounds__(1024) void part2_plan_kernel(const u64 *__restrict_
 // ---------------------------------------------------------------------------------------------
 // level 2, pass A: histogram of bucket ids (p2) per workgroup.  H2 must be zero-filled.
 // ---------------------------------------------------------------------------------------------
-template <typename PT>
-__global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restrict__ pays, const Part2Block *__restrict__ blocks,
+template <typename PT, bool CHUNKED>
+__global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restrict__ pays, ChunkSrc cs,
+                                                              const Part2Block *__restrict__ blocks,
                                                               const u64 *__restrict__ info, PartGeom g,
                                                               uint32_t *__restrict__ H2) {
     __shared__ uint32_t s_hist[1u << MAX_P2_BITS];
+    __shared__ uint32_t s_chk[CHUNKED ? CPB : 1];
+    __shared__ uint16_t s_cfill[CHUNKED ? CPB : 1];
     if ((u64)blockIdx.x >= info[0]) return;
     const Part2Block pb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     s_hist[tid] = 0;  // PART_NT == 1 << MAX_P2_BITS
+    p2_stage_chunks<CHUNKED>(cs, pb, s_chk, s_cfill, tid, PART_NT);
     __syncthreads();
     // eight independent loads in flight per lane (a one-load-per-iteration loop is latency bound)
-    const PT *__restrict__ src = pays + pb.lo;
-    const uint32_t n = (uint32_t)(pb.hi - pb.lo);
+    const uint32_t n = p2_count_of<CHUNKED>(pb);
     for (uint32_t base = 0; base < n; base += 8 * PART_NT) {
         PT v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t i = base + (uint32_t)j * PART_NT + tid;
-            v[j] = src[i < n ? i : n - 1];
-        }
+        uint32_t ok = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (base + (uint32_t)j * PART_NT + tid < n) atomicAdd(&s_hist[Pay<PT>::p2(v[j], g)], 1u);
+            ok |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + (uint32_t)j * PART_NT + tid, n, v[j]) << j;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (ok & (1u << j)) atomicAdd(&s_hist[Pay<PT>::p2(v[j], g)], 1u);
     }
     __syncthreads();
     if (tid < (1 << g.p2_bits)) H2[pb.mbase + (u64)tid * pb.mstride] = s_hist[tid];
@@ -397,8 +666,9 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restri
 constexpr int PART2_NT = 512;
 constexpr int PART2_TILE = PART2_NT * CHUNK;  // 8192
 
-template <typename PT>
-__global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__restrict__ pays, const Part2Block *__restrict__ blocks,
+template <typename PT, bool CHUNKED>
+__global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__restrict__ pays, ChunkSrc cs,
+                                                                 const Part2Block *__restrict__ blocks,
                                                                  const u64 *__restrict__ info, PartGeom g,
                                                                  const u64 *__restrict__ O2, PT *__restrict__ out) {
     __shared__ PT s_stage[PART2_TILE];   // 32 KiB (u32) / 64 KiB (u64)
@@ -406,10 +676,13 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
     __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< 8192)
     __shared__ u64 s_dst[1u << MAX_P2_BITS];  // global position of run p minus its batch-local start
     __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_chk[CHUNKED ? CPB : 1];
+    __shared__ uint16_t s_cfill[CHUNKED ? CPB : 1];
     if ((u64)blockIdx.x >= info[0]) return;
     const Part2Block pb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     const int P2 = 1 << g.p2_bits;
+    p2_stage_chunks<CHUNKED>(cs, pb, s_chk, s_cfill, tid, PART2_NT);
     // lane tid owns buckets tid and tid + 512: their running output cursors live in registers
     u64 gcur0 = 0, gcur1 = 0;
     s_cnt[tid] = 0;
@@ -420,16 +693,12 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
     // Branch-free loads: indices are block-relative 32-bit, clamped to the last valid payload (the
     // block is never empty), validity is a bit mask.  (Conditional loads made the compiler carry
     // sixteen 64-bit addresses and their phi copies through the loop: 219 VGPRs.)
-    const PT *__restrict__ src = pays + pb.lo;
-    const uint32_t n = (uint32_t)(pb.hi - pb.lo);
+    const uint32_t n = p2_count_of<CHUNKED>(pb);
     PT pay[CHUNK];
     uint32_t have = 0;  // bit j: pay[j] holds a payload
 #pragma unroll
-    for (int j = 0; j < CHUNK; ++j) {  // lane-contiguous: coalesced loads
-        const uint32_t i = (uint32_t)j * PART2_NT + tid;
-        pay[j] = src[i < n ? i : n - 1];
-        have |= (uint32_t)(i < n) << j;
-    }
+    for (int j = 0; j < CHUNK; ++j)  // lane-contiguous: coalesced loads
+        have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, (uint32_t)j * PART2_NT + tid, n, pay[j]) << j;
     for (uint32_t base = 0; base < n; base += PART2_TILE) {
         uint32_t tag[CHUNK];
 #pragma unroll
@@ -459,11 +728,8 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
         // next batch's payloads are fetched while this batch's runs are written out
         have = 0;
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            const uint32_t i = base + PART2_TILE + (uint32_t)j * PART2_NT + tid;
-            pay[j] = src[i < n ? i : n - 1];
-            have |= (uint32_t)(i < n) << j;
-        }
+        for (int j = 0; j < CHUNK; ++j)
+            have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + PART2_TILE + (uint32_t)j * PART2_NT + tid, n, pay[j]) << j;
 #pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART2_NT) {
             const PT v = s_stage[i];
@@ -474,14 +740,14 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
 }
 
 // bstart[r] = first payload of region r's bucket in the level-2 output, r in [0, R]; bstart[R] = total
-__global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restrict__ O2, const u64 *__restrict__ moff,
-                                                            const uint32_t *__restrict__ nch, const u64 *__restrict__ info,
+__global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restrict__ O2, u64 o2_total_index,
+                                                            const u64 *__restrict__ moff, const uint32_t *__restrict__ nch,
                                                             PartGeom g, u64 *__restrict__ bstart) {
     const u64 nregions = 1ull << g.rbits;
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
     if (r > nregions) return;
     if (r == nregions) {
-        bstart[r] = info[2];
+        bstart[r] = O2[o2_total_index];  // grand total of the level-2 scan
         return;
     }
     const uint32_t p1 = (uint32_t)(r >> g.p2_bits), p2 = (uint32_t)r & ((1u << g.p2_bits) - 1u);
