@@ -306,13 +306,15 @@ __device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_
 struct Roller {
     uint32_t flo, fhi, rlo, rhi, code, good;
     uint32_t kmlo, kmhi;  // kh_kmask(k)
-    uint32_t ins_sh;      // 2k-2: where the complemented new base enters rc
+    uint32_t ins_sh;      // (2k-2) mod 32: where the complemented new base enters rc ...
+    bool ins_hi;          // ... in the high word (k > 16) or the low word
 
     __device__ __forceinline__ void init(const WinCtx &w, uint32_t k, u64 wlo) {
         const u64 km = kh_kmask(k);
         kmlo = (uint32_t)km;
         kmhi = (uint32_t)(km >> 32);
-        ins_sh = 2 * k - 2;
+        ins_sh = (2 * k - 2) & 31;
+        ins_hi = k > 16;
         code = (uint32_t)w.lo64;
         flo = (uint32_t)(w.lo64 >> 32);  // chunk t-1: bases -16..-1
         fhi = w.hi;                      // chunk t-2: bases -32..-17
@@ -342,9 +344,9 @@ struct Roller {
         flo = (flo << 2) | c;
         rlo = __builtin_amdgcn_alignbit(rhi, rlo, 2);   // rc >> 2
         rhi >>= 2;
-        const u64 ins = (u64)(c ^ 3u) << ins_sh;         // complement enters at the top of the 2k bits
-        rlo |= (uint32_t)ins;
-        rhi |= (uint32_t)(ins >> 32);
+        const uint32_t ins = (c ^ 3u) << ins_sh;         // complement enters at the top of the 2k bits
+        rlo |= ins_hi ? 0u : ins;                        // (wave-uniform select: 32-bit ops instead of a 64-bit shift)
+        rhi |= ins_hi ? ins : 0u;
         const u64 fwd = ((u64)(fhi & kmhi) << 32) | (flo & kmlo);
         const u64 rc = ((u64)rhi << 32) | rlo;
         key = fwd < rc ? fwd : rc;  // integer min == the reference's lexicographic choice (kmer.rs:348-365)

@@ -74,8 +74,20 @@ KH_HD uint64_t kh_canonical_bits(uint64_t fwd, uint32_t k) {
 // the bits of H that a partition level has consumed are implied by where the payload is stored,
 // and the key is recovered with kh_unhash_n().  Quality (chi-square of region / in-region start
 // occupancy on genomic, sequential, low-complexity and strided keys) matches splitmix64.
+// For 16 <= k <= 24 the half fits 24 bits and the product uses the FULL-RATE 24-bit multiplier
+// (v_mul_u32_u24; a 32-bit v_mul_lo_u32 is quarter rate) with the constant's low 24 bits; both
+// variants pass the same occupancy tests.  The choice depends only on k, so it is one function.
 KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
-    uint32_t t = r * c;
+    uint32_t t;
+    if (k >= 16 && k <= 24) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        t = __umul24(r, (c & 0xFFFFFFu) | 1u);
+#else
+        t = (uint32_t)((uint64_t)r * ((c & 0xFFFFFFu) | 1u));
+#endif
+    } else {
+        t = r * c;
+    }
     t ^= t >> 15;
     return k < 32 ? (t >> (32 - k)) : t;
 }

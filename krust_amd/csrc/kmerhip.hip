@@ -493,15 +493,19 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         }
         {
             StageTimer t(c, ST_P1_SCATTER);
+            const char *dbg_env = getenv("KMERHIP_DEBUG");  // timing experiments only; results are then wrong
+            const uint32_t dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
             if (ra.use_qual)
                 hipLaunchKernelGGL(kh::part1_scatter_chunked_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
                                    ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA,
-                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr);
+                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr, dbg);
             else
                 hipLaunchKernelGGL(kh::part1_scatter_chunked_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
                                    ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA,
-                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr);
+                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr, dbg);
         }
+        if (const char *dbg_env = getenv("KMERHIP_DEBUG"))
+            if (atoi(dbg_env)) return sync_counters(c);  // timing experiment: level 1 only, nothing is counted
         {
             StageTimer t(c, ST_MISC);
             hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
