@@ -1,0 +1,299 @@
+//! Rust binding of `include/kmerhip.h` (C ABI of the MI355X k-mer counter).
+//!
+//! **Source only** -- never compiled in this repository's build image (no rustc).  It is the
+//! binding a krust maintainer would add behind a cargo feature: [`HipKmerMap`] stands where
+//! `KmerMap` stands in `src/run.rs:491-583`, [`KmerCounter`] mirrors the fluent builder of
+//! `src/builder.rs:95-526` for the packed / string / histogram results.
+#![allow(clippy::missing_errors_doc)]
+
+use std::collections::{BTreeMap, HashMap};
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int, c_void};
+
+use bytes::Bytes;
+
+pub mod sys {
+    use super::{c_char, c_int, c_void};
+
+    #[repr(C)]
+    pub struct KhConfig {
+        pub struct_size: u32,
+        pub k: u32,
+        pub min_quality: i32, // -1 = None
+        pub device: i32,      // -1 = current
+        pub capacity_hint: u64,
+        pub stream: *mut c_void,
+        pub flags: u32,
+        pub reserved: u32,
+    }
+
+    #[repr(C)]
+    #[derive(Default, Debug, Clone, Copy)]
+    pub struct KhStats {
+        pub bases: u64,
+        pub kmers: u64,
+        pub distinct: u64,
+        pub table_slots: u64,
+        pub grows: u64,
+        pub launches: u64,
+        pub count_kernel_ms: f64,
+        pub h2d_ms: f64,
+        pub part_batches: u64,
+        pub stage_ms: [f64; 8],
+    }
+
+    #[repr(C)]
+    pub struct KhCtx {
+        _private: [u8; 0],
+    }
+
+    extern "C" {
+        pub fn kh_abi_version() -> c_int;
+        pub fn kh_create(out: *mut *mut KhCtx, cfg: *const KhConfig) -> c_int;
+        pub fn kh_destroy(ctx: *mut KhCtx);
+        pub fn kh_reset(ctx: *mut KhCtx) -> c_int;
+        pub fn kh_push(ctx: *mut KhCtx, bases: *const u8, qual: *const u8, n: u64) -> c_int;
+        pub fn kh_finish(ctx: *mut KhCtx, stats: *mut KhStats) -> c_int;
+        pub fn kh_result_size(ctx: *mut KhCtx, min_count: u64, n: *mut u64) -> c_int;
+        pub fn kh_result_copy(ctx: *mut KhCtx, keys: *mut u64, counts: *mut u64, cap: u64,
+                              min_count: u64, n: *mut u64) -> c_int;
+        pub fn kh_histogram(ctx: *mut KhCtx, min_count: u64, count: *mut u64, freq: *mut u64,
+                            cap: u64, n: *mut u64) -> c_int;
+        pub fn kh_lookup(ctx: *mut KhCtx, keys: *const u64, n: u64, counts: *mut u64) -> c_int;
+        pub fn kh_pack(bases: *const u8, k: u32, packed: *mut u64, err_pos: *mut u32) -> c_int;
+        pub fn kh_unpack(packed: u64, k: u32, out: *mut u8) -> c_int;
+        pub fn kh_canonical(packed: u64, k: u32, canonical: *mut u64, is_rc: *mut c_int) -> c_int;
+        pub fn kh_strerror(status: c_int) -> *const c_char;
+        pub fn kh_last_error(ctx: *const KhCtx) -> *const c_char;
+    }
+}
+
+/// Errors of the device path.  `KmerLength` is `KmerLengthError` of `src/error.rs:86-95`.
+#[derive(Debug, thiserror::Error)]
+pub enum HipError {
+    #[error("k-mer length {k} is out of range: must be between 1 and 32")]
+    KmerLength { k: usize },
+    #[error("kmerhip: {0}")]
+    Device(String),
+}
+
+fn check(ctx: *const sys::KhCtx, rc: c_int) -> Result<(), HipError> {
+    if rc == 0 {
+        return Ok(());
+    }
+    // SAFETY: both functions return NUL-terminated static / context-owned strings
+    let mut msg = unsafe { CStr::from_ptr(sys::kh_strerror(rc)) }.to_string_lossy().into_owned();
+    if !ctx.is_null() {
+        let detail = unsafe { CStr::from_ptr(sys::kh_last_error(ctx)) }.to_string_lossy();
+        if !detail.is_empty() {
+            msg = format!("{msg} ({detail})");
+        }
+    }
+    Err(HipError::Device(msg))
+}
+
+/// Drop-in for `KmerMap` (`src/run.rs:491-583`): `build` / `build_with_quality` / `into_hashmap`.
+pub struct HipKmerMap {
+    ctx: *mut sys::KhCtx,
+    k: usize,
+    has_qual: bool,
+}
+
+// one producer thread per context (kmerhip.h); moving the handle between threads is fine
+unsafe impl Send for HipKmerMap {}
+
+const BATCH: usize = 256 << 20;
+
+impl HipKmerMap {
+    pub fn new(k: usize, min_quality: Option<u8>) -> Result<Self, HipError> {
+        if !(1..=32).contains(&k) {
+            return Err(HipError::KmerLength { k }); // KmerLength::new, src/kmer.rs:100-110
+        }
+        let cfg = sys::KhConfig {
+            struct_size: std::mem::size_of::<sys::KhConfig>() as u32,
+            k: k as u32,
+            min_quality: min_quality.map_or(-1, i32::from),
+            device: -1,
+            capacity_hint: 0,
+            stream: std::ptr::null_mut(),
+            flags: 0,
+            reserved: 0,
+        };
+        let mut ctx = std::ptr::null_mut();
+        check(std::ptr::null(), unsafe { sys::kh_create(&mut ctx, &cfg) })?;
+        Ok(Self { ctx, k, has_qual: min_quality.is_some() })
+    }
+
+    fn push(&self, bases: &[u8], qual: Option<&[u8]>) -> Result<(), HipError> {
+        if bases.is_empty() {
+            return Ok(());
+        }
+        let q = qual.map_or(std::ptr::null(), <[u8]>::as_ptr);
+        check(self.ctx, unsafe { sys::kh_push(self.ctx, bases.as_ptr(), q, bases.len() as u64) })
+    }
+
+    /// `KmerMap::build` (`src/run.rs:500-503`).  Records are concatenated into flat buffers with a
+    /// `\n` between them: any byte outside `ACGTacgt` separates records, no k-mer spans it.
+    pub fn build<I: Iterator<Item = Bytes>>(self, sequences: I) -> Result<Self, HipError> {
+        let mut flat = Vec::with_capacity(BATCH + (1 << 20));
+        for seq in sequences {
+            flat.extend_from_slice(&seq);
+            flat.push(b'\n');
+            if flat.len() >= BATCH {
+                self.push(&flat, None)?;
+                flat.clear();
+            }
+        }
+        self.push(&flat, None)?;
+        Ok(self)
+    }
+
+    /// `KmerMap::build_with_quality` (`src/run.rs:505-520`); the threshold was given to `new`.
+    /// A record without qualities (FASTA) is never masked (`run.rs:543`: both must be `Some`).
+    pub fn build_with_quality<I>(self, sequences: I) -> Result<Self, HipError>
+    where
+        I: Iterator<Item = (Bytes, Option<Vec<u8>>)>,
+    {
+        let (mut b, mut q) = (Vec::with_capacity(BATCH), Vec::with_capacity(BATCH));
+        for (seq, qual) in sequences {
+            b.extend_from_slice(&seq);
+            b.push(b'\n');
+            match qual {
+                Some(qs) => q.extend_from_slice(&qs),
+                None => q.resize(q.len() + seq.len(), b'~'),
+            }
+            q.push(b'\n');
+            if b.len() >= BATCH {
+                self.push(&b, self.has_qual.then_some(&q[..]))?;
+                b.clear();
+                q.clear();
+            }
+        }
+        self.push(&b, self.has_qual.then_some(&q[..]))?;
+        Ok(self)
+    }
+
+    /// Packed canonical key -> count: the shape of `count_kmers_from_sequences`
+    /// (`src/streaming.rs:198-204`).
+    pub fn into_packed(self, min_count: u64) -> Result<HashMap<u64, u64>, HipError> {
+        check(self.ctx, unsafe { sys::kh_finish(self.ctx, std::ptr::null_mut()) })?;
+        let mut n = 0u64;
+        check(self.ctx, unsafe { sys::kh_result_size(self.ctx, min_count, &mut n) })?;
+        let mut keys = vec![0u64; n as usize];
+        let mut counts = vec![0u64; n as usize];
+        let mut got = 0u64;
+        check(self.ctx, unsafe {
+            sys::kh_result_copy(self.ctx, keys.as_mut_ptr(), counts.as_mut_ptr(), n, min_count, &mut got)
+        })?;
+        Ok(keys.into_iter().zip(counts).take(got as usize).collect())
+    }
+
+    /// `KmerMap::into_hashmap` (`src/run.rs:573-582`).
+    pub fn into_hashmap(self) -> Result<HashMap<String, u64>, HipError> {
+        let k = self.k;
+        Ok(self.into_packed(1)?.into_iter().map(|(bits, c)| (unpack_to_string(bits, k), c)).collect())
+    }
+
+    /// Count-of-counts after the `min_count` filter, ascending (`src/histogram.rs:88-94`).
+    pub fn into_histogram(self, min_count: u64) -> Result<BTreeMap<u64, u64>, HipError> {
+        check(self.ctx, unsafe { sys::kh_finish(self.ctx, std::ptr::null_mut()) })?;
+        let mut cap = 1u64 << 16;
+        loop {
+            let (mut c, mut f) = (vec![0u64; cap as usize], vec![0u64; cap as usize]);
+            let mut n = 0u64;
+            let rc = unsafe { sys::kh_histogram(self.ctx, min_count, c.as_mut_ptr(), f.as_mut_ptr(), cap, &mut n) };
+            if rc == -8 {
+                cap *= 16; // KH_ERR_RANGE
+                continue;
+            }
+            check(self.ctx, rc)?;
+            return Ok(c.into_iter().zip(f).take(n as usize).collect());
+        }
+    }
+}
+
+impl Drop for HipKmerMap {
+    fn drop(&mut self) {
+        // SAFETY: ctx came from kh_create and is destroyed exactly once
+        unsafe { sys::kh_destroy(self.ctx) }
+    }
+}
+
+/// `unpack_to_string` (`src/kmer.rs:451-456`) through the library's helper.
+#[must_use]
+pub fn unpack_to_string(bits: u64, k: usize) -> String {
+    let mut out = vec![0u8; k];
+    // SAFETY: out holds k bytes; kh_unpack writes exactly k ASCII bytes
+    unsafe { sys::kh_unpack(bits, k as u32, out.as_mut_ptr()) };
+    String::from_utf8(out).unwrap_or_default()
+}
+
+/// The fluent builder of `src/builder.rs:95-526`, device-backed (sequence sources are the caller's:
+/// krust keeps its readers, `src/reader.rs`).
+#[derive(Debug, Clone, Default)]
+pub struct KmerCounter {
+    k: Option<usize>,
+    min_count: u64,
+    min_quality: Option<u8>,
+}
+
+impl KmerCounter {
+    #[must_use]
+    pub fn new() -> Self {
+        Self { k: None, min_count: 1, min_quality: None }
+    }
+    pub fn k(mut self, k: usize) -> Result<Self, HipError> {
+        if !(1..=32).contains(&k) {
+            return Err(HipError::KmerLength { k });
+        }
+        self.k = Some(k);
+        Ok(self)
+    }
+    #[must_use]
+    pub fn min_count(mut self, n: u64) -> Self {
+        self.min_count = n;
+        self
+    }
+    #[must_use]
+    pub fn min_quality(mut self, q: u8) -> Self {
+        self.min_quality = Some(q);
+        self
+    }
+    /// `count()` over in-memory sequences: `HashMap<String, u64>` filtered by `min_count`.
+    pub fn count_sequences<I: Iterator<Item = Bytes>>(&self, seqs: I) -> Result<HashMap<String, u64>, HipError> {
+        let k = self.k.ok_or(HipError::KmerLength { k: 0 })?;
+        Ok(HipKmerMap::new(k, None)?
+            .build(seqs)?
+            .into_packed(self.min_count)?
+            .into_iter()
+            .map(|(bits, c)| (unpack_to_string(bits, k), c))
+            .collect())
+    }
+    /// `histogram()` over in-memory sequences.
+    pub fn histogram_sequences<I: Iterator<Item = Bytes>>(&self, seqs: I) -> Result<BTreeMap<u64, u64>, HipError> {
+        let k = self.k.ok_or(HipError::KmerLength { k: 0 })?;
+        HipKmerMap::new(k, None)?.build(seqs)?.into_histogram(self.min_count)
+    }
+}
+
+#[cfg(test)]
+mod tests {
+    use super::*;
+
+    // the reference's own KATs (tests/library_tests.rs:23-33, 55-64; src/streaming.rs:1150-1162)
+    #[test]
+    fn kats() {
+        let c = KmerCounter::new().k(3).unwrap();
+        let m = c.count_sequences(vec![Bytes::from_static(b"ACGT")].into_iter()).unwrap();
+        assert_eq!(m.get("ACG"), Some(&2));
+        let m = c.count_sequences(vec![Bytes::from_static(b"TTT")].into_iter()).unwrap();
+        assert_eq!(m.get("AAA"), Some(&1));
+        let c4 = KmerCounter::new().k(4).unwrap();
+        let m = c4
+            .count_sequences(vec![Bytes::from_static(b"AAAA"), Bytes::from_static(b"TTTT")].into_iter())
+            .unwrap();
+        assert_eq!(m.len(), 1);
+        assert_eq!(m.values().next(), Some(&2));
+        assert!(KmerCounter::new().k(0).is_err() && KmerCounter::new().k(33).is_err());
+    }
+}
