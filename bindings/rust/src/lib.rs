@@ -40,6 +40,7 @@ pub mod sys {
         pub h2d_ms: f64,
         pub part_batches: u64,
         pub stage_ms: [f64; 8],
+        pub text_scan_ms: f64,
     }
 
     #[repr(C)]
@@ -53,6 +54,8 @@ pub mod sys {
         pub fn kh_destroy(ctx: *mut KhCtx);
         pub fn kh_reset(ctx: *mut KhCtx) -> c_int;
         pub fn kh_push(ctx: *mut KhCtx, bases: *const u8, qual: *const u8, n: u64) -> c_int;
+        /// format: 1 = FASTA, 2 = FASTQ; -9 (KH_ERR_FORMAT) = parse on the host instead
+        pub fn kh_push_text(ctx: *mut KhCtx, text: *const u8, n: u64, format: c_int) -> c_int;
         pub fn kh_finish(ctx: *mut KhCtx, stats: *mut KhStats) -> c_int;
         pub fn kh_result_size(ctx: *mut KhCtx, min_count: u64, n: *mut u64) -> c_int;
         pub fn kh_result_copy(ctx: *mut KhCtx, keys: *mut u64, counts: *mut u64, cap: u64,

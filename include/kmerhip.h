@@ -54,7 +54,9 @@ typedef enum kh_status {
     KH_ERR_TABLE_FULL = -5, /* table cannot grow further */
     KH_ERR_HIP = -6,        /* a HIP call failed; kh_last_error() has the text */
     KH_ERR_STATE = -7,      /* call not valid in the context's current state */
-    KH_ERR_RANGE = -8       /* caller-provided output array too small */
+    KH_ERR_RANGE = -8,      /* caller-provided output array too small */
+    KH_ERR_FORMAT = -9      /* kh_push_text*: a record layout the device scanner does not take
+                               (nothing was counted; parse on the host and use kh_push) */
 } kh_status;
 
 typedef struct kh_ctx kh_ctx;
@@ -100,6 +102,7 @@ typedef struct kh_stats {
     double   h2d_ms;         /* host->device staging time for kh_push */
     uint64_t part_batches;   /* batches that went through the partitioned path */
     double   stage_ms[KH_NUM_STAGES]; /* per-stage kernel time, see KH_STAGE_* */
+    double   text_scan_ms;   /* kh_push_text*: record-scanning kernels (not part of count_kernel_ms) */
 } kh_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -117,6 +120,19 @@ int  kh_reset(kh_ctx *ctx);
 int kh_push(kh_ctx *ctx, const uint8_t *bases, const uint8_t *qual, uint64_t n);
 /* Same, for buffers already resident in this device's HBM (no copy). */
 int kh_push_device(kh_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual, uint64_t n);
+/* Raw FASTA / FASTQ TEXT, scanned on the device: replaces the record readers in front of the
+ * path (SeqReader, src/reader.rs:58-79; the needletail / rust-bio loops of src/streaming.rs:858-893)
+ * for uncompressed input.  `text` holds WHOLE records: it starts at a record header and ends at a
+ * record end (a missing final newline is fine).  FASTA: wrapped records are joined, k-mers never
+ * span records.  FASTQ: 4-line records only; qualities are used iff the context has a min_quality.
+ * Returns KH_ERR_FORMAT -- with nothing counted -- for anything else (wrapped FASTQ, blank lines
+ * between FASTQ records, a missing '@' / '+' / '>' marker, |seq| != |qual|, blanks at line ends of
+ * a FASTA record): the caller then parses that text itself and uses kh_push.
+ * kh_push_text_device: d_text must be 16-byte aligned. */
+#define KH_TEXT_FASTA 1
+#define KH_TEXT_FASTQ 2
+int kh_push_text(kh_ctx *ctx, const uint8_t *text, uint64_t n, int format);
+int kh_push_text_device(kh_ctx *ctx, const uint8_t *d_text, uint64_t n, int format);
 /* Wait for all pushed work; fill stats (may be NULL). */
 int kh_finish(kh_ctx *ctx, kh_stats *stats);
 

@@ -19,6 +19,7 @@
 #include "kernels.hip.h"
 #include "partition.hip.h"
 #include "shard.hip.h"
+#include "rawparse.hip.h"
 
 using kh::Counters;
 using kh::Slot;
@@ -40,7 +41,7 @@ constexpr int GRID_CAP = 256 * 8;          // 256 CUs x 8 resident workgroups of
 constexpr int PART_G1 = 512;               // level-1 workgroups (fixed: count and scatter must agree)
 constexpr u64 PART_MIN_WINDOWS = 1ull << 22;   // below this the partition passes cannot pay off
 constexpr double LOAD_PART = 0.70;         // grow before the next partitioned batch above this load
-enum { ST_DIRECT = 0, ST_P1_COUNT, ST_P1_SCATTER, ST_P2_COUNT, ST_P2_SCATTER, ST_REGION, ST_MISC, ST_GROW, ST_N };
+enum { ST_DIRECT = 0, ST_P1_COUNT, ST_P1_SCATTER, ST_P2_COUNT, ST_P2_SCATTER, ST_REGION, ST_MISC, ST_GROW, ST_N, ST_TEXT = ST_N };
 
 }  // namespace
 
@@ -121,6 +122,22 @@ struct kh_ctx {
     double stage_ms[ST_N] = {0};
     struct StageEv { int stage; hipEvent_t a, b; };
     std::vector<StageEv> stage_events;
+
+    // ---- kh_push_text: device-side record scanning ----
+    uint8_t *txt_raw = nullptr;   u64 txt_raw_cap = 0;   // host text lands here
+    uint8_t *txt_out = nullptr;   u64 txt_out_cap = 0;   // flat bases for the count kernels
+    uint8_t *txt_qual = nullptr;  u64 txt_qual_cap = 0;
+    u64 *txt_ls = nullptr;        u64 txt_ls_cap = 0;    // line starts
+    uint8_t *txt_hdr = nullptr;   u64 txt_hdr_cap = 0;   // FASTA: line is a header
+    uint32_t *txt_tnl = nullptr;  u64 txt_tnl_cap = 0;   // per-tile newline counts
+    u64 *txt_tbase = nullptr;     u64 txt_tbase_cap = 0;
+    uint32_t *txt_tkeep = nullptr; u64 txt_tkeep_cap = 0;
+    u64 *txt_tout = nullptr;      u64 txt_tout_cap = 0;
+    uint32_t *txt_err = nullptr;  u64 txt_err_cap = 0;
+    struct TxtHost { u64 total; u64 end_mark; uint32_t err; uint8_t first, last; } *h_txt = nullptr;  // pinned
+    hipEvent_t txt_raw_free = nullptr;
+    bool txt_raw_busy = false;
+    double text_ms = 0.0;
 
     bool poisoned = false;
     std::string last_error;
@@ -288,8 +305,12 @@ int drain_events(kh_ctx *c) {
     for (auto &e : c->stage_events) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
-            c->stage_ms[e.stage] += ms;
-            c->kernel_ms += ms;
+            if (e.stage == ST_TEXT) {
+                c->text_ms += ms;
+            } else {
+                c->stage_ms[e.stage] += ms;
+                c->kernel_ms += ms;
+            }
         }
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -872,12 +893,15 @@ extern "C" void kh_destroy(kh_ctx *c) {
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
                        c->bstart, c->rfail, c->rnew, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
-                       c->pcount, c->pstart, c->pool_next};
+                       c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
+                       c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)
         if (q) (void)hipFree(q);
     if (c->table) (void)hipFree(c->table);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
+    if (c->h_txt) (void)hipHostFree(c->h_txt);
+    if (c->txt_raw_free) (void)hipEventDestroy(c->txt_raw_free);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -895,7 +919,7 @@ extern "C" int kh_reset(kh_ctx *c) {
     c->distinct_known = c->pending_bound = 0;
     c->bases_pushed = 0;
     c->launches = 0;
-    c->kernel_ms = c->h2d_ms = 0.0;
+    c->kernel_ms = c->h2d_ms = c->text_ms = 0.0;
     for (double &m : c->stage_ms) m = 0.0;
     c->table_empty = true;
     c->part_batches = 0;
@@ -971,6 +995,158 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
     return KH_OK;
 }
 
+// ---- raw text: records are found on the device (rawparse.hip.h) ------------------------------
+namespace {
+
+int text_fail(kh_ctx *c, const char *why) { return fail(c, KH_ERR_FORMAT, why); }
+
+// d_text: 16-byte aligned device text holding whole records.  raw_event: record c->txt_raw_free once
+// the scanning kernels (the only readers of d_text) are enqueued.
+int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, bool raw_event) {
+    const bool fastq = format == KH_TEXT_FASTQ;
+    const bool with_qual = fastq && c->minq >= 0;
+    const u64 ntiles = (n + kh::RAW_TILE - 1) / kh::RAW_TILE;
+    const u64 padded = (n + 15) / 16 * 16 + 64;
+    int rc;
+    if (!c->h_txt) {
+        hipError_t e = hipHostMalloc((void **)&c->h_txt, sizeof(*c->h_txt), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, KH_ERR_OOM, "hipHostMalloc(text scan)", e);
+    }
+    if ((rc = ensure_buf(c, &c->txt_tnl, &c->txt_tnl_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
+    if ((rc = ensure_buf(c, &c->txt_tbase, &c->txt_tbase_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
+    if ((rc = ensure_buf(c, &c->txt_err, &c->txt_err_cap, 4, "hipMalloc(text err)")) != KH_OK) return rc;
+    if ((rc = ensure_buf(c, &c->txt_out, &c->txt_out_cap, padded, "hipMalloc(text bases)")) != KH_OK) return rc;
+    if (with_qual && (rc = ensure_buf(c, &c->txt_qual, &c->txt_qual_cap, padded, "hipMalloc(text qualities)")) != KH_OK) return rc;
+    const unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)GRID_CAP);
+    u64 out_len = 0;
+    {
+        StageTimer tm(c, ST_TEXT);
+        hipLaunchKernelGGL(kh::raw_nl_count_kernel, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles, c->txt_tnl);
+        if ((rc = device_scan(c, c->txt_tnl, ntiles, c->txt_tbase)) != KH_OK) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->txt_err, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tbase + ntiles, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->first, d_text, 1, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->last, d_text + n - 1, 1, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const bool open_end = c->h_txt->last != '\n';           // no final newline: the text end closes the line
+        const u64 nlines = c->h_txt->total + (open_end ? 1 : 0);
+        if (c->h_txt->first != (fastq ? '@' : '>')) return text_fail(c, fastq ? "text does not start with '@'" : "text does not start with '>'");
+        if (fastq && (nlines & 3)) return text_fail(c, "FASTQ line count is not a multiple of 4");
+        if ((rc = ensure_buf(c, &c->txt_ls, &c->txt_ls_cap, nlines + 2, "hipMalloc(line starts)")) != KH_OK) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->txt_ls, 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL(kh::raw_line_starts_kernel, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+                           (const u64 *)c->txt_tbase, c->txt_ls);
+        if (open_end) {
+            c->h_txt->end_mark = n + 1;
+            HIP_TRY(c, hipMemcpyAsync(c->txt_ls + nlines, &c->h_txt->end_mark, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        }
+        if (fastq) {
+            const u64 nrec = nlines / 4;
+            hipLaunchKernelGGL(kh::fastq_validate_kernel, dim3(grid_for(nrec)), dim3(kh::BLOCK), 0, c->stream, d_text,
+                               (const u64 *)c->txt_ls, nrec, c->txt_err);
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->h_txt->err) return text_fail(c, "not 4-line FASTQ ('@' / '+' markers or |seq| != |qual|)");
+            if (with_qual)
+                hipLaunchKernelGGL(kh::fastq_mark_kernel<true>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+                                   (const u64 *)c->txt_tbase, (const u64 *)c->txt_ls, c->txt_out, c->txt_qual);
+            else
+                hipLaunchKernelGGL(kh::fastq_mark_kernel<false>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+                                   (const u64 *)c->txt_tbase, (const u64 *)c->txt_ls, c->txt_out, (uint8_t *)nullptr);
+            out_len = n;
+        } else {
+            if ((rc = ensure_buf(c, &c->txt_hdr, &c->txt_hdr_cap, nlines + 2, "hipMalloc(header flags)")) != KH_OK) return rc;
+            if ((rc = ensure_buf(c, &c->txt_tkeep, &c->txt_tkeep_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
+            if ((rc = ensure_buf(c, &c->txt_tout, &c->txt_tout_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
+            hipLaunchKernelGGL(kh::fasta_headers_kernel, dim3(grid_for(nlines + 1)), dim3(kh::BLOCK), 0, c->stream, d_text, n,
+                               (const u64 *)c->txt_ls, nlines + 1, c->txt_hdr);
+            hipLaunchKernelGGL(kh::fasta_compact_kernel<0>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+                               (const u64 *)c->txt_tbase, (const uint8_t *)c->txt_hdr, c->txt_tkeep, (const u64 *)nullptr,
+                               (uint8_t *)nullptr, c->txt_err);
+            if ((rc = device_scan(c, c->txt_tkeep, ntiles, c->txt_tout)) != KH_OK) return rc;
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tout + ntiles, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->h_txt->err) return text_fail(c, "blank before a line end inside a FASTA record");
+            out_len = c->h_txt->total;
+            hipLaunchKernelGGL(kh::fasta_compact_kernel<1>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+                               (const u64 *)c->txt_tbase, (const uint8_t *)c->txt_hdr, (uint32_t *)nullptr,
+                               (const u64 *)c->txt_tout, c->txt_out, (uint32_t *)nullptr);
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (raw_event) {
+        if (!c->txt_raw_free) HIP_TRY(c, hipEventCreateWithFlags(&c->txt_raw_free, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->txt_raw_free, c->stream));
+        c->txt_raw_busy = true;
+    }
+    if (out_len == 0) return KH_OK;
+    return count_device_range(c, c->txt_out, with_qual ? c->txt_qual : nullptr, out_len, 0);
+}
+
+int text_args(kh_ctx *c, const uint8_t *text, u64 n, int format) {
+    if (n && !text) return fail(c, KH_ERR_BAD_ARG, "text is NULL");
+    if (format != KH_TEXT_FASTA && format != KH_TEXT_FASTQ) return fail(c, KH_ERR_BAD_ARG, "format must be KH_TEXT_FASTA or KH_TEXT_FASTQ");
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
+    return KH_OK;
+}
+
+}  // namespace
+
+extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n, int format) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    if ((rc = text_args(c, d_text, n, format)) != KH_OK) return rc;
+    if (n == 0) return KH_OK;
+    if ((uintptr_t)d_text & 15) return fail(c, KH_ERR_BAD_ARG, "d_text must be 16-byte aligned");
+    rc = scan_text(c, d_text, n, format, false);
+    if (rc == KH_OK) c->bases_pushed += n;
+    return rc;
+}
+
+extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int format) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    if ((rc = text_args(c, text, n, format)) != KH_OK) return rc;
+    if (n == 0) return KH_OK;
+    if ((rc = ensure_stage(c)) != KH_OK) return rc;
+    if (c->txt_raw_cap < n + 64) {
+        u64 want = std::max<u64>(1ull << 20, c->txt_raw_cap);
+        while (want < n + 64) want *= 2;
+        if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
+        if ((rc = ensure_buf(c, &c->txt_raw, &c->txt_raw_cap, want, "hipMalloc(text)")) != KH_OK) return rc;
+        c->txt_raw_busy = false;
+    }
+    if (c->txt_raw_busy) {  // the previous text is still being scanned (its COUNTING does not read txt_raw)
+        HIP_TRY(c, hipStreamWaitEvent(c->cstream, c->txt_raw_free, 0));
+        c->txt_raw_busy = false;
+    }
+    for (u64 off = 0; off < n; off += 2 * STAGE_BYTES) {
+        const u64 len = std::min(2 * STAGE_BYTES, n - off);
+        const int p = c->stage_next;
+        c->stage_next ^= 1;
+        if (c->stage_used[p]) HIP_TRY(c, hipEventSynchronize(c->stage_done[p]));
+        memcpy(c->h_stage[p], text + off, len);
+        hipEvent_t t0, t1;
+        HIP_TRY(c, hipEventCreate(&t0));
+        HIP_TRY(c, hipEventCreate(&t1));
+        HIP_TRY(c, hipEventRecord(t0, c->cstream));
+        HIP_TRY(c, hipMemcpyAsync(c->txt_raw + off, c->h_stage[p], len, hipMemcpyHostToDevice, c->cstream));
+        HIP_TRY(c, hipEventRecord(t1, c->cstream));
+        HIP_TRY(c, hipEventRecord(c->stage_done[p], c->cstream));
+        c->stage_used[p] = true;
+        c->h2d_events.emplace_back(t0, t1);
+    }
+    hipEvent_t ready;
+    HIP_TRY(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(ready, c->cstream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
+    (void)hipEventDestroy(ready);
+    rc = scan_text(c, c->txt_raw, n, format, true);
+    if (rc == KH_OK) c->bases_pushed += n;
+    return rc;
+}
+
 extern "C" int kh_finish(kh_ctx *c, kh_stats *st) {
     int rc = enter(c);
     if (rc != KH_OK) return rc;
@@ -989,6 +1165,7 @@ extern "C" int kh_finish(kh_ctx *c, kh_stats *st) {
         st->h2d_ms = c->h2d_ms;
         st->part_batches = c->part_batches;
         for (int i = 0; i < KH_NUM_STAGES; ++i) st->stage_ms[i] = i < ST_N ? c->stage_ms[i] : 0.0;
+        st->text_scan_ms = c->text_ms;
     }
     if (c->trace)
         fprintf(stderr, "[kmerhip] bases=%llu kmers=%llu distinct=%llu slots=%llu load=%.3f launches=%llu kernel=%.3f ms h2d=%.3f ms | direct=%.2f p1c=%.2f p1s=%.2f p2c=%.2f p2s=%.2f region=%.2f misc=%.2f grow=%.2f\n",
@@ -1470,6 +1647,7 @@ extern "C" const char *kh_strerror(int s) {
     case KH_ERR_HIP: return "HIP runtime error";
     case KH_ERR_STATE: return "invalid context state";
     case KH_ERR_RANGE: return "output array too small";
+    case KH_ERR_FORMAT: return "text layout not accepted by the device record scanner";
     default: return "unknown error";
     }
 }

@@ -216,11 +216,105 @@ struct Session {
         if (ctx && kh_last_error(ctx)[0]) msg += std::string(" (") + kh_last_error(ctx) + ")";
         throw Error(msg);
     }
+    // Uncompressed or gzip files: the TEXT goes to the device in chunks of whole records and the
+    // records are found there (kh_push_text).  Returns false -- with the table reset -- when the
+    // device scanner refuses the layout; the line parser below then takes the file (and reports
+    // malformed input with the reference's messages).
+    bool count_file_text(const std::string &path, SequenceFormat fmt) {
+        const bool fastq = fmt == SequenceFormat::Fastq;
+        gzFile gz = gzopen(path.c_str(), "rb");
+        if (!gz) throw Error("failed to read sequence file '" + path + "': " + std::strerror(errno));
+        struct Closer {
+            gzFile g;
+            ~Closer() { gzclose(g); }
+        } closer{gz};
+        gzbuffer(gz, 1u << 20);
+        const size_t chunk = text_chunk_bytes();
+        std::vector<uint8_t> buf(chunk);
+        size_t have = 0;
+        bool eof = false, pushed = false;
+        auto refuse = [&]() {
+            if (pushed) check(kh_reset(ctx), "kh_reset");
+            return false;
+        };
+        while (!eof) {
+            while (have < buf.size()) {
+                const size_t want = std::min<size_t>(buf.size() - have, 1u << 30);
+                const int n = gzread(gz, buf.data() + have, (unsigned)want);
+                if (n < 0) {
+                    int en = 0;
+                    const char *msg = gzerror(gz, &en);
+                    throw Error("failed to decompress gzip file '" + path + "': " + (msg ? msg : "read error"));
+                }
+                if (n == 0) {
+                    eof = true;
+                    break;
+                }
+                have += (size_t)n;
+            }
+            size_t cut = have;
+            if (!eof) {
+                cut = fastq ? fastq_cut(buf.data(), have) : fasta_cut(buf.data(), have);
+                if (cut == 0) {  // no record boundary in a whole chunk: grow and read on
+                    if (buf.size() >= (size_t)8 << 30) return refuse();
+                    buf.resize(buf.size() * 2);
+                    continue;
+                }
+            }
+            if (cut) {
+                const int rc = kh_push_text(ctx, buf.data(), cut, fastq ? KH_TEXT_FASTQ : KH_TEXT_FASTA);
+                if (rc == KH_ERR_FORMAT) return refuse();
+                check(rc, "kh_push_text");
+                pushed = true;
+            }
+            memmove(buf.data(), buf.data() + cut, have - cut);
+            have -= cut;
+        }
+        return true;
+    }
+    static size_t text_chunk_bytes() {
+        const char *e = getenv("KMERUST_TEXT_CHUNK_KB");  // tests use small chunks to exercise the cuts
+        return (e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256 << 10) << 10;
+    }
+    // Largest p > 0 with a record starting at p ('>' at a line start); 0 if none.
+    static size_t fasta_cut(const uint8_t *b, size_t n) {
+        for (size_t p = n; p-- > 1;)
+            if (b[p] == '>' && b[p - 1] == '\n') return p;
+        return 0;
+    }
+    // Largest p > 0 where a complete 4-line record provably starts: '@' at a line start, '+' two
+    // lines on, and |seq| == |qual| (a quality line may itself start with '@').
+    static size_t fastq_cut(const uint8_t *b, size_t n) {
+        auto line_end = [&](size_t from) -> size_t {  // index of the '\n' ending the line at `from`, or n
+            const void *q = from < n ? memchr(b + from, '\n', n - from) : nullptr;
+            return q ? (size_t)((const uint8_t *)q - b) : n;
+        };
+        for (size_t p = n; p-- > 1;) {
+            if (b[p] != '@' || b[p - 1] != '\n') continue;
+            const size_t e0 = line_end(p);
+            if (e0 >= n) continue;
+            const size_t e1 = line_end(e0 + 1);
+            if (e1 >= n) continue;
+            const size_t e2 = line_end(e1 + 1);
+            if (e2 >= n || b[e1 + 1] != '+') continue;
+            const size_t e3 = line_end(e2 + 1);
+            if (e3 >= n) continue;
+            size_t ls = e1 - (e0 + 1), lq = e3 - (e2 + 1);
+            if (ls && b[e1 - 1] == '\r') --ls;
+            if (lq && b[e3 - 1] == '\r') --lq;
+            if (ls == lq) return p;
+        }
+        return 0;
+    }
     void count_file(const std::string &path, SequenceFormat fmt, bool want_qual) {
-        read_sequences(path, fmt, want_qual, 512u << 20, [&](const Batch &b) {
-            check(kh_push(ctx, b.bases.data(), want_qual && !b.qual.empty() ? b.qual.data() : nullptr, b.bases.size()),
-                  "kh_push");
-        });
+        const char *hp = getenv("KMERUST_HOST_PARSE");
+        const bool host_only = is_stdin_path(path) || (hp && hp[0] && hp[0] != '0');
+        if (host_only || !count_file_text(path, resolve_format(fmt, &path))) {
+            read_sequences(path, fmt, want_qual, 512u << 20, [&](const Batch &b) {
+                check(kh_push(ctx, b.bases.data(), want_qual && !b.qual.empty() ? b.qual.data() : nullptr, b.bases.size()),
+                      "kh_push");
+            });
+        }
         check(kh_finish(ctx, nullptr), "kh_finish");
     }
     PackedCounts result(uint64_t min_count) {

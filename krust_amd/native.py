@@ -21,6 +21,8 @@ KH_ERR_TABLE_FULL = -5
 KH_ERR_HIP = -6
 KH_ERR_STATE = -7
 KH_ERR_RANGE = -8
+KH_ERR_FORMAT = -9
+TEXT_FASTA, TEXT_FASTQ = 1, 2
 
 
 class KhConfig(C.Structure):
@@ -33,7 +35,7 @@ class KhStats(C.Structure):
     _fields_ = [("bases", C.c_uint64), ("kmers", C.c_uint64), ("distinct", C.c_uint64),
                 ("table_slots", C.c_uint64), ("grows", C.c_uint64), ("launches", C.c_uint64),
                 ("count_kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("part_batches", C.c_uint64),
-                ("stage_ms", C.c_double * 8)]
+                ("stage_ms", C.c_double * 8), ("text_scan_ms", C.c_double)]
 
 STAGES = ("direct", "p1_count", "p1_scatter", "p2_count", "p2_scatter", "region", "misc", "grow")
 FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION = 1, 2, 4
@@ -49,6 +51,8 @@ SYMBOLS = {
     "kh_reset": (C.c_int, [_P]),
     "kh_push": (C.c_int, [_P, _P, _P, _U64]),
     "kh_push_device": (C.c_int, [_P, _P, _P, _U64]),
+    "kh_push_text": (C.c_int, [_P, _P, _U64, C.c_int]),
+    "kh_push_text_device": (C.c_int, [_P, _P, _U64, C.c_int]),
     "kh_finish": (C.c_int, [_P, C.POINTER(KhStats)]),
     "kh_result_size": (C.c_int, [_P, _U64, C.POINTER(_U64)]),
     "kh_result_copy": (C.c_int, [_P, _P, _P, _U64, _U64, C.POINTER(_U64)]),
@@ -126,6 +130,10 @@ def _addr(a):
     return arr.ctypes.data, arr
 
 
+def _text_format(fmt):
+    return {"fasta": TEXT_FASTA, "fastq": TEXT_FASTQ, TEXT_FASTA: TEXT_FASTA, TEXT_FASTQ: TEXT_FASTQ}[fmt]
+
+
 class DeviceCounter:
     """One kh_ctx: a GPU-resident canonical k-mer count table.
 
@@ -181,6 +189,15 @@ class DeviceCounter:
     def push_device(self, d_bases, d_qual, n):
         """Device-resident flat buffers given as integer addresses (e.g. tensor.data_ptr())."""
         self._check(lib().kh_push_device(self._h, d_bases, d_qual, int(n)))
+
+    def push_text(self, text, fmt):
+        """Raw FASTA / FASTQ text (whole records) scanned on the device; fmt: "fasta" | "fastq".
+        Raises KmerHipError(status=KH_ERR_FORMAT) for layouts the device scanner does not take."""
+        tp, kt = _addr(text)
+        self._check(lib().kh_push_text(self._h, tp, kt.size if kt is not None else 0, _text_format(fmt)))
+
+    def push_text_device(self, d_text, n, fmt):
+        self._check(lib().kh_push_text_device(self._h, d_text, int(n), _text_format(fmt)))
 
     def finish(self):
         st = KhStats()

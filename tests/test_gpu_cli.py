@@ -15,8 +15,9 @@ with open(os.path.join(ROOT, "tests", "golden", "derived_fixture_tables.json")) 
     DERIVED = {(r["fixture"], r["k"], r["min_quality"]): r for r in json.load(f)["tables"]}
 
 
-def run(*args, stdin=None):
-    return subprocess.run([BIN, *args], input=stdin, capture_output=True, timeout=300)
+def run(*args, stdin=None, env=None):
+    return subprocess.run([BIN, *args], input=stdin, capture_output=True, timeout=300,
+                          env=None if env is None else {**os.environ, **env})
 
 
 def tsv(out):
@@ -169,3 +170,64 @@ def test_hg_like_fasta_histogram(tmp_path):
     assert len(got_tsv) == len(want)
     import krust_amd
     assert all(want[krust_amd.pack(kmer)] == c for kmer, c in list(got_tsv.items())[:20000])
+
+
+def _write_reads(tmp_path, wrapped_fastq=False):
+    import numpy as np
+    rng = np.random.default_rng(123)
+    genome = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)[rng.choice(9, size=60_000, p=[.22, .22, .22, .22, .03, .03, .02, .02, .02])].tobytes()
+    fq, fa = tmp_path / "reads.fq", tmp_path / "contigs.fa"
+    with open(fq, "wb") as f:
+        for i in range(4000):
+            a = int(rng.integers(0, len(genome) - 200)); n = int(rng.integers(1, 200))
+            q = bytes(rng.choice(list(b"#+5I@"), size=n, p=[.02, .02, .06, .8, .1]).astype(np.uint8))
+            s = genome[a:a + n]
+            if wrapped_fastq and i == 1234 and n > 10:
+                f.write(b"@r%d\n%s\n%s\n+\n%s\n%s\n" % (i, s[:5], s[5:], q[:5], q[5:]))
+            else:
+                f.write(b"@r%d\n%s\n+\n%s\n" % (i, s, q))
+    with open(fa, "wb") as f:
+        for i in range(300):
+            a = int(rng.integers(0, len(genome) - 3000)); n = int(rng.integers(0, 3000))
+            f.write(b">c%d len=%d\n" % (i, n))
+            for o in range(0, n, 70):
+                f.write(genome[a + o:a + min(n, o + 70)] + b"\n")
+    return str(fq), str(fa)
+
+
+@pytest.mark.parametrize("chunk_kb", [None, "16"], ids=["one-chunk", "16KiB-chunks"])
+def test_device_text_scan_equals_host_line_parser(tmp_path, chunk_kb):
+    """kh_push_text (records found on the device) against the host line parser, through the CLI:
+    FASTQ with / without -Q, wrapped FASTA, gzip; small chunks force cuts at record boundaries."""
+    fq, fa = _write_reads(tmp_path)
+    env = {} if chunk_kb is None else {"KMERUST_TEXT_CHUNK_KB": chunk_kb}
+    for args in (["21", fq], ["21", fq, "-Q", "20"], ["5", fq, "-Q", "10"], ["21", fa], ["32", fa], ["2", fa]):
+        args = args + ["--format", "tsv", "--quiet"]
+        dev = run(*args, env=env)
+        host = run(*args, env={"KMERUST_HOST_PARSE": "1"})
+        assert dev.returncode == 0 and host.returncode == 0, (dev.stderr, host.stderr)
+        assert tsv(dev.stdout) == tsv(host.stdout) and tsv(dev.stdout)
+    gz = fq + ".gz"
+    with open(fq, "rb") as f, gzip.open(gz, "wb") as g:
+        g.write(f.read())
+    a = run("21", gz, "-Q", "20", "--format", "tsv", "--quiet", env=env)
+    b = run("21", fq, "-Q", "20", "--format", "tsv", "--quiet", env={"KMERUST_HOST_PARSE": "1"})
+    assert a.returncode == 0 and tsv(a.stdout) == tsv(b.stdout)
+
+
+def test_wrapped_fastq_falls_back_to_the_line_parser(tmp_path):
+    """A layout the device scanner refuses mid-file (after earlier chunks were already counted) must give
+    the line parser's table, not a partial or doubled one."""
+    fq, _ = _write_reads(tmp_path, wrapped_fastq=True)
+    for env in ({"KMERUST_TEXT_CHUNK_KB": "16"}, {}):
+        dev = run("11", fq, "-Q", "10", "--format", "tsv", "--quiet", env=env)
+        host = run("11", fq, "-Q", "10", "--format", "tsv", "--quiet", env={"KMERUST_HOST_PARSE": "1"})
+        assert dev.returncode == 0 and host.returncode == 0, (dev.stderr, host.stderr)
+        assert tsv(dev.stdout) == tsv(host.stdout)
+
+
+def test_malformed_input_keeps_the_parser_error(tmp_path):
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r\nACGT\n+\nII\n")
+    r = run("3", str(bad), "--quiet")
+    assert r.returncode == 1 and b"unequal length" in r.stderr

@@ -1,0 +1,211 @@
+"""Device-side record scanning (kh_push_text) against the oracle.
+
+The expected table comes from a plain Python restatement of what the reference's readers hand to
+the counting path (rust-bio semantics as used in src/reader.rs:58-79: FASTA lines of a record are
+joined after trimming the line end; FASTQ is id / seq / '+' / qual) followed by the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from krust_amd import native
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_fasta(text):
+    recs, cur = [], None
+    for line in text.split(b"\n"):
+        line = line.rstrip(b"\r")
+        if line.startswith(b">"):
+            if cur is not None:
+                recs.append(b"".join(cur))
+            cur = []
+        elif cur is not None:
+            cur.append(line)
+    if cur is not None:
+        recs.append(b"".join(cur))
+    return recs, None
+
+
+def parse_fastq(text):
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines = [l.rstrip(b"\r") for l in lines]
+    assert len(lines) % 4 == 0
+    return lines[1::4], lines[3::4]
+
+
+def expect(text, fmt, k, minq):
+    recs, quals = (parse_fasta if fmt == "fasta" else parse_fastq)(text)
+    return O.count_records(recs, k, quals=quals if minq is not None else None, min_quality=minq).as_dict()
+
+
+def device(text, fmt, k, minq, path=None, chunks=None):
+    with native.DeviceCounter(k, min_quality=minq, path=path) as dc:
+        for part in (chunks or [text]):
+            dc.push_text(part, fmt)
+        st = dc.finish()
+        keys, counts = dc.result()
+    d = dict(zip(keys.tolist(), counts.tolist()))
+    assert st["kmers"] == sum(d.values())
+    return d
+
+
+def rand_seq(rng, n, alphabet=b"ACGTACGTACGTacgtN"):
+    return bytes(rng.choice(list(alphabet), size=n).astype(np.uint8))
+
+
+def make_fastq(rng, nreads, lo, hi, eol=b"\n", final_newline=True):
+    out = []
+    for i in range(nreads):
+        n = int(rng.integers(lo, hi + 1))
+        seq = rand_seq(rng, n)
+        qual = bytes(rng.choice(list(b"!#+5?I@+"), size=n).astype(np.uint8))  # '@' and '+' also start quality lines
+        out.append(b"@read%d some text ACGT" % i + eol + seq + eol + b"+" + eol + qual + eol)
+    text = b"".join(out)
+    if not final_newline:
+        text = text[: -len(eol)]
+    return text
+
+
+def make_fasta(rng, nrec, lo, hi, width, eol=b"\n", final_newline=True, blank_lines=False):
+    out = []
+    for i in range(nrec):
+        n = int(rng.integers(lo, hi + 1))
+        seq = rand_seq(rng, n)
+        out.append(b">chr%d ACGTACGTACGTACGTACGTACGTACGTACGT > description" % i + eol)
+        for o in range(0, n, width):
+            out.append(seq[o:o + width] + eol)
+            if blank_lines and (o // width) % 7 == 3:
+                out.append(eol)
+    text = b"".join(out)
+    if not final_newline:
+        text = text[: -len(eol)]
+    return text
+
+
+@pytest.mark.parametrize("k,minq", [(21, None), (21, 20), (5, None), (31, 30), (1, None), (32, None)])
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"], ids=["lf", "crlf"])
+def test_fastq_text_matches_oracle(k, minq, eol):
+    rng = np.random.default_rng(11 + k)
+    text = make_fastq(rng, 700, 0, 260, eol=eol)
+    assert len(text) > 3 * 4096  # several tiles, lines straddle tile and lane boundaries
+    assert device(text, "fastq", k, minq) == expect(text, "fastq", k, minq)
+
+
+def test_fastq_without_final_newline_and_in_chunks():
+    rng = np.random.default_rng(5)
+    a = make_fastq(rng, 300, 30, 151)
+    b = make_fastq(rng, 300, 30, 151, final_newline=False)
+    want = expect(a + b + b"\n", "fastq", 15, 10)
+    assert device(None, "fastq", 15, 10, chunks=[a, b]) == want
+    assert device(a + b, "fastq", 15, 10) == want
+
+
+@pytest.mark.parametrize("size", [1, 15, 16, 17, 4095, 4096, 4097, 8192, 12288 + 5])
+def test_fastq_sizes_around_tile_edges(size):
+    # one long record padded to an exact text size
+    rng = np.random.default_rng(size)
+    head = b"@r\n"
+    body = (size - len(head) - 3)  # seq + '\n+\n' + qual + '\n'
+    if body < 1:
+        pytest.skip("too small for a record")
+    n = (body - 1) // 2
+    seq = rand_seq(rng, n, b"ACGT")
+    text = head + seq + b"\n+\n" + b"I" * n + b"\n"
+    assert device(text, "fastq", 3, None) == expect(text, "fastq", 3, None)
+
+
+@pytest.mark.parametrize("k", [3, 21, 32])
+@pytest.mark.parametrize("width,eol,blank", [(60, b"\n", False), (70, b"\r\n", False), (61, b"\n", True), (10 ** 9, b"\n", False)],
+                         ids=["w60", "w70-crlf", "w61-blank", "single-line"])
+def test_fasta_text_matches_oracle(k, width, eol, blank):
+    rng = np.random.default_rng(k * 1000 + width % 997)
+    text = make_fasta(rng, 40, 0, 3000, width, eol=eol, blank_lines=blank)
+    got = device(text, "fasta", k, None)
+    assert got == expect(text, "fasta", k, None)
+    # k-mers span the line breaks of a wrapped record: same table as the unwrapped text
+    recs, _ = parse_fasta(text)
+    assert got == O.count_records(recs, k).as_dict()
+
+
+def test_fasta_header_text_is_never_counted():
+    text = b">ACGTACGTACGTACGTACGT\nAC\n>GGGGGGGGGGGG\nGT\n"
+    assert device(text, "fasta", 2, None) == expect(text, "fasta", 2, None)
+    assert sum(device(text, "fasta", 2, None).values()) == 2
+
+
+def test_fasta_without_final_newline():
+    rng = np.random.default_rng(9)
+    text = make_fasta(rng, 5, 100, 500, 60, final_newline=False)
+    assert device(text, "fasta", 11, None) == expect(text, "fasta", 11, None)
+
+
+@pytest.mark.parametrize("name", ["simple.fa", "soft_masked.fa", "with_n.fa", "simple.fq", "with_n.fq", "low_quality.fq"])
+def test_reference_fixtures_as_text(name):
+    with open(os.path.join(ROOT, "tests", "fixtures", name), "rb") as f:
+        text = f.read()
+    fmt = "fasta" if name.endswith(".fa") else "fastq"
+    for k, minq in ((3, None), (4, 20 if fmt == "fastq" else None)):
+        assert device(text, fmt, k, minq) == expect(text, fmt, k, minq)
+
+
+@pytest.mark.parametrize("path", ["direct", "partition"])
+def test_large_fastq_text_both_paths(path):
+    rng = np.random.default_rng(77)
+    genome = rand_seq(rng, 200_000, b"ACGT")
+    starts = rng.integers(0, len(genome) - 150, size=60_000)
+    recs = [genome[s:s + 150] for s in starts]
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * 150) for i, r in enumerate(recs))
+    got = device(text, "fastq", 21, None, path=path)
+    m = O.OracleMap()
+    m.process(b"\n".join(recs), 21)
+    assert got == m.as_dict()
+
+
+def _format_error(text, fmt, k=5, minq=None):
+    with native.DeviceCounter(k, min_quality=minq) as dc:
+        with pytest.raises(native.KmerHipError) as e:
+            dc.push_text(text, fmt)
+        assert e.value.status == native.KH_ERR_FORMAT
+        assert dc.finish()["kmers"] == 0  # nothing was counted; the context stays usable
+        dc.push(b"ACGTACGT")
+        assert dc.finish()["kmers"] == 4
+
+
+@pytest.mark.parametrize("text,fmt", [
+    (b"@r\nACGT\nACGT\n+\nIIII\nIIII\n", "fastq"),              # wrapped FASTQ (6 lines)
+    (b"@r\nACGT\nACGT\n+\nIIII\nIIII\n@q\nAC\n", "fastq"),      # 8 lines, markers in the wrong places
+    (b"@r\nACGT\n+\nIII\n", "fastq"),                           # |seq| != |qual|
+    (b"r\nACGT\n+\nIIII\n", "fastq"),                           # no '@'
+    (b"@r\nACGT\n-\nIIII\n", "fastq"),                          # no '+'
+    (b"@r\nACGT\n+\nIIII\n\n@q\nAC\n+\nII\n", "fastq"),         # blank line between records
+    (b"ACGT\n>r\nACGT\n", "fasta"),                             # text before the first header
+    (b">r\nACGT \nACGT\n", "fasta"),                            # blank at a line end inside a record
+    (b">r\nACGT\t\r\nACGT\n", "fasta"),
+], ids=["wrapped", "wrapped8", "lens", "no-at", "no-plus", "blank-line", "no-header", "trailing-space", "trailing-tab-crlf"])
+def test_unsupported_layouts_are_reported_not_miscounted(text, fmt):
+    _format_error(text, fmt)
+
+
+def test_push_text_device_needs_alignment_and_matches_host_text():
+    import torch
+    rng = np.random.default_rng(3)
+    text = make_fastq(rng, 500, 50, 150)
+    buf = torch.zeros(len(text) + 32, dtype=torch.uint8, device="cuda")
+    buf[16:16 + len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    with native.DeviceCounter(21, min_quality=20) as dc:
+        with pytest.raises(native.KmerHipError) as e:
+            dc.push_text_device(buf.data_ptr() + 1, len(text), "fastq")
+        assert e.value.status == native.KH_ERR_BAD_ARG
+        assert buf.data_ptr() % 16 == 0
+        dc.push_text_device(buf.data_ptr() + 16, len(text), "fastq")
+        dc.finish()
+        keys, counts = dc.result()
+    assert dict(zip(keys.tolist(), counts.tolist())) == expect(text, "fastq", 21, 20)
