@@ -252,8 +252,9 @@ def main():
                        "parallelism": f"reads sharded x{world}" + ("; RCCL all-to-all table merge" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "partitioned pipeline: part1_count + part1_scatter + part2_count + part2_scatter + "
-                                   "region_count (one launch each per batch)" if part else "count_direct_kernel",
+                         "kernel": ("partitioned pipeline: part1_scatter_chunked (single-pass level 1; k >= 22: part1_count + "
+                                    "part1_scatter) + part2_count + part2_scatter + region_count, one launch each per batch")
+                         if part else "count_direct_kernel",
                          "launches_per_step": int(st["launches"]), "kernel_ms_per_step": kernel_ms_step,
                          "alg_bytes_per_step": alg_bytes_step,
                          "kernel_kmers_per_s": st["kmers"] / (kernel_ms_step * 1e-3) if kernel_ms_step else None,
