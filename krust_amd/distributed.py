@@ -23,6 +23,22 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _host_staged(group):
+    """gloo has no device all-to-all: with it (CPU tests, and several ranks sharing ONE GPU in
+    tests/test_gpu_dist.py) device tensors make the trip through host memory.  RCCL ("nccl") moves
+    device buffers directly over xGMI."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
+    if out.is_cuda and _host_staged(group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
 def exchange_pairs(keys, counts, part_counts, group=None, return_sizes=False):
     """All-to-all of owner-grouped pairs.
 
@@ -36,12 +52,12 @@ def exchange_pairs(keys, counts, part_counts, group=None, return_sizes=False):
     dev = keys.device
     ssz = torch.tensor(send_sizes, dtype=torch.int64, device=dev)
     rsz = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(rsz, ssz, group=group)
+    _all_to_all(rsz, ssz, group=group)
     recv_sizes = [int(x) for x in rsz.tolist()]
     rk = torch.empty(sum(recv_sizes), dtype=torch.int64, device=dev)
     rc = torch.empty(sum(recv_sizes), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(rk, keys, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
-    dist.all_to_all_single(rc, counts, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
+    _all_to_all(rk, keys, recv_sizes, send_sizes, group=group)
+    _all_to_all(rc, counts, recv_sizes, send_sizes, group=group)
     if return_sizes:
         return rk, rc, recv_sizes
     return rk, rc
@@ -50,7 +66,7 @@ def exchange_pairs(keys, counts, part_counts, group=None, return_sizes=False):
 def _same_everywhere(value, group=None):
     """True iff every rank holds the same integer."""
     world = dist.get_world_size(group)
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = torch.device("cpu") if _host_staged(group) else torch.device("cuda", torch.cuda.current_device())
     mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
     allv = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine, group=group)
@@ -80,7 +96,7 @@ def merge_across_ranks(counter, group=None):
         assert nreg2 == nreg
         rk, rc, recv_sizes = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group, return_sizes=True)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices of nreg / world region counts
-        dist.all_to_all_single(rrc, rcnt, group=group)
+        _all_to_all(rrc, rcnt, group=group)
         counter.reset()
         counter.set_shard(rank, world)
         offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)

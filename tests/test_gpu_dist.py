@@ -43,3 +43,58 @@ def test_rccl_world1_merge(tmp_path):
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "NCCL_OK" in out.stdout
+
+
+# Several ranks sharing the one GPU of the box (RCCL refuses duplicate devices, so the collective is
+# gloo with host staging, krust_amd/distributed.py::_all_to_all): every rank counts ITS shard of the
+# reads into a real device table, then the real export -> exchange -> set_shard -> LDS merge runs.
+MULTI = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import oracle_lib as O
+import krust_amd
+from krust_amd.distributed import merge_across_ranks, shard_range
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+N_READS, K, SEED = 120000, 21, 20260130
+lo, hi = shard_range(N_READS, rank, world)
+bases, _ = O.synth_reads(SEED, 1 << 20, 150, lo, hi - lo, with_qual=False)
+with krust_amd.DeviceCounter(K, capacity_hint=3_000_000, path=PATH) as dc:
+    dc.push(bases)
+    info = merge_across_ranks(dc)
+    keys, cnts = dc.result()
+    assert info["path"] == EXPECT_PATH, info
+    # the shard answers lookups for its own keys and stays refusing reads until reset
+    if len(keys):
+        assert np.array_equal(dc.lookup(keys[:1000]), cnts[:1000])
+full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, N_READS, with_qual=False)
+full = O.OracleMap(); full.scan_flat(full_b, K, nthreads=2)
+fk, fc = full.arrays()
+mine = {int(k): int(c) for k, c in zip(keys.tolist(), cnts.tolist())}
+assert all(krust_amd.owner(k, K, world) == rank for k in list(mine)[:20000])
+gathered = [None] * world
+dist.all_gather_object(gathered, (keys.tolist(), cnts.tolist()))
+if rank == 0:
+    union = {}
+    for ks, cs in gathered:
+        for k_, c_ in zip(ks, cs):
+            assert k_ not in union
+            union[k_] = c_
+    assert union == full.as_dict()
+    print("MULTI_OK", world, len(union))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world,path,expect", [(2, "partition", "regions"), (4, None, "regions"), (3, None, "pairs")])
+def test_ranks_sharing_one_gpu_merge_real_tables(world, path, expect, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(f"ROOT = {ROOT!r}\nPATH = {path!r}\nEXPECT_PATH = {expect!r}\n" + MULTI)
+    port = 29500 + world + (os.getpid() % 100)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "MULTI_OK" in out.stdout
