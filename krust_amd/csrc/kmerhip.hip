@@ -85,6 +85,8 @@ struct kh_ctx {
 
     // ---- partitioned path ----
     bool table_empty = true;   // no insert since creation / reset: regions need not be read back
+    bool table_dirty = false;  // kh_reset is lazy: the slots hold stale data that the next operation either
+                               // overwrites wholesale (a FRESH region pass) or clears first (everything else)
     bool hinted = false;       // caller gave a capacity hint
     int path_mode = 0;         // 0 auto, 1 force direct, 2 force partitioned
     int pay_mode = 0;          // 0 auto, 64 = always 64-bit payloads (env KMERHIP_PAYLOAD=64, for A/B)
@@ -171,15 +173,21 @@ int grid_for(u64 items) {
 }
 
 int flush_acc(kh_ctx *c, bool carry);
+int clear_if_dirty(kh_ctx *c);
 
 // Every entry point starts here.  Host pushes are accumulated on the device and counted lazily;
-// anything that looks at the table first counts what is pending.
-int enter(kh_ctx *c, bool flush_pending = true) {
+// anything that looks at the table first counts what is pending.  need_table = false: the caller
+// decides itself whether a lazily reset table must be cleared (the input entry points: a
+// partitioned batch into an empty table overwrites every region anyway).
+int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true) {
     if (!c) return KH_ERR_BAD_ARG;
     if (c->poisoned) return fail(c, KH_ERR_STATE, "context is poisoned by an earlier error");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (flush_pending && c->acc_len) return flush_acc(c, false);
-    return KH_OK;
+    if (flush_pending && c->acc_len) {
+        int rc = flush_acc(c, false);
+        if (rc != KH_OK) return rc;
+    }
+    return need_table ? clear_if_dirty(c) : KH_OK;
 }
 
 int alloc_table(kh_ctx *c, u64 cap, Slot **out) {
@@ -192,6 +200,14 @@ int alloc_table(kh_ctx *c, u64 cap, Slot **out) {
     hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(cap)), dim3(kh::BLOCK), 0, c->stream, t, cap);
     HIP_TRY(c, hipGetLastError());
     *out = t;
+    return KH_OK;
+}
+
+int clear_if_dirty(kh_ctx *c) {
+    if (!c->table_dirty) return KH_OK;
+    hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table, c->cap);
+    HIP_TRY(c, hipGetLastError());
+    c->table_dirty = false;
     return KH_OK;
 }
 
@@ -233,9 +249,13 @@ int grow_to(kh_ctx *c, u64 newcap) {
     Slot *nt = nullptr;
     int rc = alloc_table(c, newcap, &nt);
     if (rc != KH_OK) return rc;
-    hipLaunchKernelGGL(kh::table_rehash_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
-                       c->cap, table_geom(c, nt, newcap), c->d_ctr);
-    HIP_TRY(c, hipGetLastError());
+    if (c->table_dirty) {  // logically empty: nothing to carry over, and the new table is clean
+        c->table_dirty = false;
+    } else {
+        hipLaunchKernelGGL(kh::table_rehash_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
+                           c->cap, table_geom(c, nt, newcap), c->d_ctr);
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipFree(c->table));
     if (c->trace) fprintf(stderr, "[kmerhip] table grown %llu -> %llu slots\n", c->cap, newcap);
@@ -408,20 +428,20 @@ void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot)
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
     else
         hipLaunchKernelGGL(kh::region_count_kernel64<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
 }
 template <>
 void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel32<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
     else
         hipLaunchKernelGGL(kh::region_count_kernel32<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot);
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
 }
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
@@ -600,6 +620,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
+    c->table_dirty = false;  // the FRESH region pass wrote every region
     c->launches++;
     c->part_batches++;
 
@@ -647,6 +668,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 }
 
 int direct_range(kh_ctx *c, const RangeArgs &ra, u64 first_tile, u64 end_tile) {
+    {
+        int rc = clear_if_dirty(c);
+        if (rc != KH_OK) return rc;
+    }
     u64 t = first_tile;
     u64 sub = SUB_TILES;
     while (t < end_tile) {
@@ -707,6 +732,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
             (void)hipFree(c->table);
             c->table = nt;
             c->cap = newcap;
+            c->table_dirty = false;
         }
     }
     if (part && !make_geom(c, c->cap).ok) part = false;  // table beyond 2 levels of partitioning
@@ -913,8 +939,9 @@ extern "C" int kh_reset(kh_ctx *c) {
     c->acc_len = c->acc_carry = 0;  // pushes not yet counted are forgotten with everything else
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
-    hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table, c->cap);
-    HIP_TRY(c, hipGetLastError());
+    // Lazy: no table_init here (5.5 ms for a 34 GB table).  A partitioned batch into an empty table
+    // rewrites every region; any other use clears first (clear_if_dirty).
+    if (!c->table_empty) c->table_dirty = true;
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->distinct_known = c->pending_bound = 0;
     c->bases_pushed = 0;
@@ -931,7 +958,7 @@ extern "C" int kh_reset(kh_ctx *c) {
 // input
 // =============================================================================================
 extern "C" int kh_push_device(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual, uint64_t n) {
-    int rc = enter(c);
+    int rc = enter(c, true, false);
     if (rc != KH_OK) return rc;
     if (n && !d_bases) return fail(c, KH_ERR_BAD_ARG, "d_bases is NULL");
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
@@ -941,7 +968,7 @@ extern "C" int kh_push_device(kh_ctx *c, const uint8_t *d_bases, const uint8_t *
 }
 
 extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uint64_t n) {
-    int rc = enter(c, false);
+    int rc = enter(c, false, false);
     if (rc != KH_OK) return rc;
     if (n && !bases) return fail(c, KH_ERR_BAD_ARG, "bases is NULL");
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
@@ -1094,7 +1121,7 @@ int text_args(kh_ctx *c, const uint8_t *text, u64 n, int format) {
 }  // namespace
 
 extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n, int format) {
-    int rc = enter(c);
+    int rc = enter(c, true, false);
     if (rc != KH_OK) return rc;
     if ((rc = text_args(c, d_text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
@@ -1105,7 +1132,7 @@ extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n,
 }
 
 extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int format) {
-    int rc = enter(c);
+    int rc = enter(c, true, false);
     if (rc != KH_OK) return rc;
     if ((rc = text_args(c, text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
@@ -1503,7 +1530,7 @@ extern "C" int kh_export_regions_device(kh_ctx *c, uint32_t nparts, uint64_t *d_
 extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
                                        const uint64_t *const *d_keys, const uint64_t *const *d_counts,
                                        const uint32_t *const *d_region_counts) {
-    int rc = enter(c);
+    int rc = enter(c, true, false);  // a FRESH merge rewrites every region of a lazily reset table
     if (rc != KH_OK) return rc;
     if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || !d_counts || !d_region_counts)
         return fail(c, KH_ERR_BAD_ARG, "bad nsenders / NULL argument");
@@ -1541,6 +1568,7 @@ extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t se
             (void)hipFree(c->table);
             c->table = nt;
             c->cap = newcap;
+            c->table_dirty = false;
         } else {
             rc = grow_to(c, newcap);
             if (rc != KH_OK) return rc;
@@ -1572,15 +1600,16 @@ extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t se
         StageTimer t(c, ST_REGION);
         if (c->table_empty)
             hipLaunchKernelGGL((kh::shard_merge_kernel<true, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, tg, a,
-                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr);
+                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr, (uint32_t)c->table_dirty);
         else
             hipLaunchKernelGGL((kh::shard_merge_kernel<false, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, tg, a,
-                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr);
+                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr, 0u);
         hipLaunchKernelGGL(kh::shard_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
                            (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)nregions, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
+    c->table_dirty = false;
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
     if (c->h_ctr->part_failed) {  // some target regions overflowed: grow, then insert their pairs directly
@@ -1589,7 +1618,7 @@ extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t se
         rc = grow_to(c, c->cap * 2);
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL((kh::shard_merge_kernel<false, true>), dim3((unsigned)nregions), dim3(1024), 0, c->stream,
-                           table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr);
+                           table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u);
         HIP_TRY(c, hipMemsetAsync(&c->d_ctr->part_failed, 0, sizeof(u64), c->stream));
         HIP_TRY(c, hipGetLastError());
         rc = sync_counters(c);

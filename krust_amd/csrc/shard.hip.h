@@ -72,7 +72,7 @@ struct MergeArgs {
 template <bool FRESH, bool DIRECT>
 __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, MergeArgs a, uint8_t *__restrict__ rfail,
                                                               uint32_t *__restrict__ rnew, const uint8_t *__restrict__ only_failed,
-                                                              uint32_t old_rbits, Counters *ctr) {
+                                                              uint32_t old_rbits, Counters *ctr, uint32_t dirty) {
     __shared__ u64 s_key[DIRECT ? 1 : REGION_SLOTS];
     __shared__ u64 s_cnt[DIRECT ? 1 : REGION_SLOTS];
     __shared__ uint32_t s_fail, s_new;
@@ -147,6 +147,8 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
     __syncthreads();
     if (s_fail) {
+        if (FRESH && dirty)  // lazily reset table (kernels.hip.h / kh_reset): leave an EMPTY region, not garbage
+            for (uint32_t i = tid; i < REGION_SLOTS; i += 1024) reinterpret_cast<uint4 *>(reg)[i] = make_uint4(~0u, ~0u, 0u, 0u);
         if (tid == 0) {
             rfail[t] = 1;
             rnew[t] = 0;

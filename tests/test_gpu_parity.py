@@ -231,6 +231,42 @@ def test_multiple_pushes_and_reset(K, path):
         assert dc.as_dict() == want
 
 
+def test_lazy_reset_never_leaks_old_entries(K, path):
+    """kh_reset does not clear the table (the next FRESH partitioned pass rewrites every region, any
+    other use clears first).  Fill the table, reset, then go through each way of using a reset table:
+    a second, DIFFERENT data set whose buckets leave most regions empty; immediate output calls; a
+    lookup of the old keys; a merge."""
+    rng = np.random.default_rng(17)
+    big = [_dirty(rng, 400, p_bad=0.0, lower=False) for _ in range(3000)]       # ~1.1 M distinct 15-mers
+    small = [_dirty(rng, 60, p_bad=0.0, lower=False) for _ in range(40)]       # a few thousand: most regions get no bucket
+    want_big, want_small = oracle_dict(big, 15), oracle_dict(small, 15)
+    with K.DeviceCounter(15, path=path, capacity_hint=2_000_000) as dc:
+        dc.push(flat(big)[0])
+        dc.finish()
+        assert dc.as_dict() == want_big
+        old_keys = np.fromiter(want_big.keys(), dtype=np.uint64)[:5000]
+        dc.reset()                                                               # -> output straight away
+        assert dc.result_size() == 0 and dc.histogram() == []
+        dc.reset()
+        assert not dc.lookup(old_keys).any()                                     # -> lookup straight away
+        dc.push(flat(big)[0]); dc.finish()
+        dc.reset()
+        dc.push(flat(small)[0])                                                  # -> a different, small data set
+        st = dc.finish()
+        assert st["distinct"] == len(want_small)
+        assert dc.as_dict() == want_small
+        assert not dc.lookup(np.array([k for k in old_keys.tolist() if k not in want_small][:2000], dtype=np.uint64)).any()
+        dc.reset()
+        keys = np.fromiter(want_small.keys(), dtype=np.uint64)
+        dc.merge_pairs(keys, np.ones_like(keys))                                 # -> a merge
+        dc.finish()
+        assert dc.as_dict() == {int(k): 1 for k in keys.tolist()}
+        dc.reset()
+        dc.reset()                                                               # twice in a row stays empty
+        dc.push(flat(big)[0]); dc.finish()
+        assert dc.as_dict() == want_big
+
+
 def test_table_growth_from_tiny_capacity(K, path):
     """No capacity hint: the table starts small and must grow (rehash) without losing counts."""
     bases, _ = O.synth_reads(SEED, 1 << 22, 150, 0, 60_000, with_qual=False)
