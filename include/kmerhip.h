@@ -182,6 +182,17 @@ int kh_merge_regions_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sender_regi
                             const uint64_t *const *d_keys, const uint64_t *const *d_counts,
                             const uint32_t *const *d_region_counts);
 
+/* Packed form of the same two calls -- half the bytes on the links: ONE uint64 per pair,
+ * count << 32 | the 32 bits of the table hash below the region index (the receiver knows every
+ * segment's region, and the hash is a bijection, so the key comes back exactly).  Representable iff
+ * 2k - log2(table_regions) <= 32 and every count < 2^32; otherwise the export returns KH_ERR_RANGE
+ * and the caller uses the unpacked pair of calls (all ranks must take the same route). */
+int kh_export_regions_packed_device(kh_ctx *ctx, uint32_t nparts, uint64_t *d_pairs, uint64_t cap,
+                                    uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
+                                    uint64_t *table_regions);
+int kh_merge_regions_packed_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sender_regions,
+                                   const uint64_t *const *d_pairs, const uint32_t *const *d_region_counts);
+
 /* Generic path (any number of shards, tables of any size): pairs grouped by owner, then
  * kh_merge_pairs_device re-inserts them with device atomics. */
 /* kh_export_by_owner_device: compact all live (key,count) pairs grouped by owner shard into device arrays

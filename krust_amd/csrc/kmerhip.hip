@@ -1485,12 +1485,15 @@ extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
     return KH_OK;
 }
 
-extern "C" int kh_export_regions_device(kh_ctx *c, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
-                                        uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
-                                        uint64_t *table_regions) {
+namespace {
+// packed: one u64 per pair into d_keys (d_counts unused), see region_compact_packed_kernel
+int export_regions(kh_ctx *c, bool packed, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
+                   uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions) {
     int rc = enter(c);
     if (rc != KH_OK) return rc;
     const u64 nregions = c->cap / kh::REGION_SLOTS;
+    if (packed && 2 * (int)c->k - (int)region_bits(c->cap) > 32)
+        return fail(c, KH_ERR_RANGE, "packed export needs 2k - log2(table regions) <= 32");
     if (table_regions) *table_regions = nregions;
     if (nparts < 1 || nparts > (uint32_t)kh::MAX_SENDERS || (nparts & (nparts - 1)) || nparts > nregions || !part_counts ||
         !d_region_counts)
@@ -1517,22 +1520,46 @@ extern "C" int kh_export_regions_device(kh_ctx *c, uint32_t nparts, uint64_t *d_
     for (uint32_t p = 0; p < nparts; ++p) part_counts[p] = bounds[p + 1] - bounds[p];
     const u64 total = bounds[nparts];
     if (total > cap) return fail(c, KH_ERR_RANGE, "export arrays too small");
-    if (total) {
-        if (!d_keys || !d_counts) return fail(c, KH_ERR_BAD_ARG, "NULL output");
+    if (total && (!d_keys || (!packed && !d_counts))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
+    if (total && !packed) {
         hipLaunchKernelGGL(kh::region_compact_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
                            (const Slot *)c->table, (const u64 *)c->merge_off, (u64 *)d_keys, (u64 *)d_counts);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if (total) {
+        rc = zero_cursors(c);
+        if (rc != KH_OK) return rc;
+        hipLaunchKernelGGL(kh::region_compact_packed_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                           (const Slot *)c->table, (const u64 *)c->merge_off, region_bits(c->cap), c->k, (u64 *)d_keys,
+                           &c->d_ctr->big);
+        HIP_TRY(c, hipGetLastError());
+        u64 wide = 0;
+        rc = read_cursor(c, nullptr, &wide);
+        if (rc != KH_OK) return rc;
+        if (wide) return fail(c, KH_ERR_RANGE, "a count does not fit the packed export (>= 2^32)");
     }
     return KH_OK;
 }
+}  // namespace
 
-extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
-                                       const uint64_t *const *d_keys, const uint64_t *const *d_counts,
-                                       const uint32_t *const *d_region_counts) {
+extern "C" int kh_export_regions_device(kh_ctx *c, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
+                                        uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
+                                        uint64_t *table_regions) {
+    return export_regions(c, false, nparts, d_keys, d_counts, cap, d_region_counts, region_cap, part_counts, table_regions);
+}
+
+extern "C" int kh_export_regions_packed_device(kh_ctx *c, uint32_t nparts, uint64_t *d_pairs, uint64_t cap,
+                                               uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
+                                               uint64_t *table_regions) {
+    return export_regions(c, true, nparts, d_pairs, nullptr, cap, d_region_counts, region_cap, part_counts, table_regions);
+}
+
+namespace {
+int merge_regions(kh_ctx *c, bool packed, uint32_t nsenders, uint64_t sender_regions, const uint64_t *const *d_keys,
+                  const uint64_t *const *d_counts, const uint32_t *const *d_region_counts) {
     int rc = enter(c, true, false);  // a FRESH merge rewrites every region of a lazily reset table
     if (rc != KH_OK) return rc;
-    if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || !d_counts || !d_region_counts)
+    if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || (!packed && !d_counts) || !d_region_counts)
         return fail(c, KH_ERR_BAD_ARG, "bad nsenders / NULL argument");
     if (sender_regions == 0 || (sender_regions & (sender_regions - 1)) || (sender_regions >> c->shard_shift) == 0)
         return fail(c, KH_ERR_BAD_ARG, "sender_regions must be a power of two >= the shard count");
@@ -1593,17 +1620,27 @@ extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t se
     a.dshift = (int32_t)tg.rbits - (int32_t)nr_bits;  // target t <-> sender-local region t >> dshift
     for (uint32_t s = 0; s < nsenders; ++s) {
         a.src[s].keys = (const u64 *)d_keys[s];
-        a.src[s].counts = (const u64 *)d_counts[s];
+        a.src[s].counts = packed ? nullptr : (const u64 *)d_counts[s];
         a.src[s].off = c->merge_off + (u64)s * (nr + 1);
     }
+    uint32_t sr_bits = 0;
+    while ((1ull << sr_bits) < sender_regions) ++sr_bits;
+    a.src_rbits = sr_bits;
+    a.src_region0 = (u64)c->shard_index * nr;
+    if (packed && 2 * (int)c->k - (int)sr_bits > 32) return fail(c, KH_ERR_BAD_ARG, "packed pairs need 2k - log2(sender_regions) <= 32");
     {
         StageTimer t(c, ST_REGION);
-        if (c->table_empty)
-            hipLaunchKernelGGL((kh::shard_merge_kernel<true, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, tg, a,
-                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr, (uint32_t)c->table_dirty);
+        const dim3 mg((unsigned)nregions), mb(1024);
+        const uint8_t *none = nullptr;
+        const uint32_t dirty = (uint32_t)c->table_dirty;
+        if (c->table_empty && packed)
+            hipLaunchKernelGGL((kh::shard_merge_kernel<true, false, true>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, dirty);
+        else if (c->table_empty)
+            hipLaunchKernelGGL((kh::shard_merge_kernel<true, false, false>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, dirty);
+        else if (packed)
+            hipLaunchKernelGGL((kh::shard_merge_kernel<false, false, true>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, 0u);
         else
-            hipLaunchKernelGGL((kh::shard_merge_kernel<false, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, tg, a,
-                               c->rfail, c->rnew, (const uint8_t *)nullptr, 0u, c->d_ctr, 0u);
+            hipLaunchKernelGGL((kh::shard_merge_kernel<false, false, false>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, 0u);
         hipLaunchKernelGGL(kh::shard_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
                            (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)nregions, c->d_ctr);
     }
@@ -1617,14 +1654,30 @@ extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t se
         StageTimer t(c, ST_GROW);
         rc = grow_to(c, c->cap * 2);
         if (rc != KH_OK) return rc;
-        hipLaunchKernelGGL((kh::shard_merge_kernel<false, true>), dim3((unsigned)nregions), dim3(1024), 0, c->stream,
-                           table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u);
+        if (packed)
+            hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, true>), dim3((unsigned)nregions), dim3(1024), 0, c->stream,
+                               table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u);
+        else
+            hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream,
+                               table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u);
         HIP_TRY(c, hipMemsetAsync(&c->d_ctr->part_failed, 0, sizeof(u64), c->stream));
         HIP_TRY(c, hipGetLastError());
         rc = sync_counters(c);
         if (rc != KH_OK) return rc;
     }
     return KH_OK;
+}
+}  // namespace
+
+extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
+                                       const uint64_t *const *d_keys, const uint64_t *const *d_counts,
+                                       const uint32_t *const *d_region_counts) {
+    return merge_regions(c, false, nsenders, sender_regions, d_keys, d_counts, d_region_counts);
+}
+
+extern "C" int kh_merge_regions_packed_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
+                                              const uint64_t *const *d_pairs, const uint32_t *const *d_region_counts) {
+    return merge_regions(c, true, nsenders, sender_regions, d_pairs, nullptr, d_region_counts);
 }
 
 // =============================================================================================

@@ -52,6 +52,38 @@ __global__ __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__res
     }
 }
 
+// Packed form of the same export: ONE u64 per pair = count << 32 | bits [rbits, rbits + 32) of the
+// table hash.  The receiver knows the region index of every segment, so these 32 bits identify the
+// key whenever 2k - rbits <= 32 (the hash is a bijection); halves the bytes on the xGMI links.
+// *wide is raised if a count does not fit 32 bits (the caller then uses the unpacked export).
+__global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(const Slot *__restrict__ table, const u64 *__restrict__ roff,
+                                                                      uint32_t rbits, uint32_t k, u64 *__restrict__ pairs,
+                                                                      u64 *__restrict__ wide) {
+    __shared__ uint32_t s_cur;
+    const u64 r = blockIdx.x;
+    const u64 base = roff[r];
+    if (roff[r + 1] == base) return;
+    if (threadIdx.x == 0) s_cur = 0;
+    __syncthreads();
+    const Slot *reg = table + r * REGION_SLOTS;
+    bool too_wide = false;
+    for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {
+        const Slot s = reg[i];
+        const bool live = s.key != KH_EMPTY_KEY;
+        const u64 m = __ballot(live);
+        if (m == 0) continue;
+        uint32_t wbase = 0;
+        if ((int)lane_id() == __builtin_ctzll(m)) wbase = atomicAdd(&s_cur, (uint32_t)__builtin_popcountll(m));
+        wbase = (uint32_t)__shfl((int)wbase, __builtin_ctzll(m), 64);
+        if (live) {
+            const u64 H = kh_table_hash(s.key, k);
+            too_wide |= (s.count >> 32) != 0;
+            pairs[base + wbase + mbcnt(m)] = (s.count << 32) | (uint32_t)((H << rbits) >> 32);
+        }
+    }
+    if (__any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
+}
+
 // ---- receiver side -----------------------------------------------------------------------------
 constexpr int MAX_SENDERS = 64;
 struct MergeSrc {
@@ -60,16 +92,18 @@ struct MergeSrc {
     const u64 *off;     // exclusive scan of the sender's per-region counts over this shard's region range (nr + 1)
 };
 struct MergeArgs {
-    MergeSrc src[MAX_SENDERS];
+    MergeSrc src[MAX_SENDERS];   // PACKED: keys = the packed pairs, counts unused
     uint32_t nsenders;
     int32_t dshift;  // target region t reads sender-local region t >> dshift (dshift >= 0), or the
                      // 2^-dshift sender-local regions starting at t << -dshift (dshift < 0)
+    uint32_t src_rbits;   // PACKED: region bits of the senders' tables
+    u64 src_region0;      // PACKED: the senders' region index of this shard's first region
 };
 
 // One workgroup per target region of the (sharded) receiver table.  FRESH: the table is empty.
 // DIRECT: instead of rebuilding the region in LDS, upsert straight into HBM with device atomics --
 // used only for the regions a first pass flagged as overflowing, after the table was grown.
-template <bool FRESH, bool DIRECT>
+template <bool FRESH, bool DIRECT, bool PACKED>
 __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, MergeArgs a, uint8_t *__restrict__ rfail,
                                                               uint32_t *__restrict__ rnew, const uint8_t *__restrict__ only_failed,
                                                               uint32_t old_rbits, Counters *ctr, uint32_t dirty) {
@@ -103,14 +137,26 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     uint32_t nd = 0, nf = 0;
     const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
     const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
-    for (uint32_t s = 0; s < a.nsenders; ++s) {
+    for (uint32_t s = 0; s < a.nsenders; ++s)
+    for (u64 rl = rl0; rl < rl0 + (PACKED ? nrl : 1); ++rl) {  // PACKED: segment by segment (the region index is part of the key)
         const MergeSrc src = a.src[s];
-        const u64 lo = src.off[rl0], hi = src.off[rl0 + nrl];
+        const u64 lo = src.off[rl], hi = src.off[PACKED ? rl + 1 : rl0 + nrl];
+        const u64 Hregion = (PACKED && a.src_rbits) ? (a.src_region0 + rl) << (64 - a.src_rbits) : 0;
         for (u64 i = lo + tid; i < hi; i += 1024) {
-            const u64 key = src.keys[i];
-            const u64 H = table_hash(tg, key);
-            if ((H >> (64 - match_bits)) != t) continue;  // the segment also feeds the sibling targets
-            const u64 addend = src.counts[i];
+            u64 key, H, addend;
+            if (PACKED) {
+                const u64 p = src.keys[i];
+                const u64 Hs = Hregion | ((u64)(uint32_t)p << (32 - a.src_rbits));  // the sender's (unsharded) table hash
+                H = Hs << tg.shard_shift;
+                if ((H >> (64 - match_bits)) != t) continue;  // the segment also feeds the sibling targets
+                key = kh_table_unhash(Hs, tg.k);
+                addend = p >> 32;
+            } else {
+                key = src.keys[i];
+                H = table_hash(tg, key);
+                if ((H >> (64 - match_bits)) != t) continue;
+                addend = src.counts[i];
+            }
             if (DIRECT) {
                 upsert(tg, key, addend, nd, nf);
                 continue;

@@ -63,24 +63,46 @@ def exchange_pairs(keys, counts, part_counts, group=None, return_sizes=False):
     return rk, rc
 
 
-def _same_everywhere(value, group=None):
-    """True iff every rank holds the same integer."""
+def _gather_ints(values, group=None):
+    """all_gather of a short list of integers: returns a [world][len(values)] list."""
     world = dist.get_world_size(group)
     dev = torch.device("cpu") if _host_staged(group) else torch.device("cuda", torch.cuda.current_device())
-    mine = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)
     allv = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allv, mine, group=group)
-    return all(int(v.item()) == int(value) for v in allv)
+    return [[int(x) for x in v.tolist()] for v in allv]
 
 
-def merge_across_ranks(counter, group=None):
+def _same_everywhere(value, group=None):
+    """True iff every rank holds the same integer."""
+    return all(v[0] == int(value) for v in _gather_ints([value], group))
+
+
+def exchange_segments(buf, part_counts, group=None):
+    """All-to-all of ONE owner-grouped int64 buffer.  Returns (received, per-sender sizes)."""
+    world = dist.get_world_size(group)
+    send_sizes = [int(x) for x in part_counts]
+    assert len(send_sizes) == world and sum(send_sizes) == buf.numel()
+    dev = buf.device
+    ssz = torch.tensor(send_sizes, dtype=torch.int64, device=dev)
+    rsz = torch.empty(world, dtype=torch.int64, device=dev)
+    _all_to_all(rsz, ssz, group=group)
+    recv_sizes = [int(x) for x in rsz.tolist()]
+    out = torch.empty(sum(recv_sizes), dtype=torch.int64, device=dev)
+    _all_to_all(out, buf, recv_sizes, send_sizes, group=group)
+    return out, recv_sizes
+
+
+def merge_across_ranks(counter, group=None, packed=True):
     """Turns per-rank tables (each built from that rank's read shard) into a key-sharded global
     table: afterwards `counter` on rank r holds exactly the keys with kh_owner(key, k, world) == r,
     with counts summed over all ranks.  Returns a dict of sizes for reporting.
 
     Power-of-two world and equal table sizes: the region-ordered fast path (export in region order,
     one all-to-all of pairs + one of region counts, LDS rebuild of the shard: no scatter kernel, no
-    global atomics).  Otherwise: pairs grouped by owner and re-inserted with device atomics."""
+    global atomics).  Pairs travel PACKED -- one 64-bit word: count << 32 | 32 hash bits -- whenever
+    every rank's table allows it (k small enough for its size, counts < 2^32): half the bytes on
+    the xGMI links.  Otherwise: pairs grouped by owner and re-inserted with device atomics."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     st = counter.finish()
@@ -88,33 +110,52 @@ def merge_across_ranks(counter, group=None):
     nreg = int(st["table_slots"]) // 4096
     dev = torch.device("cuda", torch.cuda.current_device())
     keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
-    cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
     pow2 = world & (world - 1) == 0
-    if pow2 and world <= 64 and nreg >= world and _same_everywhere(nreg, group):
-        rcnt = torch.empty(nreg, dtype=torch.int32, device=dev)
-        parts, nreg2 = counter.export_regions_device(world, keys.data_ptr(), cnts.data_ptr(), n_local, rcnt.data_ptr(), nreg)
-        assert nreg2 == nreg
-        rk, rc, recv_sizes = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group, return_sizes=True)
+    regions_ok = pow2 and world <= 64 and nreg >= world
+    rcnt = torch.empty(nreg, dtype=torch.int32, device=dev) if regions_ok else None
+    exported = None
+    if regions_ok and packed:  # speculative: the export itself finds out whether the counts fit
+        exported = counter.export_regions_packed_device(world, keys.data_ptr(), n_local, rcnt.data_ptr(), nreg)
+    votes = _gather_ints([nreg, 1 if exported is not None else 0], group)
+    same_size = all(v[0] == nreg for v in votes)
+    use_packed = regions_ok and same_size and all(v[1] == 1 for v in votes)
+    per = nreg // world if regions_ok else 0
+    if use_packed:
+        parts, _ = exported
+        rp, recv_sizes = exchange_segments(keys[:n_local], parts.tolist(), group=group)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices of nreg / world region counts
         _all_to_all(rrc, rcnt, group=group)
         counter.reset()
         counter.set_shard(rank, world)
         offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-        per = nreg // world
+        counter.merge_regions_packed_device(nreg, [rp.data_ptr() + 8 * int(offs[s]) for s in range(world)],
+                                            [rrc.data_ptr() + 4 * per * s for s in range(world)])
+        path, n_recv = "regions-packed", rp.numel()
+    elif regions_ok and same_size:
+        cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
+        parts, nreg2 = counter.export_regions_device(world, keys.data_ptr(), cnts.data_ptr(), n_local, rcnt.data_ptr(), nreg)
+        assert nreg2 == nreg
+        rk, rc, recv_sizes = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group, return_sizes=True)
+        rrc = torch.empty(nreg, dtype=torch.int32, device=dev)
+        _all_to_all(rrc, rcnt, group=group)
+        counter.reset()
+        counter.set_shard(rank, world)
+        offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
         counter.merge_regions_device(nreg,
                                      [rk.data_ptr() + 8 * int(offs[s]) for s in range(world)],
                                      [rc.data_ptr() + 8 * int(offs[s]) for s in range(world)],
                                      [rrc.data_ptr() + 4 * per * s for s in range(world)])
-        path = "regions"
+        path, n_recv = "regions", rk.numel()
     else:
+        cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
         parts = counter.export_by_owner_device(world, keys.data_ptr(), cnts.data_ptr(), n_local)
         rk, rc = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group)
         counter.reset()
         counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
-        path = "pairs"
+        path, n_recv = "pairs", rk.numel()
     st2 = counter.finish()
     return {"path": path, "local_distinct": n_local, "sent_pairs": int(n_local - parts[rank]),
-            "recv_pairs": int(rk.numel()), "owned_distinct": int(st2["distinct"])}
+            "recv_pairs": int(n_recv), "owned_distinct": int(st2["distinct"])}
 
 
 def group_pairs_by_owner(keys, counts, world, owner_fn):

@@ -63,6 +63,8 @@ SYMBOLS = {
     "kh_set_shard": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "kh_export_regions_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
     "kh_merge_regions_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P, _P]),
+    "kh_export_regions_packed_device": (C.c_int, [_P, C.c_uint32, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
+    "kh_merge_regions_packed_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P]),
     "kh_export_by_owner_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P]),
     "kh_merge_pairs_device": (C.c_int, [_P, _P, _P, _U64]),
     "kh_merge_pairs": (C.c_int, [_P, _P, _P, _U64]),
@@ -283,6 +285,25 @@ class DeviceCounter:
         arr = lambda xs: (_P * n)(*[_P(int(x)) for x in xs])
         ak, ac, ar = arr(d_keys), arr(d_counts), arr(d_region_counts)
         self._check(lib().kh_merge_regions_device(self._h, n, int(sender_regions), ak, ac, ar))
+
+    def export_regions_packed_device(self, nparts, d_pairs, cap, d_region_counts, region_cap):
+        """Packed export (one u64 per pair).  Returns (parts, regions), or None when the table is not
+        representable in the packed form (large k for the table size, or a count >= 2^32)."""
+        parts = np.zeros(nparts, dtype=np.uint64)
+        nreg = _U64(0)
+        rc = lib().kh_export_regions_packed_device(self._h, int(nparts), d_pairs, int(cap), d_region_counts,
+                                                   int(region_cap), parts.ctypes.data, C.byref(nreg))
+        if rc == KH_ERR_RANGE:
+            return None
+        self._check(rc)
+        return parts, int(nreg.value)
+
+    def merge_regions_packed_device(self, sender_regions, d_pairs, d_region_counts):
+        n = len(d_pairs)
+        assert len(d_region_counts) == n
+        arr = lambda xs: (_P * n)(*[_P(int(x)) for x in xs])
+        ap, ar = arr(d_pairs), arr(d_region_counts)
+        self._check(lib().kh_merge_regions_packed_device(self._h, n, int(sender_regions), ap, ar))
 
     def merge_pairs_device(self, d_keys, d_counts, n):
         self._check(lib().kh_merge_pairs_device(self._h, d_keys, d_counts, int(n)))

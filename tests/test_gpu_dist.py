@@ -22,13 +22,14 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 bases, _ = O.synth_reads(20260130, 1 << 18, 150, 0, 30000, with_qual=False)
 m = O.OracleMap(); m.scan_flat(bases, 21, nthreads=4)
-with krust_amd.DeviceCounter(21) as dc:
+with krust_amd.DeviceCounter(21, capacity_hint=3_000_000) as dc:  # 2^11 regions: 2k - 11 <= 32, the packed exchange applies
     dc.push(bases)
     info = merge_across_ranks(dc)
     keys, cnts = dc.result()
 ok, oc = m.arrays()
 assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
 assert info["sent_pairs"] == 0 and info["recv_pairs"] == len(m) == info["owned_distinct"]
+assert info["path"] == "regions-packed", info
 print("NCCL_OK", len(m))
 dist.destroy_process_group()
 '''
@@ -88,7 +89,7 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,path,expect", [(2, "partition", "regions"), (4, None, "regions"), (3, None, "pairs")])
+@pytest.mark.parametrize("world,path,expect", [(2, "partition", "regions-packed"), (4, None, "regions-packed"), (3, None, "pairs")])
 def test_ranks_sharing_one_gpu_merge_real_tables(world, path, expect, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\nPATH = {path!r}\nEXPECT_PATH = {expect!r}\n" + MULTI)

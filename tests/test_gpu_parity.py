@@ -397,8 +397,11 @@ def test_owner_partitioned_merge_logical_shards(K, nshards):
     assert merged == want
 
 
-@pytest.mark.parametrize("nshards,k,minq", [(2, 21, None), (4, 21, None), (8, 21, None), (4, 31, 20), (8, 9, None)])
-def test_region_ordered_merge_logical_shards(K, nshards, k, minq):
+@pytest.mark.parametrize("packed", [False, True], ids=["wide", "packed"])
+@pytest.mark.parametrize("nshards,k,minq,recv_hint", [(2, 21, None, 3_000_000), (4, 21, None, 3_000_000), (8, 21, None, 3_000_000),
+                                                      (4, 31, 20, 3_000_000), (8, 9, None, 3_000_000),
+                                                      (4, 21, None, 40_000_000), (4, 21, None, 20_000)])
+def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, packed):
     """The power-of-two fast path of the multi-GPU merge, as logical shards on one device:
     region-ordered export from every 'rank', then each owner rebuilds its hash-range shard in LDS
     from the senders' region segments.  Union of the shards == single-table result."""
@@ -420,7 +423,14 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq):
             dk = torch.empty(max(st["distinct"], 1), dtype=torch.int64, device="cuda")
             dcnt = torch.empty(max(st["distinct"], 1), dtype=torch.int64, device="cuda")
             rc = torch.empty(R, dtype=torch.int32, device="cuda")
-            parts, R2 = dc.export_regions_device(nshards, dk.data_ptr(), dcnt.data_ptr(), st["distinct"], rc.data_ptr(), R)
+            if packed:  # one u64 per pair: count << 32 | 32 hash bits below the region index
+                res = dc.export_regions_packed_device(nshards, dk.data_ptr(), st["distinct"], rc.data_ptr(), R)
+                if 2 * k - (R.bit_length() - 1) > 32:
+                    assert res is None  # not representable: the caller takes the wide route
+                    pytest.skip("packed form not representable for this k / table size")
+                parts, R2 = res
+            else:
+                parts, R2 = dc.export_regions_device(nshards, dk.data_ptr(), dcnt.data_ptr(), st["distinct"], rc.data_ptr(), R)
             assert R2 == R and int(parts.sum()) == st["distinct"] and int(rc.sum().item()) == st["distinct"]
             nreg = R if nreg is None else nreg
             assert R == nreg
@@ -429,12 +439,16 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq):
     merged = {}
     per_r = nreg // nshards
     for o in range(nshards):
-        with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+        with K.DeviceCounter(k, capacity_hint=recv_hint) as dc:  # receiver tables larger / smaller than the senders' too
             dc.set_shard(o, nshards)
-            dc.merge_regions_device(nreg,
-                                    [e[0].data_ptr() + 8 * int(e[3][o]) for e in exports],
-                                    [e[1].data_ptr() + 8 * int(e[3][o]) for e in exports],
-                                    [e[2].data_ptr() + 4 * per_r * o for e in exports])
+            if packed:
+                dc.merge_regions_packed_device(nreg, [e[0].data_ptr() + 8 * int(e[3][o]) for e in exports],
+                                               [e[2].data_ptr() + 4 * per_r * o for e in exports])
+            else:
+                dc.merge_regions_device(nreg,
+                                        [e[0].data_ptr() + 8 * int(e[3][o]) for e in exports],
+                                        [e[1].data_ptr() + 8 * int(e[3][o]) for e in exports],
+                                        [e[2].data_ptr() + 4 * per_r * o for e in exports])
             st = dc.finish()
             d = dc.as_dict()
             assert st["distinct"] == len(d)
