@@ -192,6 +192,16 @@ int kh_export_regions_packed_device(kh_ctx *ctx, uint32_t nparts, uint64_t *d_pa
                                     uint64_t *table_regions);
 int kh_merge_regions_packed_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sender_regions,
                                    const uint64_t *const *d_pairs, const uint32_t *const *d_region_counts);
+/* Narrowest form -- a quarter of the bytes: 32-bit "heads" = [2k - log2(table_regions) hash bits |
+ * addend - 1 in the remaining cb bits].  A pair whose count exceeds 2^cb travels as several heads of
+ * the same key (the receiver adds them up); part_counts / region counts are in heads.  Applies iff
+ * 1 <= 2k - log2(table_regions) <= 28 and no count exceeds 64 * 2^cb, else KH_ERR_RANGE.  `cap` is
+ * in heads (allow ~2x the distinct count). */
+int kh_export_regions_heads_device(kh_ctx *ctx, uint32_t nparts, uint32_t *d_heads, uint64_t cap,
+                                   uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
+                                   uint64_t *table_regions);
+int kh_merge_regions_heads_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sender_regions,
+                                  const uint32_t *const *d_heads, const uint32_t *const *d_region_counts);
 
 /* Generic path (any number of shards, tables of any size): pairs grouped by owner, then
  * kh_merge_pairs_device re-inserts them with device atomics. */

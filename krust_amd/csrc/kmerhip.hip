@@ -1486,14 +1486,27 @@ extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
 }
 
 namespace {
-// packed: one u64 per pair into d_keys (d_counts unused), see region_compact_packed_kernel
-int export_regions(kh_ctx *c, bool packed, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
+enum { XF_WIDE = 0, XF_PACKED64 = 1, XF_HEADS32 = 2 };  // exchange unit formats (shard.hip.h)
+
+// count bits of a 32-bit head for this table, or -1 if the format does not apply
+int head_count_bits(const kh_ctx *c, u64 regions) {
+    uint32_t rb = 0;
+    while ((1ull << rb) < regions) ++rb;
+    const int hb = 2 * (int)c->k - (int)rb;
+    return (hb >= 1 && hb <= 28) ? 32 - hb : -1;  // at least 4 count bits
+}
+
+// fmt XF_PACKED64: one u64 per pair into d_keys (d_counts unused); XF_HEADS32: u32 heads into d_keys
+int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap,
                    uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions) {
     int rc = enter(c);
     if (rc != KH_OK) return rc;
+    const bool packed = fmt != XF_WIDE;
     const u64 nregions = c->cap / kh::REGION_SLOTS;
-    if (packed && 2 * (int)c->k - (int)region_bits(c->cap) > 32)
+    if (fmt == XF_PACKED64 && 2 * (int)c->k - (int)region_bits(c->cap) > 32)
         return fail(c, KH_ERR_RANGE, "packed export needs 2k - log2(table regions) <= 32");
+    const int cb = fmt == XF_HEADS32 ? head_count_bits(c, nregions) : 0;
+    if (cb < 0) return fail(c, KH_ERR_RANGE, "32-bit heads need 1 <= 2k - log2(table regions) <= 28");
     if (table_regions) *table_regions = nregions;
     if (nparts < 1 || nparts > (uint32_t)kh::MAX_SENDERS || (nparts & (nparts - 1)) || nparts > nregions || !part_counts ||
         !d_region_counts)
@@ -1502,8 +1515,15 @@ int export_regions(kh_ctx *c, bool packed, uint32_t nparts, uint64_t *d_keys, ui
     if (region_cap < nregions) return fail(c, KH_ERR_RANGE, "region count array too small");
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
-    hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                       (const Slot *)c->table, d_region_counts);
+    if (fmt == XF_HEADS32) {
+        rc = zero_cursors(c);
+        if (rc != KH_OK) return rc;
+        hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                           (const Slot *)c->table, (uint32_t)cb, d_region_counts, &c->d_ctr->big);
+    } else {
+        hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                           (const Slot *)c->table, d_region_counts);
+    }
     HIP_TRY(c, hipGetLastError());
     // offsets of every region in the export (device scan), and the per-owner totals (host)
     u64 z = c->merge_off_cap;
@@ -1516,12 +1536,24 @@ int export_regions(kh_ctx *c, bool packed, uint32_t nparts, uint64_t *d_keys, ui
     const u64 per = nregions / nparts;
     for (uint32_t p = 0; p <= nparts; ++p)
         HIP_TRY(c, hipMemcpyAsync(&bounds[p], c->merge_off + (u64)p * per, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (fmt == XF_HEADS32) {
+        u64 wide = 0;
+        rc = read_cursor(c, nullptr, &wide);
+        if (rc != KH_OK) return rc;
+        if (wide) return fail(c, KH_ERR_RANGE, "a count is too large for 32-bit heads");
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (uint32_t p = 0; p < nparts; ++p) part_counts[p] = bounds[p + 1] - bounds[p];
     const u64 total = bounds[nparts];
     if (total > cap) return fail(c, KH_ERR_RANGE, "export arrays too small");
     if (total && (!d_keys || (!packed && !d_counts))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
-    if (total && !packed) {
+    if (total && fmt == XF_HEADS32) {
+        hipLaunchKernelGGL(kh::region_compact_heads_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                           (const Slot *)c->table, (const u64 *)c->merge_off, region_bits(c->cap), c->k, (uint32_t)cb,
+                           (uint32_t *)d_keys);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if (total && !packed) {
         hipLaunchKernelGGL(kh::region_compact_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
                            (const Slot *)c->table, (const u64 *)c->merge_off, (u64 *)d_keys, (u64 *)d_counts);
         HIP_TRY(c, hipGetLastError());
@@ -1545,20 +1577,27 @@ int export_regions(kh_ctx *c, bool packed, uint32_t nparts, uint64_t *d_keys, ui
 extern "C" int kh_export_regions_device(kh_ctx *c, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
                                         uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
                                         uint64_t *table_regions) {
-    return export_regions(c, false, nparts, d_keys, d_counts, cap, d_region_counts, region_cap, part_counts, table_regions);
+    return export_regions(c, XF_WIDE, nparts, d_keys, d_counts, cap, d_region_counts, region_cap, part_counts, table_regions);
 }
 
 extern "C" int kh_export_regions_packed_device(kh_ctx *c, uint32_t nparts, uint64_t *d_pairs, uint64_t cap,
                                                uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
                                                uint64_t *table_regions) {
-    return export_regions(c, true, nparts, d_pairs, nullptr, cap, d_region_counts, region_cap, part_counts, table_regions);
+    return export_regions(c, XF_PACKED64, nparts, d_pairs, nullptr, cap, d_region_counts, region_cap, part_counts, table_regions);
+}
+
+extern "C" int kh_export_regions_heads_device(kh_ctx *c, uint32_t nparts, uint32_t *d_heads, uint64_t cap,
+                                              uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
+                                              uint64_t *table_regions) {
+    return export_regions(c, XF_HEADS32, nparts, d_heads, nullptr, cap, d_region_counts, region_cap, part_counts, table_regions);
 }
 
 namespace {
-int merge_regions(kh_ctx *c, bool packed, uint32_t nsenders, uint64_t sender_regions, const uint64_t *const *d_keys,
+int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions, const void *const *d_keys,
                   const uint64_t *const *d_counts, const uint32_t *const *d_region_counts) {
     int rc = enter(c, true, false);  // a FRESH merge rewrites every region of a lazily reset table
     if (rc != KH_OK) return rc;
+    const bool packed = fmt != XF_WIDE;
     if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || (!packed && !d_counts) || !d_region_counts)
         return fail(c, KH_ERR_BAD_ARG, "bad nsenders / NULL argument");
     if (sender_regions == 0 || (sender_regions & (sender_regions - 1)) || (sender_regions >> c->shard_shift) == 0)
@@ -1627,20 +1666,30 @@ int merge_regions(kh_ctx *c, bool packed, uint32_t nsenders, uint64_t sender_reg
     while ((1ull << sr_bits) < sender_regions) ++sr_bits;
     a.src_rbits = sr_bits;
     a.src_region0 = (u64)c->shard_index * nr;
-    if (packed && 2 * (int)c->k - (int)sr_bits > 32) return fail(c, KH_ERR_BAD_ARG, "packed pairs need 2k - log2(sender_regions) <= 32");
+    if (fmt == XF_PACKED64 && 2 * (int)c->k - (int)sr_bits > 32) return fail(c, KH_ERR_BAD_ARG, "packed pairs need 2k - log2(sender_regions) <= 32");
+    if (fmt == XF_HEADS32) {
+        const int cb = head_count_bits(c, sender_regions);
+        if (cb < 0) return fail(c, KH_ERR_BAD_ARG, "32-bit heads need 1 <= 2k - log2(sender_regions) <= 28");
+        a.head_cmask = (1u << cb) - 1u;
+    }
     {
         StageTimer t(c, ST_REGION);
         const dim3 mg((unsigned)nregions), mb(1024);
         const uint8_t *none = nullptr;
         const uint32_t dirty = (uint32_t)c->table_dirty;
-        if (c->table_empty && packed)
-            hipLaunchKernelGGL((kh::shard_merge_kernel<true, false, true>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, dirty);
-        else if (c->table_empty)
-            hipLaunchKernelGGL((kh::shard_merge_kernel<true, false, false>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, dirty);
-        else if (packed)
-            hipLaunchKernelGGL((kh::shard_merge_kernel<false, false, true>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, 0u);
-        else
-            hipLaunchKernelGGL((kh::shard_merge_kernel<false, false, false>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, 0u);
+#define KH_MERGE_LAUNCH(FRESH, FMT) \
+    hipLaunchKernelGGL((kh::shard_merge_kernel<FRESH, false, FMT>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, \
+                       FRESH ? dirty : 0u)
+        if (c->table_empty) {
+            if (fmt == XF_WIDE) KH_MERGE_LAUNCH(true, 0);
+            else if (fmt == XF_PACKED64) KH_MERGE_LAUNCH(true, 1);
+            else KH_MERGE_LAUNCH(true, 2);
+        } else {
+            if (fmt == XF_WIDE) KH_MERGE_LAUNCH(false, 0);
+            else if (fmt == XF_PACKED64) KH_MERGE_LAUNCH(false, 1);
+            else KH_MERGE_LAUNCH(false, 2);
+        }
+#undef KH_MERGE_LAUNCH
         hipLaunchKernelGGL(kh::shard_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
                            (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)nregions, c->d_ctr);
     }
@@ -1654,12 +1703,13 @@ int merge_regions(kh_ctx *c, bool packed, uint32_t nsenders, uint64_t sender_reg
         StageTimer t(c, ST_GROW);
         rc = grow_to(c, c->cap * 2);
         if (rc != KH_OK) return rc;
-        if (packed)
-            hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, true>), dim3((unsigned)nregions), dim3(1024), 0, c->stream,
-                               table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u);
-        else
-            hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, false>), dim3((unsigned)nregions), dim3(1024), 0, c->stream,
-                               table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u);
+#define KH_MERGE_DIRECT(FMT) \
+    hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, FMT>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, \
+                       table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u)
+        if (fmt == XF_WIDE) KH_MERGE_DIRECT(0);
+        else if (fmt == XF_PACKED64) KH_MERGE_DIRECT(1);
+        else KH_MERGE_DIRECT(2);
+#undef KH_MERGE_DIRECT
         HIP_TRY(c, hipMemsetAsync(&c->d_ctr->part_failed, 0, sizeof(u64), c->stream));
         HIP_TRY(c, hipGetLastError());
         rc = sync_counters(c);
@@ -1672,12 +1722,17 @@ int merge_regions(kh_ctx *c, bool packed, uint32_t nsenders, uint64_t sender_reg
 extern "C" int kh_merge_regions_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
                                        const uint64_t *const *d_keys, const uint64_t *const *d_counts,
                                        const uint32_t *const *d_region_counts) {
-    return merge_regions(c, false, nsenders, sender_regions, d_keys, d_counts, d_region_counts);
+    return merge_regions(c, XF_WIDE, nsenders, sender_regions, (const void *const *)d_keys, d_counts, d_region_counts);
 }
 
 extern "C" int kh_merge_regions_packed_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
                                               const uint64_t *const *d_pairs, const uint32_t *const *d_region_counts) {
-    return merge_regions(c, true, nsenders, sender_regions, d_pairs, nullptr, d_region_counts);
+    return merge_regions(c, XF_PACKED64, nsenders, sender_regions, (const void *const *)d_pairs, nullptr, d_region_counts);
+}
+
+extern "C" int kh_merge_regions_heads_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
+                                             const uint32_t *const *d_heads, const uint32_t *const *d_region_counts) {
+    return merge_regions(c, XF_HEADS32, nsenders, sender_regions, (const void *const *)d_heads, nullptr, d_region_counts);
 }
 
 // =============================================================================================

@@ -84,6 +84,78 @@ __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(const Slot
     if (__any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
 }
 
+// ---- 32-bit "heads" -------------------------------------------------------------------------------
+// The narrowest exchange unit: one u32 = [hb = 2k - rbits hash bits | cb = 32 - hb bits: addend - 1].
+// A pair whose count exceeds 2^cb travels as several heads of the same key -- the receiver simply
+// adds them up, so there is no escape mechanism -- and a table with a count above 64 x 2^cb is
+// declared not representable (*wide), which bounds the blow-up.  S100M (k = 21, 2^19 regions):
+// 23 hash bits + 9 count bits, 4 bytes per pair instead of 16.
+__device__ __forceinline__ uint32_t heads_of(u64 count, uint32_t cb) { return (uint32_t)((count + (1ull << cb) - 1) >> cb); }
+
+__global__ __launch_bounds__(BLOCK) void region_head_count_kernel(const Slot *__restrict__ table, uint32_t cb,
+                                                                  uint32_t *__restrict__ rcount, u64 *__restrict__ wide) {
+    __shared__ uint32_t s_n;
+    const u64 r = blockIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const Slot *reg = table + r * REGION_SLOTS;
+    uint32_t n = 0;
+    bool too_wide = false;
+    for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {
+        const Slot s = reg[i];
+        if (s.key == KH_EMPTY_KEY) continue;
+        too_wide |= s.count > (64ull << cb);
+        n += too_wide ? 1u : heads_of(s.count, cb);
+    }
+    n = (uint32_t)wave_sum((u64)n);
+    if (lane_id() == 0 && n) atomicAdd(&s_n, n);
+    if (__any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
+    __syncthreads();
+    if (threadIdx.x == 0) rcount[r] = s_n;
+}
+
+// Heads of region r go to [roff[r], roff[r+1]) (any order inside the region).
+__global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(const Slot *__restrict__ table, const u64 *__restrict__ roff,
+                                                                     uint32_t rbits, uint32_t k, uint32_t cb,
+                                                                     uint32_t *__restrict__ heads) {
+    __shared__ uint32_t s_cur;
+    const u64 r = blockIdx.x;
+    const u64 base = roff[r];
+    if (roff[r + 1] == base) return;
+    if (threadIdx.x == 0) s_cur = 0;
+    __syncthreads();
+    const Slot *reg = table + r * REGION_SLOTS;
+    const uint32_t cmask = (1u << cb) - 1u;
+    for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {  // uniform trip count
+        const Slot s = reg[i];
+        const bool live = s.key != KH_EMPTY_KEY;
+        const uint32_t nh = live ? heads_of(s.count, cb) : 0u;
+        // wave-inclusive prefix of nh
+        uint32_t incl = nh;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if ((int)lane_id() >= off) incl += v;
+        }
+        const uint32_t wtotal = (uint32_t)__shfl((int)incl, 63, 64);
+        if (wtotal == 0) continue;
+        uint32_t wbase = 0;
+        if (lane_id() == 63) wbase = atomicAdd(&s_cur, wtotal);
+        wbase = (uint32_t)__shfl((int)wbase, 63, 64);
+        if (live) {
+            const u64 H = kh_table_hash(s.key, k);
+            const uint32_t hw = (uint32_t)((H << rbits) >> 32) & ~cmask;  // the hb hash bits, top-aligned
+            u64 o = base + wbase + (incl - nh);
+            u64 left = s.count;
+            for (uint32_t h = 0; h < nh; ++h) {
+                const u64 take = left < (1ull << cb) ? left : (1ull << cb);
+                heads[o + h] = hw | (uint32_t)(take - 1);
+                left -= take;
+            }
+        }
+    }
+}
+
 // ---- receiver side -----------------------------------------------------------------------------
 constexpr int MAX_SENDERS = 64;
 struct MergeSrc {
@@ -96,14 +168,16 @@ struct MergeArgs {
     uint32_t nsenders;
     int32_t dshift;  // target region t reads sender-local region t >> dshift (dshift >= 0), or the
                      // 2^-dshift sender-local regions starting at t << -dshift (dshift < 0)
-    uint32_t src_rbits;   // PACKED: region bits of the senders' tables
-    u64 src_region0;      // PACKED: the senders' region index of this shard's first region
+    uint32_t src_rbits;   // packed formats: region bits of the senders' tables
+    uint32_t head_cmask;  // heads: (1 << cb) - 1
+    u64 src_region0;      // packed formats: the senders' region index of this shard's first region
 };
 
 // One workgroup per target region of the (sharded) receiver table.  FRESH: the table is empty.
 // DIRECT: instead of rebuilding the region in LDS, upsert straight into HBM with device atomics --
 // used only for the regions a first pass flagged as overflowing, after the table was grown.
-template <bool FRESH, bool DIRECT, bool PACKED>
+// FMT: 0 = {u64 key, u64 count} in two arrays, 1 = packed u64 (count << 32 | 32 hash bits), 2 = u32 heads
+template <bool FRESH, bool DIRECT, int FMT>
 __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, MergeArgs a, uint8_t *__restrict__ rfail,
                                                               uint32_t *__restrict__ rnew, const uint8_t *__restrict__ only_failed,
                                                               uint32_t old_rbits, Counters *ctr, uint32_t dirty) {
@@ -137,6 +211,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     uint32_t nd = 0, nf = 0;
     const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
     const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
+    constexpr bool PACKED = FMT != 0;
     for (uint32_t s = 0; s < a.nsenders; ++s)
     for (u64 rl = rl0; rl < rl0 + (PACKED ? nrl : 1); ++rl) {  // PACKED: segment by segment (the region index is part of the key)
         const MergeSrc src = a.src[s];
@@ -145,12 +220,20 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
         for (u64 i = lo + tid; i < hi; i += 1024) {
             u64 key, H, addend;
             if (PACKED) {
-                const u64 p = src.keys[i];
-                const u64 Hs = Hregion | ((u64)(uint32_t)p << (32 - a.src_rbits));  // the sender's (unsharded) table hash
+                uint32_t low;
+                if (FMT == 1) {
+                    const u64 p = src.keys[i];
+                    low = (uint32_t)p;
+                    addend = p >> 32;
+                } else {
+                    const uint32_t w = reinterpret_cast<const uint32_t *>(src.keys)[i];
+                    low = w & ~a.head_cmask;
+                    addend = (u64)(w & a.head_cmask) + 1;
+                }
+                const u64 Hs = Hregion | ((u64)low << (32 - a.src_rbits));  // the sender's (unsharded) table hash
                 H = Hs << tg.shard_shift;
                 if ((H >> (64 - match_bits)) != t) continue;  // the segment also feeds the sibling targets
                 key = kh_table_unhash(Hs, tg.k);
-                addend = p >> 32;
             } else {
                 key = src.keys[i];
                 H = table_hash(tg, key);

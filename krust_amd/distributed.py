@@ -79,7 +79,7 @@ def _same_everywhere(value, group=None):
 
 
 def exchange_segments(buf, part_counts, group=None):
-    """All-to-all of ONE owner-grouped int64 buffer.  Returns (received, per-sender sizes)."""
+    """All-to-all of ONE owner-grouped buffer (any dtype).  Returns (received, per-sender sizes)."""
     world = dist.get_world_size(group)
     send_sizes = [int(x) for x in part_counts]
     assert len(send_sizes) == world and sum(send_sizes) == buf.numel()
@@ -88,7 +88,7 @@ def exchange_segments(buf, part_counts, group=None):
     rsz = torch.empty(world, dtype=torch.int64, device=dev)
     _all_to_all(rsz, ssz, group=group)
     recv_sizes = [int(x) for x in rsz.tolist()]
-    out = torch.empty(sum(recv_sizes), dtype=torch.int64, device=dev)
+    out = torch.empty(sum(recv_sizes), dtype=buf.dtype, device=dev)
     _all_to_all(out, buf, recv_sizes, send_sizes, group=group)
     return out, recv_sizes
 
@@ -100,9 +100,12 @@ def merge_across_ranks(counter, group=None, packed=True):
 
     Power-of-two world and equal table sizes: the region-ordered fast path (export in region order,
     one all-to-all of pairs + one of region counts, LDS rebuild of the shard: no scatter kernel, no
-    global atomics).  Pairs travel PACKED -- one 64-bit word: count << 32 | 32 hash bits -- whenever
-    every rank's table allows it (k small enough for its size, counts < 2^32): half the bytes on
-    the xGMI links.  Otherwise: pairs grouped by owner and re-inserted with device atomics."""
+    global atomics).  The pairs travel in the narrowest unit every rank's table allows:
+      "regions-heads"   u32 heads  = hash bits below the region index | addend - 1   (4 B per pair)
+      "regions-packed"  u64        = count << 32 | 32 hash bits                      (8 B per pair)
+      "regions"         u64 key + u64 count                                          (16 B per pair)
+    -- xGMI is point to point, so at world 2 everything crosses ONE link: bytes are what matters.
+    Otherwise: pairs grouped by owner and re-inserted with device atomics ("pairs")."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     st = counter.finish()
@@ -113,24 +116,43 @@ def merge_across_ranks(counter, group=None, packed=True):
     pow2 = world & (world - 1) == 0
     regions_ok = pow2 and world <= 64 and nreg >= world
     rcnt = torch.empty(nreg, dtype=torch.int32, device=dev) if regions_ok else None
-    exported = None
+
+    def export(fmt):
+        if fmt == 2:
+            return counter.export_regions_heads_device(world, keys.data_ptr(), 2 * n_local, rcnt.data_ptr(), nreg)
+        if fmt == 1:
+            return counter.export_regions_packed_device(world, keys.data_ptr(), n_local, rcnt.data_ptr(), nreg)
+        return None
+
+    exported, my_fmt = None, 0
     if regions_ok and packed:  # speculative: the export itself finds out whether the counts fit
-        exported = counter.export_regions_packed_device(world, keys.data_ptr(), n_local, rcnt.data_ptr(), nreg)
-    votes = _gather_ints([nreg, 1 if exported is not None else 0], group)
+        for fmt in (2, 1):
+            exported = export(fmt)
+            if exported is not None:
+                my_fmt = fmt
+                break
+    votes = _gather_ints([nreg, my_fmt], group)
     same_size = all(v[0] == nreg for v in votes)
-    use_packed = regions_ok and same_size and all(v[1] == 1 for v in votes)
+    agreed = min(v[1] for v in votes) if (regions_ok and same_size) else 0
+    if agreed and agreed != my_fmt:  # another rank could not go as narrow: redo in the common format
+        exported = export(agreed)
+        assert exported is not None
     per = nreg // world if regions_ok else 0
-    if use_packed:
+    if agreed:
         parts, _ = exported
-        rp, recv_sizes = exchange_segments(keys[:n_local], parts.tolist(), group=group)
+        total = int(parts.sum())
+        buf = keys.view(torch.int32)[:total] if agreed == 2 else keys[:total]
+        rp, recv_sizes = exchange_segments(buf, parts.tolist(), group=group)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices of nreg / world region counts
         _all_to_all(rrc, rcnt, group=group)
         counter.reset()
         counter.set_shard(rank, world)
         offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-        counter.merge_regions_packed_device(nreg, [rp.data_ptr() + 8 * int(offs[s]) for s in range(world)],
-                                            [rrc.data_ptr() + 4 * per * s for s in range(world)])
-        path, n_recv = "regions-packed", rp.numel()
+        unit = rp.element_size()
+        merge = counter.merge_regions_heads_device if agreed == 2 else counter.merge_regions_packed_device
+        merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
+              [rrc.data_ptr() + 4 * per * s for s in range(world)])
+        path, n_recv = ("regions-heads" if agreed == 2 else "regions-packed"), rp.numel()
     elif regions_ok and same_size:
         cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
         parts, nreg2 = counter.export_regions_device(world, keys.data_ptr(), cnts.data_ptr(), n_local, rcnt.data_ptr(), nreg)
@@ -154,7 +176,7 @@ def merge_across_ranks(counter, group=None, packed=True):
         counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
         path, n_recv = "pairs", rk.numel()
     st2 = counter.finish()
-    return {"path": path, "local_distinct": n_local, "sent_pairs": int(n_local - parts[rank]),
+    return {"path": path, "local_distinct": n_local, "sent_pairs": int(parts.sum() - parts[rank]),  # in exchange units
             "recv_pairs": int(n_recv), "owned_distinct": int(st2["distinct"])}
 
 

@@ -65,6 +65,8 @@ SYMBOLS = {
     "kh_merge_regions_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P, _P]),
     "kh_export_regions_packed_device": (C.c_int, [_P, C.c_uint32, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
     "kh_merge_regions_packed_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P]),
+    "kh_export_regions_heads_device": (C.c_int, [_P, C.c_uint32, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
+    "kh_merge_regions_heads_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P]),
     "kh_export_by_owner_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P]),
     "kh_merge_pairs_device": (C.c_int, [_P, _P, _P, _U64]),
     "kh_merge_pairs": (C.c_int, [_P, _P, _P, _U64]),
@@ -297,6 +299,25 @@ class DeviceCounter:
             return None
         self._check(rc)
         return parts, int(nreg.value)
+
+    def export_regions_heads_device(self, nparts, d_heads, cap, d_region_counts, region_cap):
+        """32-bit heads export.  Returns (heads per owner, regions), or None when not representable
+        (k too large for the table size, a very large count, or more than `cap` heads)."""
+        parts = np.zeros(nparts, dtype=np.uint64)
+        nreg = _U64(0)
+        rc = lib().kh_export_regions_heads_device(self._h, int(nparts), d_heads, int(cap), d_region_counts,
+                                                  int(region_cap), parts.ctypes.data, C.byref(nreg))
+        if rc == KH_ERR_RANGE:
+            return None
+        self._check(rc)
+        return parts, int(nreg.value)
+
+    def merge_regions_heads_device(self, sender_regions, d_heads, d_region_counts):
+        n = len(d_heads)
+        assert len(d_region_counts) == n
+        arr = lambda xs: (_P * n)(*[_P(int(x)) for x in xs])
+        ah, ar = arr(d_heads), arr(d_region_counts)
+        self._check(lib().kh_merge_regions_heads_device(self._h, n, int(sender_regions), ah, ar))
 
     def merge_regions_packed_device(self, sender_regions, d_pairs, d_region_counts):
         n = len(d_pairs)

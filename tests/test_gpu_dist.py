@@ -21,15 +21,18 @@ from krust_amd.distributed import merge_across_ranks
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 bases, _ = O.synth_reads(20260130, 1 << 18, 150, 0, 30000, with_qual=False)
-m = O.OracleMap(); m.scan_flat(bases, 21, nthreads=4)
-with krust_amd.DeviceCounter(21, capacity_hint=3_000_000) as dc:  # 2^11 regions: 2k - 11 <= 32, the packed exchange applies
-    dc.push(bases)
-    info = merge_across_ranks(dc)
-    keys, cnts = dc.result()
-ok, oc = m.arrays()
-assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
-assert info["sent_pairs"] == 0 and info["recv_pairs"] == len(m) == info["owned_distinct"]
-assert info["path"] == "regions-packed", info
+# capacity_hint 3 M -> 2^11 regions.  k = 19: 27 hash bits below the region index -> u32 heads;
+# k = 21: 31 bits -> the 64-bit packed unit; k = 31: neither -> key + count.
+for k, expect in ((19, "regions-heads"), (21, "regions-packed"), (31, "regions")):
+    m = O.OracleMap(); m.scan_flat(bases, k, nthreads=4)
+    with krust_amd.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+        dc.push(bases)
+        info = merge_across_ranks(dc)
+        keys, cnts = dc.result()
+    ok, oc = m.arrays()
+    assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
+    assert info["sent_pairs"] == 0 and info["recv_pairs"] >= len(m) == info["owned_distinct"]
+    assert info["path"] == expect, info
 print("NCCL_OK", len(m))
 dist.destroy_process_group()
 '''
@@ -59,7 +62,7 @@ from krust_amd.distributed import merge_across_ranks, shard_range
 torch.cuda.set_device(0)
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-N_READS, K, SEED = 120000, 21, 20260130
+N_READS, SEED = 120000, 20260130
 lo, hi = shard_range(N_READS, rank, world)
 bases, _ = O.synth_reads(SEED, 1 << 20, 150, lo, hi - lo, with_qual=False)
 with krust_amd.DeviceCounter(K, capacity_hint=3_000_000, path=PATH) as dc:
@@ -89,10 +92,11 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,path,expect", [(2, "partition", "regions-packed"), (4, None, "regions-packed"), (3, None, "pairs")])
-def test_ranks_sharing_one_gpu_merge_real_tables(world, path, expect, tmp_path):
+@pytest.mark.parametrize("world,path,k,expect", [(2, "partition", 19, "regions-heads"), (4, None, 21, "regions-packed"),
+                                                 (4, None, 17, "regions-heads"), (2, None, 31, "regions"), (3, None, 21, "pairs")])
+def test_ranks_sharing_one_gpu_merge_real_tables(world, path, k, expect, tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(f"ROOT = {ROOT!r}\nPATH = {path!r}\nEXPECT_PATH = {expect!r}\n" + MULTI)
+    script.write_text(f"ROOT = {ROOT!r}\nPATH = {path!r}\nEXPECT_PATH = {expect!r}\nK = {k}\n" + MULTI)
     port = 29500 + world + (os.getpid() % 100)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],

@@ -397,10 +397,11 @@ def test_owner_partitioned_merge_logical_shards(K, nshards):
     assert merged == want
 
 
-@pytest.mark.parametrize("packed", [False, True], ids=["wide", "packed"])
+@pytest.mark.parametrize("packed", [0, 1, 2], ids=["wide", "packed64", "heads32"])
 @pytest.mark.parametrize("nshards,k,minq,recv_hint", [(2, 21, None, 3_000_000), (4, 21, None, 3_000_000), (8, 21, None, 3_000_000),
                                                       (4, 31, 20, 3_000_000), (8, 9, None, 3_000_000),
-                                                      (4, 21, None, 40_000_000), (4, 21, None, 20_000)])
+                                                      (4, 21, None, 40_000_000), (4, 21, None, 20_000), (4, 19, None, 3_000_000),
+                                                      (2, 17, 20, 20_000)])
 def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, packed):
     """The power-of-two fast path of the multi-GPU merge, as logical shards on one device:
     region-ordered export from every 'rank', then each owner rebuilds its hash-range shard in LDS
@@ -423,15 +424,23 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, pac
             dk = torch.empty(max(st["distinct"], 1), dtype=torch.int64, device="cuda")
             dcnt = torch.empty(max(st["distinct"], 1), dtype=torch.int64, device="cuda")
             rc = torch.empty(R, dtype=torch.int32, device="cuda")
-            if packed:  # one u64 per pair: count << 32 | 32 hash bits below the region index
+            hb = 2 * k - (R.bit_length() - 1)  # hash bits below the region index
+            if packed == 1:  # one u64 per pair: count << 32 | 32 hash bits below the region index
                 res = dc.export_regions_packed_device(nshards, dk.data_ptr(), st["distinct"], rc.data_ptr(), R)
-                if 2 * k - (R.bit_length() - 1) > 32:
+                if hb > 32:
                     assert res is None  # not representable: the caller takes the wide route
                     pytest.skip("packed form not representable for this k / table size")
                 parts, R2 = res
+            elif packed == 2:  # u32 heads: hb hash bits | addend - 1; large counts split into several heads
+                res = dc.export_regions_heads_device(nshards, dk.data_ptr(), 2 * st["distinct"], rc.data_ptr(), R)
+                if not (1 <= hb <= 28):
+                    assert res is None
+                    pytest.skip("heads not representable for this k / table size")
+                parts, R2 = res
+                assert int(parts.sum()) >= st["distinct"]
             else:
                 parts, R2 = dc.export_regions_device(nshards, dk.data_ptr(), dcnt.data_ptr(), st["distinct"], rc.data_ptr(), R)
-            assert R2 == R and int(parts.sum()) == st["distinct"] and int(rc.sum().item()) == st["distinct"]
+            assert R2 == R and int(rc.sum().item()) == int(parts.sum()) and (packed == 2 or int(parts.sum()) == st["distinct"])
             nreg = R if nreg is None else nreg
             assert R == nreg
             offs = np.concatenate([[0], np.cumsum(parts)]).astype(np.int64)
@@ -441,9 +450,12 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, pac
     for o in range(nshards):
         with K.DeviceCounter(k, capacity_hint=recv_hint) as dc:  # receiver tables larger / smaller than the senders' too
             dc.set_shard(o, nshards)
-            if packed:
+            if packed == 1:
                 dc.merge_regions_packed_device(nreg, [e[0].data_ptr() + 8 * int(e[3][o]) for e in exports],
                                                [e[2].data_ptr() + 4 * per_r * o for e in exports])
+            elif packed == 2:
+                dc.merge_regions_heads_device(nreg, [e[0].data_ptr() + 4 * int(e[3][o]) for e in exports],
+                                              [e[2].data_ptr() + 4 * per_r * o for e in exports])
             else:
                 dc.merge_regions_device(nreg,
                                         [e[0].data_ptr() + 8 * int(e[3][o]) for e in exports],
@@ -458,6 +470,41 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, pac
         assert all(K.owner(key, k, nshards) == o for key in list(d)[:300])
         merged.update(d)
     assert merged == want
+
+
+def test_heads_export_splits_large_counts_and_refuses_huge_ones(K):
+    """32-bit heads carry addend - 1 in the bits the hash leaves free (k = 19, 2^11 regions: 5 bits).  Counts
+    above 32 travel as several heads of the same key; a count above 64 x 32 makes the table not
+    representable (the caller then takes a wider unit)."""
+    import torch
+    k = 19
+    for n_reads, representable in ((12_000, True), (80_000, False)):
+        bases, _ = O.synth_reads(SEED, 1 << 12, 150, 0, n_reads, with_qual=False)   # 4 kbp genome: counts ~ n_reads / 31
+        m = O.OracleMap()
+        m.scan_flat(bases, k, nthreads=NCPU)
+        want = m.as_dict()
+        assert (max(want.values()) > 64 * 32) == (not representable) and max(want.values()) > 32
+        with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+            dc.push(bases)
+            st = dc.finish()
+            R = st["table_slots"] // 4096
+            buf = torch.empty(8 * st["distinct"] + 1024, dtype=torch.int32, device="cuda")
+            rc = torch.empty(R, dtype=torch.int32, device="cuda")
+            res = dc.export_regions_heads_device(2, buf.data_ptr(), buf.numel(), rc.data_ptr(), R)
+            if not representable:
+                assert res is None
+                continue
+            parts, _ = res
+            assert int(parts.sum()) > st["distinct"]  # some keys needed more than one head
+            offs = np.concatenate([[0], np.cumsum(parts)]).astype(np.int64)
+        merged = {}
+        for o in range(2):
+            with K.DeviceCounter(k, capacity_hint=3_000_000) as sh:
+                sh.set_shard(o, 2)
+                sh.merge_regions_heads_device(R, [buf.data_ptr() + 4 * int(offs[o])], [rc.data_ptr() + 4 * (R // 2) * o])
+                sh.finish()
+                merged.update(sh.as_dict())
+        assert merged == want
 
 
 def test_shard_table_rejects_reads_until_reset(K):

@@ -37,6 +37,23 @@ for rep in range(2):
                                                    [rc.data_ptr()] * N))
     s2 = sh.finish()
     print(f"merge_regions (8 senders x {int(parts[0])} pairs, 8x re-read): {t_m:.1f} ms -> {s2['distinct']} distinct")
+# packed form (one u64 per pair)
+(res), t_pe = timed(lambda: dc.export_regions_packed_device(N, keys.data_ptr(), n, rc.data_ptr(), R))
+(res), t_pe2 = timed(lambda: dc.export_regions_packed_device(N, keys.data_ptr(), n, rc.data_ptr(), R))
+if res is None:
+    print("packed export: not representable")
+else:
+    pparts, _ = res
+    poffs = np.concatenate([[0], np.cumsum(pparts)]).astype(np.int64)
+    print(f"export_regions_packed: {t_pe:.1f} / {t_pe2:.1f} ms ({n*8/1e9:.1f} GB of pairs)")
+    for rep in range(2):
+        sh.reset(); sh.set_shard(0, N)
+        _, t_m = timed(lambda: sh.merge_regions_packed_device(R, [keys.data_ptr() + 8 * int(poffs[0])] * N, [rc.data_ptr()] * N))
+        s2 = sh.finish()
+        print(f"merge_regions_packed (8 senders x {int(pparts[0])} pairs): {t_m:.1f} ms -> {s2['distinct']} distinct")
+    if os.environ.get("SKIP_GENERIC"):
+        sys.exit(0)
+    # restore the wide export for the generic comparison below
 # generic path for comparison
 (parts2), t_e3 = timed(lambda: dc.export_by_owner_device(N, keys.data_ptr(), cnts.data_ptr(), n))
 sh.reset()
