@@ -51,6 +51,20 @@ else:
         _, t_m = timed(lambda: sh.merge_regions_packed_device(R, [keys.data_ptr() + 8 * int(poffs[0])] * N, [rc.data_ptr()] * N))
         s2 = sh.finish()
         print(f"merge_regions_packed (8 senders x {int(pparts[0])} pairs): {t_m:.1f} ms -> {s2['distinct']} distinct")
+    # 32-bit heads
+    (res), t_he = timed(lambda: dc.export_regions_heads_device(N, keys.data_ptr(), 2 * n, rc.data_ptr(), R))
+    (res), t_he2 = timed(lambda: dc.export_regions_heads_device(N, keys.data_ptr(), 2 * n, rc.data_ptr(), R))
+    if res is None:
+        print("heads export: not representable")
+    else:
+        hparts, _ = res
+        hoffs = np.concatenate([[0], np.cumsum(hparts)]).astype(np.int64)
+        print(f"export_regions_heads: {t_he:.1f} / {t_he2:.1f} ms ({int(hparts.sum())} heads for {n} pairs, {int(hparts.sum())*4/1e9:.1f} GB)")
+        for rep in range(2):
+            sh.reset(); sh.set_shard(0, N)
+            _, t_m = timed(lambda: sh.merge_regions_heads_device(R, [keys.data_ptr() + 4 * int(hoffs[0])] * N, [rc.data_ptr()] * N))
+            s2 = sh.finish()
+            print(f"merge_regions_heads (8 senders x {int(hparts[0])} heads): {t_m:.1f} ms -> {s2['distinct']} distinct")
     if os.environ.get("SKIP_GENERIC"):
         sys.exit(0)
     # restore the wide export for the generic comparison below
