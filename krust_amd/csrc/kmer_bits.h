@@ -77,9 +77,17 @@ KH_HD uint64_t kh_canonical_bits(uint64_t fwd, uint32_t k) {
 // For 16 <= k <= 24 the half fits 24 bits and the product uses the FULL-RATE 24-bit multiplier
 // (v_mul_u32_u24; a 32-bit v_mul_lo_u32 is quarter rate) with the constant's low 24 bits; both
 // variants pass the same occupancy tests.  The choice depends only on k, so it is one function.
+// MODE: which multiplier.  KH_MUL_AUTO decides from k at run time (one uniform branch per round: fine
+// for cold code, but in the extraction kernels it splits every window into a dozen basic blocks and
+// blocks instruction scheduling), so the hot kernels are instantiated for KH_MUL_24 / KH_MUL_32 and
+// the host picks by k.
+enum { KH_MUL_AUTO = 0, KH_MUL_24 = 1, KH_MUL_32 = 2 };
+KH_HD bool kh_k_uses_mul24(uint32_t k) { return k >= 16 && k <= 24; }
+
+template <int MODE = KH_MUL_AUTO>
 KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
     uint32_t t;
-    if (k >= 16 && k <= 24) {
+    if (MODE == KH_MUL_24 || (MODE == KH_MUL_AUTO && kh_k_uses_mul24(k))) {
 #if defined(__HIP_DEVICE_COMPILE__)
         t = __umul24(r, (c & 0xFFFFFFu) | 1u);
 #else
@@ -96,30 +104,34 @@ KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
 #define KH_FC2 0xC2B2AE3Du
 #define KH_FC3 0x27D4EB2Fu
 
+template <int MODE = KH_MUL_AUTO>
 KH_HD uint64_t kh_hash_n(uint64_t key, uint32_t k) {
     const uint32_t mask = k < 32 ? ((1u << k) - 1u) : 0xFFFFFFFFu;
     uint32_t L = (uint32_t)(k < 32 ? (key >> k) : (key >> 32)) & mask, R = (uint32_t)key & mask, t;
-    t = (L ^ kh_feistel_f(R, KH_FC0, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f(R, KH_FC1, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f(R, KH_FC2, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f(R, KH_FC3, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC0, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC1, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC2, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC3, k)) & mask; L = R; R = t;
     return k < 32 ? (((uint64_t)L << k) | R) : (((uint64_t)L << 32) | R);
 }
 
+template <int MODE = KH_MUL_AUTO>
 KH_HD uint64_t kh_unhash_n(uint64_t h, uint32_t k) {
     const uint32_t mask = k < 32 ? ((1u << k) - 1u) : 0xFFFFFFFFu;
     uint32_t L = (uint32_t)(k < 32 ? (h >> k) : (h >> 32)) & mask, R = (uint32_t)h & mask, t;
-    t = (R ^ kh_feistel_f(L, KH_FC3, k)) & mask; R = L; L = t;
-    t = (R ^ kh_feistel_f(L, KH_FC2, k)) & mask; R = L; L = t;
-    t = (R ^ kh_feistel_f(L, KH_FC1, k)) & mask; R = L; L = t;
-    t = (R ^ kh_feistel_f(L, KH_FC0, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_f<MODE>(L, KH_FC3, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_f<MODE>(L, KH_FC2, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_f<MODE>(L, KH_FC1, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_f<MODE>(L, KH_FC0, k)) & mask; R = L; L = t;
     return k < 32 ? (((uint64_t)L << k) | R) : (((uint64_t)L << 32) | R);
 }
 
 // H: the 2k hash bits left-aligned in 64 bits.  Table placement reads it from the top:
 //   region = H >> (64 - rbits), in-region start = the next REGION_BITS bits.
-KH_HD uint64_t kh_table_hash(uint64_t key, uint32_t k) { return kh_hash_n(key, k) << (64 - 2 * k); }
-KH_HD uint64_t kh_table_unhash(uint64_t H, uint32_t k) { return kh_unhash_n(H >> (64 - 2 * k), k); }
+template <int MODE = KH_MUL_AUTO>
+KH_HD uint64_t kh_table_hash(uint64_t key, uint32_t k) { return kh_hash_n<MODE>(key, k) << (64 - 2 * k); }
+template <int MODE = KH_MUL_AUTO>
+KH_HD uint64_t kh_table_unhash(uint64_t H, uint32_t k) { return kh_unhash_n<MODE>(H >> (64 - 2 * k), k); }
 
 // Owner shard for the multi-GPU merge: a fast-range of the TOP bits of the table hash, so that
 // ownership is a contiguous range of table regions (for a power-of-two shard count it is simply the

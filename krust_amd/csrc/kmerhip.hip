@@ -536,14 +536,20 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             StageTimer t(c, ST_P1_SCATTER);
             const char *dbg_env = getenv("KMERHIP_DEBUG");  // timing experiments only; results are then wrong
             const uint32_t dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
-            if (ra.use_qual)
-                hipLaunchKernelGGL(kh::part1_scatter_chunked_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
-                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA,
-                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr, dbg);
-            else
-                hipLaunchKernelGGL(kh::part1_scatter_chunked_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
-                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA,
-                                   c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr, dbg);
+#define KH_P1_LAUNCH(QUAL, MODE, FAST) \
+    hipLaunchKernelGGL((kh::part1_scatter_chunked_kernel<QUAL, MODE, FAST>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
+                       ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
+                       c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr, dbg)
+#define KH_P1_LAUNCH2(QUAL, MODE) \
+    do { if (fast) KH_P1_LAUNCH(QUAL, MODE, true); else KH_P1_LAUNCH(QUAL, MODE, false); } while (0)
+            const bool m24 = kh_k_uses_mul24(c->k);  // the Feistel multiplier is a compile-time choice in the hot kernel
+            const bool fast = kh::p1_fast_ok(g);
+            if (ra.use_qual && m24) KH_P1_LAUNCH2(true, KH_MUL_24);
+            else if (ra.use_qual) KH_P1_LAUNCH2(true, KH_MUL_32);
+            else if (m24) KH_P1_LAUNCH2(false, KH_MUL_24);
+            else KH_P1_LAUNCH2(false, KH_MUL_32);
+#undef KH_P1_LAUNCH2
+#undef KH_P1_LAUNCH
         }
         if (const char *dbg_env = getenv("KMERHIP_DEBUG"))
             if (atoi(dbg_env)) return sync_counters(c);  // timing experiment: level 1 only, nothing is counted

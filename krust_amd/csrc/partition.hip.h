@@ -46,7 +46,8 @@ struct PartGeom {
     uint32_t shard_index;
 };
 
-__device__ __forceinline__ u64 part_hash(const PartGeom &g, u64 key) { return kh_table_hash(key, g.k) << g.shard_shift; }
+template <int MODE = KH_MUL_AUTO>
+__device__ __forceinline__ u64 part_hash(const PartGeom &g, u64 key) { return kh_table_hash<MODE>(key, g.k) << g.shard_shift; }
 // key of a placement hash of this (possibly sharded) table
 __device__ __forceinline__ u64 part_unhash(const PartGeom &g, u64 Hs) {
     const u64 H = g.shard_shift ? ((Hs >> g.shard_shift) | ((u64)g.shard_index << (64 - g.shard_shift))) : Hs;
@@ -84,6 +85,26 @@ struct Pay<uint32_t> {  // bits [p1_bits, p1_bits+32) of H
 
 __device__ __forceinline__ uint32_t p1_of_hash(u64 H, const PartGeom &g) {
     return g.p1_bits ? (uint32_t)(H >> (64 - g.p1_bits)) : 0u;
+}
+
+// Level-1 digit and 32-bit payload straight from the two k-bit halves of the hash, h = L << k | R:
+// p1 = the top p1_bits of h, payload = the remaining 2k - p1_bits (<= 32) bits, left-aligned.  All
+// 32-bit shifts (the generic form above costs five 64-bit shifts per window).  Valid iff the table is
+// not a shard, p1_bits <= k and 1 <= 2k - p1_bits <= 32 (p1_fast_ok); same values as the generic form.
+__host__ __device__ inline bool p1_fast_ok(const PartGeom &g) {
+    return g.shard_shift == 0 && g.p1_bits <= g.k && 2 * g.k - g.p1_bits >= 1 && 2 * g.k - g.p1_bits <= 32 && g.k < 32;
+}
+template <int MODE>
+__device__ __forceinline__ void hash_p1_pay32(const PartGeom &g, u64 key, uint32_t &p1, uint32_t &pay) {
+    const uint32_t k = g.k;
+    const uint32_t mask = (1u << k) - 1u;
+    uint32_t L = (uint32_t)(key >> k) & mask, R = (uint32_t)key & mask, t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC0, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC1, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC2, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_f<MODE>(R, KH_FC3, k)) & mask; L = R; R = t;
+    p1 = L >> (k - g.p1_bits);
+    pay = ((L << k) | R) << (32u - (2u * k - g.p1_bits));  // L's top p1_bits fall off the 32-bit word
 }
 
 // ---- level-2 work unit and the two level-1 output layouts it can read -----------------------------
@@ -287,7 +308,7 @@ struct ChunkDst {  // per partition, per batch: where staged element i (local in
     u64 b;         // e >= split: pool index = b + i   (freshly taken, consecutive chunks)
 };
 
-template <bool QUAL>
+template <bool QUAL, int MODE, bool FAST>
 __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
     u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
@@ -331,12 +352,21 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
             tag[j] = 0xFFFFFFFFu;
             u64 key;
             if (roll.next(j, key)) {
-                const u64 H = part_hash(g, key);
-                const uint32_t p = p1_of_hash(H, g);
-                pay[j] = Pay<uint32_t>::make(key, H, g);
-                tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);
+                if (FAST) {
+                    uint32_t p1;
+                    hash_p1_pay32<MODE>(g, key, p1, pay[j]);
+                    tag[j] = p1 << 16;
+                } else {
+                    const u64 H = part_hash<MODE>(g, key);
+                    pay[j] = Pay<uint32_t>::make(key, H, g);
+                    tag[j] = p1_of_hash(H, g) << 16;
+                }
             }
         }
+        // ranks in a second sweep: sixteen LDS atomics in flight instead of one wait per window
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j)
+            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
 #pragma unroll
