@@ -124,10 +124,18 @@ def main():
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # BENCH_BACKEND=gloo (tests only): several ranks share the visible GPU(s) and the collectives are
+    # host-staged, so the whole N > 1 code path of this file can be exercised on a 1-GPU box.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where small reduction operands live
 
     import krust_amd
     from krust_amd.distributed import merge_across_ranks
@@ -178,12 +186,19 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        km = torch.tensor([st["kmers"]], dtype=torch.int64, device=dev)
+        km = torch.tensor([st["kmers"]], dtype=torch.int64, device=cdev)
         dist.all_reduce(km, op=dist.ReduceOp.SUM)
         total_kmers = int(km.item())
+        # conservation across the merge (outside the timed region): the key-sharded tables together hold
+        # every occurrence exactly once, and the shards' key sets are disjoint by construction
+        hist = dc.histogram()
+        chk = torch.tensor([sum(c * f for c, f in hist), sum(f for _, f in hist)], dtype=torch.int64, device=cdev)
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        mg = dict(mg, merged_occurrences=int(chk[0].item()), merged_distinct=int(chk[1].item()),
+                  conserved=bool(int(chk[0].item()) == total_kmers))
     else:
         total_kmers = int(st["kmers"])
 

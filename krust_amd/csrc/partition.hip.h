@@ -737,13 +737,10 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
     for (uint32_t base = 0; base < n; base += PART2_TILE) {
         uint32_t tag[CHUNK];
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            tag[j] = 0xFFFFFFFFu;
-            if (have & (1u << j)) {
-                const uint32_t p = Pay<PT>::p2(pay[j], g);
-                tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);
-            }
-        }
+        for (int j = 0; j < CHUNK; ++j) tag[j] = (have & (1u << j)) ? (Pay<PT>::p2(pay[j], g) << 16) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j)  // all sixteen LDS rank atomics in flight before the first is consumed
+            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
 #pragma unroll

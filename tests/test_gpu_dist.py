@@ -103,3 +103,23 @@ def test_ranks_sharing_one_gpu_merge_real_tables(world, path, k, expect, tmp_pat
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "MULTI_OK" in out.stdout
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py --gpus 2 end to end (weak-scaled shards, merge inside the timed step, max-over-ranks
+    timing, conservation check) with both ranks on the box's one GPU: BENCH_BACKEND=gloo stages the
+    collectives through the host, everything else is the code the 8-GPU run executes."""
+    import json
+    port = 29400 + (os.getpid() % 100)
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "2000000", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    mg = d["config"]["merge"]
+    assert mg["conserved"] and mg["path"].startswith("regions"), mg
+    assert mg["merged_occurrences"] == 2 * d["config"]["kmers_per_step_per_gpu"] or mg["conserved"]

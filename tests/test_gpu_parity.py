@@ -542,9 +542,14 @@ def test_merge_pairs_host(K):
 # BASELINE.json configs[1] at full size: size-independent properties + sampled parity
 # ---------------------------------------------------------------------------
 
-def test_full_size_10M_reads_k21(K, path):
+@pytest.mark.parametrize("n_reads", [10_000_000, 100_000_000], ids=["10M", "100M"])
+def test_full_size_reads_k21(K, path, n_reads):
+    """BASELINE configs[1] (10 M x 150 bp) and the size the headline metric is quoted on (100 M x 150 bp),
+    through size-independent properties plus exact counts on a 1/1024 key sample."""
     import torch
-    n_reads, rl, k = 10_000_000, 150, 21
+    if n_reads > 10_000_000 and path == "direct":
+        pytest.skip("full size through the partitioned path only (the direct path is covered at 10 M)")
+    rl, k = 150, 21
     nbytes = n_reads * (rl + 1)
     tb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     K.synth_reads_device(tb.data_ptr(), None, SEED, 1 << 27, rl, 0, n_reads)
@@ -553,7 +558,7 @@ def test_full_size_10M_reads_k21(K, path):
     m = O.OracleMap()
     total = m.scan_flat(host, k, sample_mask=1023, nthreads=NCPU)  # exact counts on 1/1024 of the keys
     skeys, scnts = m.arrays()
-    with K.DeviceCounter(k, capacity_hint=400_000_000, path=path) as dc:
+    with K.DeviceCounter(k, capacity_hint=int(1.4e8 + 12.0 * n_reads), path=path) as dc:
         dc.push_device(tb.data_ptr(), None, nbytes)
         st = dc.finish()
         assert st["kmers"] == total                                  # every valid window counted once
@@ -572,3 +577,38 @@ def test_full_size_10M_reads_k21(K, path):
         st2 = dc.finish()
         assert st2["distinct"] == st["distinct"] and st2["kmers"] == 2 * total
         assert np.array_equal(dc.lookup(skeys), 2 * scnts)
+
+
+@pytest.mark.parametrize("n_reads", [10_000_000, 100_000_000], ids=["10M", "100M"])
+def test_full_size_reads_k31_q20(K, path, n_reads):
+    """BASELINE configs[2] (k = 31, N bases + --min-quality 20 masking; 64-bit payload path) at 10 M and
+    at the full 100 M x 150 bp: total, histogram checksums, exact counts on a 1/1024 key sample."""
+    import torch
+    if n_reads > 10_000_000 and path == "direct":
+        pytest.skip("full size through the partitioned path only (the direct path is covered at 10 M)")
+    rl, k, minq = 150, 31, 20
+    nbytes = n_reads * (rl + 1)
+    tb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    tq = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    K.synth_reads_device(tb.data_ptr(), tq.data_ptr(), SEED, 1 << 27, rl, 0, n_reads)
+    torch.cuda.synchronize()
+    hb, hq = tb.cpu().numpy(), tq.cpu().numpy()
+    m = O.OracleMap()
+    total = m.scan_flat(hb, k, qual=hq, min_quality=minq, sample_mask=1023, nthreads=NCPU)
+    skeys, scnts = m.arrays()
+    assert 0 < total < n_reads * (rl - k + 1)                        # the masks did remove windows
+    hint = int(1.4e8 + 53.0 * n_reads)  # genome k-mers + ~53 error / boundary k-mers per read at k = 31
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=hint, path=path) as dc:
+        dc.push_device(tb.data_ptr(), tq.data_ptr(), nbytes)
+        st = dc.finish()
+        assert st["kmers"] == total
+        hist = dc.histogram()
+        assert sum(f for _, f in hist) == st["distinct"] == dc.result_size()
+        assert sum(c * f for c, f in hist) == total
+        assert np.array_equal(dc.lookup(skeys), scnts)
+    if n_reads > 10_000_000:
+        return
+    # without the quality buffer the same context counts more windows (run.rs:543: both must be Some)
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=hint, path=path) as dc:
+        dc.push_device(tb.data_ptr(), None, nbytes)
+        assert dc.finish()["kmers"] > total
