@@ -46,9 +46,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def estimate_distinct(reads, k, world):
-    """Genomic canonical k-mers + error k-mers (1/256 substitutions, ~k*(L-k+1)/L novel each)."""
+def estimate_distinct(reads, k, world, with_qual=False):
+    """Genomic canonical k-mers + error k-mers (1/256 substitutions, ~k*(L-k+1)/L novel each); with
+    -Q masking only windows free of low-quality bases (~2.5 % of the synthetic qualities) survive."""
     novel_per_read = READ_LEN * (1.0 / 256.0) * k * (READ_LEN - k + 1) / READ_LEN
+    if with_qual:
+        novel_per_read *= 0.975 ** k
     return int(GENOME_LEN * 1.05 + reads * novel_per_read * 1.12)
 
 
@@ -152,7 +155,7 @@ def main():
                                  first, reads, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
 
-    hint = args.capacity_hint or estimate_distinct(reads, k, world)
+    hint = args.capacity_hint or estimate_distinct(reads, k, world, with_qual)
     dc = krust_amd.DeviceCounter(k, min_quality=args.min_quality, capacity_hint=hint, device=local_rank,
                                  stream=torch.cuda.current_stream().cuda_stream)
 
