@@ -67,7 +67,7 @@ KH_HD uint64_t kh_canonical_bits(uint64_t fwd, uint32_t k) {
 
 // ---- table hash: a BIJECTION on the 2k-bit key space, left-aligned in 64 bits -----------------
 // Four Feistel rounds over the two k-bit halves of the packed k-mer; the round function is a
-// 32-bit multiply + xorshift, keeping its top k bits.  Everything is 32-bit arithmetic (a 64-bit
+// 32-bit multiply, keeping the top k bits of the low word.  Everything is 32-bit arithmetic (a 64-bit
 // multiply costs four quarter-rate 32-bit multiplies on gfx950, this costs four in total), and
 // being a bijection it lets the partitioned path carry 32-bit payloads instead of 64-bit keys
 // whenever 2k minus the level-1 partition bits fits in 32 (k <= 21 at the headline table size):
@@ -96,7 +96,10 @@ KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
     } else {
         t = r * c;
     }
-    t ^= t >> 15;
+    // the round keeps the TOP k bits of the product's low word: every input bit reaches them through
+    // the carries.  (A t ^= t >> 15 here bought nothing measurable -- tools/hash_quality.py: region /
+    // start chi-square and probe lengths equal splitmix64's with or without it -- and cost two of the
+    // five instructions of a round in the extraction kernels.)
     return k < 32 ? (t >> (32 - k)) : t;
 }
 #define KH_FC0 0x9E3779B1u
