@@ -534,12 +534,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         }
         {
             StageTimer t(c, ST_P1_SCATTER);
-            const char *dbg_env = getenv("KMERHIP_DEBUG");  // timing experiments only; results are then wrong
-            const uint32_t dbg = dbg_env ? (uint32_t)atoi(dbg_env) : 0u;
 #define KH_P1_LAUNCH(QUAL, MODE, FAST) \
     hipLaunchKernelGGL((kh::part1_scatter_chunked_kernel<QUAL, MODE, FAST>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
                        ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
-                       c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr, dbg)
+                       c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
 #define KH_P1_LAUNCH2(QUAL, MODE) \
     do { if (fast) KH_P1_LAUNCH(QUAL, MODE, true); else KH_P1_LAUNCH(QUAL, MODE, false); } while (0)
             const bool m24 = kh_k_uses_mul24(c->k);  // the Feistel multiplier is a compile-time choice in the hot kernel
@@ -551,8 +549,6 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 #undef KH_P1_LAUNCH2
 #undef KH_P1_LAUNCH
         }
-        if (const char *dbg_env = getenv("KMERHIP_DEBUG"))
-            if (atoi(dbg_env)) return sync_counters(c);  // timing experiment: level 1 only, nothing is counted
         {
             StageTimer t(c, ST_MISC);
             hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
     u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
     uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
-    Counters *ctr, uint32_t dbg) {  // dbg: timing experiments only (env KMERHIP_DEBUG), 0 in normal runs
+    Counters *ctr) {
     __shared__ uint32_t s_code[2][PART_NT + 2];
     __shared__ uint16_t s_val[2][PART_NT + 2];
     __shared__ uint32_t s_stage[PART_TILE];   // 64 KiB
@@ -413,17 +413,12 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
         }
         // next tile's bases are fetched while this tile's runs are written out
         raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        if (dbg & 2u) continue;
 #pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART_NT) {
             const uint32_t p = s_pid[i];
             const uint32_t meta = s_meta[p];
             const ChunkDst d = s_dst[p];
             const uint32_t e = i - (meta & 0xFFFFu);
-            if (dbg & 1u) {
-                if (d.a + i == 0x123456789ull) pool[0] = s_stage[i];
-                continue;
-            }
             if (e < (meta >> 16)) pool[d.a + i] = s_stage[i];
             else if (d.b != ~0ull) pool[d.b + i] = s_stage[i];
         }
