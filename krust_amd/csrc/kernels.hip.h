@@ -307,14 +307,15 @@ struct Roller {
     uint32_t flo, fhi, rlo, rhi, code, good;
     uint32_t kmlo, kmhi;  // kh_kmask(k)
     uint32_t ins_sh;      // (2k-2) mod 32: where the complemented new base enters rc ...
-    bool ins_hi;          // ... in the high word (k > 16) or the low word
+    uint32_t ins_mlo, ins_mhi;  // ... in the high word (k > 16) or the low word: all-ones mask of that word
 
     __device__ __forceinline__ void init(const WinCtx &w, uint32_t k, u64 wlo) {
         const u64 km = kh_kmask(k);
         kmlo = (uint32_t)km;
         kmhi = (uint32_t)(km >> 32);
         ins_sh = (2 * k - 2) & 31;
-        ins_hi = k > 16;
+        ins_mhi = k > 16 ? 0xFFFFFFFFu : 0u;
+        ins_mlo = ~ins_mhi;
         code = (uint32_t)w.lo64;
         flo = (uint32_t)(w.lo64 >> 32);  // chunk t-1: bases -16..-1
         fhi = w.hi;                      // chunk t-2: bases -32..-17
@@ -345,8 +346,8 @@ struct Roller {
         rlo = __builtin_amdgcn_alignbit(rhi, rlo, 2);   // rc >> 2
         rhi >>= 2;
         const uint32_t ins = (c ^ 3u) << ins_sh;         // complement enters at the top of the 2k bits
-        rlo |= ins_hi ? 0u : ins;                        // (wave-uniform select: 32-bit ops instead of a 64-bit shift)
-        rhi |= ins_hi ? ins : 0u;
+        rlo |= ins & ins_mlo;                            // (uniform masks, one v_and_or each: no 64-bit shift, no selects)
+        rhi |= ins & ins_mhi;
         const u64 fwd = ((u64)(fhi & kmhi) << 32) | (flo & kmlo);
         const u64 rc = ((u64)rhi << 32) | rlo;
         key = fwd < rc ? fwd : rc;  // integer min == the reference's lexicographic choice (kmer.rs:348-365)

@@ -349,19 +349,22 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
         roll.init(w, k, wlo);
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
-            tag[j] = 0xFFFFFFFFu;
             u64 key;
-            if (roll.next(j, key)) {
+            const bool ok = roll.next(j, key);
+            uint32_t p1 = 0;
+            // Without quality masking nearly every window is valid (N is rare): hashing unconditionally
+            // is cheaper than an exec-mask region per window.  With -Q ~40 % of the windows are masked,
+            // there the branch pays.
+            if (!QUAL || ok) {
                 if (FAST) {
-                    uint32_t p1;
                     hash_p1_pay32<MODE>(g, key, p1, pay[j]);
-                    tag[j] = p1 << 16;
                 } else {
                     const u64 H = part_hash<MODE>(g, key);
                     pay[j] = Pay<uint32_t>::make(key, H, g);
-                    tag[j] = p1_of_hash(H, g) << 16;
+                    p1 = p1_of_hash(H, g);
                 }
             }
+            tag[j] = ok ? (p1 << 16) : 0xFFFFFFFFu;
         }
         // ranks in a second sweep: sixteen LDS atomics in flight instead of one wait per window
 #pragma unroll
