@@ -692,21 +692,31 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restri
 
 // ---------------------------------------------------------------------------------------------
 // level 2, pass B: scatter into buckets (one bucket == one table region).
-// 512 lanes x 16 payloads = 8192 per batch: LDS 44 KiB (u32) / 78 KiB (u64) so that two or three
-// workgroups share a CU and one's write-out overlaps another's counting sort; 512-lane workgroups
-// also lift the 128-VGPR ceiling of 1024-lane ones (the 1024-lane version spilled).
+// 512 lanes x 32 payloads = 16384 per batch.  The batch size sets the length of the per-bucket runs
+// (batch / 512 buckets = 32 payloads = one 128-byte line): measured on S100M, 8192 -> 44.1 ms (64-byte
+// runs, writes 1.48x the algorithmic bytes), 16384 -> 36.6 ms, 24576 / 32768 -> 38 ms (one workgroup
+// per CU, nothing left to overlap with).  1024-lane workgroups are no faster at any batch size; 512
+// lanes also lift the 128-VGPR ceiling of 1024-lane workgroups.
 // ---------------------------------------------------------------------------------------------
-constexpr int PART2_NT = 512;
-constexpr int PART2_TILE = PART2_NT * CHUNK;  // 8192
+#ifndef KH_PART2_NT
+#define KH_PART2_NT 512
+#endif
+#ifndef KH_PART2_TILE
+#define KH_PART2_TILE 16384
+#endif
+constexpr int PART2_NT = KH_PART2_NT;
+constexpr int PART2_TILE = KH_PART2_TILE;
+constexpr int P2_PER = PART2_TILE / PART2_NT;   // payloads per lane per batch
+constexpr int P2_OWN = MAX_P1 / PART2_NT;       // buckets whose output cursor a lane keeps in registers
 
 template <typename PT, bool CHUNKED>
 __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__restrict__ pays, ChunkSrc cs,
                                                                  const Part2Block *__restrict__ blocks,
                                                                  const u64 *__restrict__ info, PartGeom g,
                                                                  const u64 *__restrict__ O2, PT *__restrict__ out) {
-    __shared__ PT s_stage[PART2_TILE];   // 32 KiB (u32) / 64 KiB (u64)
+    __shared__ PT s_stage[PART2_TILE];   // 64 KiB (u32) / 128 KiB (u64)
     __shared__ uint32_t s_cnt[MAX_P1];   // sized for the shared 1024-entry scan
-    __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< 8192)
+    __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< PART2_TILE <= 32768)
     __shared__ u64 s_dst[1u << MAX_P2_BITS];  // global position of run p minus its batch-local start
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_chk[CHUNKED ? CPB : 1];
@@ -716,49 +726,50 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
     const int tid = threadIdx.x;
     const int P2 = 1 << g.p2_bits;
     p2_stage_chunks<CHUNKED>(cs, pb, s_chk, s_cfill, tid, PART2_NT);
-    // lane tid owns buckets tid and tid + 512: their running output cursors live in registers
-    u64 gcur0 = 0, gcur1 = 0;
-    s_cnt[tid] = 0;
-    s_cnt[tid + PART2_NT] = 0;
-    if (tid < P2) gcur0 = O2[pb.mbase + (u64)tid * pb.mstride];
-    if (tid + PART2_NT < P2) gcur1 = O2[pb.mbase + (u64)(tid + PART2_NT) * pb.mstride];
+    // lane tid owns buckets tid + q * PART2_NT: their running output cursors live in registers
+    u64 gcur[P2_OWN];
+#pragma unroll
+    for (int q = 0; q < P2_OWN; ++q) {
+        const int b = tid + q * PART2_NT;
+        s_cnt[b] = 0;
+        gcur[q] = b < P2 ? O2[pb.mbase + (u64)b * pb.mstride] : 0;
+    }
     __syncthreads();
     // Branch-free loads: indices are block-relative 32-bit, clamped to the last valid payload (the
     // block is never empty), validity is a bit mask.  (Conditional loads made the compiler carry
     // sixteen 64-bit addresses and their phi copies through the loop: 219 VGPRs.)
     const uint32_t n = p2_count_of<CHUNKED>(pb);
-    PT pay[CHUNK];
+    PT pay[P2_PER];
     uint32_t have = 0;  // bit j: pay[j] holds a payload
 #pragma unroll
-    for (int j = 0; j < CHUNK; ++j)  // lane-contiguous: coalesced loads
+    for (int j = 0; j < P2_PER; ++j)  // lane-contiguous: coalesced loads
         have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, (uint32_t)j * PART2_NT + tid, n, pay[j]) << j;
     for (uint32_t base = 0; base < n; base += PART2_TILE) {
-        uint32_t tag[CHUNK];
+        uint32_t tag[P2_PER];
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) tag[j] = (have & (1u << j)) ? (Pay<PT>::p2(pay[j], g) << 16) : 0xFFFFFFFFu;
+        for (int j = 0; j < P2_PER; ++j) tag[j] = (have & (1u << j)) ? (Pay<PT>::p2(pay[j], g) << 16) : 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j)  // all sixteen LDS rank atomics in flight before the first is consumed
+        for (int j = 0; j < P2_PER; ++j)  // all LDS rank atomics in flight before the first is consumed
             if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j)
+        for (int j = 0; j < P2_PER; ++j)
             if (tag[j] != 0xFFFFFFFFu) s_stage[(uint32_t)s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = pay[j];
-        {  // publish run destinations, advance the cursors
-            const uint32_t c0 = s_cnt[tid], c1 = s_cnt[tid + PART2_NT];
-            s_dst[tid] = gcur0 - s_lofs[tid];
-            s_dst[tid + PART2_NT] = gcur1 - s_lofs[tid + PART2_NT];
-            gcur0 += c0;
-            gcur1 += c1;
+#pragma unroll
+        for (int q = 0; q < P2_OWN; ++q) {  // publish run destinations, advance the cursors
+            const int b = tid + q * PART2_NT;
+            s_dst[b] = gcur[q] - s_lofs[b];
+            gcur[q] += s_cnt[b];
         }
         const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
         __syncthreads();
-        s_cnt[tid] = 0;
-        s_cnt[tid + PART2_NT] = 0;
+#pragma unroll
+        for (int q = 0; q < P2_OWN; ++q) s_cnt[tid + q * PART2_NT] = 0;
         // next batch's payloads are fetched while this batch's runs are written out
         have = 0;
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j)
+        for (int j = 0; j < P2_PER; ++j)
             have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + PART2_TILE + (uint32_t)j * PART2_NT + tid, n, pay[j]) << j;
 #pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART2_NT) {
