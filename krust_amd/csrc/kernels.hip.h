@@ -32,7 +32,8 @@ struct Counters {
     u64 cursor;    // scratch cursor for compaction / counting kernels
     u64 big;       // scratch cursor for the histogram's big-count list
     u64 part_failed;  // regions that overflowed in region_count_kernel (re-inserted after growth)
-    u64 pad[2];
+    u64 heads_wide;   // a count too large for 32-bit exchange heads was seen (region_count_kernel32)
+    u64 pad[1];
 };
 
 constexpr int BLOCK = 256;           // 4 waves of 64

@@ -110,6 +110,10 @@ struct kh_ctx {
     u64 *bstart = nullptr;
     uint8_t *rfail = nullptr;
     uint32_t *rnew = nullptr;
+    uint32_t *rheads = nullptr;      // exchange heads per region, left by a FRESH region pass
+    bool rheads_valid = false;       // ... and still describing the table (nothing else touched it since)
+    bool rheads_wide = false;
+    uint32_t rheads_cb = 0;
     uint16_t *chunk_part = nullptr;  // chunk pool metadata (32-bit payload path)
     uint8_t *fill8 = nullptr;
     uint32_t *plist = nullptr;
@@ -259,6 +263,7 @@ int grow_to(kh_ctx *c, u64 newcap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipFree(c->table));
     if (c->trace) fprintf(stderr, "[kmerhip] table grown %llu -> %llu slots\n", c->cap, newcap);
+    c->rheads_valid = false;
     c->table = nt;
     c->cap = newcap;
     c->grows++;
@@ -420,6 +425,14 @@ uint32_t qual_thr(const kh_ctx *c) {
     return (uint32_t)(t > 255 ? 255 : t);
 }
 
+// count bits of a 32-bit exchange head for this table (shard.hip.h), or -1 if the format does not apply
+int head_count_bits(const kh_ctx *c, u64 regions) {
+    uint32_t rb = 0;
+    while ((1ull << rb) < regions) ++rb;
+    const int hb = 2 * (int)c->k - (int)rb;
+    return (hb >= 1 && hb <= 28) ? 32 - hb : -1;  // at least 4 count bits
+}
+
 // region rebuild launch, by payload type
 template <typename PT>
 void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot);
@@ -436,12 +449,16 @@ void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot)
 template <>
 void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
+    const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
+    c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel32<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty,
+                           c->rheads_cb, c->rheads, c->d_ctr);
     else
         hipLaunchKernelGGL(kh::region_count_kernel32<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
+                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, 0u, 0u,
+                           (uint32_t *)nullptr, c->d_ctr);
 }
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
@@ -494,6 +511,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->rfail, &z, nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
         z = c->rnew ? c->region_cap : 0;
         if ((rc = ensure_buf(c, &c->rnew, &z, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
+        z = c->rheads ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rheads, &z, nregions, "hipMalloc(rheads)")) != KH_OK) return rc;
         c->region_cap = nregions;
     }
     if (CHUNKED && c->pool_cap < pool_chunks) {
@@ -610,6 +629,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
                            (const u64 *)c->O2, (u64)n2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, c->bstart);
         HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
     }
+    const bool was_empty = c->table_empty;
     {
         StageTimer t(c, ST_REGION);
         // buckets more than 4x the mean (upper bound) take the skew-guarded probing loop
@@ -629,6 +649,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     // exact bookkeeping after every batch (batches are hundreds of ms; one sync is noise)
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
+    // the per-region exchange-head counts of a FRESH 32-bit pass describe the whole table until
+    // anything else touches it
+    c->rheads_valid = was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->h_ctr->part_failed == 0;
+    c->rheads_wide = c->h_ctr->heads_wide != 0;
     if (c->h_ctr->part_failed) {
         // some regions overflowed: they were left untouched; grow, then insert their buckets directly.
         // Worst case every key of a failed bucket is new: size the grown table for that.
@@ -692,6 +716,7 @@ int direct_range(kh_ctx *c, const RangeArgs &ra, u64 first_tile, u64 end_tile) {
         }
         HIP_TRY(c, hipGetLastError());
         c->table_empty = false;
+        c->rheads_valid = false;
         c->launches++;
         c->pending_bound += nt * kh::TILE;
         t += nt;
@@ -920,7 +945,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->rfail, c->rnew, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->bstart, c->rfail, c->rnew, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)
@@ -944,6 +969,7 @@ extern "C" int kh_reset(kh_ctx *c) {
     // Lazy: no table_init here (5.5 ms for a 34 GB table).  A partitioned batch into an empty table
     // rewrites every region; any other use clears first (clear_if_dirty).
     if (!c->table_empty) c->table_dirty = true;
+    c->rheads_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->distinct_known = c->pending_bound = 0;
     c->bases_pushed = 0;
@@ -1445,6 +1471,7 @@ extern "C" int kh_merge_pairs_device(kh_ctx *c, const uint64_t *d_keys, const ui
                            table_geom(c, c->table, c->cap), (const u64 *)d_keys + off, (const u64 *)d_counts + off, m, c->d_ctr);
         HIP_TRY(c, hipGetLastError());
         c->table_empty = false;
+        c->rheads_valid = false;
         c->pending_bound += m;
         off += m;
     }
@@ -1490,13 +1517,6 @@ extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
 namespace {
 enum { XF_WIDE = 0, XF_PACKED64 = 1, XF_HEADS32 = 2 };  // exchange unit formats (shard.hip.h)
 
-// count bits of a 32-bit head for this table, or -1 if the format does not apply
-int head_count_bits(const kh_ctx *c, u64 regions) {
-    uint32_t rb = 0;
-    while ((1ull << rb) < regions) ++rb;
-    const int hb = 2 * (int)c->k - (int)rb;
-    return (hb >= 1 && hb <= 28) ? 32 - hb : -1;  // at least 4 count bits
-}
 
 // fmt XF_PACKED64: one u64 per pair into d_keys (d_counts unused); XF_HEADS32: u32 heads into d_keys
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap,
@@ -1517,7 +1537,14 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
     if (region_cap < nregions) return fail(c, KH_ERR_RANGE, "region count array too small");
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
-    if (fmt == XF_HEADS32) {
+    bool counted_by_region_pass = false;
+    if (fmt == XF_HEADS32 && c->rheads_valid && c->rheads_cb == (uint32_t)cb) {
+        // the FRESH region pass that built this table left the head count of every region behind:
+        // no counting pass over the 34 GB table
+        if (c->rheads_wide) return fail(c, KH_ERR_RANGE, "a count is too large for 32-bit heads");
+        HIP_TRY(c, hipMemcpyAsync(d_region_counts, c->rheads, nregions * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        counted_by_region_pass = true;
+    } else if (fmt == XF_HEADS32) {
         rc = zero_cursors(c);
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
@@ -1538,7 +1565,7 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
     const u64 per = nregions / nparts;
     for (uint32_t p = 0; p <= nparts; ++p)
         HIP_TRY(c, hipMemcpyAsync(&bounds[p], c->merge_off + (u64)p * per, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    if (fmt == XF_HEADS32) {
+    if (fmt == XF_HEADS32 && !counted_by_region_pass) {
         u64 wide = 0;
         rc = read_cursor(c, nullptr, &wide);
         if (rc != KH_OK) return rc;
@@ -1697,6 +1724,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
+    c->rheads_valid = false;
     c->table_dirty = false;
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;

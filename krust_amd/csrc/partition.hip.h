@@ -1016,19 +1016,26 @@ __device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t
 template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
-                                                                   uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty) {
+                                                                   uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
+                                                                   uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr) {
+    // head_cb != 0 (FRESH only): also leave in rheads[r] the number of 32-bit exchange heads the region
+    // will need (shard.hip.h heads_of), so that a multi-GPU export right after this pass can skip its
+    // counting pass over the table.
     __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
     __shared__ uint32_t s_add[REGION_SLOTS];
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
-    __shared__ uint32_t s_special, s_sp_off, s_sp_new;
+    __shared__ uint32_t s_special, s_sp_off, s_sp_new, s_heads;
     __shared__ uint32_t s_q[REGION_RK][REGION_NT];  // per-lane payload queues (32 KiB)
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bstart[r + 1];
     if (lo == hi) {
         if (FRESH && dirty) write_empty_region(tg.table + r * REGION_SLOTS, tid);
-        if (tid == 0) rnew[r] = 0;
+        if (tid == 0) {
+            rnew[r] = 0;
+            if (head_cb) rheads[r] = 0;
+        }
         return;
     }
     if (hi - lo >= 0xFFFFFFFFull) {  // a 32-bit delta could wrap
@@ -1077,6 +1084,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         s_fail = 0;
         s_new = 0;
         s_special = 0;
+        s_heads = 0;
     }
     __syncthreads();
     uint32_t nd = 0;
@@ -1142,6 +1150,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     }
     const uint32_t sp_off = s_special ? s_sp_off : 0xFFFFFFFFu;
     uint4 *o4 = reinterpret_cast<uint4 *>(reg);
+    uint32_t nheads = 0;
+    bool too_wide = false;
 #ifdef KH_EXP_NO_WRITEBACK  // timing experiment only
     if (s_new != 0xFFFFFFF0u) { if (tid == 0) rnew[r] = s_new; return; }
 #endif
@@ -1159,8 +1169,19 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             cc += s_special;
         }
         o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
+        if (FRESH && head_cb && kk != KH_EMPTY_KEY) {
+            nheads += (uint32_t)((cc + (1ull << head_cb) - 1) >> head_cb);
+            too_wide |= cc > (64ull << head_cb);
+        }
     }
     if (tid == 0) rnew[r] = s_new;
+    if (FRESH && head_cb) {
+        const uint32_t hw = (uint32_t)wave_sum((u64)nheads);
+        if ((tid & 63) == 0 && hw) atomicAdd(&s_heads, hw);
+        if (__any(too_wide) && (tid & 63) == 0) atomicOr((unsigned long long *)&ctr->heads_wide, 1ull);
+        __syncthreads();
+        if (tid == 0) rheads[r] = s_heads;
+    }
 }
 
 // Folds the per-region results of one region_count pass into the context counters.

@@ -106,6 +106,18 @@ def merge_across_ranks(counter, group=None, packed=True):
       "regions"         u64 key + u64 count                                          (16 B per pair)
     -- xGMI is point to point, so at world 2 everything crosses ONE link: bytes are what matters.
     Otherwise: pairs grouped by owner and re-inserted with device atomics ("pairs")."""
+    import os
+    import time
+    timing = {} if os.environ.get("KMERHIP_MERGE_TIMING") else None
+    t_last = [time.perf_counter()]
+
+    def lap(name):  # phase wall times (with a device sync), only when asked for
+        if timing is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            timing[name] = timing.get(name, 0.0) + (now - t_last[0]) * 1e3
+            t_last[0] = now
+
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     st = counter.finish()
@@ -113,6 +125,7 @@ def merge_across_ranks(counter, group=None, packed=True):
     nreg = int(st["table_slots"]) // 4096
     dev = torch.device("cuda", torch.cuda.current_device())
     keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
+    lap("setup")
     pow2 = world & (world - 1) == 0
     regions_ok = pow2 and world <= 64 and nreg >= world
     rcnt = torch.empty(nreg, dtype=torch.int32, device=dev) if regions_ok else None
@@ -131,6 +144,7 @@ def merge_across_ranks(counter, group=None, packed=True):
             if exported is not None:
                 my_fmt = fmt
                 break
+    lap("export")
     votes = _gather_ints([nreg, my_fmt], group)
     same_size = all(v[0] == nreg for v in votes)
     agreed = min(v[1] for v in votes) if (regions_ok and same_size) else 0
@@ -142,9 +156,11 @@ def merge_across_ranks(counter, group=None, packed=True):
         parts, _ = exported
         total = int(parts.sum())
         buf = keys.view(torch.int32)[:total] if agreed == 2 else keys[:total]
+        lap("vote")
         rp, recv_sizes = exchange_segments(buf, parts.tolist(), group=group)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices of nreg / world region counts
         _all_to_all(rrc, rcnt, group=group)
+        lap("all_to_all")
         counter.reset()
         counter.set_shard(rank, world)
         offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
@@ -153,6 +169,7 @@ def merge_across_ranks(counter, group=None, packed=True):
         merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
               [rrc.data_ptr() + 4 * per * s for s in range(world)])
         path, n_recv = ("regions-heads" if agreed == 2 else "regions-packed"), rp.numel()
+        lap("merge")
     elif regions_ok and same_size:
         cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
         parts, nreg2 = counter.export_regions_device(world, keys.data_ptr(), cnts.data_ptr(), n_local, rcnt.data_ptr(), nreg)
@@ -176,6 +193,9 @@ def merge_across_ranks(counter, group=None, packed=True):
         counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
         path, n_recv = "pairs", rk.numel()
     st2 = counter.finish()
+    lap("finish")
+    if timing is not None:
+        print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
     return {"path": path, "local_distinct": n_local, "sent_pairs": int(parts.sum() - parts[rank]),  # in exchange units
             "recv_pairs": int(n_recv), "owned_distinct": int(st2["distinct"])}
 

@@ -507,6 +507,36 @@ def test_heads_export_splits_large_counts_and_refuses_huge_ones(K):
         assert merged == want
 
 
+def test_heads_export_uses_region_pass_counts(K):
+    """Right after a FRESH partitioned pass the heads export takes its per-region counts from that pass
+    (no counting pass over the table).  They must equal what the counting kernel finds on the same table
+    built through the direct path, with and without split heads; and be dropped once the table changes."""
+    import torch
+    k = 19
+    bases, _ = O.synth_reads(SEED, 1 << 13, 150, 0, 30_000, with_qual=False)   # counts ~ 480: several heads per key
+    more, _ = O.synth_reads(SEED + 1, 1 << 13, 150, 0, 2_000, with_qual=False)
+    got = {}
+    for path in ("partition", "direct"):
+        with K.DeviceCounter(k, capacity_hint=3_000_000, path=path) as dc:
+            dc.push(bases)
+            st = dc.finish()
+            R = st["table_slots"] // 4096
+            buf = torch.empty(64 * st["distinct"] + 1024, dtype=torch.int32, device="cuda")
+            rc = torch.empty(R, dtype=torch.int32, device="cuda")
+            parts, _ = dc.export_regions_heads_device(4, buf.data_ptr(), buf.numel(), rc.data_ptr(), R)
+            heads = buf[: int(parts.sum())].cpu().numpy().copy()
+            got[path] = (parts.copy(), rc.cpu().numpy().copy(), np.sort(heads))
+            if path == "partition":  # a later push invalidates the shortcut: counts must follow the table
+                dc.push(more)
+                dc.finish()
+                parts2, _ = dc.export_regions_heads_device(4, buf.data_ptr(), buf.numel(), rc.data_ptr(), R)
+                assert int(parts2.sum()) == int(rc.sum().item()) > int(parts.sum())
+    assert np.array_equal(got["partition"][0], got["direct"][0])
+    assert np.array_equal(got["partition"][1], got["direct"][1])
+    assert np.array_equal(got["partition"][2], got["direct"][2])
+    assert int(got["partition"][0].sum()) > st["distinct"]
+
+
 def test_shard_table_rejects_reads_until_reset(K):
     """A shard table holds only keys of its hash range: reads cannot be pushed into it (state
     error, nothing counted); kh_reset turns it back into a full table."""
