@@ -270,6 +270,7 @@ def main():
                        "parallelism": f"reads sharded x{world}" + ("; RCCL all-to-all table merge" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_of_measured_copy_peak": achieved / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s copy
                          "kernel": ("partitioned pipeline: part1_scatter_chunked (single-pass level 1; k >= 22: part1_count + "
                                     "part1_scatter) + part2_count + part2_scatter + region_count, one launch each per batch")
                          if part else "count_direct_kernel",
