@@ -203,6 +203,14 @@ int kh_export_regions_heads_device(kh_ctx *ctx, uint32_t nparts, uint32_t *d_hea
 int kh_merge_regions_heads_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sender_regions,
                                   const uint32_t *const *d_heads, const uint32_t *const *d_region_counts);
 
+/* Small k (2k <= 26): the whole key space is a dense array of 4^k counts, which -- unlike a hash
+ * table -- IS element-wise reducible: ranks merge with one all-reduce(sum) (any number of ranks,
+ * tables of any size).  kh_export_dense_device: d_dense[key] = count, 0 for absent keys.
+ * kh_merge_dense_device: count[key] += d_dense[key] for the keys shard `owner` of `nparts` owns
+ * (kh_owner); the table keeps its full geometry.  KH_ERR_RANGE for larger k. */
+int kh_export_dense_device(kh_ctx *ctx, uint64_t *d_dense, uint64_t n_entries);
+int kh_merge_dense_device(kh_ctx *ctx, const uint64_t *d_dense, uint64_t n_entries, uint32_t owner, uint32_t nparts);
+
 /* Generic path (any number of shards, tables of any size): pairs grouped by owner, then
  * kh_merge_pairs_device re-inserts them with device atomics. */
 /* kh_export_by_owner_device: compact all live (key,count) pairs grouped by owner shard into device arrays

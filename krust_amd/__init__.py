@@ -4,6 +4,7 @@ Layout:
   csrc/      hand-written gfx950 HIP kernels + the C ABI of include/kmerhip.h
   native.py  ctypes binding of that C ABI (plumbing; no CPU fallback)
 """
+from . import native  # noqa: F401
 from .native import (DeviceCounter, KmerHipError, KmerLengthError, canonical, lib, owner, pack,  # noqa: F401
                      synth_reads_device, unpack)
 

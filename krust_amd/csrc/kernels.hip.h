@@ -498,6 +498,33 @@ __global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(TableGeom tg, 
     }
 }
 
+// ---- dense form for small k (2k <= 26 bits of key space): element-wise reducible ------------------
+// dense[key] = count of every live pair (dense[] is zeroed by the host first; keys are unique).
+__global__ __launch_bounds__(BLOCK) void table_to_dense_kernel(const Slot *__restrict__ table, u64 cap, u64 *__restrict__ dense,
+                                                               u64 n_entries) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
+        const Slot s = table[i];
+        if (s.key != KH_EMPTY_KEY && s.key < n_entries) dense[s.key] = s.count;
+    }
+}
+
+// count[key] += dense[key] for every key with a non-zero entry that shard `owner` of `nparts` owns.
+__global__ __launch_bounds__(BLOCK) void table_merge_dense_kernel(TableGeom tg, const u64 *__restrict__ dense, u64 n_entries,
+                                                                  uint32_t owner, uint32_t nparts, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    uint32_t nd = 0, nf = 0;
+    for (u64 key = (u64)blockIdx.x * BLOCK + threadIdx.x; key < n_entries; key += stride) {
+        const u64 c = dense[key];
+        if (c != 0 && kh_owner_of(key, tg.k, nparts) == owner) upsert(tg, key, c, nd, nf);
+    }
+    u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (f) atomicAdd(&ctr->failed, f);
+    }
+}
+
 // Move every live pair of `old` into `nt` (table growth).
 __global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, TableGeom tg,
                                                              Counters *ctr) {

@@ -1499,6 +1499,41 @@ extern "C" int kh_merge_pairs(kh_ctx *c, const uint64_t *keys, const uint64_t *c
     return rc;
 }
 
+// ---- dense form (small k): export for an all-reduce(sum), merge back by owner ---------------------
+extern "C" int kh_export_dense_device(kh_ctx *c, uint64_t *d_dense, uint64_t n_entries) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    if (2 * c->k > 26) return fail(c, KH_ERR_RANGE, "the dense form needs 2k <= 26");
+    if (!d_dense || n_entries != (1ull << (2 * c->k))) return fail(c, KH_ERR_BAD_ARG, "d_dense must hold 4^k entries");
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, "table is already a shard");
+    HIP_TRY(c, hipMemsetAsync(d_dense, 0, n_entries * sizeof(u64), c->stream));
+    hipLaunchKernelGGL(kh::table_to_dense_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, (const Slot *)c->table,
+                       c->cap, (u64 *)d_dense, (u64)n_entries);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return KH_OK;
+}
+
+extern "C" int kh_merge_dense_device(kh_ctx *c, const uint64_t *d_dense, uint64_t n_entries, uint32_t owner, uint32_t nparts) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    if (2 * c->k > 26) return fail(c, KH_ERR_RANGE, "the dense form needs 2k <= 26");
+    if (!d_dense || n_entries != (1ull << (2 * c->k)) || nparts == 0 || owner >= nparts)
+        return fail(c, KH_ERR_BAD_ARG, "bad dense array / owner");
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, "a hash-range shard takes kh_merge_regions_*; the dense merge fills a full-geometry table");
+    // at most every canonical key is new: 4^k / 2 plus the palindromes
+    bool smaller = false;
+    rc = ensure_room(c, n_entries / 2 + (1ull << c->k), false, &smaller);
+    if (rc != KH_OK) return rc;
+    hipLaunchKernelGGL(kh::table_merge_dense_kernel, dim3(grid_for(n_entries)), dim3(kh::BLOCK), 0, c->stream,
+                       table_geom(c, c->table, c->cap), (const u64 *)d_dense, (u64)n_entries, owner, nparts, c->d_ctr);
+    HIP_TRY(c, hipGetLastError());
+    c->table_empty = false;
+    c->rheads_valid = false;
+    c->pending_bound += n_entries / 2 + (1ull << c->k);
+    return sync_counters(c);
+}
+
 // ---- hash-range sharding: region-ordered export and LDS merge ------------------------------------
 extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
     int rc = enter(c);

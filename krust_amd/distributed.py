@@ -93,7 +93,7 @@ def exchange_segments(buf, part_counts, group=None):
     return out, recv_sizes
 
 
-def merge_across_ranks(counter, group=None, packed=True):
+def merge_across_ranks(counter, group=None, packed=True, dense=True):
     """Turns per-rank tables (each built from that rank's read shard) into a key-sharded global
     table: afterwards `counter` on rank r holds exactly the keys with kh_owner(key, k, world) == r,
     with counts summed over all ranks.  Returns a dict of sizes for reporting.
@@ -105,7 +105,8 @@ def merge_across_ranks(counter, group=None, packed=True):
       "regions-packed"  u64        = count << 32 | 32 hash bits                      (8 B per pair)
       "regions"         u64 key + u64 count                                          (16 B per pair)
     -- xGMI is point to point, so at world 2 everything crosses ONE link: bytes are what matters.
-    Otherwise: pairs grouped by owner and re-inserted with device atomics ("pairs")."""
+    Otherwise: pairs grouped by owner and re-inserted with device atomics ("pairs").
+    k <= 13 ("dense"): the 4^k key space as a dense count array, merged by ONE all-reduce(sum)."""
     import os
     import time
     timing = {} if os.environ.get("KMERHIP_MERGE_TIMING") else None
@@ -124,6 +125,28 @@ def merge_across_ranks(counter, group=None, packed=True):
     n_local = int(st["distinct"])
     nreg = int(st["table_slots"]) // 4096
     dev = torch.device("cuda", torch.cuda.current_device())
+    if dense and 2 * counter.k <= 26:
+        # Small k: the key space itself is a dense array of 4^k counts, and THAT is element-wise
+        # reducible: one all-reduce(sum), any world size, then every rank keeps the keys it owns.
+        n = 1 << (2 * counter.k)
+        arr = torch.empty(n, dtype=torch.int64, device=dev)
+        counter.export_dense_device(arr.data_ptr(), n)
+        lap("export")
+        if _host_staged(group):
+            h = arr.cpu()
+            dist.all_reduce(h, group=group)
+            arr.copy_(h)
+        else:
+            dist.all_reduce(arr, group=group)
+        lap("all_reduce")
+        counter.reset()
+        counter.merge_dense_device(arr.data_ptr(), n, rank, world)
+        st2 = counter.finish()
+        lap("merge")
+        if timing is not None:
+            print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
+        return {"path": "dense", "local_distinct": n_local, "sent_pairs": n, "recv_pairs": n,
+                "owned_distinct": int(st2["distinct"])}
     keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
     lap("setup")
     pow2 = world & (world - 1) == 0

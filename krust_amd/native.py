@@ -67,6 +67,8 @@ SYMBOLS = {
     "kh_merge_regions_packed_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P]),
     "kh_export_regions_heads_device": (C.c_int, [_P, C.c_uint32, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
     "kh_merge_regions_heads_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P]),
+    "kh_export_dense_device": (C.c_int, [_P, _P, _U64]),
+    "kh_merge_dense_device": (C.c_int, [_P, _P, _U64, C.c_uint32, C.c_uint32]),
     "kh_export_by_owner_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P]),
     "kh_merge_pairs_device": (C.c_int, [_P, _P, _P, _U64]),
     "kh_merge_pairs": (C.c_int, [_P, _P, _P, _U64]),
@@ -325,6 +327,13 @@ class DeviceCounter:
         arr = lambda xs: (_P * n)(*[_P(int(x)) for x in xs])
         ap, ar = arr(d_pairs), arr(d_region_counts)
         self._check(lib().kh_merge_regions_packed_device(self._h, n, int(sender_regions), ap, ar))
+
+    def export_dense_device(self, d_dense, n_entries):
+        """Small k (2k <= 26): d_dense[key] = count over the whole 4^k key space."""
+        self._check(lib().kh_export_dense_device(self._h, d_dense, int(n_entries)))
+
+    def merge_dense_device(self, d_dense, n_entries, owner, nparts):
+        self._check(lib().kh_merge_dense_device(self._h, d_dense, int(n_entries), int(owner), int(nparts)))
 
     def merge_pairs_device(self, d_keys, d_counts, n):
         self._check(lib().kh_merge_pairs_device(self._h, d_keys, d_counts, int(n)))

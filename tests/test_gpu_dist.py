@@ -23,7 +23,7 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 bases, _ = O.synth_reads(20260130, 1 << 18, 150, 0, 30000, with_qual=False)
 # capacity_hint 3 M -> 2^11 regions.  k = 19: 27 hash bits below the region index -> u32 heads;
 # k = 21: 31 bits -> the 64-bit packed unit; k = 31: neither -> key + count.
-for k, expect in ((19, "regions-heads"), (21, "regions-packed"), (31, "regions")):
+for k, expect in ((19, "regions-heads"), (21, "regions-packed"), (31, "regions"), (11, "dense")):
     m = O.OracleMap(); m.scan_flat(bases, k, nthreads=4)
     with krust_amd.DeviceCounter(k, capacity_hint=3_000_000) as dc:
         dc.push(bases)
@@ -31,7 +31,7 @@ for k, expect in ((19, "regions-heads"), (21, "regions-packed"), (31, "regions")
         keys, cnts = dc.result()
     ok, oc = m.arrays()
     assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
-    assert info["sent_pairs"] == 0 and info["recv_pairs"] >= len(m) == info["owned_distinct"]
+    assert (expect == "dense" or info["sent_pairs"] == 0) and info["recv_pairs"] >= len(m) == info["owned_distinct"]
     assert info["path"] == expect, info
 print("NCCL_OK", len(m))
 dist.destroy_process_group()
@@ -93,7 +93,8 @@ dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,path,k,expect", [(2, "partition", 19, "regions-heads"), (4, None, 21, "regions-packed"),
-                                                 (4, None, 17, "regions-heads"), (2, None, 31, "regions"), (3, None, 21, "pairs")])
+                                                 (4, None, 17, "regions-heads"), (2, None, 31, "regions"), (3, None, 21, "pairs"),
+                                                 (3, None, 13, "dense")])
 def test_ranks_sharing_one_gpu_merge_real_tables(world, path, k, expect, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\nPATH = {path!r}\nEXPECT_PATH = {expect!r}\nK = {k}\n" + MULTI)

@@ -537,6 +537,49 @@ def test_heads_export_uses_region_pass_counts(K):
     assert int(got["partition"][0].sum()) > st["distinct"]
 
 
+@pytest.mark.parametrize("k,nshards", [(5, 3), (11, 4), (13, 2)])
+def test_dense_export_and_merge_small_k(K, k, nshards):
+    """k <= 13: the table as a dense array of 4^k counts (what an all-reduce(sum) merges), and back into
+    per-owner tables.  The 'all-reduce' is a sum over logical ranks here."""
+    import torch
+    n_reads = 6000
+    bases, _ = O.synth_reads(SEED, 1 << 16, 150, 0, n_reads, with_qual=False)
+    m = O.OracleMap()
+    m.scan_flat(bases, k, nthreads=NCPU)
+    want = m.as_dict()
+    n = 1 << (2 * k)
+    total = torch.zeros(n, dtype=torch.int64, device="cuda")
+    per = n_reads // nshards
+    for s_ in range(nshards):
+        lo, hi = s_ * per, (n_reads if s_ == nshards - 1 else (s_ + 1) * per)
+        with K.DeviceCounter(k) as dc:
+            dc.push(bases[lo * 151: hi * 151])
+            dc.finish()
+            arr = torch.full((n,), -1, dtype=torch.int64, device="cuda")   # the export must zero what it does not set
+            torch.cuda.synchronize()  # (the context has its own stream: torch's fill must be done first)
+            dc.export_dense_device(arr.data_ptr(), n)
+            d = dc.as_dict()
+        host = arr.cpu().numpy()
+        nz = np.flatnonzero(host)
+        assert len(nz) == len(d) and all(d.get(int(i)) == int(host[i]) for i in nz)
+        total += arr
+    torch.cuda.synchronize()
+    merged = {}
+    for o in range(nshards):
+        with K.DeviceCounter(k) as dc:
+            dc.merge_dense_device(total.data_ptr(), n, o, nshards)
+            dc.finish()
+            d = dc.as_dict()
+        assert all(K.owner(key, k, nshards) == o for key in d)
+        assert not (set(d) & set(merged))
+        merged.update(d)
+    assert merged == want
+    with K.DeviceCounter(14) as dc:
+        with pytest.raises(K.native.KmerHipError) as e:
+            dc.export_dense_device(total.data_ptr(), 1 << 28)
+        assert e.value.status == K.native.KH_ERR_RANGE
+
+
 def test_shard_table_rejects_reads_until_reset(K):
     """A shard table holds only keys of its hash range: reads cannot be pushed into it (state
     error, nothing counted); kh_reset turns it back into a full table."""
