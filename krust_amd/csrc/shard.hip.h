@@ -184,6 +184,8 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     __shared__ u64 s_key[DIRECT ? 1 : REGION_SLOTS];
     __shared__ u64 s_cnt[DIRECT ? 1 : REGION_SLOTS];
     __shared__ uint32_t s_fail, s_new;
+    __shared__ u64 s_seg_lo[MAX_SENDERS];
+    __shared__ uint32_t s_seg_len[MAX_SENDERS];
     const int tid = threadIdx.x;
     // In DIRECT mode the grid still walks the ORIGINAL target regions (old_rbits); tg is the grown table.
     const u64 t = blockIdx.x;
@@ -212,57 +214,96 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
     const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
     constexpr bool PACKED = FMT != 0;
-    for (uint32_t s = 0; s < a.nsenders; ++s)
-    for (u64 rl = rl0; rl < rl0 + (PACKED ? nrl : 1); ++rl) {  // PACKED: segment by segment (the region index is part of the key)
-        const MergeSrc src = a.src[s];
-        const u64 lo = src.off[rl], hi = src.off[PACKED ? rl + 1 : rl0 + nrl];
-        const u64 Hregion = (PACKED && a.src_rbits) ? (a.src_region0 + rl) << (64 - a.src_rbits) : 0;
-        for (u64 i = lo + tid; i < hi; i += 1024) {
-            u64 key, H, addend;
-            if (PACKED) {
-                uint32_t low;
-                if (FMT == 1) {
-                    const u64 p = src.keys[i];
-                    low = (uint32_t)p;
-                    addend = p >> 32;
-                } else {
-                    const uint32_t w = reinterpret_cast<const uint32_t *>(src.keys)[i];
-                    low = w & ~a.head_cmask;
-                    addend = (u64)(w & a.head_cmask) + 1;
-                }
-                const u64 Hs = Hregion | ((u64)low << (32 - a.src_rbits));  // the sender's (unsharded) table hash
-                H = Hs << tg.shard_shift;
-                if ((H >> (64 - match_bits)) != t) continue;  // the segment also feeds the sibling targets
-                key = kh_table_unhash(Hs, tg.k);
-            } else {
-                key = src.keys[i];
-                H = table_hash(tg, key);
-                if ((H >> (64 - match_bits)) != t) continue;
-                addend = src.counts[i];
-            }
-            if (DIRECT) {
-                upsert(tg, key, addend, nd, nf);
-                continue;
-            }
-            uint32_t off = start_of(tg, H);
-            uint32_t probes = 0;
-            for (; probes < REGION_SLOTS; ++probes) {
-                u64 cur = s_key[off];
+    // one incoming unit: raw0 = key / packed pair / head, raw1 = count (FMT 0 only)
+    auto take = [&](u64 raw0, u64 raw1, u64 Hregion) {
+        u64 key, H, addend;
+        if (PACKED) {
+            const uint32_t low = FMT == 1 ? (uint32_t)raw0 : ((uint32_t)raw0 & ~a.head_cmask);
+            addend = FMT == 1 ? (raw0 >> 32) : (u64)((uint32_t)raw0 & a.head_cmask) + 1;
+            const u64 Hs = Hregion | ((u64)low << (32 - a.src_rbits));  // the sender's (unsharded) table hash
+            H = Hs << tg.shard_shift;
+            if ((H >> (64 - match_bits)) != t) return;  // the segment also feeds the sibling targets
+            key = kh_table_unhash(Hs, tg.k);
+        } else {
+            key = raw0;
+            H = table_hash(tg, key);
+            if ((H >> (64 - match_bits)) != t) return;
+            addend = raw1;
+        }
+        if (DIRECT) {
+            upsert(tg, key, addend, nd, nf);
+            return;
+        }
+        uint32_t off = start_of(tg, H);
+        uint32_t probes = 0;
+        for (; probes < REGION_SLOTS; ++probes) {
+            u64 cur = s_key[off];
+            if (cur == KH_EMPTY_KEY) {
+                cur = atomicCAS(&s_key[off], (u64)KH_EMPTY_KEY, key);
                 if (cur == KH_EMPTY_KEY) {
-                    cur = atomicCAS(&s_key[off], (u64)KH_EMPTY_KEY, key);
-                    if (cur == KH_EMPTY_KEY) {
-                        ++nd;
-                        cur = key;
+                    ++nd;
+                    cur = key;
+                }
+            }
+            if (cur == key) {
+                atomicAdd(&s_cnt[off], addend);
+                break;
+            }
+            off = (off + 1) & REGION_MASK;
+        }
+        if (probes == REGION_SLOTS) s_fail = 1;
+    };
+    auto load0 = [&](const MergeSrc &src, u64 i) -> u64 {
+        return FMT == 2 ? (u64)reinterpret_cast<const uint32_t *>(src.keys)[i] : src.keys[i];
+    };
+    if (nrl == 1) {
+        // The usual shape (receiver table at least as large as the senders'): every sender contributes ONE
+        // segment.  Walking the senders one after the other put, per sender, two dependent offset
+        // loads and a unit load in series (~25 us per region).  So: all offsets first, then the units
+        // of four senders in flight at a time (branch-free clamped loads).
+        if (tid < (int)a.nsenders) {
+            const u64 lo = a.src[tid].off[rl0];
+            s_seg_lo[tid] = lo;
+            s_seg_len[tid] = (uint32_t)(a.src[tid].off[rl0 + 1] - lo);  // a region holds <= 4096 keys x <= 64 heads
+        }
+        __syncthreads();
+        const u64 Hregion = (PACKED && a.src_rbits) ? (a.src_region0 + rl0) << (64 - a.src_rbits) : 0;
+        for (uint32_t s0 = 0; s0 < a.nsenders; s0 += 4) {
+            uint32_t len[4], maxlen = 0;
+            u64 lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = s0 + q < a.nsenders;
+                len[q] = on ? s_seg_len[s0 + q] : 0u;
+                lo[q] = on ? s_seg_lo[s0 + q] : 0ull;
+                maxlen = len[q] > maxlen ? len[q] : maxlen;
+            }
+            for (uint32_t base = 0; base < maxlen; base += 1024) {
+                u64 r0[4], r1[4];
+                const uint32_t idx = base + tid;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r0[q] = r1[q] = 0;
+                    if (len[q]) {  // uniform
+                        const MergeSrc &src = a.src[(s0 + q) < a.nsenders ? (s0 + q) : 0];
+                        const u64 i = lo[q] + (idx < len[q] ? idx : len[q] - 1);
+                        r0[q] = load0(src, i);
+                        if (FMT == 0) r1[q] = src.counts[i];
                     }
                 }
-                if (cur == key) {
-                    atomicAdd(&s_cnt[off], addend);
-                    break;
-                }
-                off = (off + 1) & REGION_MASK;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (idx < len[q]) take(r0[q], r1[q], Hregion);
             }
-            if (probes == REGION_SLOTS) s_fail = 1;
         }
+    } else {
+        for (uint32_t s = 0; s < a.nsenders; ++s)
+            for (u64 rl = rl0; rl < rl0 + (PACKED ? nrl : 1); ++rl) {  // PACKED: segment by segment (the region index is part of the key)
+                const MergeSrc src = a.src[s];
+                const u64 lo = src.off[rl], hi = src.off[PACKED ? rl + 1 : rl0 + nrl];
+                const u64 Hregion = (PACKED && a.src_rbits) ? (a.src_region0 + rl) << (64 - a.src_rbits) : 0;
+                for (u64 i = lo + tid; i < hi; i += 1024) take(load0(src, i), FMT == 0 ? src.counts[i] : 0ull, Hregion);
+            }
     }
     if (DIRECT) {
         const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
