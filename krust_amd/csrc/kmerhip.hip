@@ -1536,7 +1536,7 @@ extern "C" int kh_merge_dense_device(kh_ctx *c, const uint64_t *d_dense, uint64_
 
 // ---- hash-range sharding: region-ordered export and LDS merge ------------------------------------
 extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
-    int rc = enter(c);
+    int rc = enter(c, true, false);  // touches no slot: a lazily reset table stays lazily reset
     if (rc != KH_OK) return rc;
     if (count == 0 || (count & (count - 1)) || index >= count || count > (uint32_t)kh::MAX_SENDERS)
         return fail(c, KH_ERR_BAD_ARG, "shard count must be a power of two (<= 64) and index < count");
