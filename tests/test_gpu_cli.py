@@ -231,3 +231,33 @@ def test_malformed_input_keeps_the_parser_error(tmp_path):
     bad.write_bytes(b"@r\nACGT\n+\nII\n")
     r = run("3", str(bad), "--quiet")
     assert r.returncode == 1 and b"unequal length" in r.stderr
+
+
+def test_records_larger_than_the_text_chunk(tmp_path):
+    """hg38-like shape in miniature: FASTA records far larger than the text chunk (the chunk buffer has
+    to grow until it holds a whole record), a FASTQ whose reads straddle every chunk edge, no final
+    newline.  Device record scanning against the host line parser."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    fa = tmp_path / "big_records.fa"
+    with open(fa, "wb") as f:
+        for i, n in enumerate([700_000, 30, 250_000, 1_200_000, 5]):
+            s = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)[rng.choice(9, size=n, p=[.23, .23, .23, .23, .02, .02, .01, .01, .02])].tobytes()
+            f.write(b">chr%d\n" % i)
+            for o in range(0, n, 60):
+                f.write(s[o:o + 60] + (b"\n" if (o + 60 < n or i < 4) else b""))
+    for k in ("21", "31"):
+        dev = run(k, str(fa), "--format", "tsv", "--quiet", env={"KMERUST_TEXT_CHUNK_KB": "64"})
+        host = run(k, str(fa), "--format", "tsv", "--quiet", env={"KMERUST_HOST_PARSE": "1"})
+        assert dev.returncode == 0 and host.returncode == 0, (dev.stderr, host.stderr)
+        assert tsv(dev.stdout) == tsv(host.stdout) and len(tsv(dev.stdout)) > 100_000
+    fq = tmp_path / "reads.fq"
+    with open(fq, "wb") as f:
+        for i in range(3000):
+            n = int(rng.integers(50, 3000))
+            s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].tobytes()
+            f.write(b"@r%d\n%s\n+\n%s" % (i, s, b"I" * n) + (b"\n" if i < 2999 else b""))
+    dev = run("15", str(fq), "-Q", "5", "--format", "histogram", "--quiet", env={"KMERUST_TEXT_CHUNK_KB": "8"})
+    host = run("15", str(fq), "-Q", "5", "--format", "histogram", "--quiet", env={"KMERUST_HOST_PARSE": "1"})
+    assert dev.returncode == 0 and host.returncode == 0, (dev.stderr, host.stderr)
+    assert dev.stdout == host.stdout and dev.stdout
