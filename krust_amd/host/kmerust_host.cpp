@@ -2,6 +2,8 @@
 // for the reference lines each piece mirrors.  Counting is always the HIP path (kh_*).
 #include "kmerust_host.h"
 
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -222,13 +224,41 @@ struct Session {
     // malformed input with the reference's messages).
     bool count_file_text(const std::string &path, SequenceFormat fmt) {
         const bool fastq = fmt == SequenceFormat::Fastq;
-        gzFile gz = gzopen(path.c_str(), "rb");
-        if (!gz) throw Error("failed to read sequence file '" + path + "': " + std::strerror(errno));
+        // plain files are read() straight into the chunk buffer; gzip (magic 1f 8b) goes through zlib
+        const int fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw Error("failed to read sequence file '" + path + "': " + std::strerror(errno));
+        unsigned char magic[2] = {0, 0};
+        const bool is_gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        gzFile gz = is_gz ? gzdopen(fd, "rb") : nullptr;
+        if (is_gz && !gz) {
+            close(fd);
+            throw Error("failed to read sequence file '" + path + "': " + std::strerror(errno));
+        }
         struct Closer {
             gzFile g;
-            ~Closer() { gzclose(g); }
-        } closer{gz};
-        gzbuffer(gz, 1u << 20);
+            int fd;
+            ~Closer() {
+                if (g) gzclose(g);  // closes fd too
+                else close(fd);
+            }
+        } closer{gz, fd};
+        if (gz) gzbuffer(gz, 1u << 20);
+        auto read_some = [&](uint8_t *dst, size_t want) -> size_t {  // 0 = end of file
+            if (gz) {
+                const int n = gzread(gz, dst, (unsigned)std::min<size_t>(want, 1u << 30));
+                if (n < 0) {
+                    int en = 0;
+                    const char *msg = gzerror(gz, &en);
+                    throw Error("failed to decompress gzip file '" + path + "': " + (msg ? msg : "read error"));
+                }
+                return (size_t)n;
+            }
+            for (;;) {
+                const ssize_t n = read(fd, dst, std::min<size_t>(want, (size_t)1 << 30));
+                if (n >= 0) return (size_t)n;
+                if (errno != EINTR) throw Error("failed to read sequence file '" + path + "': " + std::strerror(errno));
+            }
+        };
         const size_t chunk = text_chunk_bytes();
         std::vector<uint8_t> buf(chunk);
         size_t have = 0;
@@ -239,18 +269,12 @@ struct Session {
         };
         while (!eof) {
             while (have < buf.size()) {
-                const size_t want = std::min<size_t>(buf.size() - have, 1u << 30);
-                const int n = gzread(gz, buf.data() + have, (unsigned)want);
-                if (n < 0) {
-                    int en = 0;
-                    const char *msg = gzerror(gz, &en);
-                    throw Error("failed to decompress gzip file '" + path + "': " + (msg ? msg : "read error"));
-                }
+                const size_t n = read_some(buf.data() + have, buf.size() - have);
                 if (n == 0) {
                     eof = true;
                     break;
                 }
-                have += (size_t)n;
+                have += n;
             }
             size_t cut = have;
             if (!eof) {

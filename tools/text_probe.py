@@ -54,7 +54,7 @@ for minq in (None, 20):
             print(f"push_text_device minq={minq}: {dt * 1e3:.1f} ms wall, scan={st['text_scan_ms']:.2f} ms count={st['count_kernel_ms']:.2f} ms", flush=True)
         del d
 
-path = "/tmp/text_probe.fq"
+path = os.environ.get("PROBE_FILE", "/tmp/text_probe.fq")
 text.tofile(path)
 BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "krust_amd", "host", "kmerust")
 for label, env in (("device scan", {}), ("host parser", {"KMERUST_HOST_PARSE": "1"})):
