@@ -316,8 +316,8 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     Counters *ctr) {
     __shared__ uint32_t s_code[2][PART_NT + 2];
     __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ uint32_t s_stage[PART_TILE];   // 64 KiB
-    __shared__ uint16_t s_pid[PART_TILE];     // 32 KiB
+    __shared__ uint32_t s_stage[PART_TILE + 2];   // 64 KiB (+ a trash slot for windows without a key)
+    __shared__ uint16_t s_pid[PART_TILE + 2];     // 32 KiB
     __shared__ uint32_t s_cnt[MAX_P1];
     __shared__ uint32_t s_meta[MAX_P1];       // lofs | split << 16
     __shared__ ChunkDst s_dst[MAX_P1];        // 16 KiB
@@ -372,13 +372,17 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
             if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
+        // Branch-free staging: every lane reads its sixteen run starts back to back (one wait instead of
+        // sixteen exposed LDS round trips behind sixteen branches); windows without a key go to a trash slot.
+        uint32_t rs[CHUNK];
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) {
-                const uint32_t slot = (uint32_t)s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu);
-                s_stage[slot] = pay[j];
-                s_pid[slot] = (uint16_t)(tag[j] >> 16);
-            }
+        for (int j = 0; j < CHUNK; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            const uint32_t slot = tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)PART_TILE;
+            s_stage[slot] = pay[j];
+            s_pid[slot] = (uint16_t)(tag[j] >> 16);
+        }
         {  // lane tid places partition tid's run: the rest of its current chunk, then fresh chunks
             const uint32_t c = s_cnt[tid], lo = s_lofs[tid];
             const uint32_t space = CHUNK_PAY - fill;
@@ -714,7 +718,7 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
                                                                  const Part2Block *__restrict__ blocks,
                                                                  const u64 *__restrict__ info, PartGeom g,
                                                                  const u64 *__restrict__ O2, PT *__restrict__ out) {
-    __shared__ PT s_stage[PART2_TILE];   // 64 KiB (u32) / 128 KiB (u64)
+    __shared__ PT s_stage[PART2_TILE + 1];   // 64 KiB (u32) / 128 KiB (u64), + a trash slot
     __shared__ uint32_t s_cnt[MAX_P1];   // sized for the shared 1024-entry scan
     __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< PART2_TILE <= 32768)
     __shared__ u64 s_dst[1u << MAX_P2_BITS];  // global position of run p minus its batch-local start
@@ -753,9 +757,14 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
             if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
         block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
+        {  // branch-free staging (see part1_scatter_chunked_kernel): all run starts first, then the stores
+            uint32_t rs[P2_PER];
 #pragma unroll
-        for (int j = 0; j < P2_PER; ++j)
-            if (tag[j] != 0xFFFFFFFFu) s_stage[(uint32_t)s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = pay[j];
+            for (int j = 0; j < P2_PER; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
+#pragma unroll
+            for (int j = 0; j < P2_PER; ++j)
+                s_stage[tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)PART2_TILE] = pay[j];
+        }
 #pragma unroll
         for (int q = 0; q < P2_OWN; ++q) {  // publish run destinations, advance the cursors
             const int b = tid + q * PART2_NT;
