@@ -1115,10 +1115,6 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             const u64 i64 = base + (u64)(REGION_RK + j) * REGION_NT + tid;
             kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
         }
-#ifdef KH_EXP_NO_INSERT  // timing experiment only
-        if (s_q[0][tid] == 0x12345678u && lo == 77) s_fail = 1;
-        continue;
-#endif
         if (hot) region32_probe_round<true>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
         else region32_probe_round<false>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
     }
@@ -1161,9 +1157,6 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     uint4 *o4 = reinterpret_cast<uint4 *>(reg);
     uint32_t nheads = 0;
     bool too_wide = false;
-#ifdef KH_EXP_NO_WRITEBACK  // timing experiment only
-    if (s_new != 0xFFFFFFF0u) { if (tid == 0) rnew[r] = s_new; return; }
-#endif
 #pragma unroll
     for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
         const uint32_t i = (uint32_t)q * REGION_NT + tid;
