@@ -14,6 +14,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.hip.h"
@@ -796,6 +797,33 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     return KH_OK;
 }
 
+// Staging copy host -> pinned.  One thread moves ~10 GB/s, PCIe takes ~55 GB/s: large copies are split
+// over a few short-lived threads (the caller's buffer is pageable memory we cannot DMA from directly).
+void staged_memcpy(void *dst, const void *src, size_t n) {
+    static const unsigned hw = [] {
+        unsigned t = std::thread::hardware_concurrency();
+        if (const char *e = getenv("KMERHIP_COPY_THREADS")) t = (unsigned)atoi(e);
+        return t < 1 ? 1u : (t > 6 ? 6u : t);
+    }();
+    const size_t min_part = 4u << 20;
+    unsigned parts = (unsigned)std::min<size_t>(hw, n / min_part);
+    if (parts <= 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    const size_t per = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    th.reserve(parts - 1);
+    for (unsigned i = 1; i < parts; ++i) {
+        const size_t off = (size_t)i * per;
+        if (off >= n) break;
+        const size_t len = std::min(per, n - off);
+        th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (auto &t : th) t.join();
+}
+
 int ensure_stage(kh_ctx *c) {
     if (!c->cstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
@@ -806,6 +834,33 @@ int ensure_stage(kh_ctx *c) {
             HIP_TRY(c, hipEventCreateWithFlags(&c->acc_free[i], hipEventDisableTiming));
         }
     }
+    return KH_OK;
+}
+
+// Device -> pageable host memory through the two pinned staging buffers: the D2H of chunk i+1 runs
+// while chunk i is copied out (by several threads: first-touch page faults of a fresh destination
+// array cost more than the copy itself).
+int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes) {
+    int rc = ensure_stage(c);
+    if (rc != KH_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // d_src was produced on the compute stream
+    HIP_TRY(c, hipStreamSynchronize(c->cstream));  // the staging buffers are free
+    const u64 CH = 2 * STAGE_BYTES;
+    const u64 nch = (bytes + CH - 1) / CH;
+    auto issue = [&](u64 i) -> hipError_t {
+        const u64 off = i * CH, len = std::min(CH, bytes - off);
+        hipError_t e = hipMemcpyAsync(c->h_stage[i & 1], (const char *)d_src + off, len, hipMemcpyDeviceToHost, c->cstream);
+        if (e == hipSuccess) e = hipEventRecord(c->stage_done[i & 1], c->cstream);
+        return e;
+    };
+    if (nch) HIP_TRY(c, issue(0));
+    for (u64 i = 0; i < nch; ++i) {
+        HIP_TRY(c, hipEventSynchronize(c->stage_done[i & 1]));
+        if (i + 1 < nch) HIP_TRY(c, issue(i + 1));
+        const u64 off = i * CH, len = std::min(CH, bytes - off);
+        staged_memcpy((char *)dst + off, c->h_stage[i & 1], len);
+    }
+    c->stage_used[0] = c->stage_used[1] = false;  // nothing in flight on the staging buffers any more
     return KH_OK;
 }
 
@@ -1027,8 +1082,8 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
         const int p = c->stage_next;
         c->stage_next ^= 1;
         if (c->stage_used[p]) HIP_TRY(c, hipEventSynchronize(c->stage_done[p]));
-        memcpy(c->h_stage[p], bases + off, len);
-        if (with_qual) memcpy(c->h_stage[p] + STAGE_BYTES, qual + off, len);
+        staged_memcpy(c->h_stage[p], bases + off, len);
+        if (with_qual) staged_memcpy(c->h_stage[p] + STAGE_BYTES, qual + off, len);
         hipEvent_t t0, t1;
         HIP_TRY(c, hipEventCreate(&t0));
         HIP_TRY(c, hipEventCreate(&t1));
@@ -1181,7 +1236,7 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
         const int p = c->stage_next;
         c->stage_next ^= 1;
         if (c->stage_used[p]) HIP_TRY(c, hipEventSynchronize(c->stage_done[p]));
-        memcpy(c->h_stage[p], text + off, len);
+        staged_memcpy(c->h_stage[p], text + off, len);
         hipEvent_t t0, t1;
         HIP_TRY(c, hipEventCreate(&t0));
         HIP_TRY(c, hipEventCreate(&t1));
@@ -1307,12 +1362,9 @@ extern "C" int kh_result_copy(kh_ctx *c, uint64_t *keys, uint64_t *counts, uint6
     }
     uint64_t got = 0;
     rc = kh_result_copy_device(c, dk, dc, need, min_count, &got);
-    if (rc == KH_OK) {
-        hipError_t e1 = hipMemcpy(keys, dk, got * sizeof(u64), hipMemcpyDeviceToHost);
-        hipError_t e2 = hipMemcpy(counts, dc, got * sizeof(u64), hipMemcpyDeviceToHost);
-        if (e1 != hipSuccess || e2 != hipSuccess) rc = fail(c, KH_ERR_HIP, "hipMemcpy(result)", e1 != hipSuccess ? e1 : e2);
-        else *n = got;
-    }
+    if (rc == KH_OK) rc = d2h_staged(c, keys, dk, got * sizeof(u64));
+    if (rc == KH_OK) rc = d2h_staged(c, counts, dc, got * sizeof(u64));
+    if (rc == KH_OK) *n = got;
     (void)hipFree(dk);
     (void)hipFree(dc);
     return rc;
