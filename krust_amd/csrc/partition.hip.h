@@ -35,7 +35,10 @@ constexpr uint32_t MAX_P1_BITS = 10;
 constexpr uint32_t MAX_P2_BITS = 10;             // <= 1024 regions per level-1 partition
 constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // payloads per level-2 workgroup (262144)
 constexpr int REGION_NT = 1024;                  // lanes per workgroup in region_count_kernel
-constexpr int REGION_RK = 8;                     // keys prefetched per lane per round
+#ifndef KH_REGION_RK
+#define KH_REGION_RK 8
+#endif
+constexpr int REGION_RK = KH_REGION_RK;                     // keys prefetched per lane per round
 
 struct PartGeom {
     uint32_t rbits;        // log2(regions) = p1_bits + p2_bits

@@ -93,7 +93,7 @@ def exchange_segments(buf, part_counts, group=None):
     return out, recv_sizes
 
 
-def merge_across_ranks(counter, group=None, packed=True, dense=True):
+def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times=False):
     """Turns per-rank tables (each built from that rank's read shard) into a key-sharded global
     table: afterwards `counter` on rank r holds exactly the keys with kh_owner(key, k, world) == r,
     with counts summed over all ranks.  Returns a dict of sizes for reporting.
@@ -109,7 +109,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True):
     k <= 13 ("dense"): the 4^k key space as a dense count array, merged by ONE all-reduce(sum)."""
     import os
     import time
-    timing = {} if os.environ.get("KMERHIP_MERGE_TIMING") else None
+    timing = {} if (phase_times or os.environ.get("KMERHIP_MERGE_TIMING")) else None
     t_last = [time.perf_counter()]
 
     def lap(name):  # phase wall times (with a device sync), only when asked for
@@ -143,10 +143,10 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True):
         counter.merge_dense_device(arr.data_ptr(), n, rank, world)
         st2 = counter.finish()
         lap("merge")
-        if timing is not None:
+        if timing is not None and os.environ.get("KMERHIP_MERGE_TIMING"):
             print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
         return {"path": "dense", "local_distinct": n_local, "sent_pairs": n, "recv_pairs": n,
-                "owned_distinct": int(st2["distinct"])}
+                "owned_distinct": int(st2["distinct"]), "phase_ms": timing}
     keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
     lap("setup")
     pow2 = world & (world - 1) == 0
@@ -217,10 +217,10 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True):
         path, n_recv = "pairs", rk.numel()
     st2 = counter.finish()
     lap("finish")
-    if timing is not None:
+    if timing is not None and os.environ.get("KMERHIP_MERGE_TIMING"):
         print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
     return {"path": path, "local_distinct": n_local, "sent_pairs": int(parts.sum() - parts[rank]),  # in exchange units
-            "recv_pairs": int(n_recv), "owned_distinct": int(st2["distinct"])}
+            "recv_pairs": int(n_recv), "owned_distinct": int(st2["distinct"]), "phase_ms": timing}
 
 
 def group_pairs_by_owner(keys, counts, world, owner_fn):
