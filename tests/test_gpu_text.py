@@ -209,3 +209,76 @@ def test_push_text_device_needs_alignment_and_matches_host_text():
         dc.finish()
         keys, counts = dc.result()
     assert dict(zip(keys.tolist(), counts.tolist())) == expect(text, "fastq", 21, 20)
+
+
+# ---------------------------------------------------------------------------
+# property tests: arbitrary small texts, device scanner vs a line-by-line restatement
+# ---------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st, HealthCheck  # noqa: E402
+
+_seq_line = st.text(alphabet="ACGTacgtNn", min_size=0, max_size=40).map(str.encode)
+_eol = st.sampled_from([b"\n", b"\r\n"])
+
+
+@st.composite
+def fasta_texts(draw):
+    eol = draw(_eol)
+    out = []
+    for i in range(draw(st.integers(1, 6))):
+        out.append(b">" + draw(st.text(alphabet="ACGT >@+x", max_size=12)).encode() + eol)
+        for _ in range(draw(st.integers(0, 5))):
+            out.append(draw(_seq_line) + eol)
+    text = b"".join(out)
+    if draw(st.booleans()) and text.endswith(eol):
+        text = text[: -len(eol)]
+    return text
+
+
+@st.composite
+def fastq_texts(draw):
+    eol = draw(_eol)
+    out = []
+    for i in range(draw(st.integers(1, 8))):
+        seq = draw(_seq_line)
+        qual = bytes(draw(st.lists(st.sampled_from(list(b"!#+5?I@+>")), min_size=len(seq), max_size=len(seq))))
+        out.append(b"@" + draw(st.text(alphabet="ACGT @+x", max_size=8)).encode() + eol + seq + eol + b"+" + eol + qual + eol)
+    text = b"".join(out)
+    if draw(st.booleans()) and len(seq):  # (an EMPTY last quality line without its newline is not a line at all)
+        text = text[: -len(eol)]
+    return text
+
+
+@pytest.fixture(scope="module")
+def text_counters():
+    """One context per (k, min_quality) reused across examples (context creation dominates otherwise)."""
+    made = {}
+
+    def get(k, minq):
+        if (k, minq) not in made:
+            made[(k, minq)] = native.DeviceCounter(k, min_quality=minq)
+        dc = made[(k, minq)]
+        dc.reset()
+        return dc
+
+    yield get
+    for dc in made.values():
+        dc.close()
+
+
+def _device_dict(dc, text, fmt):
+    dc.push_text(text, fmt)
+    dc.finish()
+    keys, counts = dc.result()
+    return dict(zip(keys.tolist(), counts.tolist()))
+
+
+@given(fasta_texts(), st.sampled_from([1, 2, 3, 5, 11]))
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+def test_prop_fasta_text(text_counters, text, k):
+    assert _device_dict(text_counters(k, None), text, "fasta") == expect(text, "fasta", k, None)
+
+
+@given(fastq_texts(), st.sampled_from([1, 3, 7]), st.sampled_from([None, 0, 10, 20, 40]))
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+def test_prop_fastq_text(text_counters, text, k, minq):
+    assert _device_dict(text_counters(k, minq), text, "fastq") == expect(text, "fastq", k, minq)
