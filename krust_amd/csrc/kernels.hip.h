@@ -199,9 +199,13 @@ __device__ __forceinline__ uint32_t swar_flags4(uint32_t m) {
     return ((m >> 4) & 8u) | ((m >> 13) & 4u) | ((m >> 22) & 2u) | (m >> 31);
 }
 __device__ __forceinline__ uint32_t swar_valid4(uint32_t w, uint32_t q, uint32_t thr4, bool qual) {
-    const uint32_t u = w & 0xDFDFDFDFu;  // fold case: accepted bytes are exactly ACGTacgt (src/kmer.rs:271-273)
-    uint32_t m = swar_zero_bytes(u ^ 0x41414141u) | swar_zero_bytes(u ^ 0x43434343u) | swar_zero_bytes(u ^ 0x47474747u) |
-                 swar_zero_bytes(u ^ 0x54545454u);
+    // Accepted bytes are exactly ACGTacgt (src/kmer.rs:271-273).  Every byte has SOME 2-bit code; a
+    // byte is a base iff, case folded, it equals the letter of its own code.  The four letters come
+    // from one byte-select (v_perm_b32 with the codes as selectors) instead of four SWAR compares.
+    const uint32_t u = w & 0xDFDFDFDFu;
+    const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;               // as in swar_codes4
+    const uint32_t letters = __builtin_amdgcn_perm(0u, 0x54474341u, t);  // selector 0..3 -> 'A','C','G','T'
+    uint32_t m = swar_zero_bytes(u ^ letters);
     if (qual) m &= swar_ge_bytes(q, thr4);  // run.rs:545: skip iff qv < threshold
     return swar_flags4(m);
 }
