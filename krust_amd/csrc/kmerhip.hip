@@ -39,7 +39,10 @@ constexpr u64 ACC_MAX = 2ull << 30;        // device accumulation buffer of kh_p
 constexpr u64 ACC_MIN = 1ull << 20;
 constexpr u64 HALO = 32;                   // >= k-1 bytes re-sent in front of every staged chunk
 constexpr int GRID_CAP = 256 * 8;          // 256 CUs x 8 resident workgroups of 256 threads
-constexpr int PART_G1 = 512;               // level-1 workgroups (fixed: count and scatter must agree)
+#ifndef KH_PART_G1
+#define KH_PART_G1 512
+#endif
+constexpr int PART_G1 = KH_PART_G1;               // level-1 workgroups (fixed: count and scatter must agree)
 constexpr u64 PART_MIN_WINDOWS = 1ull << 22;   // below this the partition passes cannot pay off
 constexpr double LOAD_PART = 0.70;         // grow before the next partitioned batch above this load
 enum { ST_DIRECT = 0, ST_P1_COUNT, ST_P1_SCATTER, ST_P2_COUNT, ST_P2_SCATTER, ST_REGION, ST_MISC, ST_GROW, ST_N, ST_TEXT = ST_N };
