@@ -467,9 +467,10 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
 // PT = payload type carried through the partition buffers (partition.hip.h).
-template <typename PT>
+// CHUNKED: single-pass level 1 into a chunk pool (the default for both payload types); false = the
+// older count + scan + scatter level 1 with dense partitions (u64 only, env KMERHIP_LEVEL1=two-pass).
+template <typename PT, bool CHUNKED>
 int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 tile0, u64 ntiles) {
-    constexpr bool CHUNKED = sizeof(PT) == 4;  // 32-bit payloads: single-pass level 1 into a chunk pool
     const u64 nregions = 1ull << g.rbits;
     const u64 P1 = 1ull << g.p1_bits;
     const u64 n_ub = ntiles * kh::PART_TILE;  // upper bound on keys
@@ -543,7 +544,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
     const dim3 g1(PART_G1), b1(kh::PART_NT);
     kh::ChunkSrc cs;
-    cs.pay = reinterpret_cast<const uint32_t *>(c->keysA);
+    cs.pay = c->keysA;
     cs.plist = c->plist;
     cs.fill8 = c->fill8;
 
@@ -558,13 +559,13 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         {
             StageTimer t(c, ST_P1_SCATTER);
 #define KH_P1_LAUNCH(QUAL, MODE, FAST) \
-    hipLaunchKernelGGL((kh::part1_scatter_chunked_kernel<QUAL, MODE, FAST>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
-                       ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
+    hipLaunchKernelGGL((kh::part1_scatter_chunked_kernel<QUAL, MODE, FAST, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
+                       ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (PT *)c->keysA, \
                        c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
 #define KH_P1_LAUNCH2(QUAL, MODE) \
     do { if (fast) KH_P1_LAUNCH(QUAL, MODE, true); else KH_P1_LAUNCH(QUAL, MODE, false); } while (0)
             const bool m24 = kh_k_uses_mul24(c->k);  // the Feistel multiplier is a compile-time choice in the hot kernel
-            const bool fast = kh::p1_fast_ok(g);
+            const bool fast = sizeof(PT) == 4 && kh::p1_fast_ok(g);
             if (ra.use_qual && m24) KH_P1_LAUNCH2(true, KH_MUL_24);
             else if (ra.use_qual) KH_P1_LAUNCH2(true, KH_MUL_32);
             else if (m24) KH_P1_LAUNCH2(false, KH_MUL_24);
@@ -793,7 +794,12 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         const u64 nb = (left + batch_tiles - 1) / batch_tiles;  // equal-sized batches
         batch_tiles = (left + nb - 1) / nb;
         const u64 nt = std::min(batch_tiles, left);
-        int rc = gc.use32 ? partition_batch<uint32_t>(c, ra, gc.g, t, nt) : partition_batch<u64>(c, ra, gc.g, t, nt);
+        static const bool two_pass = [] {
+            const char *e = getenv("KMERHIP_LEVEL1");
+            return e && !strcmp(e, "two-pass");
+        }();
+        int rc = gc.use32 ? partition_batch<uint32_t, true>(c, ra, gc.g, t, nt)
+                          : two_pass ? partition_batch<u64, false>(c, ra, gc.g, t, nt) : partition_batch<u64, true>(c, ra, gc.g, t, nt);
         if (rc != KH_OK) return rc;
         t += nt;
     }

@@ -131,7 +131,7 @@ constexpr uint32_t CPB = 1024;          // chunks per level-2 workgroup (262144 
 constexpr uint16_t PART_NONE = 0xFFFFu; // chunk_part[] of a chunk nobody owns
 
 struct ChunkSrc {                 // how level 2 reads a chunked level-1 output
-    const uint32_t *pay;          // pool
+    const void *pay;              // pool (PT payloads)
     const uint32_t *plist;        // chunk ids ordered by partition
     const uint8_t *fill8;         // payloads in the chunk minus one
 };
@@ -163,7 +163,7 @@ __device__ __forceinline__ bool p2_load(const PT *__restrict__ dense, const Chun
     const uint32_t chunk = s_chk[ec >> 8];
     const uint32_t off = ec & (CHUNK_PAY - 1);
     const uint32_t have = s_cfill[ec >> 8];
-    out = (PT)cs.pay[(u64)chunk * CHUNK_PAY + (off < have ? off : 0)];
+    out = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (off < have ? off : 0)];
     return e < n && off < have;
 }
 template <bool CHUNKED>
@@ -311,22 +311,28 @@ struct ChunkDst {  // per partition, per batch: where staged element i (local in
     u64 b;         // e >= split: pool index = b + i   (freshly taken, consecutive chunks)
 };
 
-template <bool QUAL, int MODE, bool FAST>
+// PT = uint32_t: one sorting round of 16 windows per lane per tile.  PT = u64 (k >= 22): TWO rounds of 8
+// windows per lane, so that the staged payloads take the same 64 KiB of LDS and the per-partition runs
+// the same 64 bytes; the extraction state (Roller) simply carries on between the rounds.
+template <bool QUAL, int MODE, bool FAST, typename PT>
 __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
+    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, PT *__restrict__ pool,
     uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
     Counters *ctr) {
+    constexpr int ROUNDS = sizeof(PT) == 8 ? 2 : 1;
+    constexpr int WPR = CHUNK / ROUNDS;         // windows per lane per round
+    constexpr int RTILE = PART_NT * WPR;        // staged payloads per round
     __shared__ uint32_t s_code[2][PART_NT + 2];
     __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ uint32_t s_stage[PART_TILE + 2];   // 64 KiB (+ a trash slot for windows without a key)
-    __shared__ uint16_t s_pid[PART_TILE + 2];     // 32 KiB
+    __shared__ PT s_stage[RTILE + 2];           // 64 KiB (+ a trash slot for windows without a key)
+    __shared__ uint16_t s_pid[RTILE + 2];       // 32 / 16 KiB
     __shared__ uint32_t s_cnt[MAX_P1];
-    __shared__ uint32_t s_meta[MAX_P1];       // lofs | split << 16
-    __shared__ ChunkDst s_dst[MAX_P1];        // 16 KiB
+    __shared__ uint32_t s_meta[MAX_P1];         // lofs | split << 16
+    __shared__ ChunkDst s_dst[MAX_P1];          // 16 KiB
     __shared__ uint32_t s_wsum[4];
     __shared__ uint16_t s_lofs[MAX_P1];
-    __shared__ u64 s_priv_next, s_priv_end;   // the workgroup's private range of chunk ids
+    __shared__ u64 s_priv_next, s_priv_end;     // the workgroup's private range of chunk ids
     const int tid = threadIdx.x;
     s_cnt[tid] = 0;
     if (tid == 0) {
@@ -346,93 +352,104 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
         const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
-        uint32_t pay[CHUNK];
-        uint32_t tag[CHUNK];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
         Roller roll;
         roll.init(w, k, wlo);
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            u64 key;
-            const bool ok = roll.next(j, key);
-            uint32_t p1 = 0;
-            // Without quality masking nearly every window is valid (N is rare): hashing unconditionally
-            // is cheaper than an exec-mask region per window.  With -Q ~40 % of the windows are masked,
-            // there the branch pays.
-            if (!QUAL || ok) {
-                if (FAST) {
-                    hash_p1_pay32<MODE>(g, key, p1, pay[j]);
-                } else {
-                    const u64 H = part_hash<MODE>(g, key);
-                    pay[j] = Pay<uint32_t>::make(key, H, g);
-                    p1 = p1_of_hash(H, g);
+        for (int h = 0; h < ROUNDS; ++h) {
+            PT pay[WPR];
+            uint32_t tag[WPR];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
+#pragma unroll
+            for (int j = 0; j < WPR; ++j) {
+                u64 key;
+                const bool ok = roll.next(h * WPR + j, key);
+                uint32_t p1 = 0;
+                // Without quality masking nearly every window is valid (N is rare): hashing unconditionally
+                // is cheaper than an exec-mask region per window.  With -Q ~40 % of the windows are masked,
+                // there the branch pays.
+                if (!QUAL || ok) {
+                    if (sizeof(PT) == 8) {
+                        pay[j] = (PT)key;
+                        p1 = p1_of_hash(part_hash<MODE>(g, key), g);
+                    } else if (FAST) {
+                        uint32_t pw;
+                        hash_p1_pay32<MODE>(g, key, p1, pw);
+                        pay[j] = (PT)pw;
+                    } else {
+                        const u64 H = part_hash<MODE>(g, key);
+                        pay[j] = (PT)Pay<uint32_t>::make(key, H, g);
+                        p1 = p1_of_hash(H, g);
+                    }
                 }
+                tag[j] = ok ? (p1 << 16) : 0xFFFFFFFFu;
             }
-            tag[j] = ok ? (p1 << 16) : 0xFFFFFFFFu;
-        }
-        // ranks in a second sweep: sixteen LDS atomics in flight instead of one wait per window
+            // ranks in a second sweep: all LDS atomics in flight instead of one wait per window
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
-        __syncthreads();
-        block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
-        // Branch-free staging: every lane reads its sixteen run starts back to back (one wait instead of
-        // sixteen exposed LDS round trips behind sixteen branches); windows without a key go to a trash slot.
-        uint32_t rs[CHUNK];
+            for (int j = 0; j < WPR; ++j)
+                if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
+            __syncthreads();
+            block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
+            // Branch-free staging: every lane reads its run starts back to back (one wait instead of an
+            // exposed LDS round trip behind a branch per window); windows without a key go to a trash slot.
+            uint32_t rs[WPR];
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
+            for (int j = 0; j < WPR; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            const uint32_t slot = tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)PART_TILE;
-            s_stage[slot] = pay[j];
-            s_pid[slot] = (uint16_t)(tag[j] >> 16);
-        }
-        {  // lane tid places partition tid's run: the rest of its current chunk, then fresh chunks
-            const uint32_t c = s_cnt[tid], lo = s_lofs[tid];
-            const uint32_t space = CHUNK_PAY - fill;
-            ChunkDst d;
-            d.a = cur * CHUNK_PAY + fill - lo;
-            d.b = 0;
-            if (c > space) {
-                const uint32_t r = c - space;
-                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
-                u64 first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
-                if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
-                if (first + nnew > pool_chunks) {  // cannot happen with the host's pool sizing; never write past it
-                    lost += r;
-                    first = 0;
-                    d.b = ~0ull;  // marks "drop" for the write-out
+            for (int j = 0; j < WPR; ++j) {
+                const uint32_t slot = tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)RTILE;
+                s_stage[slot] = pay[j];
+                s_pid[slot] = (uint16_t)(tag[j] >> 16);
+            }
+            {  // lane tid places partition tid's run: the rest of its current chunk, then fresh chunks
+                const uint32_t c = s_cnt[tid], lo = s_lofs[tid];
+                const uint32_t space = CHUNK_PAY - fill;
+                ChunkDst d;
+                d.a = cur * CHUNK_PAY + fill - lo;
+                d.b = 0;
+                if (c > space) {
+                    const uint32_t r = c - space;
+                    const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
+                    u64 first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
+                    if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
+                    if (first + nnew > pool_chunks) {  // cannot happen with the host's pool sizing; never write past it
+                        lost += r;
+                        first = 0;
+                        d.b = ~0ull;  // marks "drop" for the write-out
+                    } else {
+                        for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
+                        d.b = first * CHUNK_PAY - space - lo;
+                        cur = first + nnew - 1;
+                        fill = r - (nnew - 1) * CHUNK_PAY;
+                        have_chunk = true;
+                    }
                 } else {
-                    for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
-                    d.b = first * CHUNK_PAY - space - lo;
-                    cur = first + nnew - 1;
-                    fill = r - (nnew - 1) * CHUNK_PAY;
-                    have_chunk = true;
+                    fill += c;
                 }
-            } else {
-                fill += c;
+                s_dst[tid] = d;
+                s_meta[tid] = lo | (space << 16);
             }
-            s_dst[tid] = d;
-            s_meta[tid] = lo | (space << 16);
-        }
-        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
-        __syncthreads();
-        s_cnt[tid] = 0;  // the next tile's stage_tile() barrier orders this before its atomics
-        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next tile
-            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-            s_priv_end = s_priv_next + POOL_GRAB;
-        }
-        // next tile's bases are fetched while this tile's runs are written out
-        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+            const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
+            __syncthreads();
+            s_cnt[tid] = 0;  // ordered before the next atomics by the barrier below / the next tile's stage_tile() barrier
+            if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next round
+                s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+                s_priv_end = s_priv_next + POOL_GRAB;
+            }
+            // next tile's bases are fetched while this tile's last runs are written out
+            if (h == ROUNDS - 1)
+                raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
 #pragma unroll 2
-        for (uint32_t i = tid; i < total; i += PART_NT) {
-            const uint32_t p = s_pid[i];
-            const uint32_t meta = s_meta[p];
-            const ChunkDst d = s_dst[p];
-            const uint32_t e = i - (meta & 0xFFFFu);
-            if (e < (meta >> 16)) pool[d.a + i] = s_stage[i];
-            else if (d.b != ~0ull) pool[d.b + i] = s_stage[i];
+            for (uint32_t i = tid; i < total; i += PART_NT) {
+                const uint32_t p = s_pid[i];
+                const uint32_t meta = s_meta[p];
+                const ChunkDst d = s_dst[p];
+                const uint32_t e = i - (meta & 0xFFFFu);
+                if (e < (meta >> 16)) pool[d.a + i] = s_stage[i];
+                else if (d.b != ~0ull) pool[d.b + i] = s_stage[i];
+            }
+            // s_stage / s_dst / s_meta are rewritten only after the next round's / tile's barriers; the
+            // counters, though, are hit by the next round's atomics right away
+            if (h + 1 < ROUNDS) __syncthreads();
         }
-        // s_stage / s_dst / s_meta are rewritten only after the next tile's barriers
     }
     if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
     const u64 l = wave_sum((u64)lost);
