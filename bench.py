@@ -231,9 +231,9 @@ def main():
         achieved = alg_bytes_step / (kernel_ms_step * 1e-3) / 1e9 if kernel_ms_step > 0 else 0.0
         stages = {name: ms / args.steps for name, ms in stage_ms.items() if ms > 0}
         part = st["part_batches"] > 0
-        pay = 4 if (part and k <= 21) else 8
+        pay = 4 if (part and k <= 21) else 8  # payload bytes carried through the partition buffers
         # bytes each stage must move at minimum (its own algorithmic traffic)
-        stage_bytes = {"direct": alg_bytes_step, "p1_count": nbytes * (2 if with_qual else 1),
+        stage_bytes = {"direct": alg_bytes_step,
                        "p1_scatter": nbytes * (2 if with_qual else 1) + pay * st["kmers"],
                        "p2_count": pay * st["kmers"], "p2_scatter": 2 * pay * st["kmers"],
                        "region": pay * st["kmers"] + 16 * st["table_slots"]}
@@ -271,8 +271,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "frac_of_measured_copy_peak": achieved / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s copy
-                         "kernel": ("partitioned pipeline: part1_scatter_chunked (single-pass level 1; k >= 22: part1_count + "
-                                    "part1_scatter) + part2_count + part2_scatter + region_count, one launch each per batch")
+                         "kernel": "partitioned pipeline: part1_scatter_chunked (single-pass level 1) + part2_count + part2_scatter + "
+                                   "region_count, one launch each per batch"
                          if part else "count_direct_kernel",
                          "launches_per_step": int(st["launches"]), "kernel_ms_per_step": kernel_ms_step,
                          "alg_bytes_per_step": alg_bytes_step,

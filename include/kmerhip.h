@@ -83,8 +83,8 @@ typedef struct kh_config {
 /* indices into kh_stats.stage_ms */
 #define KH_NUM_STAGES 8
 #define KH_STAGE_DIRECT 0      /* count_direct_kernel */
-#define KH_STAGE_P1_COUNT 1    /* part1_count_kernel */
-#define KH_STAGE_P1_SCATTER 2  /* part1_scatter_kernel */
+#define KH_STAGE_P1_COUNT 1    /* (no longer used: level 1 is a single pass; always 0) */
+#define KH_STAGE_P1_SCATTER 2  /* part1_scatter_chunked_kernel */
 #define KH_STAGE_P2_COUNT 3    /* part2_count_kernel */
 #define KH_STAGE_P2_SCATTER 4  /* part2_scatter_kernel */
 #define KH_STAGE_REGION 5      /* region_count_kernel */

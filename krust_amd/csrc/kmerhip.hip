@@ -101,8 +101,6 @@ struct kh_ctx {
     u64 part_budget = 0;       // bytes for the two key buffers (0 = decide at first use)
     uint8_t *keysA = nullptr, *keysB = nullptr;  // partition ping-pong buffers
     u64 key_cap = 0;           // bytes per buffer
-    uint32_t *H1 = nullptr;
-    u64 *O1 = nullptr;
     kh::Part2Block *blocks = nullptr;
     u64 blocks_cap = 0;
     u64 *moff = nullptr;
@@ -467,27 +465,20 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
 // PT = payload type carried through the partition buffers (partition.hip.h).
-// CHUNKED: single-pass level 1 into a chunk pool (the default for both payload types); false = the
-// older count + scan + scatter level 1 with dense partitions (u64 only, env KMERHIP_LEVEL1=two-pass).
-template <typename PT, bool CHUNKED>
+template <typename PT>
 int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 tile0, u64 ntiles) {
+    constexpr bool CHUNKED = true;  // level 1 always goes into the chunk pool (partition.hip.h)
     const u64 nregions = 1ull << g.rbits;
     const u64 P1 = 1ull << g.p1_bits;
     const u64 n_ub = ntiles * kh::PART_TILE;  // upper bound on keys
     // chunk pool: every payload + one partial chunk per (workgroup, partition) + the unused tail of
     // every workgroup's private ranges
-    const u64 pool_chunks = CHUNKED ? (n_ub / kh::CHUNK_PAY) + (n_ub / kh::CHUNK_PAY) / 24 +
-                                          (u64)PART_G1 * (P1 + kh::POOL_GRAB) + 1024
-                                    : 0;
-    const u64 max_blocks = CHUNKED ? pool_chunks / kh::CPB + P1 + 1 : (n_ub + kh::PART2_CHUNK - 1) / kh::PART2_CHUNK + P1;
-    const u64 n1 = P1 * PART_G1;
+    const u64 pool_chunks = (n_ub / kh::CHUNK_PAY) + (n_ub / kh::CHUNK_PAY) / 24 + (u64)PART_G1 * (P1 + kh::POOL_GRAB) + 1024;
+    const u64 max_blocks = pool_chunks / kh::CPB + P1 + 1;
     const u64 n2 = max_blocks << g.p2_bits;
     int rc;
-    if (!c->H1) {  // fixed-size scratch, allocated once
+    if (!c->moff) {  // fixed-size scratch, allocated once
         u64 z = 0;
-        if ((rc = ensure_buf(c, &c->H1, &z, (u64)kh::MAX_P1 * PART_G1, "hipMalloc(H1)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->O1, &z, (u64)kh::MAX_P1 * PART_G1 + 1, "hipMalloc(O1)")) != KH_OK) return rc;
         z = 0;
         if ((rc = ensure_buf(c, &c->moff, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(moff)")) != KH_OK) return rc;
         z = 0;
@@ -520,7 +511,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->rheads, &z, nregions, "hipMalloc(rheads)")) != KH_OK) return rc;
         c->region_cap = nregions;
     }
-    if (CHUNKED && c->pool_cap < pool_chunks) {
+    if (c->pool_cap < pool_chunks) {
         u64 z = c->chunk_part ? c->pool_cap : 0;
         if ((rc = ensure_buf(c, &c->chunk_part, &z, pool_chunks, "hipMalloc(chunk_part)")) != KH_OK) return rc;
         z = c->fill8 ? c->pool_cap : 0;
@@ -529,7 +520,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->plist, &z, pool_chunks, "hipMalloc(plist)")) != KH_OK) return rc;
         c->pool_cap = pool_chunks;
     }
-    const u64 a_bytes = CHUNKED ? pool_chunks * kh::CHUNK_PAY * sizeof(PT) : n_ub * sizeof(PT);
+    const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
     const u64 key_bytes = std::max(a_bytes, n_ub * (u64)sizeof(PT));
     if (c->key_cap < key_bytes) {  // key_cap is in BYTES per buffer
         u64 z = c->keysA ? c->key_cap : 0;
@@ -548,7 +539,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     cs.plist = c->plist;
     cs.fill8 = c->fill8;
 
-    if (CHUNKED) {
+    {
         {
             StageTimer t(c, ST_MISC);
             HIP_TRY(c, hipMemsetAsync(c->chunk_part, 0xFF, pool_chunks * sizeof(uint16_t), c->stream));
@@ -582,35 +573,6 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
                                c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount);
             hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
                                (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
-            HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
-        }
-    } else {
-        {
-            StageTimer t(c, ST_P1_COUNT);
-            if (ra.use_qual)
-                hipLaunchKernelGGL(kh::part1_count_kernel<true>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
-                                   ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
-            else
-                hipLaunchKernelGGL(kh::part1_count_kernel<false>, g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg,
-                                   ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, c->H1);
-        }
-        {
-            StageTimer t(c, ST_MISC);
-            if ((rc = device_scan(c, c->H1, n1, c->O1)) != KH_OK) return rc;
-        }
-        {
-            StageTimer t(c, ST_P1_SCATTER);
-            if (ra.use_qual)
-                hipLaunchKernelGGL((kh::part1_scatter_kernel<true, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
-                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
-            else
-                hipLaunchKernelGGL((kh::part1_scatter_kernel<false, PT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned,
-                                   ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (const u64 *)c->O1, bufA);
-        }
-        {
-            StageTimer t(c, ST_MISC);
-            hipLaunchKernelGGL(kh::part2_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->O1, (uint32_t)PART_G1, g,
-                               n1, c->blocks, max_blocks, c->moff, c->nch, c->info);
             HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
         }
     }
@@ -794,12 +756,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         const u64 nb = (left + batch_tiles - 1) / batch_tiles;  // equal-sized batches
         batch_tiles = (left + nb - 1) / nb;
         const u64 nt = std::min(batch_tiles, left);
-        static const bool two_pass = [] {
-            const char *e = getenv("KMERHIP_LEVEL1");
-            return e && !strcmp(e, "two-pass");
-        }();
-        int rc = gc.use32 ? partition_batch<uint32_t, true>(c, ra, gc.g, t, nt)
-                          : two_pass ? partition_batch<u64, false>(c, ra, gc.g, t, nt) : partition_batch<u64, true>(c, ra, gc.g, t, nt);
+        int rc = gc.use32 ? partition_batch<uint32_t>(c, ra, gc.g, t, nt) : partition_batch<u64>(c, ra, gc.g, t, nt);
         if (rc != KH_OK) return rc;
         t += nt;
     }
@@ -1008,7 +965,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
         if (c->acc_free[i]) (void)hipEventDestroy(c->acc_free[i]);
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
-    void *scratch[] = {c->keysA, c->keysB, c->H1, c->O1, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
+    void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
                        c->bstart, c->rfail, c->rnew, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};

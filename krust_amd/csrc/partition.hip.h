@@ -15,11 +15,13 @@
 //             whenever 2k - p1_bits <= 32 (k <= 21 with 1024 level-1 partitions).  Halves the
 //             HBM traffic of every stage after the extraction.
 //
-// Both partition levels are "count, scan, scatter" with deterministic offsets (no global cursor
-// atomics): workgroup b owns a fixed contiguous range of its input, the count pass writes its
-// per-partition histogram as a column of a [partition][workgroup] matrix, an exclusive scan of the
-// flattened matrix yields every (partition, workgroup) output offset, and the scatter pass
-// re-reads the same range, counting-sorts each batch in LDS and writes per-partition runs.
+// Level 1 is ONE pass: a workgroup counting-sorts the payloads of a tile in LDS and appends every
+// partition's run to that partition's current chunk of a chunk pool (see below), so no counting pass
+// is needed to know where data goes.  Level 2 is "count, scan, scatter" with deterministic offsets (no
+// global cursor atomics): workgroup b owns a fixed slice of one level-1 partition's chunk list, the
+// count pass writes its per-bucket histogram as a column of a [bucket][workgroup] matrix, an exclusive
+// scan of the flattened matrix yields every (bucket, workgroup) output offset, and the scatter pass
+// re-reads the same slice, counting-sorts each batch in LDS and writes per-bucket runs.
 //
 // Reference counterpart: none (the reference is src/run.rs:526-571 + DashMap); results are the
 // same multiset of (key,count) as the direct path.
@@ -119,7 +121,7 @@ struct Part2Block {
     uint32_t p1;
 };
 
-// ---- level-1 output as a pool of fixed-size chunks (32-bit payload path) -------------------------
+// ---- level-1 output as a pool of fixed-size chunks ------------------------------------------------
 // Level 1 can then run in ONE pass: no counting pass is needed to know where a partition's data
 // goes, a workgroup just takes the next free chunk when a partition's current chunk fills up.
 // Chunks are handed out in per-workgroup ranges (one global atomic per POOL_GRAB chunks; a lone
@@ -204,107 +206,7 @@ __device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt,
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 1, pass A: per-workgroup histogram of level-1 partition ids, straight from the bases
-// ---------------------------------------------------------------------------------------------
-// H1 layout: [p1][workgroup]  (nblocks = gridDim.x columns)
-template <bool QUAL>
-__global__ __launch_bounds__(PART_NT) void part1_count_kernel(
-    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ H1) {
-    __shared__ uint32_t s_code[2][PART_NT + 2];
-    __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ uint32_t s_hist[MAX_P1];
-    const int tid = threadIdx.x;
-    s_hist[tid] = 0;  // PART_NT == MAX_P1
-    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
-    u64 te = tb + tiles_per_block;
-    if (te > tile0 + ntiles) te = tile0 + ntiles;
-    int buf = 0;
-    __syncthreads();
-    for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        const WinCtx w = stage_tile<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, abase, qbase, qaligned, t, vbeg, vend, thr);
-        Roller roll;
-        roll.init(w, k, wlo);
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            u64 key;
-            if (roll.next(j, key)) atomicAdd(&s_hist[p1_of_hash(part_hash(g, key), g)], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid < (1 << g.p1_bits)) H1[(u64)tid * gridDim.x + blockIdx.x] = s_hist[tid];
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 1, pass B: scatter payloads into level-1 partitions.  O1 = exclusive scan of H1.
-// ---------------------------------------------------------------------------------------------
-template <bool QUAL, typename PT>
-__global__ __launch_bounds__(PART_NT) void part1_scatter_kernel(
-    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g,
-    const u64 *__restrict__ O1, PT *__restrict__ out) {
-    // Staged element = one 8-byte LDS word: a u64 payload is the key itself (its partition is
-    // recomputed from the hash); a u32 payload has lost its partition bits, so the word carries
-    // (partition << 32 | payload).  One LDS write + one LDS read per key either way.
-    constexpr bool P32 = sizeof(PT) == 4;
-    __shared__ uint32_t s_code[2][PART_NT + 2];
-    __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ u64 s_stage[PART_TILE];   // 128 KiB
-    __shared__ uint32_t s_cnt[MAX_P1];
-    __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< 16384)
-    __shared__ u64 s_dst[MAX_P1];        // global position of run p minus its batch-local start
-    __shared__ uint32_t s_wsum[4];
-    const int tid = threadIdx.x;
-    s_cnt[tid] = 0;
-    u64 gcur = (tid < (1 << g.p1_bits)) ? O1[(u64)tid * gridDim.x + blockIdx.x] : 0;  // lane tid owns partition tid
-    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
-    u64 te = tb + tiles_per_block;
-    if (te > tile0 + ntiles) te = tile0 + ntiles;
-    int buf = 0;
-    __syncthreads();
-    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
-    for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
-        u64 item[CHUNK];
-        uint32_t tag[CHUNK];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
-        Roller roll;
-        roll.init(w, k, wlo);
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            tag[j] = 0xFFFFFFFFu;
-            u64 key;
-            if (roll.next(j, key)) {
-                const u64 H = part_hash(g, key);
-                const uint32_t p = p1_of_hash(H, g);
-                item[j] = P32 ? (((u64)p << 32) | (u64)Pay<uint32_t>::make(key, H, g)) : key;
-                tag[j] = (p << 16) | atomicAdd(&s_cnt[p], 1u);  // rank < 16384 fits 16 bits
-            }
-        }
-        __syncthreads();
-        block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) s_stage[(uint32_t)s_lofs[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = item[j];
-        const uint32_t mycnt = s_cnt[tid];
-        s_dst[tid] = gcur - s_lofs[tid];
-        gcur += mycnt;
-        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
-        __syncthreads();
-        s_cnt[tid] = 0;  // the next tile's stage_tile() barrier orders this before its atomics
-        // next tile's bases are fetched while this tile's runs are written out
-        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-#pragma unroll 2
-        for (uint32_t i = tid; i < total; i += PART_NT) {
-            const u64 v = s_stage[i];
-            const uint32_t p = P32 ? (uint32_t)(v >> 32) : p1_of_hash(part_hash(g, v), g);
-            out[s_dst[p] + i] = (PT)v;  // consecutive lanes -> consecutive addresses inside a run
-        }
-        // s_stage / s_dst are rewritten only after the next tile's barriers
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 1, single pass (32-bit payloads): scatter into pool chunks, no counting pass
+// level 1, single pass: extraction + scatter into pool chunks, no counting pass
 // ---------------------------------------------------------------------------------------------
 struct ChunkDst {  // per partition, per batch: where staged element i (local index e = i - lofs) goes
     u64 a;         // e <  split: pool index = a + i   (the partition's current chunk)
@@ -631,54 +533,6 @@ __global__ __launch_bounds__(SCAN_NT) void scan_apply_kernel(const uint32_t *__r
         run += v[i];
     }
     if (blockIdx.x == gridDim.x - 1 && tid == SCAN_NT - 1) out[n] = run;  // grand total
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 2 plan.  Single workgroup.  Level-1 partition p1 starts at O1[p1 * o1_stride]; the grand
-// total is O1[o1_total_index].  Writes the block list, info[0] = number of blocks, info[1] = H2
-// entries used, info[2] = total keys, moff[p1] = H2 index of (p1, p2 = 0, chunk 0), nch[p1] =
-// chunks of p1.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void part2_plan_kernel(const u64 *__restrict__ O1, uint32_t o1_stride, PartGeom g,
-                                                          u64 o1_total_index, Part2Block *__restrict__ blocks,
-                                                          u64 max_blocks, u64 *__restrict__ moff,
-                                                          uint32_t *__restrict__ nch, u64 *__restrict__ info) {
-    __shared__ u64 s_seg[MAX_P1 + 1];
-    __shared__ u64 s_bbase[MAX_P1 + 1];
-    const int tid = threadIdx.x;
-    const int P1 = 1 << g.p1_bits;
-    if (tid < P1) s_seg[tid] = O1[(u64)tid * o1_stride];
-    if (tid == 0) s_seg[P1] = O1[o1_total_index];
-    __syncthreads();
-    if (tid == 0) {  // P1 <= 1024: a serial prefix is cheap
-        u64 b = 0;
-        for (int p = 0; p < P1; ++p) {
-            s_bbase[p] = b;
-            b += (s_seg[p + 1] - s_seg[p] + PART2_CHUNK - 1) / PART2_CHUNK;
-        }
-        s_bbase[P1] = b;
-        info[0] = b;
-        info[1] = b << g.p2_bits;
-        info[2] = s_seg[P1];
-    }
-    __syncthreads();
-    if (tid < P1) {
-        const u64 lo = s_seg[tid], hi = s_seg[tid + 1];
-        const u64 b0 = s_bbase[tid];
-        const uint32_t n = (uint32_t)(s_bbase[tid + 1] - b0);
-        moff[tid] = b0 << g.p2_bits;
-        nch[tid] = n;
-        for (uint32_t c = 0; c < n; ++c) {
-            if (b0 + c >= max_blocks) break;
-            Part2Block pb;
-            pb.lo = lo + (u64)c * PART2_CHUNK;
-            pb.hi = pb.lo + PART2_CHUNK < hi ? pb.lo + PART2_CHUNK : hi;
-            pb.mbase = (b0 << g.p2_bits) + c;
-            pb.mstride = n;
-            pb.p1 = (uint32_t)tid;
-            blocks[b0 + c] = pb;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
