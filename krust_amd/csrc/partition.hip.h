@@ -886,6 +886,46 @@ __device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t
     }
 }
 
+// The same round for regions in which no payload can equal the free marker (the top p2_bits of every
+// payload are the region's own level-2 digit: unless that digit is all ones, 0xFFFFFFFF cannot occur)
+// and that are not hot -- i.e. nearly all of them: predicated straight-line code instead of nested
+// branches (the general round spends more scalar than vector instructions on exec-mask bookkeeping).
+__device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t (*s_q)[REGION_NT], uint32_t *s_pay,
+                                                    uint32_t *s_add, uint32_t *s_fail, int tid, uint32_t sshift, uint32_t &nd) {
+    uint32_t idx = 0, probes = 0;
+    bool active = nk > 0;
+    uint32_t pay = s_q[0][tid];  // (every queue slot holds a loaded payload, real or clamped)
+    uint32_t off = (pay >> sshift) & REGION_MASK;
+    while (__ballot(active) != 0) {
+        uint32_t cur = s_pay[off];
+        const bool claim = active && cur == R32_FREE;
+        if (__ballot(claim) != 0) {  // uniform; rare once the region's keys are in
+            if (claim) {
+                const uint32_t old = atomicCAS(&s_pay[off], R32_FREE, pay);
+                if (old == R32_FREE) ++nd;
+                cur = old == R32_FREE ? pay : old;
+            }
+        }
+        const bool hit = active && cur == pay;
+        if (hit) atomicAdd(&s_add[off], 1u);  // no-return ds_add_u32
+        const bool miss = active && !hit;
+        probes += miss ? 1u : 0u;
+        bool done = hit;
+        if (miss && probes >= REGION_SLOTS) {  // region full
+            *s_fail = 1;
+            done = true;
+        }
+        off = miss ? ((off + 1) & REGION_MASK) : off;
+        if (done) {
+            ++idx;
+            active = idx < nk;
+            probes = 0;
+            pay = s_q[active ? idx : 0][tid];
+            off = (pay >> sshift) & REGION_MASK;
+        }
+    }
+}
+
 // uint32_t payloads: the LDS image is two 32-bit arrays, s_pay[] (0xFFFFFFFF = free) and s_add[] (count
 // added by this batch), 32 KiB per region, plus 32 KiB of per-lane payload queues (see the probing
 // loop); the count update is a no-return ds_add_u32.  Slots that were
@@ -937,6 +977,9 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     const uint32_t *__restrict__ src = pays + lo;
     const uint32_t n = (uint32_t)(hi - lo);  // < 2^32 - 1 (checked above)
     const bool hot = (hi - lo) > hot_threshold;  // far above the mean bucket: skewed keys likely
+    // can a payload of this region equal the free marker 0xFFFFFFFF?  Only if its level-2 digit is all ones.
+    const uint32_t p2mask = (1u << g.p2_bits) - 1u;
+    const bool may_special = g.p2_bits == 0 || ((uint32_t)r & p2mask) == p2mask;
     uint32_t kbuf[REGION_RK];
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {  // branch-free: clamped index
@@ -990,7 +1033,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
         }
         if (hot) region32_probe_round<true>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
-        else region32_probe_round<false>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
+        else if (may_special) region32_probe_round<false>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
+        else region32_probe_lean(nk, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
