@@ -779,14 +779,19 @@ void staged_memcpy(void *dst, const void *src, size_t n) {
     }
     const size_t per = ((n + parts - 1) / parts + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;
-    th.reserve(parts - 1);
-    for (unsigned i = 1; i < parts; ++i) {
-        const size_t off = (size_t)i * per;
-        if (off >= n) break;
-        const size_t len = std::min(per, n - off);
-        th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+    size_t done_by_threads_from = n;  // [this, n) is copied by helper threads, [0, this) by the caller
+    try {  // (no exception may cross the C ABI: if a thread cannot be started the caller copies that part)
+        th.reserve(parts - 1);
+        for (unsigned i = parts - 1; i >= 1; --i) {
+            const size_t off = (size_t)i * per;
+            if (off >= n) continue;
+            const size_t len = std::min(per, n - off);
+            th.emplace_back([=] { memcpy((char *)dst + off, (const char *)src + off, len); });
+            done_by_threads_from = off;
+        }
+    } catch (...) {
     }
-    memcpy(dst, src, std::min(per, n));
+    memcpy(dst, src, done_by_threads_from);
     for (auto &t : th) t.join();
 }
 
