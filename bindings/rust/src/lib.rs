@@ -176,6 +176,19 @@ impl HipKmerMap {
         Ok(self)
     }
 
+    /// Raw FASTA / FASTQ text (whole records, uncompressed), records found on the device instead of by
+    /// the `bio` readers (`src/reader.rs:58-79`).  `Ok(false)`: the device scanner declined the layout
+    /// (wrapped FASTQ, ...) and counted nothing; the caller parses the text as today and calls
+    /// `build` / `build_with_quality`.
+    pub fn push_text(&mut self, text: &[u8], fastq: bool) -> Result<bool, HipError> {
+        let rc = unsafe { sys::kh_push_text(self.ctx, text.as_ptr(), text.len() as u64, if fastq { 2 } else { 1 }) };
+        if rc == -9 {
+            return Ok(false); // KH_ERR_FORMAT
+        }
+        check(self.ctx, rc)?;
+        Ok(true)
+    }
+
     /// Packed canonical key -> count: the shape of `count_kmers_from_sequences`
     /// (`src/streaming.rs:198-204`).
     pub fn into_packed(self, min_count: u64) -> Result<HashMap<u64, u64>, HipError> {
