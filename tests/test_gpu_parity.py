@@ -695,22 +695,25 @@ def _np_mix64(z):
     return z ^ (z >> np.uint64(31))
 
 
-def test_full_map_digest_10M_reads(K):
+@pytest.mark.parametrize("k,minq", [(21, None), (31, 20)], ids=["k21", "k31-q20"])
+def test_full_map_digest_10M_reads(K, k, minq):
     """BASELINE configs[1] with the WHOLE map compared, not a key sample: the CPU counts every k-mer of
     the 10 M reads (oracle radix formulation) and the order-independent digest sum(mix(key ^ mix(count)))
     of all ~235 M (key, count) pairs must equal the digest of the pairs copied back from the device,
     together with the distinct count and the total."""
     import torch
-    n_reads, rl, k = 10_000_000, 150, 21
+    n_reads, rl = 10_000_000, 150
     nbytes = n_reads * (rl + 1)
     tb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    K.synth_reads_device(tb.data_ptr(), None, SEED, 1 << 27, rl, 0, n_reads)
+    tq = torch.empty(nbytes, dtype=torch.uint8, device="cuda") if minq is not None else None
+    K.synth_reads_device(tb.data_ptr(), tq.data_ptr() if tq is not None else None, SEED, 1 << 27, rl, 0, n_reads)
     torch.cuda.synchronize()
     host = tb.cpu().numpy()
-    total, distinct, digest = O.count_flat_radix(host, k, nthreads=NCPU)
+    hq = tq.cpu().numpy() if tq is not None else None
+    total, distinct, digest = O.count_flat_radix(host, k, qual=hq, min_quality=minq, nthreads=NCPU)
     assert _np_mix64(np.array([12345], dtype=np.uint64))[0] == O.mix64(12345)  # the vectorised mix is the oracle's
-    with K.DeviceCounter(k, capacity_hint=int(1.4e8 + 12.0 * n_reads), path="partition") as dc:
-        dc.push_device(tb.data_ptr(), None, nbytes)
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=int(1.4e8 + 12.0 * n_reads), path="partition") as dc:
+        dc.push_device(tb.data_ptr(), tq.data_ptr() if tq is not None else None, nbytes)
         st = dc.finish()
         keys, cnts = dc.result(sort=False)
     assert st["kmers"] == total and st["distinct"] == distinct == keys.size
