@@ -637,6 +637,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if (c->trace)
             fprintf(stderr, "[kmerhip] %llu regions overflowed (%llu keys): growing and re-inserting them directly\n",
                     (u64)c->h_ctr->part_failed, failed_keys);
+        c->hinted = false;  // the capacity hint (if any) was too small: size later batches for the worst case
         {
             StageTimer t(c, ST_GROW);
             rc = grow_to(c, newcap);
@@ -716,17 +717,43 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     bool part = false;
     if (c->path_mode == 2) part = true;
     else if (c->path_mode == 0) part = windows >= PART_MIN_WINDOWS && (double)c->cap <= 7.0 * (double)windows;
-    if (part && c->table_empty && !c->hinted && c->cap < windows / 8) {
-        // no hint and an obviously undersized empty table: size it for the batch up front
-        Slot *nt = nullptr;
-        const u64 newcap = round_cap((double)windows / 8.0);
-        int rc = alloc_table(c, newcap, &nt);
-        if (rc == KH_OK) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            (void)hipFree(c->table);
-            c->table = nt;
-            c->cap = newcap;
-            c->table_dirty = false;
+    if (part && !c->hinted) {
+        // No capacity hint: this batch may bring up to `windows` NEW keys.  A region pass that overflows
+        // falls back to re-inserting the overflowing buckets through device atomics -- correct, but
+        // ~30x slower than the pass itself -- so room for the worst case is made first: an empty table
+        // is simply re-allocated, a live one rehashed (cheap next to a failed pass).  Never beyond a
+        // quarter of the device memory; past that the fallback remains the safety net.
+        if (c->pending_bound) {
+            int rc = sync_counters(c);
+            if (rc != KH_OK) return rc;
+        }
+        u64 limit = c->cap;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const u64 bytes = ((u64)fr + c->cap * sizeof(Slot)) / 4;
+            u64 lim = MIN_CAP;
+            while (lim * 2 * sizeof(Slot) <= bytes) lim *= 2;
+            limit = std::max(limit, lim);
+        }
+        const u64 want = std::min(round_cap((double)(c->distinct_known + windows) / LOAD_PART), limit);
+        if (want > c->cap) {
+            if (c->table_empty) {
+                Slot *nt = nullptr;
+                int rc = alloc_table(c, want, &nt);
+                if (rc == KH_OK) {
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    (void)hipFree(c->table);
+                    c->table = nt;
+                    c->cap = want;
+                    c->table_dirty = false;
+                } else {
+                    c->poisoned = false;  // a smaller table still works: the overflow path grows on demand
+                }
+            } else {
+                StageTimer t(c, ST_GROW);
+                int rc = grow_to(c, want);
+                if (rc != KH_OK) c->poisoned = false;
+            }
         }
     }
     if (part && !make_geom(c, c->cap).ok) part = false;  // table beyond 2 levels of partitioning
