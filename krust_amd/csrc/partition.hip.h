@@ -212,6 +212,10 @@ struct ChunkDst {  // per partition, per batch: where staged element i (local in
     u64 a;         // e <  split: pool index = a + i   (the partition's current chunk)
     u64 b;         // e >= split: pool index = b + i   (freshly taken, consecutive chunks)
 };
+// a and b are biased by -lofs (and b by -split), so they wrap below zero for the first chunks of the pool:
+// b lies in [-(RTILE + CHUNK_PAY), pool size) modulo 2^64, any value in there is a real destination
+// (-1 included: it comes up once in a few hundred batches).  The "drop" marker sits far outside.
+constexpr u64 CHUNK_DST_DROP = 1ull << 63;
 
 // PT = uint32_t: one sorting round of 16 windows per lane per tile.  PT = u64 (k >= 22): TWO rounds of 8
 // windows per lane, so that the staged payloads take the same 64 KiB of LDS and the per-partition runs
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
                     if (first + nnew > pool_chunks) {  // cannot happen with the host's pool sizing; never write past it
                         lost += r;
                         first = 0;
-                        d.b = ~0ull;  // marks "drop" for the write-out
+                        d.b = CHUNK_DST_DROP;  // marks "drop" for the write-out
                     } else {
                         for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
                         d.b = first * CHUNK_PAY - space - lo;
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
                 const ChunkDst d = s_dst[p];
                 const uint32_t e = i - (meta & 0xFFFFu);
                 if (e < (meta >> 16)) pool[d.a + i] = s_stage[i];
-                else if (d.b != ~0ull) pool[d.b + i] = s_stage[i];
+                else if (d.b != CHUNK_DST_DROP) pool[d.b + i] = s_stage[i];
             }
             // s_stage / s_dst / s_meta are rewritten only after the next round's / tile's barriers; the
             // counters, though, are hit by the next round's atomics right away
