@@ -231,6 +231,33 @@ def test_multiple_pushes_and_reset(K, path):
         assert dc.as_dict() == want
 
 
+def test_many_batches_into_one_table_match_the_direct_path(K):
+    """2000 partitioned batches at shifting offsets against the same pushes through the direct path.
+    Regression for a level-1 write-out bug: the destination of a partition's run is biased by the run's
+    tile-local offset and wraps below zero for the pool's first chunks; the value -1 (about one batch
+    in 300, in the workgroup that takes the pool's first chunks) was also the "drop" marker, so that run
+    was never written and level 2 read whatever the previous batch had left there -- totals conserved,
+    a handful of wrong keys.  Each batch has exactly one such workgroup, hence many small batches."""
+    import torch
+    reads, rl, k = 110_000, 150, 21
+    tb = torch.empty(reads * (rl + 1), dtype=torch.uint8, device="cuda")
+    K.synth_reads_device(tb.data_ptr(), None, SEED, 1 << 20, rl, 0, reads)
+    torch.cuda.synchronize()
+    span, step, nb = 131072, 7963, 2000  # 8 tiles per batch; offsets are arbitrary (records may be cut: same cut both ways)
+    assert (nb - 1) * step + span <= tb.numel()
+    tables = {}
+    for path in ("direct", "partition"):
+        with K.DeviceCounter(k, path=path, capacity_hint=8_000_000) as dc:
+            for b in range(nb):
+                dc.push_device(tb.data_ptr() + b * step, None, span)
+            st = dc.finish()
+            assert st["grows"] == 0
+            tables[path] = dc.result(sort=True) + (st["kmers"],)
+    (dk, dcnt, dn), (pk, pcnt, pn) = tables["direct"], tables["partition"]
+    assert dn == pn == int(dcnt.sum()) == int(pcnt.sum())
+    assert dk.size == pk.size and np.array_equal(dk, pk) and np.array_equal(dcnt, pcnt)
+
+
 def test_lazy_reset_never_leaks_old_entries(K, path):
     """kh_reset does not clear the table (the next FRESH partitioned pass rewrites every region, any
     other use clears first).  Fill the table, reset, then go through each way of using a reset table:
