@@ -231,7 +231,9 @@ def test_multiple_pushes_and_reset(K, path):
         assert dc.as_dict() == want
 
 
-def test_many_batches_into_one_table_match_the_direct_path(K):
+@pytest.mark.parametrize("k,minq", [(21, None), (31, 20), (25, None), (15, None), (17, 20)],
+                         ids=["k21", "k31q20", "k25", "k15", "k17q20"])
+def test_many_batches_into_one_table_match_the_direct_path(K, k, minq):
     """2000 partitioned batches at shifting offsets against the same pushes through the direct path.
     Regression for a level-1 write-out bug: the destination of a partition's run is biased by the run's
     tile-local offset and wraps below zero for the pool's first chunks; the value -1 (about one batch
@@ -239,17 +241,19 @@ def test_many_batches_into_one_table_match_the_direct_path(K):
     was never written and level 2 read whatever the previous batch had left there -- totals conserved,
     a handful of wrong keys.  Each batch has exactly one such workgroup, hence many small batches."""
     import torch
-    reads, rl, k = 110_000, 150, 21
+    reads, rl = 110_000, 150
     tb = torch.empty(reads * (rl + 1), dtype=torch.uint8, device="cuda")
-    K.synth_reads_device(tb.data_ptr(), None, SEED, 1 << 20, rl, 0, reads)
+    tq = torch.empty_like(tb) if minq is not None else None
+    qp = tq.data_ptr() if tq is not None else None
+    K.synth_reads_device(tb.data_ptr(), qp, SEED, 1 << 20, rl, 0, reads)
     torch.cuda.synchronize()
     span, step, nb = 131072, 7963, 2000  # 8 tiles per batch; offsets are arbitrary (records may be cut: same cut both ways)
     assert (nb - 1) * step + span <= tb.numel()
     tables = {}
     for path in ("direct", "partition"):
-        with K.DeviceCounter(k, path=path, capacity_hint=8_000_000) as dc:
+        with K.DeviceCounter(k, min_quality=minq, path=path, capacity_hint=8_000_000) as dc:
             for b in range(nb):
-                dc.push_device(tb.data_ptr() + b * step, None, span)
+                dc.push_device(tb.data_ptr() + b * step, None if qp is None else qp + b * step, span)
             st = dc.finish()
             assert st["grows"] == 0
             tables[path] = dc.result(sort=True) + (st["kmers"],)
