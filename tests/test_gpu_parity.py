@@ -262,6 +262,71 @@ def test_many_batches_into_one_table_match_the_direct_path(K, k, minq):
     assert dk.size == pk.size and np.array_equal(dk, pk) and np.array_equal(dcnt, pcnt)
 
 
+# restatement of the table hash (krust_amd/csrc/kmer_bits.h kh_hash_n / kh_unhash_n), to BUILD keys with chosen hash bits
+_FC = (0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F)
+
+
+def _feistel_f(r, c, k):
+    t = (r * ((c & 0xFFFFFF) | 1)) & 0xFFFFFFFF if 16 <= k <= 24 else (r * c) & 0xFFFFFFFF
+    return t >> (32 - k) if k < 32 else t
+
+
+def _table_hash(key, k):
+    mask = (1 << k) - 1
+    L, R = (key >> k) & mask, key & mask
+    for c in _FC:
+        L, R = R, (L ^ _feistel_f(R, c, k)) & mask
+    return (L << k) | R
+
+
+def _table_unhash(h, k):
+    mask = (1 << k) - 1
+    L, R = (h >> k) & mask, h & mask
+    for c in reversed(_FC):
+        L, R = (R ^ _feistel_f(L, c, k)) & mask, L
+    return (L << k) | R
+
+
+def test_payload_equal_to_the_lds_free_marker(K):
+    """At k = 21 with 1024 level-1 partitions the 32-bit payload is ALL of the hash below the partition
+    digit, and the LDS image of region_count_kernel32 marks free slots with 0xFFFFFFFF: a key whose
+    payload is 0xFFFFFFFF (one per partition; ~1 in 4 full-size runs meets one) takes the "special"
+    route -- counted on the side, placed at write-back.  Random data never gets there, so build those
+    keys by inverting the hash, plus their neighbours 0xFFFFFFFE / 0xFFFFFFFD that probe into the same
+    slots, and count them among ordinary reads: fresh table, then a second push into the filled one."""
+    k = 21
+    rng = np.random.default_rng(11)
+    for key in [int(x) for x in rng.integers(0, 1 << 42, size=200)]:  # pin the restatement on the library's own hash
+        assert _table_unhash(_table_hash(key, k), k) == key
+        assert K.owner(key, k, 1 << 20) == _table_hash(key, k) >> (2 * k - 20)
+    recs, n_special = [], 0
+    for p1 in range(1024):
+        for low, reps in ((0xFFFFFFFF, 1 + p1 % 5), (0xFFFFFFFE, 2), (0xFFFFFFFD, 1)):
+            key = _table_unhash((p1 << 32) | low, k)
+            if K.canonical(key, k)[0] != key:
+                continue  # its reverse complement is the canonical one, with some other hash
+            n_special += low == 0xFFFFFFFF
+            recs += [K.unpack(key, k).encode()] * reps
+    assert n_special > 300
+    genome = _dirty(rng, 1 << 16, p_bad=0.0, lower=False)
+    recs += [genome[o:o + 150] for o in rng.integers(0, (1 << 16) - 150, size=20_000)]
+    order = rng.permutation(len(recs))
+    recs = [recs[i] for i in order]
+    want = oracle_dict(recs, k)
+    b, _ = flat(recs)
+    for hint in (8_000_000, 3_000_000):  # 4 / 1 level-2 buckets per partition
+        with K.DeviceCounter(k, path="partition", capacity_hint=hint) as dc:
+            dc.push(b)
+            st = dc.finish()
+            assert st["grows"] == 0 and dc.as_dict() == want
+            dc.push(b)  # the special keys are now OLD keys of their regions
+            half = len(recs) // 2
+            dc.push(flat(recs[:half])[0])
+            dc.finish()
+            want3 = oracle_dict(recs + recs + recs[:half], k)
+            assert dc.as_dict() == want3
+
+
 def test_lazy_reset_never_leaks_old_entries(K, path):
     """kh_reset does not clear the table (the next FRESH partitioned pass rewrites every region, any
     other use clears first).  Fill the table, reset, then go through each way of using a reset table:
