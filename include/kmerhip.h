@@ -203,6 +203,17 @@ int kh_export_regions_heads_device(kh_ctx *ctx, uint32_t nparts, uint32_t *d_hea
 int kh_merge_regions_heads_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sender_regions,
                                   const uint32_t *const *d_heads, const uint32_t *const *d_region_counts);
 
+/* Exchange in pieces, so that export, all-to-all and merge of successive pieces overlap: after
+ * kh_set_region_window(ctx, piece, npieces) (npieces a power of two <= 64) the three export calls above
+ * cover only piece `piece` of every owner's region range -- the counts of the other regions come back as
+ * zero and nothing of them is written, so the caller sees an ordinary export of a table that is empty
+ * elsewhere -- and the three merge calls rebuild only the matching share of the shard's regions (the
+ * senders' region-count arrays keep their full length, zero outside the piece).  Pieces may come in any
+ * order; a merge into an empty shard table stays a "fresh" rebuild for every piece.  Anything else that
+ * touches the table in between is allowed (the pieces still missing then count as empty).
+ * (0, 1) restores whole-range calls.  KH_ERR_BAD_ARG if a range has fewer regions than pieces. */
+int kh_set_region_window(kh_ctx *ctx, uint32_t piece, uint32_t npieces);
+
 /* Small k (2k <= 26): the whole key space is a dense array of 4^k counts, which -- unlike a hash
  * table -- IS element-wise reducible: ranks merge with one all-reduce(sum) (any number of ranks,
  * tables of any size).  kh_export_dense_device: d_dense[key] = count, 0 for absent keys.

@@ -89,6 +89,14 @@ struct kh_ctx {
 
     // ---- partitioned path ----
     bool table_empty = true;   // no insert since creation / reset: regions need not be read back
+    // kh_set_region_window: the next region-ordered exports / merges cover piece win_piece of win_n of
+    // every owner's region range.  A FRESH merge done in pieces leaves the regions of the pieces not
+    // yet merged unwritten (stale if the table was lazily reset): win_open / win_mask / win_dirty
+    // track that until the last piece, or until anything else touches the table (close_fresh_window).
+    uint32_t win_piece = 0, win_n = 1;
+    bool win_open = false, win_dirty = false;
+    uint32_t win_open_n = 0;
+    u64 win_mask = 0;
     bool table_dirty = false;  // kh_reset is lazy: the slots hold stale data that the next operation either
                                // overwrites wholesale (a FRESH region pass) or clears first (everything else)
     bool hinted = false;       // caller gave a capacity hint
@@ -185,10 +193,16 @@ int clear_if_dirty(kh_ctx *c);
 // anything that looks at the table first counts what is pending.  need_table = false: the caller
 // decides itself whether a lazily reset table must be cleared (the input entry points: a
 // partitioned batch into an empty table overwrites every region anyway).
-int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true) {
+int close_fresh_window(kh_ctx *c);
+
+int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool keep_window = false) {
     if (!c) return KH_ERR_BAD_ARG;
     if (c->poisoned) return fail(c, KH_ERR_STATE, "context is poisoned by an earlier error");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->win_open && !keep_window) {
+        int rc = close_fresh_window(c);
+        if (rc != KH_OK) return rc;
+    }
     if (flush_pending && c->acc_len) {
         int rc = flush_acc(c, false);
         if (rc != KH_OK) return rc;
@@ -214,6 +228,22 @@ int clear_if_dirty(kh_ctx *c) {
     hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table, c->cap);
     HIP_TRY(c, hipGetLastError());
     c->table_dirty = false;
+    return KH_OK;
+}
+
+// A FRESH merge in pieces (kh_set_region_window) was interrupted, or needs the table as a whole (growth):
+// the regions of the pieces not merged yet hold whatever the lazily reset table held -- make them empty.
+int close_fresh_window(kh_ctx *c) {
+    if (!c->win_open) return KH_OK;
+    c->win_open = false;
+    if (!c->win_dirty) return KH_OK;
+    const u64 per_piece = c->cap / c->win_open_n;  // slots; a piece is a contiguous range of target regions
+    for (uint32_t p = 0; p < c->win_open_n; ++p) {
+        if (c->win_mask & (1ull << p)) continue;
+        hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(per_piece)), dim3(kh::BLOCK), 0, c->stream,
+                           c->table + (u64)p * per_piece, per_piece);
+    }
+    HIP_TRY(c, hipGetLastError());
     return KH_OK;
 }
 
@@ -1013,6 +1043,10 @@ extern "C" void kh_destroy(kh_ctx *c) {
 }
 
 extern "C" int kh_reset(kh_ctx *c) {
+    if (c && c->win_open) {  // the unwritten pieces are simply part of the lazy reset
+        c->win_open = false;
+        if (c->win_dirty) c->table_dirty = true;
+    }
     int rc = enter(c, false);
     if (rc != KH_OK) return rc;
     if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
@@ -1620,6 +1654,7 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
         return fail(c, KH_ERR_BAD_ARG, "bad nparts / NULL argument");
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "table is already a shard");
     if (region_cap < nregions) return fail(c, KH_ERR_RANGE, "region count array too small");
+    if (c->win_n > 1 && (nregions / nparts) % c->win_n) return fail(c, KH_ERR_BAD_ARG, "region window: fewer regions per owner than pieces");
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
     bool counted_by_region_pass = false;
@@ -1639,6 +1674,13 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
                            (const Slot *)c->table, d_region_counts);
     }
     HIP_TRY(c, hipGetLastError());
+    if (c->win_n > 1) {
+        // One piece of every owner's region range: the other regions count as empty, so the offsets, the
+        // per-owner totals and the compaction (which skips empty ranges) all follow.
+        hipLaunchKernelGGL(kh::region_window_mask_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream, d_region_counts,
+                           nregions, nregions / nparts, (nregions / nparts) / c->win_n, c->win_piece);
+        HIP_TRY(c, hipGetLastError());
+    }
     // offsets of every region in the export (device scan), and the per-owner totals (host)
     u64 z = c->merge_off_cap;
     rc = ensure_buf(c, &c->merge_off, &z, nregions + 1, "hipMalloc(merge_off)");
@@ -1688,6 +1730,15 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
 }
 }  // namespace
 
+extern "C" int kh_set_region_window(kh_ctx *c, uint32_t piece, uint32_t npieces) {
+    if (!c) return KH_ERR_BAD_ARG;
+    if (npieces < 1 || npieces > 64 || (npieces & (npieces - 1)) || piece >= npieces)
+        return fail(c, KH_ERR_BAD_ARG, "region window: npieces must be a power of two <= 64, piece < npieces");
+    c->win_piece = piece;
+    c->win_n = npieces;
+    return KH_OK;
+}
+
 extern "C" int kh_export_regions_device(kh_ctx *c, uint32_t nparts, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
                                         uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
                                         uint64_t *table_regions) {
@@ -1709,7 +1760,10 @@ extern "C" int kh_export_regions_heads_device(kh_ctx *c, uint32_t nparts, uint32
 namespace {
 int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions, const void *const *d_keys,
                   const uint64_t *const *d_counts, const uint32_t *const *d_region_counts) {
-    int rc = enter(c, true, false);  // a FRESH merge rewrites every region of a lazily reset table
+    // a FRESH merge rewrites every region of a lazily reset table; in pieces (kh_set_region_window), the
+    // pieces still to come stay unwritten until then (win_open)
+    const bool windowed = c && c->win_n > 1;
+    int rc = enter(c, true, false, windowed && c->win_open && c->win_open_n == c->win_n && !(c->win_mask & (1ull << c->win_piece)));
     if (rc != KH_OK) return rc;
     const bool packed = fmt != XF_WIDE;
     if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || (!packed && !d_counts) || !d_region_counts)
@@ -1717,6 +1771,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     if (sender_regions == 0 || (sender_regions & (sender_regions - 1)) || (sender_regions >> c->shard_shift) == 0)
         return fail(c, KH_ERR_BAD_ARG, "sender_regions must be a power of two >= the shard count");
     const u64 nr = sender_regions >> c->shard_shift;  // sender regions inside this shard's hash range
+    if (windowed && nr % c->win_n) return fail(c, KH_ERR_BAD_ARG, "region window: fewer sender regions in the shard than pieces");
     // per-sender offsets of every region segment (device scans), and the incoming total (host)
     u64 z = c->merge_off_cap;
     rc = ensure_buf(c, &c->merge_off, &z, (u64)nsenders * (nr + 1), "hipMalloc(merge_off)");
@@ -1737,9 +1792,15 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
         rc = sync_counters(c);
         if (rc != KH_OK) return rc;
     }
-    if ((double)(c->distinct_known + incoming) > LOAD_HARD * (double)c->cap) {
+    // a first piece sizes for all of them (pieces are equal shares of the hash range)
+    const u64 expect = (windowed && c->table_empty) ? incoming * c->win_n : incoming;
+    if ((double)(c->distinct_known + expect) > LOAD_HARD * (double)c->cap) {
         u64 newcap = c->cap;
-        while ((double)(c->distinct_known + incoming) > LOAD_HARD * (double)newcap) newcap *= 2;
+        while ((double)(c->distinct_known + expect) > LOAD_HARD * (double)newcap) newcap *= 2;
+        if (c->win_open) {  // growing rehashes the whole table: the unwritten pieces must be empty first
+            rc = close_fresh_window(c);
+            if (rc != KH_OK) return rc;
+        }
         if (c->table_empty) {
             Slot *nt = nullptr;
             rc = alloc_table(c, newcap, &nt);
@@ -1786,15 +1847,32 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
         if (cb < 0) return fail(c, KH_ERR_BAD_ARG, "32-bit heads need 1 <= 2k - log2(sender_regions) <= 28");
         a.head_cmask = (1u << cb) - 1u;
     }
+    // the target regions this call covers: all of them, or the window's contiguous share
+    u64 region0 = 0, nwin = nregions;
+    bool fresh = c->table_empty;
+    if (windowed) {
+        // (targets coarser than the senders' regions are fine: nr / win_n sender regions are then still
+        // whole target regions, as both counts are powers of two and nregions >= win_n)
+        if (nregions < c->win_n) return fail(c, KH_ERR_BAD_ARG, "region window: the shard table has fewer regions than pieces");
+        nwin = nregions / c->win_n;
+        region0 = (u64)c->win_piece * nwin;
+        if (c->table_empty) {  // first piece of a FRESH merge
+            c->win_open = true;
+            c->win_open_n = c->win_n;
+            c->win_mask = 0;
+            c->win_dirty = c->table_dirty;
+        }
+        fresh = c->win_open && !(c->win_mask & (1ull << c->win_piece));  // (enter() closed a window this piece does not fit)
+    }
     {
         StageTimer t(c, ST_REGION);
-        const dim3 mg((unsigned)nregions), mb(1024);
+        const dim3 mg((unsigned)nwin), mb(1024);
         const uint8_t *none = nullptr;
-        const uint32_t dirty = (uint32_t)c->table_dirty;
+        const uint32_t dirty = (uint32_t)(windowed ? (fresh && c->win_dirty) : c->table_dirty);
 #define KH_MERGE_LAUNCH(FRESH, FMT) \
     hipLaunchKernelGGL((kh::shard_merge_kernel<FRESH, false, FMT>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, \
-                       FRESH ? dirty : 0u)
-        if (c->table_empty) {
+                       FRESH ? dirty : 0u, (uint32_t)region0)
+        if (fresh) {
             if (fmt == XF_WIDE) KH_MERGE_LAUNCH(true, 0);
             else if (fmt == XF_PACKED64) KH_MERGE_LAUNCH(true, 1);
             else KH_MERGE_LAUNCH(true, 2);
@@ -1804,23 +1882,30 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
             else KH_MERGE_LAUNCH(false, 2);
         }
 #undef KH_MERGE_LAUNCH
-        hipLaunchKernelGGL(kh::shard_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
-                           (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)nregions, c->d_ctr);
+        hipLaunchKernelGGL(kh::shard_reduce_kernel, dim3(grid_for(nwin)), dim3(kh::BLOCK), 0, c->stream,
+                           (const uint8_t *)c->rfail + region0, (const uint32_t *)c->rnew + region0, (u64)nwin, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
     c->rheads_valid = false;
     c->table_dirty = false;
+    if (windowed && c->win_open) {
+        c->win_mask |= 1ull << c->win_piece;
+        if (c->win_mask == (c->win_open_n == 64 ? ~0ull : (1ull << c->win_open_n) - 1)) c->win_open = false;  // every region written
+    }
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
     if (c->h_ctr->part_failed) {  // some target regions overflowed: grow, then insert their pairs directly
         const uint32_t old_rbits = tg.rbits;
         StageTimer t(c, ST_GROW);
+        rc = close_fresh_window(c);  // growing rehashes the whole table
+        if (rc != KH_OK) return rc;
         rc = grow_to(c, c->cap * 2);
         if (rc != KH_OK) return rc;
 #define KH_MERGE_DIRECT(FMT) \
-    hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, FMT>), dim3((unsigned)nregions), dim3(1024), 0, c->stream, \
-                       table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u)
+    hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, FMT>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, \
+                       table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u, \
+                       (uint32_t)region0)
         if (fmt == XF_WIDE) KH_MERGE_DIRECT(0);
         else if (fmt == XF_PACKED64) KH_MERGE_DIRECT(1);
         else KH_MERGE_DIRECT(2);

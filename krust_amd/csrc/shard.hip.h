@@ -156,6 +156,15 @@ __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(const Slot 
     }
 }
 
+// Region window of an export (kh_set_region_window): every owner's range of `per` regions is cut into
+// pieces of `wper`; the counts of all pieces but `piece` become zero.
+__global__ __launch_bounds__(BLOCK) void region_window_mask_kernel(uint32_t *__restrict__ rcount, u64 nregions, u64 per, u64 wper,
+                                                                   uint32_t piece) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x; r < nregions; r += stride)
+        if ((r % per) / wper != piece) rcount[r] = 0;
+}
+
 // ---- receiver side -----------------------------------------------------------------------------
 constexpr int MAX_SENDERS = 64;
 struct MergeSrc {
@@ -180,7 +189,8 @@ struct MergeArgs {
 template <bool FRESH, bool DIRECT, int FMT>
 __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, MergeArgs a, uint8_t *__restrict__ rfail,
                                                               uint32_t *__restrict__ rnew, const uint8_t *__restrict__ only_failed,
-                                                              uint32_t old_rbits, Counters *ctr, uint32_t dirty) {
+                                                              uint32_t old_rbits, Counters *ctr, uint32_t dirty,
+                                                              uint32_t region0) {
     __shared__ u64 s_key[DIRECT ? 1 : REGION_SLOTS];
     __shared__ u64 s_cnt[DIRECT ? 1 : REGION_SLOTS];
     __shared__ uint32_t s_fail, s_new;
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     __shared__ uint32_t s_seg_len[MAX_SENDERS];
     const int tid = threadIdx.x;
     // In DIRECT mode the grid still walks the ORIGINAL target regions (old_rbits); tg is the grown table.
-    const u64 t = blockIdx.x;
+    const u64 t = (u64)blockIdx.x + region0;  // region0: first target region of this call's window (kh_set_region_window)
     if (DIRECT && !only_failed[t]) return;
     const uint32_t match_bits = DIRECT ? old_rbits : tg.rbits;
     Slot *reg = tg.table + t * REGION_SLOTS;

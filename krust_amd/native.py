@@ -61,6 +61,7 @@ SYMBOLS = {
     "kh_lookup": (C.c_int, [_P, _P, _U64, _P]),
     "kh_owner": (C.c_uint32, [_U64, C.c_uint32, C.c_uint32]),
     "kh_set_shard": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "kh_set_region_window": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "kh_export_regions_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
     "kh_merge_regions_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P, _P]),
     "kh_export_regions_packed_device": (C.c_int, [_P, C.c_uint32, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
@@ -272,6 +273,11 @@ class DeviceCounter:
     def set_shard(self, index, count):
         """Make the (empty) table shard `index` of `count` (power of two) by hash range."""
         self._check(lib().kh_set_shard(self._h, int(index), int(count)))
+
+    def set_region_window(self, piece=0, npieces=1):
+        """The next region-ordered exports / merges cover piece `piece` of `npieces` of every owner's
+        region range (kh_set_region_window); (0, 1) = everything."""
+        self._check(lib().kh_set_region_window(self._h, int(piece), int(npieces)))
 
     def export_regions_device(self, nparts, d_keys, d_counts, cap, d_region_counts, region_cap):
         """Live pairs in region order (grouped by owner) + per-region live counts.

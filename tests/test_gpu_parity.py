@@ -568,6 +568,148 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, pac
     assert merged == want
 
 
+@pytest.mark.parametrize("fmt", [0, 1, 2], ids=["wide", "packed64", "heads32"])
+@pytest.mark.parametrize("nshards,npieces", [(2, 2), (4, 4), (2, 8)])
+@pytest.mark.parametrize("scenario", ["fresh", "dirty-reversed", "interrupted", "tiny-table"])
+def test_region_merge_in_pieces_logical_shards(K, fmt, nshards, npieces, scenario):
+    """kh_set_region_window: the region-ordered exchange cut into pieces of every owner's region range (so
+    that export / all-to-all / merge of successive pieces can overlap).  A windowed export looks like the
+    export of a table that is empty outside the piece; the merge rebuilds the matching share of the
+    shard.  Receivers: a fresh table; a lazily reset (dirty) one with the pieces in reverse order; one
+    that is queried between two pieces (the rest then merges into a non-empty table); one that has to
+    grow.  Union of the shards == single-table result, whatever the route."""
+    import torch
+    k, n_reads = 19, 30_000
+    bases, _ = O.synth_reads(SEED, 1 << 17, 150, 0, n_reads)
+    m = O.OracleMap()
+    m.scan_flat(bases, k, nthreads=NCPU)
+    want = m.as_dict()
+    per = n_reads // nshards
+    unit = 4 if fmt == 2 else 8
+    exports, nreg = [], None
+    for s_ in range(nshards):
+        lo, hi = s_ * per, (n_reads if s_ == nshards - 1 else (s_ + 1) * per)
+        with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+            dc.push(bases[lo * 151: hi * 151])
+            st = dc.finish()
+            R = st["table_slots"] // 4096
+            nreg = R if nreg is None else nreg
+            assert R == nreg
+            pieces, total = [], 0
+            for piece in range(npieces):
+                dc.set_region_window(piece, npieces)
+                dk = torch.empty(2 * st["distinct"], dtype=torch.int64, device="cuda")
+                dcnt = torch.empty(st["distinct"], dtype=torch.int64, device="cuda")
+                rc = torch.empty(R, dtype=torch.int32, device="cuda")
+                if fmt == 1:
+                    parts, _ = dc.export_regions_packed_device(nshards, dk.data_ptr(), st["distinct"], rc.data_ptr(), R)
+                elif fmt == 2:
+                    parts, _ = dc.export_regions_heads_device(nshards, dk.data_ptr(), 2 * st["distinct"], rc.data_ptr(), R)
+                else:
+                    parts, _ = dc.export_regions_device(nshards, dk.data_ptr(), dcnt.data_ptr(), st["distinct"], rc.data_ptr(), R)
+                rch = rc.cpu().numpy().reshape(nshards, npieces, -1)
+                assert int(rch.sum()) == int(parts.sum()) and int(rch[:, piece].sum()) == int(parts.sum())  # zero outside the piece
+                total += int(parts.sum())
+                pieces.append((dk, dcnt, rc, np.concatenate([[0], np.cumsum(parts)]).astype(np.int64)))
+            dc.set_region_window(0, 1)
+            assert total >= st["distinct"] and (fmt == 2 or total == st["distinct"])
+            exports.append(pieces)
+    merged = {}
+    per_r = nreg // nshards
+    order = list(range(npieces))
+    if scenario == "dirty-reversed":
+        order.reverse()
+    for o in range(nshards):
+        with K.DeviceCounter(k, capacity_hint=1000 if scenario == "tiny-table" else 3_000_000) as dc:
+            if scenario == "dirty-reversed":  # leave other keys in the table, then the lazy reset
+                dc.push(bases[:151 * 3000][::-1].copy())
+                dc.finish()
+                dc.reset()
+            dc.set_shard(o, nshards)
+            for i, piece in enumerate(order):
+                dc.set_region_window(piece, npieces)
+                ptrs = [e[piece][0].data_ptr() + unit * int(e[piece][3][o]) for e in exports]
+                rcs = [e[piece][2].data_ptr() + 4 * per_r * o for e in exports]
+                if fmt == 1:
+                    dc.merge_regions_packed_device(nreg, ptrs, rcs)
+                elif fmt == 2:
+                    dc.merge_regions_heads_device(nreg, ptrs, rcs)
+                else:
+                    dc.merge_regions_device(nreg, ptrs, [e[piece][1].data_ptr() + 8 * int(e[piece][3][o]) for e in exports], rcs)
+                if scenario == "interrupted" and i == 0:
+                    mid = dc.finish()["distinct"]  # touches the table: the pieces still missing count as empty
+                    assert 0 < mid == dc.result_size()
+            dc.set_region_window(0, 1)
+            st = dc.finish()
+            d = dc.as_dict()
+            assert st["distinct"] == len(d)
+        assert not (set(d) & set(merged))
+        merged.update(d)
+    assert merged == want
+
+
+@pytest.mark.parametrize("fmt", [0, 1, 2], ids=["wide", "packed64", "heads32"])
+def test_region_merge_in_pieces_growth_while_pieces_are_missing(K, fmt):
+    """The first piece sizes the shard table for npieces pieces like itself.  Here it comes from a small
+    table and the later ones from a large one, so the table has to grow while pieces are still
+    unwritten: they are emptied first (growing rehashes every region), the rest merges the ordinary way."""
+    import torch
+    k, nshards, npieces = 19, 2, 4
+    bases, _ = O.synth_reads(SEED, 1 << 17, 150, 0, 30_000)
+    unit = 4 if fmt == 2 else 8
+    tables, exports = [], []
+    for n_reads in (1_500, 30_000):  # the small sender, the large sender
+        m = O.OracleMap()
+        m.scan_flat(bases[:151 * n_reads], k, nthreads=NCPU)
+        tables.append(m.as_dict())
+        with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+            dc.push(bases[:151 * n_reads])
+            st = dc.finish()
+            R = st["table_slots"] // 4096
+            pieces = []
+            for piece in range(npieces):
+                dc.set_region_window(piece, npieces)
+                dk = torch.empty(2 * st["distinct"], dtype=torch.int64, device="cuda")
+                dcnt = torch.empty(st["distinct"], dtype=torch.int64, device="cuda")
+                rc = torch.empty(R, dtype=torch.int32, device="cuda")
+                if fmt == 1:
+                    parts, _ = dc.export_regions_packed_device(nshards, dk.data_ptr(), st["distinct"], rc.data_ptr(), R)
+                elif fmt == 2:
+                    parts, _ = dc.export_regions_heads_device(nshards, dk.data_ptr(), 2 * st["distinct"], rc.data_ptr(), R)
+                else:
+                    parts, _ = dc.export_regions_device(nshards, dk.data_ptr(), dcnt.data_ptr(), st["distinct"], rc.data_ptr(), R)
+                pieces.append((dk, dcnt, rc, np.concatenate([[0], np.cumsum(parts)]).astype(np.int64)))
+            exports.append(pieces)
+    per_r = R // nshards
+    for o in range(nshards):
+        with K.DeviceCounter(k, capacity_hint=1000) as dc:
+            dc.push(bases[:151 * 2000][::-1].copy())  # something else first, then the lazy reset
+            dc.finish()
+            dc.reset()
+            dc.set_shard(o, nshards)
+            for piece in range(npieces):
+                e = exports[0 if piece == 0 else 1][piece]
+                dc.set_region_window(piece, npieces)
+                ptr, rcp = [e[0].data_ptr() + unit * int(e[3][o])], [e[2].data_ptr() + 4 * per_r * o]
+                if fmt == 1:
+                    dc.merge_regions_packed_device(R, ptr, rcp)
+                elif fmt == 2:
+                    dc.merge_regions_heads_device(R, ptr, rcp)
+                else:
+                    dc.merge_regions_device(R, ptr, [e[1].data_ptr() + 8 * int(e[3][o])], rcp)
+            dc.set_region_window(0, 1)
+            st = dc.finish()
+            assert st["grows"] >= 1
+            got = dc.as_dict()
+        want = {}
+        for src, keep in ((tables[0], lambda p: p == 0), (tables[1], lambda p: p != 0)):
+            for key, cnt in src.items():
+                fine = K.owner(key, k, nshards * npieces)  # top bits of the hash: owner, then the piece inside it
+                if fine // npieces == o and keep(fine % npieces):
+                    want[key] = cnt
+        assert got == want
+
+
 def test_heads_export_splits_large_counts_and_refuses_huge_ones(K):
     """32-bit heads carry addend - 1 in the bits the hash leaves free (k = 19, 2^11 regions: 5 bits).  Counts
     above 32 travel as several heads of the same key; a count above 64 x 32 makes the table not
