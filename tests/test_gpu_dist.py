@@ -23,16 +23,20 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 bases, _ = O.synth_reads(20260130, 1 << 18, 150, 0, 30000, with_qual=False)
 # capacity_hint 3 M -> 2^11 regions.  k = 19: 27 hash bits below the region index -> u32 heads;
 # k = 21: 31 bits -> the 64-bit packed unit; k = 31: neither -> key + count.
-for k, expect in ((19, "regions-heads"), (21, "regions-packed"), (31, "regions"), (11, "dense")):
+# pieces: the heads / packed routes as a pipeline of async all-to-alls over shares of the region range
+for k, expect, pieces in ((19, "regions-heads", 1), (19, "regions-heads-x4", None), (19, "regions-heads-x8", 8), (21, "regions-packed", 1),
+                          (21, "regions-packed-x2", 2), (31, "regions", None), (11, "dense", None)):
     m = O.OracleMap(); m.scan_flat(bases, k, nthreads=4)
     with krust_amd.DeviceCounter(k, capacity_hint=3_000_000) as dc:
-        dc.push(bases)
-        info = merge_across_ranks(dc)
-        keys, cnts = dc.result()
-    ok, oc = m.arrays()
-    assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
-    assert (expect == "dense" or info["sent_pairs"] == 0) and info["recv_pairs"] >= len(m) == info["owned_distinct"]
-    assert info["path"] == expect, info
+        for rep in range(2):  # twice: the second merge starts from a lazily reset (dirty) table
+            dc.reset()
+            dc.push(bases)
+            info = merge_across_ranks(dc, pieces=pieces, phase_times=bool(rep))
+            keys, cnts = dc.result()
+            ok, oc = m.arrays()
+            assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
+            assert (expect == "dense" or info["sent_pairs"] == 0) and info["recv_pairs"] >= len(m) == info["owned_distinct"]
+            assert info["path"] == expect, info
 print("NCCL_OK", len(m))
 dist.destroy_process_group()
 '''
@@ -67,7 +71,7 @@ lo, hi = shard_range(N_READS, rank, world)
 bases, _ = O.synth_reads(SEED, 1 << 20, 150, lo, hi - lo, with_qual=False)
 with krust_amd.DeviceCounter(K, capacity_hint=3_000_000, path=PATH) as dc:
     dc.push(bases)
-    info = merge_across_ranks(dc)
+    info = merge_across_ranks(dc, pieces=PIECES)
     keys, cnts = dc.result()
     assert info["path"] == EXPECT_PATH, info
     # the shard answers lookups for its own keys and stays refusing reads until reset
@@ -92,12 +96,13 @@ dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("world,path,k,expect", [(2, "partition", 19, "regions-heads"), (4, None, 21, "regions-packed"),
-                                                 (4, None, 17, "regions-heads"), (2, None, 31, "regions"), (3, None, 21, "pairs"),
-                                                 (3, None, 13, "dense")])
-def test_ranks_sharing_one_gpu_merge_real_tables(world, path, k, expect, tmp_path):
+@pytest.mark.parametrize("world,path,k,expect,pieces",
+                         [(2, "partition", 19, "regions-heads", 1), (2, "partition", 19, "regions-heads-x4", None),
+                          (4, None, 21, "regions-packed", 1), (4, None, 21, "regions-packed-x4", 4), (4, None, 17, "regions-heads-x2", 2),
+                          (2, None, 31, "regions", None), (3, None, 21, "pairs", None), (3, None, 13, "dense", None)])
+def test_ranks_sharing_one_gpu_merge_real_tables(world, path, k, expect, pieces, tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(f"ROOT = {ROOT!r}\nPATH = {path!r}\nEXPECT_PATH = {expect!r}\nK = {k}\n" + MULTI)
+    script.write_text(f"ROOT = {ROOT!r}\nPATH = {path!r}\nEXPECT_PATH = {expect!r}\nK = {k}\nPIECES = {pieces!r}\n" + MULTI)
     port = 29500 + world + (os.getpid() % 100)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
