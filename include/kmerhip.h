@@ -213,6 +213,12 @@ int kh_merge_regions_heads_device(kh_ctx *ctx, uint32_t nsenders, uint64_t sende
  * touches the table in between is allowed (the pieces still missing then count as empty).
  * (0, 1) restores whole-range calls.  KH_ERR_BAD_ARG if a range has fewer regions than pieces. */
 int kh_set_region_window(kh_ctx *ctx, uint32_t piece, uint32_t npieces);
+/* Exchange units held by every region of the whole table (ignores the window): heads (unit_bytes 4),
+ * packed pairs (8) or pairs (16) -- the first phase of the matching export on its own, so that a
+ * pipelined exchange can announce the sizes of all its pieces before the first one is compacted.
+ * Blocks until d_region_counts is complete.  KH_ERR_RANGE as the matching export. */
+int kh_region_unit_counts_device(kh_ctx *ctx, uint32_t unit_bytes, uint32_t *d_region_counts, uint64_t region_cap,
+                                 uint64_t *table_regions);
 
 /* Small k (2k <= 26): the whole key space is a dense array of 4^k counts, which -- unlike a hash
  * table -- IS element-wise reducible: ranks merge with one all-reduce(sum) (any number of ranks,

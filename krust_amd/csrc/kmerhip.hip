@@ -1730,6 +1730,46 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
 }
 }  // namespace
 
+// Phase one of an export on its own: how many exchange units every region holds (whole range, whatever
+// the window) -- what a pipelined exchange needs to announce the sizes of ALL its pieces up front.
+extern "C" int kh_region_unit_counts_device(kh_ctx *c, uint32_t unit_bytes, uint32_t *d_region_counts, uint64_t region_cap,
+                                            uint64_t *table_regions) {
+    int rc = enter(c);
+    if (rc != KH_OK) return rc;
+    if (unit_bytes != 4 && unit_bytes != 8 && unit_bytes != 16) return fail(c, KH_ERR_BAD_ARG, "unit_bytes is 4 (heads), 8 (packed) or 16 (pairs)");
+    const u64 nregions = c->cap / kh::REGION_SLOTS;
+    if (table_regions) *table_regions = nregions;
+    if (!d_region_counts) return fail(c, KH_ERR_BAD_ARG, "NULL argument");
+    if (region_cap < nregions) return fail(c, KH_ERR_RANGE, "region count array too small");
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, "table is already a shard");
+    rc = sync_counters(c);
+    if (rc != KH_OK) return rc;
+    if (unit_bytes == 4) {
+        const int cb = head_count_bits(c, nregions);
+        if (cb < 0) return fail(c, KH_ERR_RANGE, "32-bit heads need 1 <= 2k - log2(table regions) <= 28");
+        if (c->rheads_valid && c->rheads_cb == (uint32_t)cb) {
+            if (c->rheads_wide) return fail(c, KH_ERR_RANGE, "a count is too large for 32-bit heads");
+            HIP_TRY(c, hipMemcpyAsync(d_region_counts, c->rheads, nregions * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            rc = zero_cursors(c);
+            if (rc != KH_OK) return rc;
+            hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                               (const Slot *)c->table, (uint32_t)cb, d_region_counts, &c->d_ctr->big);
+            HIP_TRY(c, hipGetLastError());
+            u64 wide = 0;
+            rc = read_cursor(c, nullptr, &wide);
+            if (rc != KH_OK) return rc;
+            if (wide) return fail(c, KH_ERR_RANGE, "a count is too large for 32-bit heads");
+        }
+    } else {
+        hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
+                           (const Slot *)c->table, d_region_counts);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return KH_OK;
+}
+
 extern "C" int kh_set_region_window(kh_ctx *c, uint32_t piece, uint32_t npieces) {
     if (!c) return KH_ERR_BAD_ARG;
     if (npieces < 1 || npieces > 64 || (npieces & (npieces - 1)) || piece >= npieces)

@@ -113,24 +113,6 @@ def _wait_all(works):
         torch.cuda.current_stream().synchronize()
 
 
-_SIDE_GROUPS = {}
-
-
-def _side_group(group):
-    """A second communicator over the same ranks for the few-byte size exchanges of the pipeline: on the
-    main one they would queue behind the all-to-all in flight (one stream per communicator), and the host
-    could not run ahead to the next export.  Created once per group (a collective: every rank gets here
-    at the same point of its first pipelined merge).  KMERHIP_MERGE_SIDE_GROUP=0: use the main group."""
-    import os
-    if os.environ.get("KMERHIP_MERGE_SIDE_GROUP", "1") == "0" or _host_staged(group):
-        return group
-    key = id(group) if group is not None else None
-    if key not in _SIDE_GROUPS:
-        ranks = None if group is None else dist.get_process_group_ranks(group)
-        _SIDE_GROUPS[key] = dist.new_group(ranks=ranks, backend=dist.get_backend(group))
-    return _SIDE_GROUPS[key]
-
-
 def default_pieces():
     import os
     return int(os.environ.get("KMERHIP_MERGE_PIECES", "4"))
@@ -154,7 +136,8 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
     pieces (default: KMERHIP_MERGE_PIECES or 4; 1 = off): the heads / packed routes run as a pipeline over
     `pieces` equal shares of every owner's region range (kh_set_region_window): the all-to-all of piece i
     is in flight (RCCL's own stream) while piece i + 1 is exported, and later while earlier pieces are
-    merged -- export 6.8 ms + merge 13.4 ms at headline size are otherwise serial with the exchange."""
+    merged -- export 6.8 ms + merge 13.4 ms at headline size are otherwise serial with the exchange.  The
+    sizes of all pieces and all region counts are exchanged once, up front (kh_region_unit_counts_device)."""
     import os
     import time
     timing = {} if (phase_times or os.environ.get("KMERHIP_MERGE_TIMING")) else None
@@ -236,17 +219,31 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
     if piped:
         # ---- pipeline over the pieces: [export i+1 | all-to-all i], then [merge i | all-to-all > i] ----
         unit32 = agreed == 2
+        ub = 4 if unit32 else 8
         sendbuf = keys.view(torch.int32) if unit32 else keys
         cap_total = sendbuf.numel() if unit32 else n_local
-        side = _side_group(group)
+        wper = per // npieces
         t_exp = t_wait = t_merge = 0.0
         t0 = time.perf_counter()
+        # every piece's sizes and every region's unit count, announced up front: ONE small exchange each,
+        # so that nothing but the big all-to-alls sits on the communicator's stream afterwards
+        counts_all = torch.empty(nreg, dtype=torch.int32, device=dev)
+        if counter.region_unit_counts_device(ub, counts_all.data_ptr(), nreg) != nreg:
+            raise RuntimeError("the table stopped fitting the exchange format between two calls")
+        send_mat = counts_all.view(world, npieces, wper).sum(dim=2, dtype=torch.int64).contiguous()  # [owner, piece]
+        recv_mat = torch.empty_like(send_mat)                                                        # [sender, piece]
+        _all_to_all(recv_mat, send_mat, group=group)
+        rrc_full = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices: sender s's counts of MY regions
+        _all_to_all(rrc_full, counts_all, group=group)
+        send_h, recv_h = send_mat.cpu().numpy(), recv_mat.cpu().numpy()
+        t1 = time.perf_counter()
+        t_wait += t1 - t0
+        t0 = t1
         flights, used, sent, parts = [], 0, 0, exported[0]
         for i in range(npieces):
             if i > 0:
                 counter.set_region_window(i, npieces)
-                rcnt = torch.empty(nreg, dtype=torch.int32, device=dev)
-                ptr = keys.data_ptr() + used * (4 if unit32 else 8)
+                ptr = keys.data_ptr() + used * ub
                 if unit32:
                     res = counter.export_regions_heads_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
                 else:
@@ -254,21 +251,18 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
                 if res is None:
                     raise RuntimeError("a later piece of the table does not fit the exchange format of the first")
                 parts = res[0]
-            t1 = time.perf_counter()
-            t_exp += t1 - t0
-            total = int(parts.sum())
+            send_sizes = [int(x) for x in parts.tolist()]
+            assert send_sizes == [int(x) for x in send_h[:, i]], "piece sizes differ from the announced ones"
+            recv_sizes = [int(x) for x in recv_h[:, i]]
+            total = sum(send_sizes)
             buf = sendbuf[used:used + total]
             used += total
-            sent += total - int(parts[rank])
-            send_sizes = [int(x) for x in parts.tolist()]
-            ssz = torch.tensor(send_sizes, dtype=torch.int64, device=dev)
-            rsz = torch.empty(world, dtype=torch.int64, device=dev)
-            _all_to_all(rsz, ssz, group=side)
-            recv_sizes = [int(x) for x in rsz.tolist()]
+            sent += total - send_sizes[rank]
             rp = torch.empty(sum(recv_sizes), dtype=buf.dtype, device=dev)
-            rrc = torch.empty(nreg, dtype=torch.int32, device=dev)
-            works = [_all_to_all_async(rp, buf, recv_sizes, send_sizes, group=group), _all_to_all_async(rrc, rcnt, group=group)]
-            flights.append((rp, recv_sizes, rrc, works, buf, rcnt))  # (buf / rcnt stay alive while in flight)
+            t1 = time.perf_counter()
+            t_exp += t1 - t0
+            work = _all_to_all_async(rp, buf, recv_sizes, send_sizes, group=group)
+            flights.append((rp, recv_sizes, work, buf))  # (buf stays alive while in flight)
             t0 = time.perf_counter()
             t_wait += t0 - t1
         counter.set_region_window(0, 1)
@@ -276,9 +270,13 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         counter.set_shard(rank, world)
         merge = counter.merge_regions_heads_device if unit32 else counter.merge_regions_packed_device
         n_recv = 0
-        for i, (rp, recv_sizes, rrc, works, _, _) in enumerate(flights):
+        rrc_v = rrc_full.view(world, npieces, wper)
+        for i, (rp, recv_sizes, work, _) in enumerate(flights):
             t1 = time.perf_counter()
-            _wait_all(works)
+            rrc = torch.zeros_like(rrc_v)  # the senders' region counts as the merge of piece i wants them: zero elsewhere
+            rrc[:, i, :] = rrc_v[:, i, :]
+            _wait_all([work])
+            torch.cuda.current_stream().synchronize()  # (rrc is written on torch's stream, read on the counter's)
             t2 = time.perf_counter()
             t_wait += t2 - t1
             offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)

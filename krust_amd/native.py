@@ -62,6 +62,7 @@ SYMBOLS = {
     "kh_owner": (C.c_uint32, [_U64, C.c_uint32, C.c_uint32]),
     "kh_set_shard": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "kh_set_region_window": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "kh_region_unit_counts_device": (C.c_int, [_P, C.c_uint32, _P, _U64, _P]),
     "kh_export_regions_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
     "kh_merge_regions_device": (C.c_int, [_P, C.c_uint32, _U64, _P, _P, _P]),
     "kh_export_regions_packed_device": (C.c_int, [_P, C.c_uint32, _P, _U64, _P, _U64, _P, C.POINTER(_U64)]),
@@ -278,6 +279,16 @@ class DeviceCounter:
         """The next region-ordered exports / merges cover piece `piece` of `npieces` of every owner's
         region range (kh_set_region_window); (0, 1) = everything."""
         self._check(lib().kh_set_region_window(self._h, int(piece), int(npieces)))
+
+    def region_unit_counts_device(self, unit_bytes, d_region_counts, region_cap):
+        """Exchange units (4: heads, 8: packed pairs, 16: pairs) per region of the whole table; returns
+        the number of table regions, or None where the matching export would not be representable."""
+        nreg = _U64(0)
+        rc = lib().kh_region_unit_counts_device(self._h, int(unit_bytes), C.c_void_p(int(d_region_counts)), int(region_cap), C.byref(nreg))
+        if rc == KH_ERR_RANGE:
+            return None
+        self._check(rc)
+        return int(nreg.value)
 
     def export_regions_device(self, nparts, d_keys, d_counts, cap, d_region_counts, region_cap):
         """Live pairs in region order (grouped by owner) + per-region live counts.
