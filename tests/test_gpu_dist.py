@@ -37,6 +37,16 @@ for k, expect, pieces in ((19, "regions-heads", 1), (19, "regions-heads-x4", Non
             assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
             assert (expect == "dense" or info["sent_pairs"] == 0) and info["recv_pairs"] >= len(m) == info["owned_distinct"]
             assert info["path"] == expect, info
+with krust_amd.DeviceCounter(19, capacity_hint=3_000_000) as dc:  # nothing counted: every piece is empty
+    info = merge_across_ranks(dc)
+    assert info["owned_distinct"] == 0 and dc.result_size() == 0, info
+    dc.reset()
+    dc.push(bases[:151 * 100])  # and a table whose pieces are nearly empty
+    want = O.OracleMap(); want.scan_flat(bases[:151 * 100], 19, nthreads=1)
+    info = merge_across_ranks(dc)
+    keys, cnts = dc.result()
+    ok, oc = want.arrays()
+    assert np.array_equal(keys, ok) and np.array_equal(cnts, oc), info
 print("NCCL_OK", len(m))
 dist.destroy_process_group()
 '''
