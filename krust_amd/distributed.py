@@ -109,8 +109,18 @@ def _wait_all(works):
         if w is not None:
             w.wait()
             waited = True
-    if waited:
+    if waited and torch.cuda.is_available():
         torch.cuda.current_stream().synchronize()
+
+
+def _stream_sync():
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+
+
+def _device_sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 def default_pieces():
@@ -145,7 +155,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
 
     def lap(name):  # phase wall times (with a device sync), only when asked for
         if timing is not None:
-            torch.cuda.synchronize()
+            _device_sync()
             now = time.perf_counter()
             timing[name] = timing.get(name, 0.0) + (now - t_last[0]) * 1e3
             t_last[0] = now
@@ -155,7 +165,8 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
     st = counter.finish()
     n_local = int(st["distinct"])
     nreg = int(st["table_slots"]) // 4096
-    dev = torch.device("cuda", torch.cuda.current_device())
+    # (a counter may name the device its buffers live on: the CPU stand-in of tests/test_dist_gloo.py does)
+    dev = getattr(counter, "torch_device", None) or torch.device("cuda", torch.cuda.current_device())
     if dense and 2 * counter.k <= 26:
         # Small k: the key space itself is a dense array of 4^k counts, and THAT is element-wise
         # reducible: one all-reduce(sum), any world size, then every rank keeps the keys it owns.
@@ -276,7 +287,8 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
             rrc = torch.zeros_like(rrc_v)  # the senders' region counts as the merge of piece i wants them: zero elsewhere
             rrc[:, i, :] = rrc_v[:, i, :]
             _wait_all([work])
-            torch.cuda.current_stream().synchronize()  # (rrc is written on torch's stream, read on the counter's)
+            _stream_sync()  # (rrc is written on torch's stream, read on the counter's; NOT a device-wide sync:
+                            #  the later all-to-alls stay in flight)
             t2 = time.perf_counter()
             t_wait += t2 - t1
             offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
@@ -289,7 +301,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         counter.set_region_window(0, 1)
         st2 = counter.finish()
         if timing is not None:
-            torch.cuda.synchronize()
+            _device_sync()
             timing.update({"export": timing.get("export", 0.0) + t_exp * 1e3, "exchange_wait": t_wait * 1e3, "merge": t_merge * 1e3,
                            "pieces": npieces})
             t_last[0] = time.perf_counter()

@@ -62,6 +62,145 @@ def test_gloo_sharded_merge(world, tmp_path):
     assert f"DIST_OK {world}" in out.stdout
 
 
+# merge_across_ranks itself (format vote, region-ordered export, the pipeline over pieces of the region
+# range with all sizes announced up front, async handles, shard merge) with a CPU stand-in for the
+# device table: same calls, same exchange units (32-bit heads, region order, masked region counts),
+# numpy instead of kernels.  What is under test is the host sequence in krust_amd/distributed.py.
+STANDIN = r'''
+import os, sys, ctypes
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import oracle_lib as O
+import krust_amd
+from krust_amd.distributed import merge_across_ranks, shard_range
+
+FC = (0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F)
+def ff(r, c, k):
+    t = (r * ((c & 0xFFFFFF) | 1)) & 0xFFFFFFFF if 16 <= k <= 24 else (r * c) & 0xFFFFFFFF
+    return t >> (32 - k) if k < 32 else t
+def table_hash(key, k):
+    mask = (1 << k) - 1
+    L, R = (key >> k) & mask, key & mask
+    for c in FC:
+        L, R = R, (L ^ ff(R, c, k)) & mask
+    return (L << k) | R
+def table_unhash(h, k):
+    mask = (1 << k) - 1
+    L, R = (h >> k) & mask, h & mask
+    for c in reversed(FC):
+        L, R = (R ^ ff(L, c, k)) & mask, L
+    return (L << k) | R
+
+def view(ptr, n, dtype):
+    return np.ctypeslib.as_array(ctypes.cast(int(ptr), ctypes.POINTER(ctypes.c_uint8)), shape=(n * np.dtype(dtype).itemsize,)).view(dtype)
+
+class StandIn:
+    """The calls of krust_amd.DeviceCounter that merge_across_ranks makes, on host memory."""
+    torch_device = torch.device("cpu")
+    def __init__(self, k, rbits):
+        self.k, self.rbits, self.table, self.shard, self.win = k, rbits, {}, None, (0, 1)
+        self.hb = 2 * k - rbits; self.cb = 32 - self.hb
+        assert 1 <= self.hb <= 28
+    def finish(self):
+        return {"distinct": len(self.table), "table_slots": 4096 << self.rbits}
+    def reset(self):
+        self.table, self.shard = {}, None
+    def set_shard(self, index, count):
+        assert not self.table
+        self.shard = (index, count)
+    def set_region_window(self, piece=0, npieces=1):
+        self.win = (piece, npieces)
+    def _heads_by_region(self):
+        regs = [[] for _ in range(1 << self.rbits)]
+        for key, cnt in self.table.items():
+            h = table_hash(key, self.k)
+            r, low = h >> self.hb, h & ((1 << self.hb) - 1)
+            while cnt > 0:  # a large count travels as several heads
+                take = min(cnt, 1 << self.cb)
+                regs[r].append((low << self.cb) | (take - 1))
+                cnt -= take
+        return regs
+    def region_unit_counts_device(self, unit_bytes, rc_ptr, region_cap):
+        assert unit_bytes == 4 and self.shard is None
+        view(rc_ptr, 1 << self.rbits, np.uint32)[:] = [len(r) for r in self._heads_by_region()]
+        return 1 << self.rbits
+    def export_regions_heads_device(self, nparts, ptr, cap, rc_ptr, region_cap):
+        nreg = 1 << self.rbits
+        per = nreg // nparts
+        piece, npieces = self.win
+        wper = per // npieces
+        regs = self._heads_by_region()
+        rc = view(rc_ptr, nreg, np.uint32)
+        out, parts = [], np.zeros(nparts, dtype=np.uint64)
+        for r in range(nreg):
+            inside = (r % per) // wper == piece
+            rc[r] = len(regs[r]) if inside else 0
+            if inside:
+                out += regs[r]
+                parts[r // per] += len(regs[r])
+        assert len(out) <= cap
+        view(ptr, max(len(out), 1), np.uint32)[:len(out)] = out
+        return parts, nreg
+    def export_regions_packed_device(self, *a):
+        raise AssertionError("heads are representable: the packed route must not be tried")
+    def merge_regions_heads_device(self, sender_regions, ptrs, rc_ptrs):
+        index, count = self.shard
+        nr = sender_regions // count
+        piece, npieces = self.win
+        for ptr, rcp in zip(ptrs, rc_ptrs):
+            rc = view(rcp, nr, np.uint32)
+            offs = np.concatenate([[0], np.cumsum(rc.astype(np.int64))])
+            assert all(rc[j] == 0 for j in range(nr) if j // (nr // npieces) != piece)
+            units = view(ptr, max(int(offs[-1]), 1), np.uint32)
+            for j in range(nr):
+                for u in units[int(offs[j]):int(offs[j + 1])].tolist():
+                    h = ((index * nr + j) << self.hb) | (u >> self.cb)
+                    key = table_unhash(h, self.k)
+                    self.table[key] = self.table.get(key, 0) + (u & ((1 << self.cb) - 1)) + 1
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+N_READS, K, SEED, RBITS = 4000, 19, 20260130, 11
+lo, hi = shard_range(N_READS, rank, world)
+bases, _ = O.synth_reads(SEED, 1 << 14, 150, lo, hi - lo, with_qual=False)
+m = O.OracleMap(); m.scan_flat(bases, K)
+full_b, _ = O.synth_reads(SEED, 1 << 14, 150, 0, N_READS, with_qual=False)
+full = O.OracleMap(); full.scan_flat(full_b, K)
+for pieces, path in ((1, "regions-heads"), (None, "regions-heads-x4"), (2, "regions-heads-x2")):
+    c = StandIn(K, RBITS)
+    c.table = dict(m.as_dict())
+    c.table[next(iter(c.table))] += 5000  # one count that needs several heads
+    bumped = next(iter(c.table))
+    info = merge_across_ranks(c, pieces=pieces, phase_times=True)
+    assert info["path"] == path, info
+    assert all(krust_amd.owner(key, K, world) == rank for key in c.table)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (c.table, bumped))
+    if rank == 0:
+        union, want = {}, dict(full.as_dict())
+        for tab, b in gathered:
+            assert not (set(tab) & set(union))
+            union.update(tab)
+            want[b] += 5000
+        assert union == want, "merged shards differ from the single-process result"
+print("PIPE_OK", world)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_merge_across_ranks_pipeline_with_cpu_standin(world, tmp_path):
+    script = tmp_path / "standin.py"
+    script.write_text(f"ROOT = {ROOT!r}\n" + STANDIN)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    port = 29650 + world + (os.getpid() % 200)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stdout.count(f"PIPE_OK {world}") == world
+
+
 def test_shard_range_partition():
     from krust_amd.distributed import shard_range
     for n in (0, 1, 7, 100, 10**9 + 7):
