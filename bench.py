@@ -156,8 +156,9 @@ def main():
     torch.cuda.synchronize()
 
     hint = args.capacity_hint or estimate_distinct(reads, k, world, with_qual)
-    dc = krust_amd.DeviceCounter(k, min_quality=args.min_quality, capacity_hint=hint, device=local_rank,
-                                 stream=torch.cuda.current_stream().cuda_stream)
+    # stream=None: the context launches on its own non-blocking stream (the merge pipeline overlaps it with
+    # RCCL's); every hand-over between torch work and the counter is fenced by a device-wide synchronize here
+    dc = krust_amd.DeviceCounter(k, min_quality=args.min_quality, capacity_hint=hint, device=local_rank, stream=None)
 
     def step():
         dc.reset()

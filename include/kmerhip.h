@@ -69,7 +69,10 @@ typedef struct kh_config {
     int32_t  min_quality;    /* -1 = None; 0..255 = Some(q) (Phred, +33 applied inside) */
     int32_t  device;         /* HIP device ordinal; -1 = current device */
     uint64_t capacity_hint;  /* expected number of DISTINCT canonical k-mers; 0 = grow on demand */
-    void    *stream;         /* hipStream_t to launch on; NULL = context-owned stream */
+    void    *stream;         /* hipStream_t to launch on.  NULL = the context creates its own NON-BLOCKING stream
+                                (not ordered with the legacy default stream: synchronise buffers handed to
+                                kh_push_device yourself) -- unless KH_FLAG_CALLER_STREAM says that NULL means
+                                the legacy default stream itself (what torch.cuda.current_stream() usually is) */
     uint32_t flags;          /* KH_FLAG_* */
     uint32_t reserved;
 } kh_config;
@@ -79,6 +82,7 @@ typedef struct kh_config {
 #define KH_FLAG_FORCE_PARTITION 4u /* always use the partitioned (LDS region rebuild) path;
                                       default: chosen per push from batch and table size
                                       (env KMERHIP_PATH=direct|partition overrides) */
+#define KH_FLAG_CALLER_STREAM 8u   /* launch on cfg->stream even when it is NULL (= the legacy default stream) */
 
 /* indices into kh_stats.stage_ms */
 #define KH_NUM_STAGES 8

@@ -991,8 +991,8 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
     int rc = KH_OK;
     do {
         if (hipSetDevice(dev) != hipSuccess) { rc = KH_ERR_NO_DEVICE; break; }
-        if (cfg->stream) {
-            c->stream = (hipStream_t)cfg->stream;
+        if (cfg->stream || (cfg->flags & KH_FLAG_CALLER_STREAM)) {
+            c->stream = (hipStream_t)cfg->stream;  // NULL with KH_FLAG_CALLER_STREAM: the legacy default stream
         } else {
             if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = KH_ERR_HIP; break; }
             c->own_stream = true;
@@ -1209,7 +1209,7 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, bool raw_even
             HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tout + ntiles, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (c->h_txt->err) return text_fail(c, "blank before a line end inside a FASTA record");
+            if (c->h_txt->err) return text_fail(c, "blank before a line end, or a CR not followed by LF, inside a FASTA record");
             out_len = c->h_txt->total;
             hipLaunchKernelGGL(kh::fasta_compact_kernel<1>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
                                (const u64 *)c->txt_tbase, (const uint8_t *)c->txt_hdr, (uint32_t *)nullptr,

@@ -161,7 +161,8 @@ __device__ __forceinline__ bool fasta_keep(uint32_t b, bool header) {
 // PASS 0: tile_keep[t] = bytes kept in tile t.   PASS 1: write them at out[tile_out[t] + ...].
 // PASS 0 also raises err for a blank (' ' / TAB) right before a line end inside a record: the line
 // parsers strip those before joining wrapped lines (rust-bio trims line ends), the byte-wise rule
-// here would keep them as a separator in the middle of the record.
+// here would keep them as a separator in the middle of the record; and for a CR that is not directly
+// followed by the line's '\n' (the parsers keep it as an invalid base, this rule would drop it).
 template <int PASS>
 __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__restrict__ raw, u64 n, u64 ntiles,
                                                               const u64 *__restrict__ tile_base, const uint8_t *__restrict__ hdr,
@@ -185,6 +186,13 @@ __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__r
             if (PASS == 0 && !header && (b == ' ' || b == '\t')) {
                 const uint32_t nx = j < 15 ? byte_of(v, (j + 1) & 15) : after;
                 bad |= (nx == '\n' || nx == '\r' || p0 + j + 1 >= n);
+            }
+            // A CR is a line-end byte only right before '\n' (or at the very end of the text): rust-bio's
+            // trim_end() and the host line parser strip nothing else.  A bare CR in the middle of a line
+            // stays an invalid base there and breaks windows; dropping it here would join "AC\rGT" to ACGT.
+            if (PASS == 0 && !header && b == '\r' && p0 + j < n) {
+                const uint32_t nx = j < 15 ? byte_of(v, (j + 1) & 15) : after;
+                bad |= !(nx == '\n' || p0 + j + 1 >= n);
             }
             if (b == '\n') {
                 ++line;

@@ -128,6 +128,95 @@ def default_pieces():
     return int(os.environ.get("KMERHIP_MERGE_PIECES", "4"))
 
 
+def _merge_pipelined(counter, group, agreed, npieces, exported, counts_all, keys, rcnt, nreg, n_local, dev, timing, t_last):
+    """The heads / packed route as a pipeline over `npieces` equal shares of every owner's region range:
+    [export i+1 | all-to-all i], then [merge i | all-to-all > i].  The caller has verified (collectively)
+    that every piece fits the send buffer and holds piece 0's export in `exported`; it also restores the
+    region window afterwards."""
+    import os
+    import time
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per = nreg // world
+    unit32 = agreed == 2
+    ub = 4 if unit32 else 8
+    sendbuf = keys.view(torch.int32) if unit32 else keys
+    cap_total = sendbuf.numel() if unit32 else n_local
+    wper = per // npieces
+    t_exp = t_wait = t_merge = 0.0
+    t0 = time.perf_counter()
+    # every piece's sizes and every region's unit count, announced up front: ONE small exchange each,
+    # so that nothing but the big all-to-alls sits on the communicator's stream afterwards
+    send_mat = counts_all.view(world, npieces, wper).sum(dim=2, dtype=torch.int64).contiguous()  # [owner, piece]
+    recv_mat = torch.empty_like(send_mat)                                                        # [sender, piece]
+    _all_to_all(recv_mat, send_mat, group=group)
+    rrc_full = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices: sender s's counts of MY regions
+    _all_to_all(rrc_full, counts_all, group=group)
+    send_h, recv_h = send_mat.cpu().numpy(), recv_mat.cpu().numpy()
+    t1 = time.perf_counter()
+    t_wait += t1 - t0
+    t0 = t1
+    flights, used, sent, parts = [], 0, 0, exported[0]
+    for i in range(npieces):
+        if i > 0:
+            counter.set_region_window(i, npieces)
+            ptr = keys.data_ptr() + used * ub
+            if unit32:
+                res = counter.export_regions_heads_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
+            else:
+                res = counter.export_regions_packed_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
+            if res is None:  # (cannot happen: the sizes were checked against the buffer before the first send)
+                raise RuntimeError("a later piece of the table does not fit the exchange format of the first")
+            parts = res[0]
+        send_sizes = [int(x) for x in parts.tolist()]
+        assert send_sizes == [int(x) for x in send_h[:, i]], "piece sizes differ from the announced ones"
+        recv_sizes = [int(x) for x in recv_h[:, i]]
+        total = sum(send_sizes)
+        buf = sendbuf[used:used + total]
+        used += total
+        sent += total - send_sizes[rank]
+        rp = torch.empty(sum(recv_sizes), dtype=buf.dtype, device=dev)
+        t1 = time.perf_counter()
+        t_exp += t1 - t0
+        work = _all_to_all_async(rp, buf, recv_sizes, send_sizes, group=group)
+        flights.append((rp, recv_sizes, work, buf))  # (buf stays alive while in flight)
+        t0 = time.perf_counter()
+        t_wait += t0 - t1
+    counter.set_region_window(0, 1)
+    counter.reset()
+    counter.set_shard(rank, world)
+    merge = counter.merge_regions_heads_device if unit32 else counter.merge_regions_packed_device
+    n_recv = 0
+    rrc_v = rrc_full.view(world, npieces, wper)
+    for i, (rp, recv_sizes, work, _) in enumerate(flights):
+        t1 = time.perf_counter()
+        rrc = torch.zeros_like(rrc_v)  # the senders' region counts as the merge of piece i wants them: zero elsewhere
+        rrc[:, i, :] = rrc_v[:, i, :]
+        _wait_all([work])
+        _stream_sync()  # (rrc is written on torch's stream, read on the counter's; NOT a device-wide sync:
+                        #  the later all-to-alls stay in flight)
+        t2 = time.perf_counter()
+        t_wait += t2 - t1
+        offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
+        unit = rp.element_size()
+        counter.set_region_window(i, npieces)
+        merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
+              [rrc.data_ptr() + 4 * per * s for s in range(world)])
+        n_recv += rp.numel()
+        t_merge += time.perf_counter() - t2
+    counter.set_region_window(0, 1)
+    st2 = counter.finish()
+    if timing is not None:
+        _device_sync()
+        timing.update({"export": timing.get("export", 0.0) + t_exp * 1e3, "exchange_wait": t_wait * 1e3, "merge": t_merge * 1e3,
+                       "pieces": npieces})
+        t_last[0] = time.perf_counter()
+        if os.environ.get("KMERHIP_MERGE_TIMING"):
+            print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
+    return {"path": ("regions-heads" if unit32 else "regions-packed") + f"-x{npieces}", "local_distinct": n_local,
+            "sent_pairs": int(sent), "recv_pairs": int(n_recv), "owned_distinct": int(st2["distinct"]), "phase_ms": timing}
+
+
 def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times=False, pieces=None):
     """Turns per-rank tables (each built from that rank's read shard) into a key-sharded global
     table: afterwards `counter` on rank r holds exactly the keys with kh_owner(key, k, world) == r,
@@ -180,6 +269,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
             arr.copy_(h)
         else:
             dist.all_reduce(arr, group=group)
+        _stream_sync()  # the collective runs on torch's stream, the merge on the counter's own
         lap("all_reduce")
         counter.reset()
         counter.merge_dense_device(arr.data_ptr(), n, rank, world)
@@ -227,88 +317,39 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         exported = export(agreed)
         assert exported is not None
     per = nreg // world if regions_ok else 0
+    counts_all = None
     if piped:
-        # ---- pipeline over the pieces: [export i+1 | all-to-all i], then [merge i | all-to-all > i] ----
+        # Every piece's size is known before anything is sent (kh_region_unit_counts_device): a table that needs
+        # more heads than the send buffer holds (counts far above 2^cb) is found out HERE, and all ranks leave
+        # the pipeline together -- after the first all-to-all a rank that bails out would hang the others.
         unit32 = agreed == 2
         ub = 4 if unit32 else 8
-        sendbuf = keys.view(torch.int32) if unit32 else keys
-        cap_total = sendbuf.numel() if unit32 else n_local
-        wper = per // npieces
-        t_exp = t_wait = t_merge = 0.0
-        t0 = time.perf_counter()
-        # every piece's sizes and every region's unit count, announced up front: ONE small exchange each,
-        # so that nothing but the big all-to-alls sits on the communicator's stream afterwards
+        cap_total = 2 * n_local if unit32 else n_local
         counts_all = torch.empty(nreg, dtype=torch.int32, device=dev)
-        if counter.region_unit_counts_device(ub, counts_all.data_ptr(), nreg) != nreg:
-            raise RuntimeError("the table stopped fitting the exchange format between two calls")
-        send_mat = counts_all.view(world, npieces, wper).sum(dim=2, dtype=torch.int64).contiguous()  # [owner, piece]
-        recv_mat = torch.empty_like(send_mat)                                                        # [sender, piece]
-        _all_to_all(recv_mat, send_mat, group=group)
-        rrc_full = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices: sender s's counts of MY regions
-        _all_to_all(rrc_full, counts_all, group=group)
-        send_h, recv_h = send_mat.cpu().numpy(), recv_mat.cpu().numpy()
-        t1 = time.perf_counter()
-        t_wait += t1 - t0
-        t0 = t1
-        flights, used, sent, parts = [], 0, 0, exported[0]
-        for i in range(npieces):
-            if i > 0:
-                counter.set_region_window(i, npieces)
-                ptr = keys.data_ptr() + used * ub
-                if unit32:
-                    res = counter.export_regions_heads_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
-                else:
-                    res = counter.export_regions_packed_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
-                if res is None:
-                    raise RuntimeError("a later piece of the table does not fit the exchange format of the first")
-                parts = res[0]
-            send_sizes = [int(x) for x in parts.tolist()]
-            assert send_sizes == [int(x) for x in send_h[:, i]], "piece sizes differ from the announced ones"
-            recv_sizes = [int(x) for x in recv_h[:, i]]
-            total = sum(send_sizes)
-            buf = sendbuf[used:used + total]
-            used += total
-            sent += total - send_sizes[rank]
-            rp = torch.empty(sum(recv_sizes), dtype=buf.dtype, device=dev)
-            t1 = time.perf_counter()
-            t_exp += t1 - t0
-            work = _all_to_all_async(rp, buf, recv_sizes, send_sizes, group=group)
-            flights.append((rp, recv_sizes, work, buf))  # (buf stays alive while in flight)
-            t0 = time.perf_counter()
-            t_wait += t0 - t1
-        counter.set_region_window(0, 1)
-        counter.reset()
-        counter.set_shard(rank, world)
-        merge = counter.merge_regions_heads_device if unit32 else counter.merge_regions_packed_device
-        n_recv = 0
-        rrc_v = rrc_full.view(world, npieces, wper)
-        for i, (rp, recv_sizes, work, _) in enumerate(flights):
-            t1 = time.perf_counter()
-            rrc = torch.zeros_like(rrc_v)  # the senders' region counts as the merge of piece i wants them: zero elsewhere
-            rrc[:, i, :] = rrc_v[:, i, :]
-            _wait_all([work])
-            _stream_sync()  # (rrc is written on torch's stream, read on the counter's; NOT a device-wide sync:
-                            #  the later all-to-alls stay in flight)
-            t2 = time.perf_counter()
-            t_wait += t2 - t1
-            offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-            unit = rp.element_size()
-            counter.set_region_window(i, npieces)
-            merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
-                  [rrc.data_ptr() + 4 * per * s for s in range(world)])
-            n_recv += rp.numel()
-            t_merge += time.perf_counter() - t2
-        counter.set_region_window(0, 1)
-        st2 = counter.finish()
-        if timing is not None:
-            _device_sync()
-            timing.update({"export": timing.get("export", 0.0) + t_exp * 1e3, "exchange_wait": t_wait * 1e3, "merge": t_merge * 1e3,
-                           "pieces": npieces})
-            t_last[0] = time.perf_counter()
-            if os.environ.get("KMERHIP_MERGE_TIMING"):
-                print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
-        return {"path": ("regions-heads" if unit32 else "regions-packed") + f"-x{npieces}", "local_distinct": n_local,
-                "sent_pairs": int(sent), "recv_pairs": int(n_recv), "owned_distinct": int(st2["distinct"]), "phase_ms": timing}
+        fits = counter.region_unit_counts_device(ub, counts_all.data_ptr(), nreg) == nreg
+        if fits:
+            _stream_sync()
+            fits = int(counts_all.sum(dtype=torch.int64)) <= cap_total
+        if not all(v[0] for v in _gather_ints([int(bool(fits))], group)):
+            piped = False
+            counter.set_region_window(0, 1)
+            exported, my_fmt = None, 0
+            for fmt in (2, 1):  # one shot, whole table: the export itself says whether the narrow unit fits
+                exported = export(fmt)
+                if exported is not None:
+                    my_fmt = fmt
+                    break
+            votes = _gather_ints([my_fmt], group)
+            agreed = min(v[0] for v in votes)
+            if agreed and agreed != my_fmt:
+                exported = export(agreed)
+                assert exported is not None
+    if piped:
+        try:
+            return _merge_pipelined(counter, group, agreed, npieces, exported, counts_all, keys, rcnt, nreg, n_local, dev,
+                                    timing, t_last)
+        finally:
+            counter.set_region_window(0, 1)  # whatever happened: later exports / merges cover the whole range again
     if agreed:
         parts, _ = exported
         total = int(parts.sum())
@@ -317,6 +358,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         rp, recv_sizes = exchange_segments(buf, parts.tolist(), group=group)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices of nreg / world region counts
         _all_to_all(rrc, rcnt, group=group)
+        _stream_sync()  # a non-async collective only orders torch's stream; the merge kernels run on the counter's
         lap("all_to_all")
         counter.reset()
         counter.set_shard(rank, world)
@@ -334,6 +376,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         rk, rc, recv_sizes = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group, return_sizes=True)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)
         _all_to_all(rrc, rcnt, group=group)
+        _stream_sync()
         counter.reset()
         counter.set_shard(rank, world)
         offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
@@ -346,6 +389,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
         parts = counter.export_by_owner_device(world, keys.data_ptr(), cnts.data_ptr(), n_local)
         rk, rc = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group)
+        _stream_sync()
         counter.reset()
         counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
         path, n_recv = "pairs", rk.numel()

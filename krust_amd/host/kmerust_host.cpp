@@ -432,9 +432,39 @@ void write_histogram(FILE *out, const std::vector<std::pair<uint64_t, uint64_t>>
     fflush(out);
 }
 
+namespace {
+// BufWriter of run.rs:446: lines are formatted into an own buffer and handed to fwrite in 1 MiB pieces
+// (no setvbuf: the C standard leaves it undefined once the stream has been used).
+struct OutBuf {
+    FILE *out;
+    std::string buf;
+    explicit OutBuf(FILE *o) : out(o) { buf.reserve((1u << 20) + 256); }
+    void put(const char *s, size_t n) {
+        buf.append(s, n);
+        if (buf.size() >= (1u << 20)) flush();
+    }
+    void put(const char *s) { put(s, strlen(s)); }
+    void put_u64(unsigned long long v) {
+        char t[24];
+        int n = 0;
+        do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        char r[24];
+        for (int i = 0; i < n; ++i) r[i] = t[n - 1 - i];
+        put(r, (size_t)n);
+    }
+    void flush() {
+        if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), out);
+        buf.clear();
+    }
+    ~OutBuf() {
+        flush();
+        fflush(out);
+    }
+};
+}  // namespace
+
 void write_counts(FILE *out, const PackedCounts &pc, OutputFormat fmt, uint64_t min_count) {
-    std::vector<char> buf(1u << 20);
-    setvbuf(out, buf.data(), _IOFBF, buf.size());  // BufWriter (run.rs:446)
+    OutBuf w(out);
     char kmer[33];
     auto each = [&](const std::function<void(const char *, unsigned long long, bool)> &fn) {
         bool first = true;
@@ -449,31 +479,33 @@ void write_counts(FILE *out, const PackedCounts &pc, OutputFormat fmt, uint64_t 
     };
     switch (fmt) {
     case OutputFormat::Fasta:  // ">{count}\n{kmer}\n"  (run.rs:453-456)
-        each([&](const char *km, unsigned long long c, bool) { fprintf(out, ">%llu\n%s\n", c, km); });
+        each([&](const char *km, unsigned long long c, bool) {
+            w.put(">", 1); w.put_u64(c); w.put("\n", 1); w.put(km, pc.k); w.put("\n", 1);
+        });
         break;
     case OutputFormat::Tsv:  // "{kmer}\t{count}\n"  (run.rs:458-461)
-        each([&](const char *km, unsigned long long c, bool) { fprintf(out, "%s\t%llu\n", km, c); });
+        each([&](const char *km, unsigned long long c, bool) {
+            w.put(km, pc.k); w.put("\t", 1); w.put_u64(c); w.put("\n", 1);
+        });
         break;
     case OutputFormat::Json: {  // serde_json::to_writer_pretty of Vec<{kmer,count}> + newline (run.rs:463-470)
         bool any = false;
         each([&](const char *km, unsigned long long c, bool first) {
-            fputs(first ? "[\n" : ",\n", out);
-            fprintf(out, "  {\n    \"kmer\": \"%s\",\n    \"count\": %llu\n  }", km, c);
+            w.put(first ? "[\n" : ",\n");
+            w.put("  {\n    \"kmer\": \""); w.put(km, pc.k); w.put("\",\n    \"count\": "); w.put_u64(c); w.put("\n  }");
             any = true;
         });
-        fputs(any ? "\n]\n" : "[]\n", out);
+        w.put(any ? "\n]\n" : "[]\n");
         break;
     }
     case OutputFormat::Histogram: {  // host fallback: count-of-counts after the filter (run.rs:471-481)
         std::map<uint64_t, uint64_t> h;
         for (size_t i = 0; i < pc.keys.size(); ++i)
             if (pc.counts[i] >= min_count) h[pc.counts[i]]++;
-        for (const auto &cf : h) fprintf(out, "%llu\t%llu\n", (unsigned long long)cf.first, (unsigned long long)cf.second);
+        for (const auto &cf : h) { w.put_u64(cf.first); w.put("\t", 1); w.put_u64(cf.second); w.put("\n", 1); }
         break;
     }
     }
-    fflush(out);
-    setvbuf(out, nullptr, _IOLBF, 0);
 }
 
 // =============================================================================================

@@ -38,7 +38,7 @@ class KhStats(C.Structure):
                 ("stage_ms", C.c_double * 8), ("text_scan_ms", C.c_double)]
 
 STAGES = ("direct", "p1_count", "p1_scatter", "p2_count", "p2_scatter", "region", "misc", "grow")
-FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION = 1, 2, 4
+FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION, FLAG_CALLER_STREAM = 1, 2, 4, 8
 
 
 # every symbol include/kmerhip.h declares: name -> (restype, argtypes)
@@ -149,12 +149,15 @@ class DeviceCounter:
     build_with_quality() -> push()/push_device(); into_hashmap() -> result()."""
 
     def __init__(self, k, min_quality=None, capacity_hint=0, device=-1, stream=None, trace=False, path=None):
+        """stream: None = the context creates its own non-blocking stream (NOT ordered with torch's streams:
+        synchronise buffers you hand over yourself); an integer = launch on that hipStream_t, where 0 is the
+        legacy default stream (torch.cuda.current_stream().cuda_stream is usually 0)."""
         if not (1 <= int(k) <= 32):
             raise KmerLengthError(int(k))
         cfg = KhConfig(C.sizeof(KhConfig), int(k), -1 if min_quality is None else int(min_quality),
-                       int(device), int(capacity_hint), stream,
-                       (FLAG_TRACE if trace else 0) | {None: 0, "auto": 0, "direct": FLAG_FORCE_DIRECT,
-                                                       "partition": FLAG_FORCE_PARTITION}[path], 0)
+                       int(device), int(capacity_hint), stream or None,
+                       (FLAG_TRACE if trace else 0) | (FLAG_CALLER_STREAM if stream is not None else 0)
+                       | {None: 0, "auto": 0, "direct": FLAG_FORCE_DIRECT, "partition": FLAG_FORCE_PARTITION}[path], 0)
         h = _P()
         rc = lib().kh_create(C.byref(h), C.byref(cfg))
         if rc != KH_OK:

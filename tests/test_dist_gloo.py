@@ -138,11 +138,39 @@ class StandIn:
             if inside:
                 out += regs[r]
                 parts[r // per] += len(regs[r])
-        assert len(out) <= cap
+        if len(out) > cap:
+            return None  # KH_ERR_RANGE: more heads than the caller's buffer holds
         view(ptr, max(len(out), 1), np.uint32)[:len(out)] = out
         return parts, nreg
-    def export_regions_packed_device(self, *a):
-        raise AssertionError("heads are representable: the packed route must not be tried")
+    allow_packed = False
+    def export_regions_packed_device(self, nparts, ptr, cap, rc_ptr, region_cap):
+        assert self.allow_packed, "heads are representable: the packed route must not be tried"
+        nreg = 1 << self.rbits
+        per = nreg // nparts
+        assert self.win == (0, 1)
+        regs = [[] for _ in range(nreg)]
+        for key, cnt in self.table.items():
+            h = table_hash(key, self.k)
+            regs[h >> self.hb].append((cnt << 32) | ((h & ((1 << self.hb) - 1)) << (32 - self.hb)))
+        rc = view(rc_ptr, nreg, np.uint32)
+        out, parts = [], np.zeros(nparts, dtype=np.uint64)
+        for r in range(nreg):
+            rc[r] = len(regs[r]); out += regs[r]; parts[r // per] += len(regs[r])
+        assert len(out) <= cap
+        view(ptr, max(len(out), 1), np.uint64)[:len(out)] = out
+        return parts, nreg
+    def merge_regions_packed_device(self, sender_regions, ptrs, rc_ptrs):
+        index, count = self.shard
+        nr = sender_regions // count
+        for ptr, rcp in zip(ptrs, rc_ptrs):
+            rc = view(rcp, nr, np.uint32)
+            offs = np.concatenate([[0], np.cumsum(rc.astype(np.int64))])
+            units = view(ptr, max(int(offs[-1]), 1), np.uint64)
+            for j in range(nr):
+                for u in units[int(offs[j]):int(offs[j + 1])].tolist():
+                    h = ((index * nr + j) << self.hb) | ((u & 0xFFFFFFFF) >> (32 - self.hb))
+                    key = table_unhash(h, self.k)
+                    self.table[key] = self.table.get(key, 0) + (u >> 32)
     def merge_regions_heads_device(self, sender_regions, ptrs, rc_ptrs):
         index, count = self.shard
         nr = sender_regions // count
@@ -183,6 +211,24 @@ for pieces, path in ((1, "regions-heads"), (None, "regions-heads-x4"), (2, "regi
             union.update(tab)
             want[b] += 5000
         assert union == want, "merged shards differ from the single-process result"
+# A table whose counts need more heads than the send buffer holds (> 2 per key on average): piece 0 alone
+# would fit, so only the up-front size check can tell -- every rank must then leave the pipeline TOGETHER and
+# take the one-shot packed route (a rank that bailed out after the first all-to-all would hang the others),
+# and the region window must be back to (0, 1) afterwards.
+c = StandIn(K, RBITS)
+c.allow_packed = True
+c.table = {key: cnt + 100 for key, cnt in m.as_dict().items()} if rank == 0 else dict(m.as_dict())
+info = merge_across_ranks(c, pieces=None, phase_times=False)
+assert info["path"] == "regions-packed", info
+assert c.win == (0, 1)
+gathered = [None] * world
+dist.all_gather_object(gathered, (c.table, len(m) if rank == 0 else 0))
+if rank == 0:
+    union = {}
+    for tab, _ in gathered:
+        assert not (set(tab) & set(union))
+        union.update(tab)
+    assert sum(union.values()) == full.total() + 100 * len(m) and set(union) == set(full.as_dict())
 print("PIPE_OK", world)
 dist.destroy_process_group()
 '''

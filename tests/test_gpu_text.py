@@ -188,7 +188,10 @@ def _format_error(text, fmt, k=5, minq=None):
     (b"ACGT\n>r\nACGT\n", "fasta"),                             # text before the first header
     (b">r\nACGT \nACGT\n", "fasta"),                            # blank at a line end inside a record
     (b">r\nACGT\t\r\nACGT\n", "fasta"),
-], ids=["wrapped", "wrapped8", "lens", "no-at", "no-plus", "blank-line", "no-header", "trailing-space", "trailing-tab-crlf"])
+    (b">r\nACGTAC\rGTACGT\nACGT\n", "fasta"),                   # bare CR in the middle of a line: the line parsers keep
+    (b">r\nACGTACGT\r\r\nACGT\n", "fasta"),                     # it as an invalid base, dropping it would join AC|GT
+], ids=["wrapped", "wrapped8", "lens", "no-at", "no-plus", "blank-line", "no-header", "trailing-space", "trailing-tab-crlf",
+        "mid-line-cr", "double-cr"])
 def test_unsupported_layouts_are_reported_not_miscounted(text, fmt):
     _format_error(text, fmt)
 
