@@ -478,6 +478,7 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
 /* ======================================================================== */
 
 #define KO_RADIX_P 256
+#define KO_HIST_DENSE 65536
 
 typedef struct { uint64_t *v; uint64_t n, cap; } kvec_t;
 
@@ -486,6 +487,7 @@ typedef struct {
     size_t lo, hi;
     size_t k;
     int min_quality;
+    unsigned plo, phi; /* only keys of partitions [plo, phi) are kept in this pass */
     kvec_t part[KO_RADIX_P];
     uint64_t total;
 } rscan_t;
@@ -521,7 +523,8 @@ static void *rscan_main(void *arg) {
         if (++run >= k && i >= s->lo) {
             uint64_t key = fwd < rc ? fwd : rc;
             total++;
-            kvec_push(&s->part[ko_mix64(key) >> 56], key);
+            unsigned p = (unsigned)(ko_mix64(key) >> 56);
+            if (p >= s->plo && p < s->phi) kvec_push(&s->part[p], key);
         }
     }
     s->total = total;
@@ -532,6 +535,10 @@ typedef struct {
     rscan_t *scans;
     int nscan;
     atomic_ullong *next;
+    unsigned phi;
+    uint64_t min_count;
+    uint64_t *dense; /* [KO_HIST_DENSE] per thread, or NULL: no histogram wanted */
+    kvec_t big;      /* counts >= KO_HIST_DENSE */
     uint64_t distinct, digest;
 } rcount_t;
 
@@ -547,7 +554,7 @@ static void *rcount_main(void *arg) {
     uint64_t distinct = 0, digest = 0;
     for (;;) {
         uint64_t p = atomic_fetch_add(c->next, 1);
-        if (p >= KO_RADIX_P) break;
+        if (p >= c->phi) break;
         uint64_t n = 0;
         for (int t = 0; t < c->nscan; t++) n += c->scans[t].part[p].n;
         if (!n) continue;
@@ -556,11 +563,20 @@ static void *rcount_main(void *arg) {
         ko_map m;
         map_alloc(&m, cap);
         for (int t = 0; t < c->nscan; t++) {
-            const kvec_t *a = &c->scans[t].part[p];
+            kvec_t *a = &c->scans[t].part[p];
             for (uint64_t i = 0; i < a->n; i++) map_insert_raw(&m, a->v[i], 1);
+            free(a->v); /* the partition's keys are not needed again */
+            a->v = NULL; a->n = a->cap = 0;
         }
         distinct += m.len;
         digest += ko_map_digest(&m);
+        if (c->dense)
+            for (uint64_t i = 0; i < m.cap; i++) {
+                uint64_t v = m.e[i].val;
+                if (!v || v < c->min_count) continue;
+                if (v < KO_HIST_DENSE) c->dense[v]++;
+                else kvec_push(&c->big, v);
+            }
         free(m.e);
     }
     c->distinct = distinct;
@@ -568,38 +584,88 @@ static void *rcount_main(void *arg) {
     return NULL;
 }
 
-uint64_t ko_count_flat_radix_mt(const uint8_t *seq, size_t len, const uint8_t *qual, size_t k,
-                                int min_quality, int nthreads, uint64_t *distinct, uint64_t *digest) {
+/* The radix count in `npasses` passes over the input (pass j keeps only the keys of 256 / npasses hash
+ * partitions, so the key lists never hold more than ~1 / npasses of all k-mers at a time: an hg38-sized
+ * input would otherwise need > 25 GB of lists).  With count != NULL also the count-of-counts histogram
+ * after the min_count filter, ascending (compute_histogram, src/histogram.rs:88-94 as used by
+ * src/run.rs:447-450,471-481); *n_pairs receives the number of distinct counts (only cap are written). */
+uint64_t ko_hist_flat_radix_mt(const uint8_t *seq, size_t len, const uint8_t *qual, size_t k, int min_quality,
+                               int nthreads, int npasses, uint64_t min_count, uint64_t *count, uint64_t *freq,
+                               uint64_t cap, uint64_t *n_pairs, uint64_t *distinct, uint64_t *digest) {
     if (nthreads < 1) nthreads = 1;
+    if (npasses < 1) npasses = 1;
+    if (npasses > KO_RADIX_P) npasses = KO_RADIX_P;
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
     rscan_t *ss = (rscan_t *)calloc((size_t)nthreads, sizeof(rscan_t));
     rcount_t *cs = (rcount_t *)calloc((size_t)nthreads, sizeof(rcount_t));
-    if (!th || !ss || !cs) abort();
+    uint64_t *dense = count ? (uint64_t *)calloc((size_t)nthreads * KO_HIST_DENSE, sizeof(uint64_t)) : NULL;
+    if (!th || !ss || !cs || (count && !dense)) abort();
     size_t per = (len + (size_t)nthreads - 1) / (size_t)nthreads;
-    for (int t = 0; t < nthreads; t++) {
-        size_t lo = per * (size_t)t, hi = lo + per;
-        if (lo > len) lo = len;
-        if (hi > len) hi = len;
-        ss[t].seq = seq; ss[t].qual = qual; ss[t].lo = lo; ss[t].hi = hi; ss[t].k = k;
-        ss[t].min_quality = min_quality;
-        pthread_create(&th[t], NULL, rscan_main, &ss[t]);
+    uint64_t total = 0, d = 0, g = 0;
+    for (int pass = 0; pass < npasses; pass++) {
+        const unsigned plo = (unsigned)((uint64_t)KO_RADIX_P * (uint64_t)pass / (uint64_t)npasses);
+        const unsigned phi = (unsigned)((uint64_t)KO_RADIX_P * (uint64_t)(pass + 1) / (uint64_t)npasses);
+        for (int t = 0; t < nthreads; t++) {
+            size_t lo = per * (size_t)t, hi = lo + per;
+            if (lo > len) lo = len;
+            if (hi > len) hi = len;
+            ss[t].seq = seq; ss[t].qual = qual; ss[t].lo = lo; ss[t].hi = hi; ss[t].k = k;
+            ss[t].min_quality = min_quality; ss[t].plo = plo; ss[t].phi = phi;
+            pthread_create(&th[t], NULL, rscan_main, &ss[t]);
+        }
+        uint64_t tot = 0;
+        for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); tot += ss[t].total; }
+        total = tot; /* every pass sees every window */
+        atomic_ullong next;
+        atomic_init(&next, plo);
+        for (int t = 0; t < nthreads; t++) {
+            cs[t].scans = ss; cs[t].nscan = nthreads; cs[t].next = &next; cs[t].phi = phi;
+            cs[t].min_count = min_count;
+            cs[t].dense = dense ? dense + (size_t)t * KO_HIST_DENSE : NULL;
+            pthread_create(&th[t], NULL, rcount_main, &cs[t]);
+        }
+        for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); d += cs[t].distinct; g += cs[t].digest; }
     }
-    uint64_t total = 0;
-    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); total += ss[t].total; }
-    atomic_ullong next;
-    atomic_init(&next, 0);
-    for (int t = 0; t < nthreads; t++) {
-        cs[t].scans = ss; cs[t].nscan = nthreads; cs[t].next = &next;
-        pthread_create(&th[t], NULL, rcount_main, &cs[t]);
-    }
-    uint64_t d = 0, g = 0;
-    for (int t = 0; t < nthreads; t++) { pthread_join(th[t], NULL); d += cs[t].distinct; g += cs[t].digest; }
     for (int t = 0; t < nthreads; t++)
         for (int p = 0; p < KO_RADIX_P; p++) free(ss[t].part[p].v);
-    free(th); free(ss); free(cs);
+    if (count) {
+        uint64_t nd = 0;
+        for (uint64_t v = 1; v < KO_HIST_DENSE; v++) {
+            uint64_t f = 0;
+            for (int t = 0; t < nthreads; t++) f += dense[(size_t)t * KO_HIST_DENSE + v];
+            if (!f) continue;
+            if (nd < cap) { count[nd] = v; freq[nd] = f; }
+            nd++;
+        }
+        uint64_t nbig = 0;
+        for (int t = 0; t < nthreads; t++) nbig += cs[t].big.n;
+        uint64_t *bv = (uint64_t *)malloc((nbig ? nbig : 1) * sizeof(uint64_t));
+        if (!bv) abort();
+        uint64_t o = 0;
+        for (int t = 0; t < nthreads; t++) {
+            for (uint64_t i = 0; i < cs[t].big.n; i++) bv[o++] = cs[t].big.v[i];
+            free(cs[t].big.v);
+        }
+        qsort(bv, nbig, sizeof(uint64_t), cmp_u64);
+        for (uint64_t i = 0; i < nbig;) {
+            uint64_t j = i;
+            while (j < nbig && bv[j] == bv[i]) j++;
+            if (nd < cap) { count[nd] = bv[i]; freq[nd] = j - i; }
+            nd++;
+            i = j;
+        }
+        free(bv);
+        if (n_pairs) *n_pairs = nd;
+    }
+    free(dense); free(th); free(ss); free(cs);
     if (distinct) *distinct = d;
     if (digest) *digest = g;
     return total;
+}
+
+uint64_t ko_count_flat_radix_mt(const uint8_t *seq, size_t len, const uint8_t *qual, size_t k,
+                                int min_quality, int nthreads, uint64_t *distinct, uint64_t *digest) {
+    return ko_hist_flat_radix_mt(seq, len, qual, k, min_quality, nthreads, 1, 1, NULL, NULL, 0, NULL, distinct, digest);
 }
 
 /* ======================================================================== */
@@ -648,4 +714,112 @@ void ko_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t read_len,
         bo[read_len] = '\n';
         if (qo) qo[read_len] = '\n';
     }
+}
+
+/* ======================================================================== */
+/* "hg-like" synthetic assembly (BASELINE.json configs[4] stand-in)          */
+/* ======================================================================== */
+/* hg38 itself is not on the box.  This generator has the features of a mammalian assembly that matter to
+ * the counting path: a few very long records (the caller passes hg38's chromosome lengths), ~50 % of the
+ * bases soft-masked (lowercase, in 1 KiB blocks), ~5 % N in long runs (gaps) plus a run at every record
+ * start (telomere), interspersed repeat families whose copy numbers span five orders of magnitude (diverged
+ * copies: 1 substitution in 64), and tandem repeats / homopolymer tracts (counts far above 2^16).  It is
+ * counter based -- base i depends only on (seed, i) -- so any range can be produced by any thread. */
+
+#define HG_BLOCK 4096ULL
+
+static inline uint8_t hg_base_at(uint64_t kg, uint64_t kb, uint64_t km, uint64_t kn, uint64_t kc, uint64_t i) {
+    static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+    const uint64_t blk = i / HG_BLOCK, j = i % HG_BLOCK;
+    if (draw(kn, blk >> 4) % 20 == 0) return 'N';               /* gaps: runs of 16 blocks, ~5 % */
+    const uint64_t u = draw(kb, blk);
+    const unsigned type = (unsigned)(u & 7);
+    uint64_t c;
+    if (type == 7 && ((u >> 3) & 15) == 0) {                    /* tandem repeat / homopolymer block */
+        const unsigned unit = 1 + (unsigned)((u >> 8) % 6);     /* unit length 1..6 */
+        const uint64_t motif = draw(kg, (u >> 16) % 5 + (1ULL << 50)); /* five motifs in all */
+        c = (motif >> (2 * (j % unit))) & 3;
+    } else if (type < 3) {                                      /* copy of a repeat-family consensus */
+        const unsigned fbits = (unsigned)((u >> 40) % 17);      /* family drawn from 2^fbits: copy numbers vary */
+        const uint64_t fam = (u >> 8) & ((1ULL << fbits) - 1);
+        c = draw(kg, (1ULL << 40) + fam * HG_BLOCK + j) & 3;
+        const uint64_t m = draw(km, i);
+        if ((m & 63) == 0) c = (c + 1 + ((m >> 8) % 3)) & 3;    /* diverged copies */
+    } else {
+        c = draw(kg, i) & 3;                                    /* unique sequence */
+    }
+    uint8_t b = (uint8_t)ACGT[c];
+    if (draw(kc, i >> 10) & 1) b |= 0x20;                       /* soft-masked 1 KiB blocks, ~50 % */
+    return b;
+}
+
+typedef struct {
+    uint64_t seed;
+    const uint64_t *rec_off; /* global start of every record, nrec + 1 entries */
+    uint64_t nrec;
+    uint8_t *out;            /* flat: records separated by '\n' */
+    uint64_t lo, hi;         /* output byte range of this thread */
+} hg_job_t;
+
+static void *hg_main(void *arg) {
+    hg_job_t *j = (hg_job_t *)arg;
+    const uint64_t kg = stream_key(j->seed, 10), kb = stream_key(j->seed, 11), km = stream_key(j->seed, 12),
+                   kn = stream_key(j->seed, 13), kc = stream_key(j->seed, 14);
+    /* output position o of record r, offset x: o = rec_off[r] + r + x  (one '\n' after every record) */
+    uint64_t r = 0;
+    while (r + 1 < j->nrec && j->rec_off[r + 1] + (r + 1) <= j->lo) r++;
+    for (uint64_t o = j->lo; o < j->hi; o++) {
+        while (r + 1 < j->nrec && j->rec_off[r + 1] + (r + 1) <= o) r++;
+        const uint64_t x = o - (j->rec_off[r] + r);
+        const uint64_t rlen = j->rec_off[r + 1] - j->rec_off[r];
+        if (x == rlen) { j->out[o] = '\n'; continue; }
+        const uint64_t gi = j->rec_off[r] + x;
+        j->out[o] = (x < 10000 && rlen > 1000000) ? (uint8_t)'N' : hg_base_at(kg, kb, km, kn, kc, gi);
+    }
+    return NULL;
+}
+
+/* Writes sum(lens) + nrec bytes: record r (lens[r] bases) followed by '\n'. */
+void ko_synth_hg(uint64_t seed, const uint64_t *lens, uint64_t nrec, uint8_t *out, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    uint64_t *off = (uint64_t *)malloc((nrec + 1) * sizeof(uint64_t));
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    hg_job_t *jobs = (hg_job_t *)calloc((size_t)nthreads, sizeof(hg_job_t));
+    if (!off || !th || !jobs) abort();
+    off[0] = 0;
+    for (uint64_t r = 0; r < nrec; r++) off[r + 1] = off[r] + lens[r];
+    const uint64_t total = off[nrec] + nrec;
+    const uint64_t per = (total + (uint64_t)nthreads - 1) / (uint64_t)nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        uint64_t lo = per * (uint64_t)t, hi = lo + per;
+        if (lo > total) lo = total;
+        if (hi > total) hi = total;
+        jobs[t] = (hg_job_t){seed, off, nrec, out, lo, hi};
+        pthread_create(&th[t], NULL, hg_main, &jobs[t]);
+    }
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    free(off); free(th); free(jobs);
+}
+
+#include <stdio.h>
+/* The same records as FASTA text: ">chr{r+1} ...\n" then lines of `width` columns.  Returns 0, or -1 on
+ * an I/O error. */
+int ko_write_fasta(const char *path, const uint8_t *flat, const uint64_t *lens, uint64_t nrec, uint32_t width) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    static char iobuf[1 << 22];
+    setvbuf(f, iobuf, _IOFBF, sizeof iobuf);
+    uint64_t o = 0;
+    int ok = 1;
+    for (uint64_t r = 0; r < nrec && ok; r++) {
+        ok = fprintf(f, ">chr%llu hg-like synthetic record, %llu bp\n", (unsigned long long)(r + 1),
+                     (unsigned long long)lens[r]) > 0;
+        for (uint64_t x = 0; x < lens[r] && ok; x += width) {
+            const uint64_t n = lens[r] - x < width ? lens[r] - x : width;
+            ok = fwrite(flat + o + x, 1, n, f) == n && fputc('\n', f) != EOF;
+        }
+        o += lens[r] + 1;
+    }
+    if (fclose(f) != 0) ok = 0;
+    return ok ? 0 : -1;
 }

@@ -127,6 +127,13 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
  * describe the result without materialising one big map. */
 uint64_t ko_count_flat_radix_mt(const uint8_t *seq, size_t len, const uint8_t *qual, size_t k,
                                 int min_quality, int nthreads, uint64_t *distinct, uint64_t *digest);
+/* The same count in `npasses` passes over the input (bounded memory: pass j holds the keys of 256 / npasses
+ * hash partitions only), optionally with the count-of-counts histogram after the min_count filter, ascending
+ * (compute_histogram, src/histogram.rs:88-94 as used by output_counts, src/run.rs:447-450,471-481):
+ * count / freq may be NULL; *n_pairs = number of distinct counts (only cap are written). */
+uint64_t ko_hist_flat_radix_mt(const uint8_t *seq, size_t len, const uint8_t *qual, size_t k, int min_quality,
+                               int nthreads, int npasses, uint64_t min_count, uint64_t *count, uint64_t *freq,
+                               uint64_t cap, uint64_t *n_pairs, uint64_t *distinct, uint64_t *digest);
 /* the same digest of an existing map (to cross-check the two CPU formulations and the GPU) */
 uint64_t ko_map_digest(const ko_map *m);
 
@@ -140,6 +147,17 @@ uint64_t ko_mix64(uint64_t z);
 void ko_synth_reads(uint64_t seed, uint64_t genome_len, uint32_t read_len,
                     uint64_t first_read, uint64_t n_reads, uint8_t *bases,
                     uint8_t *qual);
+
+
+/* ---- "hg-like" synthetic assembly (BASELINE.json configs[4] stand-in) --- */
+
+/* Counter-based generator of an assembly-shaped FASTA: nrec records of lens[r] bases (the caller passes
+ * hg38's chromosome lengths), ~50 % soft-masked, ~5 % N in long runs, repeat families with copy numbers
+ * from 1 to ~10^5, tandem repeats.  Writes sum(lens) + nrec bytes to out: every record followed by '\n'
+ * (the flat layout the scan functions above take). */
+void ko_synth_hg(uint64_t seed, const uint64_t *lens, uint64_t nrec, uint8_t *out, int nthreads);
+/* The same records as FASTA text (">chr{r+1} ..." headers, lines of `width` columns); 0 or -1 (I/O). */
+int ko_write_fasta(const char *path, const uint8_t *flat, const uint64_t *lens, uint64_t nrec, uint32_t width);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,14 @@ def _load():
     lib.ko_count_flat_radix_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int,
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ko_count_flat_radix_mt.restype = C.c_uint64
+    lib.ko_hist_flat_radix_mt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                          C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.ko_hist_flat_radix_mt.restype = C.c_uint64
+    lib.ko_synth_hg.argtypes = [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    lib.ko_synth_hg.restype = None
+    lib.ko_write_fasta.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+    lib.ko_write_fasta.restype = C.c_int
     lib.ko_map_digest.argtypes = [C.c_void_p]
     lib.ko_map_digest.restype = C.c_uint64
     lib.ko_mix64.argtypes = [C.c_uint64]
@@ -175,6 +183,47 @@ def count_flat_radix(seq, k, qual=None, min_quality=None, nthreads=1):
     tot = lib().ko_count_flat_radix_mt(sp, sn, qp, k, -1 if min_quality is None else int(min_quality), nthreads,
                                        C.byref(d), C.byref(g))
     return int(tot), int(d.value), int(g.value)
+
+
+def hist_flat_radix(seq, k, qual=None, min_quality=None, nthreads=1, npasses=1, min_count=1):
+    """Full count of a flat buffer in `npasses` bounded-memory passes: (kmers, distinct, digest, histogram) with
+    the histogram as ascending (count, frequency) pairs after the min_count filter (src/run.rs:447-450,471-481)."""
+    sp, sn, _ks = _buf(seq)
+    qp, _, _kq = _buf(qual)
+    d, g, n = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    cap = 1 << 17
+    while True:
+        cnt = np.empty(cap, dtype=np.uint64)
+        frq = np.empty(cap, dtype=np.uint64)
+        tot = lib().ko_hist_flat_radix_mt(sp, sn, qp, k, -1 if min_quality is None else int(min_quality), nthreads,
+                                          npasses, int(min_count), cnt.ctypes.data, frq.ctypes.data, cap,
+                                          C.byref(n), C.byref(d), C.byref(g))
+        if n.value <= cap:
+            break
+        cap = int(n.value)
+    return int(tot), int(d.value), int(g.value), list(zip(cnt[: n.value].tolist(), frq[: n.value].tolist()))
+
+
+# hg38 (GRCh38.p14 primary assembly) chromosome lengths: chr1..22, X, Y, M -- 3.09 Gbp, chr1 = 248,956,422 bp
+HG38_LENGTHS = (248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+                133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+                58617616, 64444167, 46709983, 50818468, 156040895, 57227415, 16569)
+
+
+def synth_hg(seed, lens, nthreads=1):
+    """'hg-like' synthetic assembly: flat uint8 buffer, record r = lens[r] bases followed by '\\n'."""
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    out = np.empty(int(lens.sum()) + lens.size, dtype=np.uint8)
+    lib().ko_synth_hg(int(seed), lens.ctypes.data, lens.size, out.ctypes.data, int(nthreads))
+    return out
+
+
+def write_fasta(path, flat, lens, width=60):
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    flat = np.ascontiguousarray(flat, dtype=np.uint8)
+    assert flat.size == int(lens.sum()) + lens.size
+    if lib().ko_write_fasta(os.fsencode(path), flat.ctypes.data, lens.ctypes.data, lens.size, int(width)) != 0:
+        raise OSError(f"writing {path} failed")
 
 
 def pack(seq):

@@ -261,3 +261,19 @@ def test_records_larger_than_the_text_chunk(tmp_path):
     host = run("15", str(fq), "-Q", "5", "--format", "histogram", "--quiet", env={"KMERUST_HOST_PARSE": "1"})
     assert dev.returncode == 0 and host.returncode == 0, (dev.stderr, host.stderr)
     assert dev.stdout == host.stdout and dev.stdout
+
+
+def test_bare_cr_inside_a_fasta_line_is_an_invalid_base(tmp_path):
+    """rust-bio trims only the END of a line (the reference's default reader, src/reader.rs:35-54): a bare CR in
+    the middle of a sequence line stays in the record as an invalid base and breaks windows.  The device scanner
+    must not join AC\\rGT to ACGT: it declines the text and the host line parser counts the file."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    fa = tmp_path / "cr.fa"
+    fa.write_bytes(b">a\nACGTAC\rGTACGTTGCA\nACGTTTGA\r\n>b\nGGGCCCAAATTT\n")
+    want = O.count_records([b"ACGTAC\rGTACGTTGCAACGTTTGA", b"GGGCCCAAATTT"], 4).as_str_dict(4)
+    for env in ({}, {"KMERUST_HOST_PARSE": "1"}):
+        r = run("4", str(fa), "--format", "tsv", "--quiet", env=env)
+        assert r.returncode == 0, r.stderr
+        assert tsv(r.stdout) == want

@@ -260,6 +260,22 @@ def test_many_batches_into_one_table_match_the_direct_path(K, k, minq):
     (dk, dcnt, dn), (pk, pcnt, pn) = tables["direct"], tables["partition"]
     assert dn == pn == int(dcnt.sum()) == int(pcnt.sum())
     assert dk.size == pk.size and np.array_equal(dk, pk) and np.array_equal(dcnt, pcnt)
+    # third leg: the CPU oracle on the same 2000 spans (k-mers never span pushes: one separator between spans),
+    # whole map by total, distinct count and the order-independent digest of all (key, count) pairs
+    hb = tb.cpu().numpy()
+    hq = tq.cpu().numpy() if tq is not None else None
+    idx = (np.arange(nb, dtype=np.int64)[:, None] * step + np.arange(span + 1, dtype=np.int64)[None, :]).ravel()
+    sep = np.tile(np.arange(span + 1) == span, nb)
+    cat = hb[np.minimum(idx, hb.size - 1)]
+    cat[sep] = ord("\n")
+    catq = None
+    if hq is not None:
+        catq = hq[np.minimum(idx, hq.size - 1)]
+        catq[sep] = ord("\n")
+    total, distinct, digest = O.count_flat_radix(cat, k, qual=catq, min_quality=minq, nthreads=NCPU)
+    with np.errstate(over="ignore"):
+        got = int(_np_mix64(pk ^ _np_mix64(pcnt)).sum(dtype=np.uint64))
+    assert (pn, pk.size, got) == (total, distinct, digest)
 
 
 # restatement of the table hash (krust_amd/csrc/kmer_bits.h kh_hash_n / kh_unhash_n), to BUILD keys with chosen hash bits

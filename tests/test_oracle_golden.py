@@ -255,3 +255,24 @@ def test_synth_reads_shape_and_rates():
     # deterministic + window-independent (counter based)
     b2, _ = O.synth_reads(20260130, 1 << 20, 150, 1000, 10)
     assert (b2.reshape(10, 151) == b[1000:1010]).all()
+
+
+def test_passes_radix_histogram_equals_the_map_histogram(tmp_path):
+    """ko_hist_flat_radix_mt (bounded-memory passes; used for the hg38-sized parity test) against the plain
+    map on an hg-like miniature: total, distinct, digest, histogram with and without a min_count filter; and
+    the FASTA writer round-trips the generated records."""
+    lens = [700_000, 150_000, 16_569, 40, 7]
+    flat = O.synth_hg(38, lens, nthreads=4)
+    assert flat.size == sum(lens) + len(lens)
+    assert np.array_equal(flat, O.synth_hg(38, lens, nthreads=1))          # counter based: any thread split
+    m = O.OracleMap()
+    total = m.scan_flat(flat, 21, nthreads=3)
+    for npasses, threads, minc in ((1, 2, 1), (4, 3, 1), (8, 5, 3), (256, 1, 1)):
+        t, d, g, h = O.hist_flat_radix(flat, 21, nthreads=threads, npasses=npasses, min_count=minc)
+        assert (t, d, g) == (total, len(m), m.digest()) and h == m.histogram(minc)
+    path = tmp_path / "mini.fa"
+    O.write_fasta(str(path), flat, lens, width=60)
+    txt = path.read_bytes()
+    assert max(len(l) for l in txt.split(b"\n")) == 60
+    recs = [r.split(b"\n", 1)[1].replace(b"\n", b"") for r in txt.split(b">")[1:]]
+    assert b"\n".join(recs) + b"\n" == flat.tobytes()
