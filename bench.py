@@ -160,11 +160,32 @@ def main():
     # RCCL's); every hand-over between torch work and the counter is fenced by a device-wide synchronize here
     dc = krust_amd.DeviceCounter(k, min_quality=args.min_quality, capacity_hint=hint, device=local_rank, stream=None)
 
+    # N > 1: the exchange runs INSIDE the library (kh_merge_across: RCCL send/recv groups on its own stream,
+    # pipelined against the export and LDS-merge kernels) -- the route a Rust / C++ host takes.  torch.distributed
+    # only carries the 128-byte communicator id and the final timing reductions.  BENCH_MERGE=python (or the gloo
+    # backend of the 1-GPU tests, where ranks share a device and RCCL cannot be used) selects the
+    # torch.distributed harness krust_amd/distributed.py instead; both leave identical shard tables.
+    merge_impl = os.environ.get("BENCH_MERGE", "c" if backend == "nccl" else "python")
+    if world > 1 and merge_impl == "c":
+        box = [krust_amd.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        dc.comm_init(world, rank, box[0])
+
+    def merge():
+        if merge_impl == "c":
+            mi = dc.merge_across()
+            return {"impl": "kh_merge_across (C ABI, RCCL)", "path": mi["path"], "local_distinct": mi["local_distinct"],
+                    "sent_pairs": mi["sent_units"], "recv_pairs": mi["recv_units"], "unit_bytes": mi["unit_bytes"],
+                    "owned_distinct": mi["owned_distinct"],
+                    "phase_ms": {"export": mi["export_ms"], "exchange_wait": mi["wait_ms"], "merge": mi["merge_ms"],
+                                 "total": mi["total_ms"], "pieces": mi["pieces"]}}
+        return dict(merge_across_ranks(dc, phase_times=True), impl="krust_amd.distributed (torch.distributed)")
+
     def step():
         dc.reset()
         dc.push_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, nbytes)
         st = dc.finish()
-        mg = merge_across_ranks(dc, phase_times=True) if world > 1 else None  # (phase walls of rank 0 go into the JSON)
+        mg = merge() if world > 1 else None  # (phase walls of rank 0 go into the JSON)
         return st, mg
 
     def fence():

@@ -48,6 +48,36 @@ pub mod sys {
         _private: [u8; 0],
     }
 
+    /// ncclUniqueId (opaque): names one communicator; rank 0 makes it, every rank gets a copy.
+    #[repr(C)]
+    #[derive(Clone, Copy)]
+    pub struct KhUniqueId {
+        pub internal: [c_char; 128],
+    }
+
+    /// What one rank's `kh_merge_across` did.
+    #[repr(C)]
+    #[derive(Default, Debug, Clone, Copy)]
+    pub struct KhMergeInfo {
+        pub route: u32,
+        pub pieces: u32,
+        pub unit_bytes: u32,
+        pub nranks: u32,
+        pub local_distinct: u64,
+        pub sent_units: u64,
+        pub recv_units: u64,
+        pub owned_distinct: u64,
+        pub export_ms: f64,
+        pub wait_ms: f64,
+        pub merge_ms: f64,
+        pub total_ms: f64,
+    }
+
+    #[repr(C)]
+    pub struct KhGroup {
+        _private: [u8; 0],
+    }
+
     extern "C" {
         pub fn kh_abi_version() -> c_int;
         pub fn kh_create(out: *mut *mut KhCtx, cfg: *const KhConfig) -> c_int;
@@ -68,6 +98,16 @@ pub mod sys {
         pub fn kh_canonical(packed: u64, k: u32, canonical: *mut u64, is_rc: *mut c_int) -> c_int;
         pub fn kh_strerror(status: c_int) -> *const c_char;
         pub fn kh_last_error(ctx: *const KhCtx) -> *const c_char;
+        // the multi-GPU exchange (RCCL over xGMI) behind the ABI
+        pub fn kh_owner(key: u64, k: u32, nparts: u32) -> u32;
+        pub fn kh_comm_unique_id(out: *mut KhUniqueId) -> c_int;
+        pub fn kh_comm_init(ctx: *mut KhCtx, nranks: u32, rank: u32, id: *const KhUniqueId) -> c_int;
+        pub fn kh_merge_across(ctx: *mut KhCtx, info: *mut KhMergeInfo) -> c_int;
+        pub fn kh_group_create(out: *mut *mut KhGroup, cfg: *const KhConfig, devices: *const i32, ndevices: u32) -> c_int;
+        pub fn kh_group_ctx(g: *mut KhGroup, rank: u32) -> *mut KhCtx;
+        pub fn kh_group_size(g: *const KhGroup) -> u32;
+        pub fn kh_group_merge(g: *mut KhGroup, infos: *mut KhMergeInfo) -> c_int;
+        pub fn kh_group_destroy(g: *mut KhGroup);
     }
 }
 
@@ -225,6 +265,127 @@ impl HipKmerMap {
             check(self.ctx, rc)?;
             return Ok(c.into_iter().zip(f).take(n as usize).collect());
         }
+    }
+}
+
+/// Several GPUs of one node from ONE process (no reference counterpart: the reference's only parallelism is
+/// rayon over records, `src/run.rs:500-503`): one device table per GPU, reads dealt out in batches of whole
+/// records, then `kh_group_merge` -- the library's RCCL exchange -- turns the N tables into one table sharded
+/// by hash range, and the result is the concatenation of the shards.
+pub struct HipKmerMapGroup {
+    group: *mut sys::KhGroup,
+    k: usize,
+    next: usize,
+}
+
+unsafe impl Send for HipKmerMapGroup {}
+
+impl HipKmerMapGroup {
+    /// `devices`: HIP ordinals, one rank each (`&[0, 1, 2, 3, 4, 5, 6, 7]` for a whole MI355X node).
+    pub fn new(k: usize, min_quality: Option<u8>, devices: &[i32]) -> Result<Self, HipError> {
+        if !(1..=32).contains(&k) {
+            return Err(HipError::KmerLength { k });
+        }
+        let cfg = sys::KhConfig {
+            struct_size: std::mem::size_of::<sys::KhConfig>() as u32,
+            k: k as u32,
+            min_quality: min_quality.map_or(-1, i32::from),
+            device: -1,
+            capacity_hint: 0,
+            stream: std::ptr::null_mut(),
+            flags: 0,
+            reserved: 0,
+        };
+        let mut group = std::ptr::null_mut();
+        check(std::ptr::null(), unsafe { sys::kh_group_create(&mut group, &cfg, devices.as_ptr(), devices.len() as u32) })?;
+        Ok(Self { group, k, next: 0 })
+    }
+
+    fn ctx(&self, rank: usize) -> *mut sys::KhCtx {
+        unsafe { sys::kh_group_ctx(self.group, rank as u32) }
+    }
+
+    /// `KmerMap::build` over all devices: batches of whole records go to the ranks in turn.
+    pub fn build<I: Iterator<Item = Bytes>>(mut self, sequences: I) -> Result<Self, HipError> {
+        let n = unsafe { sys::kh_group_size(self.group) } as usize;
+        let mut flat = Vec::with_capacity(BATCH / 4 + (1 << 20));
+        let mut flush = |flat: &mut Vec<u8>, next: &mut usize| -> Result<(), HipError> {
+            if !flat.is_empty() {
+                let c = unsafe { sys::kh_group_ctx(self.group, (*next % n) as u32) };
+                *next += 1;
+                check(c, unsafe { sys::kh_push(c, flat.as_ptr(), std::ptr::null(), flat.len() as u64) })?;
+                flat.clear();
+            }
+            Ok(())
+        };
+        let mut next = self.next;
+        for seq in sequences {
+            flat.extend_from_slice(&seq);
+            flat.push(b'\n');
+            if flat.len() >= BATCH / 4 {
+                flush(&mut flat, &mut next)?;
+            }
+        }
+        flush(&mut flat, &mut next)?;
+        self.next = next;
+        Ok(self)
+    }
+
+    /// Merge (collective over the group's ranks, one host thread each inside the library) and collect:
+    /// the shards' key sets are disjoint, so their union is the map.
+    pub fn into_packed(self, min_count: u64) -> Result<HashMap<u64, u64>, HipError> {
+        let n = unsafe { sys::kh_group_size(self.group) } as usize;
+        for r in 0..n {
+            check(self.ctx(r), unsafe { sys::kh_finish(self.ctx(r), std::ptr::null_mut()) })?;
+        }
+        check(self.ctx(0), unsafe { sys::kh_group_merge(self.group, std::ptr::null_mut()) })?;
+        let mut out = HashMap::new();
+        for r in 0..n {
+            let c = self.ctx(r);
+            let mut cnt = 0u64;
+            check(c, unsafe { sys::kh_result_size(c, min_count, &mut cnt) })?;
+            let (mut keys, mut counts) = (vec![0u64; cnt as usize], vec![0u64; cnt as usize]);
+            let mut got = 0u64;
+            check(c, unsafe { sys::kh_result_copy(c, keys.as_mut_ptr(), counts.as_mut_ptr(), cnt, min_count, &mut got) })?;
+            out.extend(keys.into_iter().zip(counts).take(got as usize));
+        }
+        Ok(out)
+    }
+
+    /// `KmerMap::into_hashmap` (`src/run.rs:573-582`).
+    pub fn into_hashmap(self) -> Result<HashMap<String, u64>, HipError> {
+        let k = self.k;
+        Ok(self.into_packed(1)?.into_iter().map(|(bits, c)| (unpack_to_string(bits, k), c)).collect())
+    }
+}
+
+impl Drop for HipKmerMapGroup {
+    fn drop(&mut self) {
+        // SAFETY: the group came from kh_group_create; its contexts are destroyed with it
+        unsafe { sys::kh_group_destroy(self.group) }
+    }
+}
+
+/// One process per GPU instead (MPI-style hosts): rank 0 calls `comm_unique_id()` and hands the 128 bytes
+/// to every rank; each rank then `join`s with its own `HipKmerMap`, counts its share and calls `merge_across`.
+pub fn comm_unique_id() -> Result<sys::KhUniqueId, HipError> {
+    let mut id = sys::KhUniqueId { internal: [0; 128] };
+    check(std::ptr::null(), unsafe { sys::kh_comm_unique_id(&mut id) })?;
+    Ok(id)
+}
+
+impl HipKmerMap {
+    /// Collective: blocks until all `nranks` ranks have joined.
+    pub fn join(&mut self, nranks: u32, rank: u32, id: &sys::KhUniqueId) -> Result<(), HipError> {
+        check(self.ctx, unsafe { sys::kh_comm_init(self.ctx, nranks, rank, id) })
+    }
+
+    /// Collective: afterwards this map holds exactly the keys with `kh_owner(key, k, nranks) == rank`,
+    /// counts summed over all ranks.
+    pub fn merge_across(&mut self) -> Result<sys::KhMergeInfo, HipError> {
+        let mut info = sys::KhMergeInfo::default();
+        check(self.ctx, unsafe { sys::kh_merge_across(self.ctx, &mut info) })?;
+        Ok(info)
     }
 }
 

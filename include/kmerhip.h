@@ -55,8 +55,9 @@ typedef enum kh_status {
     KH_ERR_HIP = -6,        /* a HIP call failed; kh_last_error() has the text */
     KH_ERR_STATE = -7,      /* call not valid in the context's current state */
     KH_ERR_RANGE = -8,      /* caller-provided output array too small */
-    KH_ERR_FORMAT = -9      /* kh_push_text*: a record layout the device scanner does not take
+    KH_ERR_FORMAT = -9,     /* kh_push_text*: a record layout the device scanner does not take
                                (nothing was counted; parse on the host and use kh_push) */
+    KH_ERR_RCCL = -10       /* an RCCL call failed (kh_comm_init / kh_merge_across); kh_last_error() has the text */
 } kh_status;
 
 typedef struct kh_ctx kh_ctx;
@@ -242,6 +243,66 @@ int kh_export_by_owner_device(kh_ctx *ctx, uint32_t nparts, uint64_t *d_keys,
 /* count[key] += counts[i] for n device-resident / host-resident pairs. */
 int kh_merge_pairs_device(kh_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_counts, uint64_t n);
 int kh_merge_pairs(kh_ctx *ctx, const uint64_t *keys, const uint64_t *counts, uint64_t n);
+
+/* ---- the exchange itself, behind this ABI (RCCL over xGMI) --------------- */
+/* north_star: "reads shard naturally per GPU ... with a final RCCL reduce of per-GPU hash tables over xGMI".
+ * The reference's only parallelism is rayon over records (src/run.rs:500-503); these calls are what stands
+ * in for it at N > 1 GPUs, so that a host (Rust, C++) needs nothing but this library:
+ *
+ *   rank 0:        kh_comm_unique_id(&id);   ... the host hands the 128 bytes to every rank (any means) ...
+ *   every rank r:  kh_create(&ctx, &cfg) on its own device;   kh_comm_init(ctx, nranks, r, &id);
+ *                  kh_push*(ctx, its share of the reads) ...;     kh_merge_across(ctx, &info);
+ *                  kh_result_* / kh_histogram / kh_lookup         -> the keys with kh_owner(key, k, nranks) == r
+ *
+ * kh_merge_across is a COLLECTIVE: every rank of the communicator calls it, once per merge.  It picks, by a
+ * vote among the ranks, the narrowest exchange unit every table can represent (32-bit heads, packed u64,
+ * 16-byte pairs; dense counts + one all-reduce for 2k <= 26), sends every owner its region segments with
+ * ncclSend / ncclRecv groups on an own stream -- in KMERHIP_MERGE_PIECES (default 4) pieces, so that the
+ * export of piece i + 1 and the LDS merge of piece i - 1 overlap the transfer of piece i -- and leaves this
+ * context holding its hash-range shard (kh_set_shard state; kh_reset makes it a full table again).
+ * One rank per context; ranks may be processes (one per GPU) or threads of one process (kh_group_*). */
+typedef struct kh_unique_id { char internal[128]; } kh_unique_id;  /* ncclUniqueId, opaque */
+int kh_comm_unique_id(kh_unique_id *out);
+/* Collective over all ranks (it blocks until every rank has called it).  The context must be on the GPU this
+ * rank uses; a context has at most one communicator (KH_ERR_STATE otherwise); kh_destroy releases it. */
+int kh_comm_init(kh_ctx *ctx, uint32_t nranks, uint32_t rank, const kh_unique_id *id);
+
+#define KH_ROUTE_NONE 0           /* single rank: nothing to exchange */
+#define KH_ROUTE_DENSE 1          /* 2k <= 26: dense 4^k counts, one all-reduce(sum) */
+#define KH_ROUTE_REGIONS_HEADS 2  /* region-ordered 32-bit heads */
+#define KH_ROUTE_REGIONS_PACKED 3 /* region-ordered packed u64 */
+#define KH_ROUTE_REGIONS_WIDE 4   /* region-ordered (u64 key, u64 count) */
+#define KH_ROUTE_PAIRS 5          /* owner-grouped pairs, device-atomic re-insert (any world size / table sizes) */
+typedef struct kh_merge_info {
+    uint32_t route;           /* KH_ROUTE_* */
+    uint32_t pieces;          /* pipeline pieces used (1 = one shot) */
+    uint32_t unit_bytes;      /* bytes per exchanged unit */
+    uint32_t nranks;
+    uint64_t local_distinct;  /* entries of this rank's table before the merge */
+    uint64_t sent_units;      /* units that left this rank (its own share excluded) */
+    uint64_t recv_units;      /* units this rank merged (its own share included) */
+    uint64_t owned_distinct;  /* entries of this rank's shard after the merge */
+    double   export_ms;       /* host wall time in the export calls */
+    double   wait_ms;         /* host wall time waiting for transfers / small collectives */
+    double   merge_ms;        /* host wall time in the merge calls */
+    double   total_ms;
+} kh_merge_info;
+int kh_merge_across(kh_ctx *ctx, kh_merge_info *info /* may be NULL */);
+
+/* Single-process form: one context per device and one host thread per context inside the library
+ * ("internal HIP streams / one host thread per GPU").  devices[i] = HIP ordinal of rank i.
+ * Distinct devices talk RCCL (xGMI); a device listed more than once (tests on a 1-GPU box; RCCL refuses
+ * duplicate devices) makes the whole group exchange by device-to-device copies inside the process instead.
+ * cfg->device and cfg->stream are ignored (every context owns its stream).  The contexts belong to the
+ * group: use them with every kh_* call, but destroy them only through kh_group_destroy. */
+typedef struct kh_group kh_group;
+int kh_group_create(kh_group **out, const kh_config *cfg, const int32_t *devices, uint32_t ndevices);
+kh_ctx *kh_group_ctx(kh_group *g, uint32_t rank);
+uint32_t kh_group_size(const kh_group *g);
+/* kh_merge_across on every context, each on its own host thread; infos: ndevices entries or NULL.
+ * Returns the first failing rank's status. */
+int kh_group_merge(kh_group *g, kh_merge_info *infos);
+void kh_group_destroy(kh_group *g);
 
 /* ---- pure helpers (host, no device) ------------------------------------- */
 /* pack_bytes / Kmer::pack, src/kmer.rs:304-312,467-471.  KH_ERR_BAD_ARG if a

@@ -49,8 +49,13 @@ enum { ST_DIRECT = 0, ST_P1_COUNT, ST_P1_SCATTER, ST_P2_COUNT, ST_P2_SCATTER, ST
 
 }  // namespace
 
+namespace {
+struct Comm;  // exchange.hip.h: RCCL communicator (or the process-local hub) of this rank
+}
+
 struct kh_ctx {
     int device = 0;
+    Comm *comm = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint32_t k = 0;
@@ -188,6 +193,7 @@ int grid_for(u64 items) {
 
 int flush_acc(kh_ctx *c, bool carry);
 int clear_if_dirty(kh_ctx *c);
+void comm_release(kh_ctx *c);
 
 // Every entry point starts here.  Host pushes are accumulated on the device and counted lazily;
 // anything that looks at the table first counts what is pending.  need_table = false: the caller
@@ -617,8 +623,12 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     }
     {
         StageTimer t(c, ST_P2_SCATTER);
-        hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
-                           (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
+        if (g.p2_bits <= 9)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
+            hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 512>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
+        else
+            hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 1024>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
     }
     {
         StageTimer t(c, ST_MISC);
@@ -1018,6 +1028,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     drain_events(c);
     if (c->cstream) (void)hipStreamSynchronize(c->cstream);
     for (int i = 0; i < 2; ++i) {
@@ -2025,6 +2036,7 @@ extern "C" const char *kh_strerror(int s) {
     case KH_ERR_STATE: return "invalid context state";
     case KH_ERR_RANGE: return "output array too small";
     case KH_ERR_FORMAT: return "text layout not accepted by the device record scanner";
+    case KH_ERR_RCCL: return "RCCL error";
     default: return "unknown error";
     }
 }
@@ -2045,3 +2057,8 @@ extern "C" int kh_synth_reads_device(int device, void *stream, uint64_t seed, ui
                        (u64)seed, (u64)genome_len, read_len, (u64)first_read, (u64)n_reads, d_bases, d_qual);
     return hipGetLastError() == hipSuccess ? KH_OK : KH_ERR_HIP;
 }
+
+// =============================================================================================
+// the exchange behind the ABI: kh_comm_* / kh_merge_across / kh_group_* (RCCL over xGMI)
+// =============================================================================================
+#include "exchange.hip.h"

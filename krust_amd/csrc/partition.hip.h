@@ -173,13 +173,13 @@ __device__ __forceinline__ uint32_t p2_count_of(const Part2Block &pb) {
     return CHUNKED ? (uint32_t)(pb.hi - pb.lo) * CHUNK_PAY : (uint32_t)(pb.hi - pb.lo);
 }
 
-// Exclusive scan of s_cnt[0..1024) into s_lofs[0..1024) by a workgroup of >= 256 lanes.
+// Exclusive scan of s_cnt[0..N) into s_lofs[0..N) (N = 512 or 1024) by a workgroup of >= N / 4 lanes.
 // s_wsum: 4 words of scratch.  Ends with a barrier.
-template <typename LT>
-__device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt, LT *s_lofs, uint32_t *s_wsum,
-                                                          int tid) {
+template <int N, typename LT>
+__device__ __forceinline__ void block_exclusive_scan_n(const uint32_t *s_cnt, LT *s_lofs, uint32_t *s_wsum, int tid) {
+    constexpr int LANES = N / 4;
     uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, incl = 0;
-    if (tid < 256) {
+    if (tid < LANES) {
         v0 = s_cnt[4 * tid];
         v1 = s_cnt[4 * tid + 1];
         v2 = s_cnt[4 * tid + 2];
@@ -193,7 +193,7 @@ __device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt,
         if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < LANES) {
         uint32_t base = 0;
         for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
         const uint32_t excl = base + incl - (v0 + v1 + v2 + v3);
@@ -203,6 +203,10 @@ __device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt,
         s_lofs[4 * tid + 3] = (LT)(excl + v0 + v1 + v2);
     }
     __syncthreads();
+}
+template <typename LT>
+__device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt, LT *s_lofs, uint32_t *s_wsum, int tid) {
+    block_exclusive_scan_n<1024, LT>(s_cnt, s_lofs, s_wsum, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -589,17 +593,20 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restri
 constexpr int PART2_NT = KH_PART2_NT;
 constexpr int PART2_TILE = KH_PART2_TILE;
 constexpr int P2_PER = PART2_TILE / PART2_NT;   // payloads per lane per batch
-constexpr int P2_OWN = MAX_P1 / PART2_NT;       // buckets whose output cursor a lane keeps in registers
 
-template <typename PT, bool CHUNKED>
-__global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__restrict__ pays, ChunkSrc cs,
-                                                                 const Part2Block *__restrict__ blocks,
-                                                                 const u64 *__restrict__ info, PartGeom g,
-                                                                 const u64 *__restrict__ O2, PT *__restrict__ out) {
-    __shared__ PT s_stage[PART2_TILE + 1];   // 64 KiB (u32) / 128 KiB (u64), + a trash slot
-    __shared__ uint32_t s_cnt[MAX_P1];   // sized for the shared 1024-entry scan
-    __shared__ uint16_t s_lofs[MAX_P1];  // batch-local run starts (< PART2_TILE <= 32768)
-    __shared__ u64 s_dst[1u << MAX_P2_BITS];  // global position of run p minus its batch-local start
+// NBK = size of the per-bucket LDS arrays: 1024 (any p2_bits <= 10), or 512 when the geometry has at most 512
+// buckets per partition (the headline table: p2_bits = 9).  With 512 the workgroup's LDS drops from 86 to 79 KB,
+// so that TWO workgroups share a CU (4 waves per SIMD instead of 2: the scattered line-sized writes and the LDS
+// round trips of one overlap the other's); registers are capped at 128 for that.
+template <typename PT, bool CHUNKED, int NBK>
+__global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) void part2_scatter_kernel(
+    const PT *__restrict__ pays, ChunkSrc cs, const Part2Block *__restrict__ blocks, const u64 *__restrict__ info, PartGeom g,
+    const u64 *__restrict__ O2, PT *__restrict__ out) {
+    constexpr int OWN = NBK / PART2_NT;         // buckets whose output cursor a lane keeps in registers
+    __shared__ PT s_stage[PART2_TILE + 1];      // 64 KiB (u32) / 128 KiB (u64), + a trash slot
+    __shared__ uint32_t s_cnt[NBK];
+    __shared__ uint16_t s_lofs[NBK];            // batch-local run starts (< PART2_TILE <= 32768)
+    __shared__ u64 s_dst[NBK];                  // global position of run p minus its batch-local start
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_chk[CHUNKED ? CPB : 1];
     __shared__ uint16_t s_cfill[CHUNKED ? CPB : 1];
@@ -609,9 +616,9 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
     const int P2 = 1 << g.p2_bits;
     p2_stage_chunks<CHUNKED>(cs, pb, s_chk, s_cfill, tid, PART2_NT);
     // lane tid owns buckets tid + q * PART2_NT: their running output cursors live in registers
-    u64 gcur[P2_OWN];
+    u64 gcur[OWN];
 #pragma unroll
-    for (int q = 0; q < P2_OWN; ++q) {
+    for (int q = 0; q < OWN; ++q) {
         const int b = tid + q * PART2_NT;
         s_cnt[b] = 0;
         gcur[q] = b < P2 ? O2[pb.mbase + (u64)b * pb.mstride] : 0;
@@ -634,25 +641,25 @@ __global__ __launch_bounds__(PART2_NT) void part2_scatter_kernel(const PT *__res
         for (int j = 0; j < P2_PER; ++j)  // all LDS rank atomics in flight before the first is consumed
             if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
-        block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
+        block_exclusive_scan_n<NBK>(s_cnt, s_lofs, s_wsum, tid);
         {  // branch-free staging (see part1_scatter_chunked_kernel): all run starts first, then the stores
             uint32_t rs[P2_PER];
 #pragma unroll
-            for (int j = 0; j < P2_PER; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
+            for (int j = 0; j < P2_PER; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (NBK - 1)];
 #pragma unroll
             for (int j = 0; j < P2_PER; ++j)
                 s_stage[tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)PART2_TILE] = pay[j];
         }
 #pragma unroll
-        for (int q = 0; q < P2_OWN; ++q) {  // publish run destinations, advance the cursors
+        for (int q = 0; q < OWN; ++q) {  // publish run destinations, advance the cursors
             const int b = tid + q * PART2_NT;
             s_dst[b] = gcur[q] - s_lofs[b];
             gcur[q] += s_cnt[b];
         }
-        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
+        const uint32_t total = (uint32_t)s_lofs[NBK - 1] + s_cnt[NBK - 1];
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < P2_OWN; ++q) s_cnt[tid + q * PART2_NT] = 0;
+        for (int q = 0; q < OWN; ++q) s_cnt[tid + q * PART2_NT] = 0;
         // next batch's payloads are fetched while this batch's runs are written out
         have = 0;
 #pragma unroll
@@ -991,6 +998,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         kbuf[j] = src[i < n ? i : n - 1];
     }
     Slot old[R32_SLOTS_PER_LANE];
+    bool unrepresentable = false;
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
 #pragma unroll
     for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
@@ -1003,9 +1011,20 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             const uint4 v = g4[i];
             old[q].key = ((u64)v.y << 32) | v.x;
             old[q].count = ((u64)v.w << 32) | v.z;
-            if (old[q].key != KH_EMPTY_KEY) w = Pay<uint32_t>::make(old[q].key, table_hash(tg, old[q].key), g);
-            // an old key whose payload equals the free marker keeps w == FREE: new arrivals of that
-            // payload are counted in s_special and merged below
+            if (old[q].key != KH_EMPTY_KEY) {
+                w = Pay<uint32_t>::make(old[q].key, table_hash(tg, old[q].key), g);
+                if (w == R32_FREE) {
+                    // An old key whose payload equals the free marker: new arrivals of that payload are counted
+                    // in s_special and merged below, but its SLOT must not look free to the other payloads (a
+                    // claim there would add the newcomer's count to this key and lose the newcomer).  Every
+                    // payload of this region carries the region's level-2 digit -- all ones here -- in its top
+                    // bits, so 0 can neither arrive nor be probed for: it marks the slot as taken.  Without a
+                    // level-2 digit (tables of <= 1024 regions) there is no such value: fail the region, its
+                    // bucket then goes through the direct path.
+                    if (g.p2_bits) w = 0u;
+                    else unrepresentable = true;
+                }
+            }
         }
         s_pay[i] = w;
         s_add[i] = 0;
@@ -1017,6 +1036,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         s_heads = 0;
     }
     __syncthreads();
+    if (unrepresentable) s_fail = 1;
     uint32_t nd = 0;
     // Lane-decoupled probing.  A wave that walks key j of all 64 lanes together pays, for every
     // key, the LONGEST probe sequence among its lanes (~6 at load 0.5).  Here each lane keeps its own

@@ -7,7 +7,9 @@
 #include <cstring>
 #include <string>
 #include <sys/stat.h>
+#include <algorithm>
 #include <unordered_map>
+#include <vector>
 
 #include "kmerust_host.h"
 
@@ -28,6 +30,8 @@ static const char *USAGE =
     "  -i, --input-format <INPUT_FORMAT>  Input file format [default: auto] [possible values: auto, fasta, fastq]\n"
     "      --save <SAVE>                  Save k-mer counts to an index file (.kmix, .kmix.gz)\n"
     "  -Q, --min-quality <MIN_QUALITY>    Minimum Phred quality score (0-93) for FASTQ bases\n"
+    "      --gpus <N>                     Count on the first N GPUs of the node (RCCL merge of the per-GPU tables) [default: 1]\n"
+    "      --devices <LIST>               The same with explicit HIP device ordinals, e.g. 0,2,5\n"
     "  -h, --help                         Print help\n"
     "  -V, --version                      Print version\n";
 
@@ -126,6 +130,7 @@ int cli_main(int argc, char **argv) {
     SequenceFormat in_fmt = SequenceFormat::Auto;
     uint64_t min_count = 1;
     int min_quality = -1;
+    std::vector<int> devices;  // extension: several GPUs (no counterpart in src/cli.rs)
 
     auto value_of = [&](int &i, const std::string &arg, const char *name) -> std::string {
         const size_t eq = arg.find('=');
@@ -165,6 +170,20 @@ int cli_main(int argc, char **argv) {
             min_quality = (int)parse_u64(value_of(i, a, "--min-quality <MIN_QUALITY>"), "--min-quality <MIN_QUALITY>", 255);
         } else if (key == "--save") {
             save = value_of(i, a, "--save <SAVE>");
+        } else if (key == "--gpus") {
+            const uint64_t n = parse_u64(value_of(i, a, "--gpus <N>"), "--gpus <N>", 64);
+            if (n == 0) usage_error("invalid value '0' for '--gpus <N>': at least one GPU is needed");
+            devices.clear();
+            for (uint64_t d = 0; d < n; ++d) devices.push_back((int)d);
+        } else if (key == "--devices") {
+            const std::string v = value_of(i, a, "--devices <LIST>");
+            devices.clear();
+            size_t pos = 0;
+            while (pos <= v.size()) {
+                const size_t comma = std::min(v.find(',', pos), v.size());
+                devices.push_back((int)parse_u64(v.substr(pos, comma - pos), "--devices <LIST>", 1023));
+                pos = comma + 1;
+            }
         } else if (a.size() > 1 && a[0] == '-' && a != "-") {
             usage_error("unexpected argument '" + a + "' found");
         } else if (!have_k) {
@@ -208,7 +227,7 @@ int cli_main(int argc, char **argv) {
 
     try {
         KmerCounter kc;
-        kc.k(k).min_count(min_count).format(fmt).input_format(in_fmt).min_quality(min_quality);
+        kc.k(k).min_count(min_count).format(fmt).input_format(in_fmt).min_quality(min_quality).devices(devices);
         if (const char *h = getenv("KMERHIP_CAPACITY_HINT")) kc.capacity_hint(strtoull(h, nullptr, 10));
         if (!save.empty()) {  // src/main.rs:155-212: the index holds ALL k-mers, stdout honours --min-count
             const PackedCounts all = kc.count_packed(path, false);

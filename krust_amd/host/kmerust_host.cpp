@@ -9,8 +9,11 @@
 #include <algorithm>
 #include <cctype>
 #include <cerrno>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 namespace kmerust {
 
@@ -198,8 +201,15 @@ uint64_t read_sequences(const std::string &path, SequenceFormat fmt, bool want_q
 // counting session over the C ABI
 // =============================================================================================
 struct Session {
-    kh_ctx *ctx = nullptr;
+    // One context per device.  More than one device (KmerCounter::devices, `kmerust --gpus N`): a kh_group --
+    // chunks of whole records go to the devices in turn, every device counts its share into its own table, and
+    // kh_group_merge (RCCL all-to-all of region segments + LDS merge, inside the library) turns the N tables into
+    // one table sharded by hash range; results are then read shard by shard.
+    std::vector<kh_ctx *> ctxs;
+    kh_group *group = nullptr;
+    kh_ctx *ctx = nullptr;  // ctxs[0]
     uint32_t k;
+    size_t next_ctx = 0;
     Session(const KmerCounter &kc, bool use_qual) : k((uint32_t)kc.k_) {
         if (!kc.k_set_) throw Error("k-mer length not set");
         kh_config cfg;
@@ -209,17 +219,35 @@ struct Session {
         cfg.min_quality = use_qual ? kc.min_quality_ : -1;
         cfg.device = kc.device_;
         cfg.capacity_hint = kc.capacity_hint_;
-        check(kh_create(&ctx, &cfg), "kh_create");
+        if (kc.devices_.size() > 1) {
+            std::vector<int32_t> devs(kc.devices_.begin(), kc.devices_.end());
+            const int rc = kh_group_create(&group, &cfg, devs.data(), (uint32_t)devs.size());
+            if (rc != KH_OK) throw Error(std::string("kh_group_create: ") + kh_strerror(rc));
+            for (uint32_t i = 0; i < kh_group_size(group); ++i) ctxs.push_back(kh_group_ctx(group, i));
+        } else {
+            if (kc.devices_.size() == 1) cfg.device = kc.devices_[0];
+            kh_ctx *c = nullptr;
+            check_on(nullptr, kh_create(&c, &cfg), "kh_create");
+            ctxs.push_back(c);
+        }
+        ctx = ctxs[0];
     }
-    ~Session() { kh_destroy(ctx); }
-    void check(int rc, const char *what) const {
+    ~Session() {
+        if (group) kh_group_destroy(group);
+        else if (ctx) kh_destroy(ctx);
+    }
+    static void check_on(kh_ctx *c, int rc, const char *what) {
         if (rc == KH_OK) return;
         std::string msg = std::string(what) + ": " + kh_strerror(rc);
-        if (ctx && kh_last_error(ctx)[0]) msg += std::string(" (") + kh_last_error(ctx) + ")";
+        if (c && kh_last_error(c)[0]) msg += std::string(" (") + kh_last_error(c) + ")";
         throw Error(msg);
     }
+    void check(int rc, const char *what) const { check_on(ctx, rc, what); }
+    void reset_all() {
+        for (kh_ctx *c : ctxs) check_on(c, kh_reset(c), "kh_reset");
+    }
     // Uncompressed or gzip files: the TEXT goes to the device in chunks of whole records and the
-    // records are found there (kh_push_text).  Returns false -- with the table reset -- when the
+    // records are found there (kh_push_text).  Returns false -- with the table(s) reset -- when the
     // device scanner refuses the layout; the line parser below then takes the file (and reports
     // malformed input with the reference's messages).
     bool count_file_text(const std::string &path, SequenceFormat fmt) {
@@ -259,12 +287,67 @@ struct Session {
                 if (errno != EINTR) throw Error("failed to read sequence file '" + path + "': " + std::strerror(errno));
             }
         };
+        // One worker per device: the reader fills a chunk buffer while the devices scan and count the previous
+        // chunks (with one device this is the plain read -> push loop on the caller's thread).
+        const size_t ndev = ctxs.size();
+        struct Worker {
+            std::thread th;
+            std::mutex m;
+            std::condition_variable cv;
+            std::vector<uint8_t> job;  // whole records handed over by the reader
+            bool has_job = false, quit = false;
+            int rc = KH_OK;
+        };
+        std::vector<std::unique_ptr<Worker>> workers;
+        const int text_fmt = fastq ? KH_TEXT_FASTQ : KH_TEXT_FASTA;
+        if (ndev > 1)
+            for (size_t d = 0; d < ndev; ++d) {
+                workers.emplace_back(new Worker());
+                Worker *w = workers.back().get();
+                kh_ctx *c = ctxs[d];
+                w->th = std::thread([w, c, text_fmt] {
+                    for (;;) {
+                        std::unique_lock<std::mutex> lk(w->m);
+                        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+                        if (!w->has_job) return;
+                        lk.unlock();
+                        const int rc = kh_push_text(c, w->job.data(), w->job.size(), text_fmt);
+                        lk.lock();
+                        if (rc != KH_OK && w->rc == KH_OK) w->rc = rc;
+                        w->has_job = false;
+                        w->cv.notify_all();
+                    }
+                });
+            }
+        auto stop_workers = [&]() -> int {  // waits for the queued chunks; first error of any device
+            int rc = KH_OK;
+            for (auto &w : workers) {
+                {
+                    std::unique_lock<std::mutex> lk(w->m);
+                    w->cv.wait(lk, [&] { return !w->has_job; });
+                    w->quit = true;
+                    w->cv.notify_all();
+                    if (rc == KH_OK) rc = w->rc;
+                }
+                w->th.join();
+            }
+            workers.clear();
+            return rc;
+        };
+        struct Joiner {  // (exceptions from the reader must not leave threads behind)
+            std::function<int()> &f;
+            ~Joiner() { f(); }
+        };
+        std::function<int()> stopper = stop_workers;
+        Joiner joiner{stopper};
+
         const size_t chunk = text_chunk_bytes();
         std::vector<uint8_t> buf(chunk);
         size_t have = 0;
         bool eof = false, pushed = false;
         auto refuse = [&]() {
-            if (pushed) check(kh_reset(ctx), "kh_reset");
+            (void)stop_workers();
+            if (pushed) reset_all();
             return false;
         };
         while (!eof) {
@@ -285,15 +368,39 @@ struct Session {
                     continue;
                 }
             }
-            if (cut) {
-                const int rc = kh_push_text(ctx, buf.data(), cut, fastq ? KH_TEXT_FASTQ : KH_TEXT_FASTA);
+            if (cut && ndev == 1) {
+                const int rc = kh_push_text(ctx, buf.data(), cut, text_fmt);
                 if (rc == KH_ERR_FORMAT) return refuse();
                 check(rc, "kh_push_text");
+                pushed = true;
+            } else if (cut) {
+                Worker *w = workers[next_ctx++ % ndev].get();
+                std::unique_lock<std::mutex> lk(w->m);
+                w->cv.wait(lk, [&] { return !w->has_job; });
+                if (w->rc == KH_ERR_FORMAT) {
+                    lk.unlock();
+                    return refuse();
+                }
+                if (w->rc != KH_OK) {
+                    const int rc = w->rc;
+                    lk.unlock();
+                    (void)stop_workers();
+                    check(rc, "kh_push_text");
+                }
+                w->job.assign(buf.begin(), buf.begin() + (ptrdiff_t)cut);
+                w->has_job = true;
+                w->cv.notify_all();
                 pushed = true;
             }
             memmove(buf.data(), buf.data() + cut, have - cut);
             have -= cut;
         }
+        const int rc = stop_workers();
+        if (rc == KH_ERR_FORMAT) {
+            if (pushed) reset_all();
+            return false;
+        }
+        check(rc, "kh_push_text");
         return true;
     }
     static size_t text_chunk_bytes() {
@@ -334,41 +441,69 @@ struct Session {
         const char *hp = getenv("KMERUST_HOST_PARSE");
         const bool host_only = is_stdin_path(path) || (hp && hp[0] && hp[0] != '0');
         if (host_only || !count_file_text(path, resolve_format(fmt, &path))) {
-            read_sequences(path, fmt, want_qual, 512u << 20, [&](const Batch &b) {
-                check(kh_push(ctx, b.bases.data(), want_qual && !b.qual.empty() ? b.qual.data() : nullptr, b.bases.size()),
-                      "kh_push");
+            const size_t batch = ctxs.size() > 1 ? (size_t)64 << 20 : (size_t)512 << 20;
+            read_sequences(path, fmt, want_qual, batch, [&](const Batch &b) {
+                kh_ctx *c = ctxs[next_ctx++ % ctxs.size()];
+                check_on(c, kh_push(c, b.bases.data(), want_qual && !b.qual.empty() ? b.qual.data() : nullptr, b.bases.size()),
+                         "kh_push");
             });
         }
-        check(kh_finish(ctx, nullptr), "kh_finish");
+        for (kh_ctx *c : ctxs) check_on(c, kh_finish(c, nullptr), "kh_finish");
+        if (group) {
+            const int rc = kh_group_merge(group, nullptr);
+            if (rc != KH_OK) {
+                std::string msg = std::string("kh_group_merge: ") + kh_strerror(rc);
+                for (kh_ctx *c : ctxs)
+                    if (kh_last_error(c)[0]) msg += std::string(" (") + kh_last_error(c) + ")";
+                throw Error(msg);
+            }
+        }
     }
     PackedCounts result(uint64_t min_count) {
         PackedCounts pc;
         pc.k = k;
-        uint64_t n = 0;
-        check(kh_result_size(ctx, min_count, &n), "kh_result_size");
-        pc.keys.resize(n);
-        pc.counts.resize(n);
-        uint64_t got = 0;
-        check(kh_result_copy(ctx, pc.keys.data(), pc.counts.data(), n, min_count, &got), "kh_result_copy");
-        pc.keys.resize(got);
-        pc.counts.resize(got);
+        std::vector<uint64_t> ns(ctxs.size(), 0);
+        uint64_t total = 0;
+        for (size_t i = 0; i < ctxs.size(); ++i) {
+            check_on(ctxs[i], kh_result_size(ctxs[i], min_count, &ns[i]), "kh_result_size");
+            total += ns[i];
+        }
+        pc.keys.resize(total);
+        pc.counts.resize(total);
+        uint64_t off = 0;
+        for (size_t i = 0; i < ctxs.size(); ++i) {  // the shards' key sets are disjoint: concatenation is the map
+            uint64_t got = 0;
+            check_on(ctxs[i], kh_result_copy(ctxs[i], pc.keys.data() + off, pc.counts.data() + off, ns[i], min_count, &got),
+                     "kh_result_copy");
+            off += got;
+        }
+        pc.keys.resize(off);
+        pc.counts.resize(off);
         return pc;
     }
     std::vector<std::pair<uint64_t, uint64_t>> histogram(uint64_t min_count) {
-        uint64_t cap = 1u << 16;
-        for (;;) {
-            std::vector<uint64_t> c(cap), f(cap);
-            uint64_t n = 0;
-            const int rc = kh_histogram(ctx, min_count, c.data(), f.data(), cap, &n);
-            if (rc == KH_ERR_RANGE) {
-                cap *= 16;
-                continue;
+        std::map<uint64_t, uint64_t> sum;  // a histogram of disjoint shards is element-wise additive
+        for (kh_ctx *c : ctxs) {
+            uint64_t cap = 1u << 16;
+            for (;;) {
+                std::vector<uint64_t> cc(cap), f(cap);
+                uint64_t n = 0;
+                const int rc = kh_histogram(c, min_count, cc.data(), f.data(), cap, &n);
+                if (rc == KH_ERR_RANGE) {
+                    cap *= 16;
+                    continue;
+                }
+                check_on(c, rc, "kh_histogram");
+                if (ctxs.size() == 1) {
+                    std::vector<std::pair<uint64_t, uint64_t>> h(n);
+                    for (uint64_t i = 0; i < n; ++i) h[i] = {cc[i], f[i]};
+                    return h;
+                }
+                for (uint64_t i = 0; i < n; ++i) sum[cc[i]] += f[i];
+                break;
             }
-            check(rc, "kh_histogram");
-            std::vector<std::pair<uint64_t, uint64_t>> h(n);
-            for (uint64_t i = 0; i < n; ++i) h[i] = {c[i], f[i]};
-            return h;
         }
+        return std::vector<std::pair<uint64_t, uint64_t>>(sum.begin(), sum.end());
     }
 };
 

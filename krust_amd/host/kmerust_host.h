@@ -75,6 +75,9 @@ public:
     KmerCounter &min_quality(int q) { min_quality_ = q; return *this; }  // -1 = None
     KmerCounter &capacity_hint(uint64_t n) { capacity_hint_ = n; return *this; }
     KmerCounter &device(int d) { device_ = d; return *this; }
+    // No reference counterpart (the reference is one process on CPU cores): count on several GPUs of the node,
+    // one table per device, merged by the library's RCCL exchange (kh_group_*) into a table sharded by hash range.
+    KmerCounter &devices(std::vector<int> d) { devices_ = std::move(d); return *this; }
 
     // count(): HashMap<String,u64> filtered by min_count (builder.rs:242-262)
     std::unordered_map<std::string, uint64_t> count(const std::string &path) const;
@@ -99,6 +102,7 @@ private:
     int min_quality_ = -1;
     uint64_t capacity_hint_ = 0;
     int device_ = -1;
+    std::vector<int> devices_;
 };
 
 // ---- output (src/run.rs:441-486) -------------------------------------------------------------

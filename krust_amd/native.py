@@ -22,6 +22,7 @@ KH_ERR_HIP = -6
 KH_ERR_STATE = -7
 KH_ERR_RANGE = -8
 KH_ERR_FORMAT = -9
+KH_ERR_RCCL = -10
 TEXT_FASTA, TEXT_FASTQ = 1, 2
 
 
@@ -37,6 +38,18 @@ class KhStats(C.Structure):
                 ("count_kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("part_batches", C.c_uint64),
                 ("stage_ms", C.c_double * 8), ("text_scan_ms", C.c_double)]
 
+class KhUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class KhMergeInfo(C.Structure):
+    _fields_ = [("route", C.c_uint32), ("pieces", C.c_uint32), ("unit_bytes", C.c_uint32), ("nranks", C.c_uint32),
+                ("local_distinct", C.c_uint64), ("sent_units", C.c_uint64), ("recv_units", C.c_uint64),
+                ("owned_distinct", C.c_uint64), ("export_ms", C.c_double), ("wait_ms", C.c_double),
+                ("merge_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+ROUTES = ("none", "dense", "regions-heads", "regions-packed", "regions", "pairs")  # KH_ROUTE_*
 STAGES = ("direct", "p1_count", "p1_scatter", "p2_count", "p2_scatter", "region", "misc", "grow")
 FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION, FLAG_CALLER_STREAM = 1, 2, 4, 8
 
@@ -74,6 +87,14 @@ SYMBOLS = {
     "kh_export_by_owner_device": (C.c_int, [_P, C.c_uint32, _P, _P, _U64, _P]),
     "kh_merge_pairs_device": (C.c_int, [_P, _P, _P, _U64]),
     "kh_merge_pairs": (C.c_int, [_P, _P, _P, _U64]),
+    "kh_comm_unique_id": (C.c_int, [C.POINTER(KhUniqueId)]),
+    "kh_comm_init": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(KhUniqueId)]),
+    "kh_merge_across": (C.c_int, [_P, C.POINTER(KhMergeInfo)]),
+    "kh_group_create": (C.c_int, [C.POINTER(_P), C.POINTER(KhConfig), C.POINTER(C.c_int32), C.c_uint32]),
+    "kh_group_ctx": (_P, [_P, C.c_uint32]),
+    "kh_group_size": (C.c_uint32, [_P]),
+    "kh_group_merge": (C.c_int, [_P, C.POINTER(KhMergeInfo)]),
+    "kh_group_destroy": (None, [_P]),
     "kh_pack": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(_U64), C.POINTER(C.c_uint32)]),
     "kh_unpack": (C.c_int, [_U64, C.c_uint32, C.c_char_p]),
     "kh_canonical": (C.c_int, [_U64, C.c_uint32, C.POINTER(_U64), C.POINTER(C.c_int)]),
@@ -163,13 +184,22 @@ class DeviceCounter:
         if rc != KH_OK:
             raise KmerHipError(rc)
         self._h = h
+        self._owned = True
         self.k = int(k)
         self.min_quality = min_quality
+
+    @classmethod
+    def _adopt(cls, handle, k, min_quality):
+        """A context that belongs to a DeviceGroup (destroyed with the group, not here)."""
+        self = cls.__new__(cls)
+        self._h, self._owned, self.k, self.min_quality = _P(handle), False, int(k), min_quality
+        return self
 
     # -- lifecycle ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
-            lib().kh_destroy(self._h)
+            if getattr(self, "_owned", True):
+                lib().kh_destroy(self._h)
             self._h = None
 
     __del__ = close
@@ -269,6 +299,20 @@ class DeviceCounter:
         return out
 
     # -- multi-GPU merge ---------------------------------------------------
+    def comm_init(self, nranks, rank, unique_id):
+        """Joins the RCCL communicator named by `unique_id` (128 bytes from comm_unique_id() of rank 0) as
+        `rank` of `nranks`: collective, blocks until every rank has called it."""
+        uid = KhUniqueId()
+        C.memmove(C.byref(uid), bytes(unique_id), 128)
+        self._check(lib().kh_comm_init(self._h, int(nranks), int(rank), C.byref(uid)))
+
+    def merge_across(self):
+        """kh_merge_across: the whole exchange inside the library (collective over the communicator's ranks).
+        Afterwards this context holds the keys with owner(key, k, nranks) == rank.  Returns the merge info."""
+        info = KhMergeInfo()
+        self._check(lib().kh_merge_across(self._h, C.byref(info)))
+        return merge_info_dict(info)
+
     def export_by_owner_device(self, nparts, d_keys, d_counts, cap):
         parts = np.zeros(nparts, dtype=np.uint64)
         self._check(lib().kh_export_by_owner_device(self._h, int(nparts), d_keys, d_counts, int(cap), parts.ctypes.data))
@@ -363,6 +407,71 @@ class DeviceCounter:
         counts = np.ascontiguousarray(counts, dtype=np.uint64)
         assert keys.size == counts.size
         self._check(lib().kh_merge_pairs(self._h, keys.ctypes.data, counts.ctypes.data, keys.size))
+
+
+def merge_info_dict(info):
+    d = {f: getattr(info, f) for f, _ in KhMergeInfo._fields_}
+    d["path"] = ROUTES[info.route] + (f"-x{info.pieces}" if info.pieces > 1 else "")
+    return d
+
+
+def comm_unique_id():
+    """128 opaque bytes (an ncclUniqueId) that name a new communicator; rank 0 makes it, every rank gets a copy."""
+    uid = KhUniqueId()
+    rc = lib().kh_comm_unique_id(C.byref(uid))
+    if rc != KH_OK:
+        raise KmerHipError(rc)
+    return bytes(C.string_at(C.byref(uid), 128))
+
+
+class DeviceGroup:
+    """kh_group: one context per listed device inside ONE process, one host thread per context for the merge.
+    Distinct devices exchange over RCCL; a device listed twice (1-GPU test boxes) makes the group exchange by
+    device-to-device copies inside the process."""
+
+    def __init__(self, k, devices, min_quality=None, capacity_hint=0, trace=False, path=None):
+        if not (1 <= int(k) <= 32):
+            raise KmerLengthError(int(k))
+        cfg = KhConfig(C.sizeof(KhConfig), int(k), -1 if min_quality is None else int(min_quality), -1,
+                       int(capacity_hint), None,
+                       (FLAG_TRACE if trace else 0) | {None: 0, "auto": 0, "direct": FLAG_FORCE_DIRECT,
+                                                       "partition": FLAG_FORCE_PARTITION}[path], 0)
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        g = _P()
+        rc = lib().kh_group_create(C.byref(g), C.byref(cfg), devs, len(devices))
+        if rc != KH_OK:
+            raise KmerHipError(rc)
+        self._g = g
+        self.counters = [DeviceCounter._adopt(lib().kh_group_ctx(g, i), k, min_quality) for i in range(len(devices))]
+
+    def __len__(self):
+        return len(self.counters)
+
+    def __getitem__(self, i):
+        return self.counters[i]
+
+    def merge(self):
+        infos = (KhMergeInfo * len(self.counters))()
+        rc = lib().kh_group_merge(self._g, infos)
+        if rc != KH_OK:
+            detail = "; ".join(lib().kh_last_error(c._h).decode() for c in self.counters)
+            raise KmerHipError(rc, detail)
+        return [merge_info_dict(i) for i in infos]
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for c in self.counters:
+                c._h = None
+            lib().kh_group_destroy(self._g)
+            self._g = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 # ---- pure helpers (host) ----------------------------------------------------

@@ -167,7 +167,7 @@ def test_ctypes_structs_match_header():
     """native.py's ctypes structs: same field names, order and widths as the header's structs."""
     from krust_amd import native
     hs, _ = header_structs_and_functions()
-    width = {"u32": 4, "i32": 4, "u64": 8, "f64": 8, "c_int": 4, "u8": 1}
+    width = {"u32": 4, "i32": 4, "u64": 8, "f64": 8, "c_int": 4, "u8": 1, "c_char": 1}
 
     def rust_size(t):
         m = re.match(r"\[(\w+); (\d+)\]", t)

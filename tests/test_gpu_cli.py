@@ -277,3 +277,35 @@ def test_bare_cr_inside_a_fasta_line_is_an_invalid_base(tmp_path):
         r = run("4", str(fa), "--format", "tsv", "--quiet", env=env)
         assert r.returncode == 0, r.stderr
         assert tsv(r.stdout) == want
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0", "0,0,0"], ids=["2-ranks", "4-ranks", "3-ranks-pairs-route"])
+def test_cli_on_several_ranks_equals_one_gpu(tmp_path, devices):
+    """`kmerust --devices a,b,...` (what `--gpus N` expands to): chunks of whole records go to the ranks in turn,
+    every rank counts into its own table, the library's exchange (kh_group_merge) shards the tables by hash
+    range, and the output is the concatenation of the shards.  The box has one GPU, so the ranks share device 0
+    (process-local transport instead of RCCL); the CLI, the chunk distribution, the merge sequence and the result
+    assembly are the code a multi-GPU node runs.  Must equal the single-GPU output line for line (as a multiset)."""
+    fq, fa = _write_reads(tmp_path)
+    env = {"KMERUST_TEXT_CHUNK_KB": "16"}  # many chunks, so every rank gets work
+    for args in (["21", fq], ["21", fq, "-Q", "20"], ["21", fa], ["9", fa]):
+        one = run(*args, "--format", "tsv", "--quiet", env=env)
+        many = run(*args, "--format", "tsv", "--quiet", "--devices", devices, env=env)
+        assert one.returncode == 0 and many.returncode == 0, (one.stderr, many.stderr)
+        assert tsv(many.stdout) == tsv(one.stdout) and len(many.stdout.splitlines()) == len(one.stdout.splitlines())
+        h1 = run(*args, "--format", "histogram", "--quiet", env=env)
+        hn = run(*args, "--format", "histogram", "--quiet", "--min-count", "2", "--devices", devices, env=env)
+        h2 = run(*args, "--format", "histogram", "--quiet", "--min-count", "2", env=env)
+        assert hn.returncode == 0 and hn.stdout == h2.stdout and h1.stdout
+    # the host line parser path (stdin) on several ranks
+    data = open(fa, "rb").read()
+    a = run("15", "-", "--format", "tsv", "--quiet", "--devices", devices, stdin=data)
+    b = run("15", "-", "--format", "tsv", "--quiet", stdin=data)
+    assert a.returncode == 0 and tsv(a.stdout) == tsv(b.stdout)
+
+
+def test_gpus_flag_validation():
+    r = run("21", fx("simple.fa"), "--gpus", "0")
+    assert r.returncode == 2 and b"at least one GPU" in r.stderr
+    r = run("21", fx("simple.fa"), "--quiet", "--gpus", "1", "--format", "tsv")
+    assert r.returncode == 0 and r.stdout == run("21", fx("simple.fa"), "--quiet", "--format", "tsv").stdout

@@ -341,6 +341,23 @@ def test_payload_equal_to_the_lds_free_marker(K):
             dc.finish()
             want3 = oracle_dict(recs + recs + recs[:half], k)
             assert dc.as_dict() == want3
+            # NEW keys whose probe sequence runs over the slot of an OLD key with the free-marker payload: that
+            # slot is marked taken in the LDS image (it used to look free -- a newcomer claimed it, its count went
+            # to the old key and the newcomer was lost: distinct short by one, totals conserved; seen as
+            # 2,102,811,924 instead of ...926 distinct on the hg38-sized input of tests/test_gpu_scale.py)
+            late = []
+            for p1 in range(1024):
+                for low in (0xFFFFFFFC, 0xFFFFFFFB, 0xFFFFFFFA, 0xFFFFFFF9):
+                    key = _table_unhash((p1 << 32) | low, k)
+                    if K.canonical(key, k)[0] == key:
+                        late.append(K.unpack(key, k).encode())
+            assert len(late) > 1000
+            dc.push(flat(late)[0])
+            st = dc.finish()
+            want4 = dict(want3)
+            for key, c in oracle_dict(late, k).items():
+                want4[key] = want4.get(key, 0) + c
+            assert st["distinct"] == len(want4) and dc.as_dict() == want4
 
 
 def test_lazy_reset_never_leaks_old_entries(K, path):
