@@ -71,38 +71,50 @@ def usable_cpus():
 
 
 def cpu_baseline(host_bases, k, target_seconds):
-    """krust-equivalent port (oracle/ko_count_records_mt: one task per record, literal per-window
-    algorithm, sharded lock-per-shard map, 4 x threads shards) on a bounded sample of the same
-    reads.  The thread count is the best of a short probe (a sharded-lock map does not scale to
-    every core count); `cores` is what the timed run used."""
+    """krust-equivalent port (oracle/ko_count_records_mt2: one task per record, literal per-window algorithm,
+    sharded lock-per-shard map with 4 x threads shards, the lock a spin-then-park mutex like DashMap's, every
+    shard pre-sized so that nothing rehashes under a lock) on a bounded sample of the same reads.  The thread
+    count is the best of a short probe (a sharded-lock map does not scale to every core count); `cores` is what
+    the timed run used.  Reported with it: the same port on ONE thread, the share of thread time spent waiting
+    for shard locks, and the lock-free radix formulation -- so the JSON says where the port's time goes."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
     ncpu = usable_cpus()
     stride = READ_LEN + 1
     avail = host_bases.size // stride
+    per_read = READ_LEN - k + 1
 
     def run(n, threads):
         offs = np.arange(n, dtype=np.uint64) * stride
         lens = np.full(n, READ_LEN, dtype=np.uint32)
         m = O.OracleMap()
+        st = {}
         t0 = time.perf_counter()
-        cnt = m.count_records_mt(host_bases[: n * stride], offs, lens, k, nthreads=threads)
-        return cnt, time.perf_counter() - t0
+        # nearly every k-mer of a small sample is new (coverage << 1): size the shards for that
+        cnt = m.count_records_mt(host_bases[: n * stride], offs, lens, k, nthreads=threads, expect_distinct=n * per_read, stats=st)
+        return cnt, time.perf_counter() - t0, st
 
     probe_n = min(avail, 60_000)
     best = None
     for threads in sorted({max(1, ncpu // 2), ncpu, min(2 * ncpu, os.cpu_count() or ncpu)}):
-        cnt, dt = run(probe_n, threads)
+        cnt, dt, _ = run(probe_n, threads)
         if best is None or cnt / dt > best[0]:
             best = (cnt / dt, threads)
     rate, threads = best
-    # the map grows while it fills, so the rate drops with sample size: aim below the target
-    n = int(min(avail, max(probe_n, 0.5 * target_seconds * rate / (READ_LEN - k + 1))))
-    cnt, dt = run(n, threads)
+    n = int(min(avail, max(probe_n, 0.6 * target_seconds * rate / per_read)))
+    cnt, dt, st = run(n, threads)
+    n1 = int(min(avail, max(10_000, n // (2 * threads))))
+    cnt1, dt1, _ = run(n1, 1)
     out = {"value": cnt / dt, "unit": "k-mers/s", "cores": threads, "kind": "port",
            "sample": f"first {n} reads of the same synthetic set ({cnt} k-mers, {dt:.1f} s) on {threads} threads "
-                     f"({ncpu} usable CPUs by cgroup quota, {os.cpu_count()} visible); krust-equivalent C port (oracle/kmer_oracle.c ko_count_records_mt), not krust itself"}
+                     f"({ncpu} usable CPUs by cgroup quota, {os.cpu_count()} visible); krust-equivalent C port "
+                     "(oracle/kmer_oracle.c ko_count_records_mt2), not krust itself",
+           "per_thread": cnt / dt / threads,
+           "single_thread": {"value": cnt1 / dt1, "sample": f"first {n1} reads, 1 thread, {dt1:.1f} s"},
+           "lock_wait_share": st["wait_ns"] / 1e9 / (dt * threads),
+           "contended_acquisitions": st["contended"] / max(1, st["upserts"]),
+           "rehashes_under_lock": st["rehashes_under_lock"]}
     # an optimised CPU formulation beside it, so the GPU figure is not flattered by the port's
     # allocations and locks: rolling registers + two-phase radix count (no locks, no merge)
     n2 = min(avail, 3_000_000)
@@ -112,6 +124,17 @@ def cpu_baseline(host_bases, k, target_seconds):
     out["optimised_cpu"] = {"value": tot / dt2, "unit": "k-mers/s", "cores": ncpu,
                             "sample": f"first {n2} reads ({tot} k-mers, {distinct} distinct, {dt2:.1f} s): rolling scan + "
                                       "two-phase radix count (oracle ko_count_flat_radix_mt)"}
+    ratio = out["optimised_cpu"]["value"] / out["value"]
+    out["port_vs_optimised"] = {
+        "ratio": ratio,
+        "why": ("the port keeps the reference's shape on purpose: every window is copied and validated (O(k)), packed (O(k)) "
+                "and canonicalised by a two-ended compare (O(k)), then upserted under a shard lock into a table far larger "
+                "than the caches -- one lock cache line handed between cores and one DRAM miss per k-mer.  "
+                f"On one thread it does {cnt1 / dt1 / 1e6:.2f} M k-mers/s; on {threads} threads {cnt / dt / threads / 1e6:.2f} M/s "
+                f"per thread, {100 * st['wait_ns'] / 1e9 / (dt * threads):.0f} % of the thread time waiting for shard locks "
+                f"({100 * st['contended'] / max(1, st['upserts']):.1f} % of the acquisitions contended, no rehash under a lock).  "
+                "The radix formulation rolls the window in registers and counts partitions in private tables: no locks, "
+                "cache-sized working sets.")}
     return out
 
 

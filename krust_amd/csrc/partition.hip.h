@@ -100,16 +100,15 @@ __host__ __device__ inline bool p1_fast_ok(const PartGeom &g) {
     return g.shard_shift == 0 && g.p1_bits <= g.k && 2 * g.k - g.p1_bits >= 1 && 2 * g.k - g.p1_bits <= 32 && g.k < 32;
 }
 template <int MODE>
-__device__ __forceinline__ void hash_p1_pay32(const PartGeom &g, u64 key, uint32_t &p1, uint32_t &pay) {
-    const uint32_t k = g.k;
+__device__ __forceinline__ void hash_p1_pay32(const uint32_t k, const uint32_t p1_bits, u64 key, uint32_t &p1, uint32_t &pay) {
     const uint32_t mask = (1u << k) - 1u;
     uint32_t L = (uint32_t)(key >> k) & mask, R = (uint32_t)key & mask, t;
     t = (L ^ kh_feistel_f<MODE>(R, KH_FC0, k)) & mask; L = R; R = t;
     t = (L ^ kh_feistel_f<MODE>(R, KH_FC1, k)) & mask; L = R; R = t;
     t = (L ^ kh_feistel_f<MODE>(R, KH_FC2, k)) & mask; L = R; R = t;
     t = (L ^ kh_feistel_f<MODE>(R, KH_FC3, k)) & mask; L = R; R = t;
-    p1 = L >> (k - g.p1_bits);
-    pay = ((L << k) | R) << (32u - (2u * k - g.p1_bits));  // L's top p1_bits fall off the 32-bit word
+    p1 = L >> (k - p1_bits);
+    pay = ((L << k) | R) << (32u - (2u * k - p1_bits));  // L's top p1_bits fall off the 32-bit word
 }
 
 // ---- level-2 work unit and the two level-1 output layouts it can read -----------------------------
@@ -224,7 +223,11 @@ constexpr u64 CHUNK_DST_DROP = 1ull << 63;
 // PT = uint32_t: one sorting round of 16 windows per lane per tile.  PT = u64 (k >= 22): TWO rounds of 8
 // windows per lane, so that the staged payloads take the same 64 KiB of LDS and the per-partition runs
 // the same 64 bytes; the extraction state (Roller) simply carries on between the rounds.
-template <bool QUAL, int MODE, bool FAST, typename PT>
+// KT: 0 = k is a run-time value; 21 / 31 = the kernel is compiled for that k (the BASELINE configurations):
+// window masks, the revcomp insert position and the Feistel shifts become immediates, the 64-bit shift that
+// splits the key into its halves becomes one v_alignbit, and for 21 the level-1 geometry (1024 partitions,
+// payload = the low 32 hash bits) is fixed too.  Same values as the generic form (the tests run both).
+template <bool QUAL, int MODE, bool FAST, typename PT, int KT>
 __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
     u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, PT *__restrict__ pool,
@@ -244,6 +247,8 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     __shared__ uint16_t s_lofs[MAX_P1];
     __shared__ u64 s_priv_next, s_priv_end;     // the workgroup's private range of chunk ids
     const int tid = threadIdx.x;
+    if (KT) k = KT;
+    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
     s_cnt[tid] = 0;
     if (tid == 0) {
         s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
@@ -279,10 +284,11 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
                 if (!QUAL || ok) {
                     if (sizeof(PT) == 8) {
                         pay[j] = (PT)key;
-                        p1 = p1_of_hash(part_hash<MODE>(g, key), g);
+                        const u64 H = kh_table_hash<MODE>(key, k) << g.shard_shift;
+                        p1 = p1_of_hash(H, g);
                     } else if (FAST) {
                         uint32_t pw;
-                        hash_p1_pay32<MODE>(g, key, p1, pw);
+                        hash_p1_pay32<MODE>(k, p1b, key, p1, pw);
                         pay[j] = (PT)pw;
                     } else {
                         const u64 H = part_hash<MODE>(g, key);
@@ -360,6 +366,166 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
             // counters, though, are hit by the next round's atomics right away
             if (h + 1 < ROUNDS) __syncthreads();
         }
+    }
+    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
+    const u64 l = wave_sum((u64)lost);
+    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 1 for 32-bit payloads, software-pipelined: the write-out of tile t runs INTERLEAVED with the
+// extraction of tile t + 1.
+// ---------------------------------------------------------------------------------------------
+// The kernel above does, per tile, [extract + hash: ~50 VALU instructions per window, no LDS] then [rank, scan,
+// stage, write-out: LDS round trips with little arithmetic between them], one 1024-lane workgroup per CU
+// (134 KB of LDS), so the VALU and the LDS pipe take turns: 30 ms of VALU issue + 15 ms of LDS activity
+// = the 45 ms it takes (profiles/r01f).  The extraction needs no staging memory, though -- its results live
+// in registers until the rank step -- so here window j of the NEXT tile is computed between the LDS reads and
+// the global store of write-out iteration j of THIS tile: one wave keeps both pipes busy, without a second
+// workgroup (which the LDS could not hold at this tile size).  Same results, same chunk pool layout.
+template <bool QUAL, int MODE, bool FAST, int KT>
+__global__ __launch_bounds__(PART_NT) void part1_pipe32_kernel(
+    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
+    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
+    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
+    Counters *ctr) {
+    constexpr int RTILE = PART_NT * CHUNK;  // 16384 staged payloads per tile
+    __shared__ uint32_t s_code[2][PART_NT + 2];
+    __shared__ uint16_t s_val[2][PART_NT + 2];
+    __shared__ uint32_t s_stage[RTILE + 2];     // 64 KiB (+ a trash slot for windows without a key)
+    __shared__ uint16_t s_pid[RTILE + 2];       // 32 KiB
+    __shared__ uint32_t s_cnt[MAX_P1];
+    __shared__ uint32_t s_meta[MAX_P1];         // lofs | split << 16
+    __shared__ ChunkDst s_dst[MAX_P1];          // 16 KiB
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint16_t s_lofs[MAX_P1];
+    __shared__ u64 s_priv_next, s_priv_end;     // the workgroup's private range of chunk ids
+    const int tid = threadIdx.x;
+    if (KT) k = KT;
+    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
+    s_cnt[tid] = 0;
+    if (tid == 0) {
+        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+        s_priv_end = s_priv_next + POOL_GRAB;
+    }
+    u64 cur = 0;                // lane tid owns partition tid: its current chunk and how full it is
+    uint32_t fill = CHUNK_PAY;  // "full": the first payload takes a chunk
+    bool have_chunk = false;
+    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
+    u64 te = tb + tiles_per_block;
+    if (te > tile0 + ntiles) te = tile0 + ntiles;
+    uint32_t lost = 0;
+    __syncthreads();
+    if (tb >= te) return;  // (uniform)
+
+    // one window of a tile: canonical key -> level-1 digit + payload
+    auto window = [&](Roller &roll, int j, uint32_t &pay, uint32_t &tag) {
+        u64 key;
+        const bool ok = roll.next(j, key);
+        uint32_t p1 = 0;
+        pay = 0;
+        if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
+            if (FAST) {
+                hash_p1_pay32<MODE>(k, p1b, key, p1, pay);
+            } else {
+                const u64 H = part_hash<MODE>(g, key);
+                pay = Pay<uint32_t>::make(key, H, g);
+                p1 = p1_of_hash(H, g);
+            }
+        }
+        tag = ok ? (p1 << 16) : 0xFFFFFFFFu;
+    };
+
+    uint32_t pay[CHUNK], tag[CHUNK];
+    int buf = 0;
+    {  // prologue: the first tile's windows
+        const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, vend);
+        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
+        Roller roll;
+        roll.init(w, k, wlo);
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) window(roll, j, pay[j], tag[j]);
+    }
+    for (u64 t = tb; t < te; ++t) {
+        // ---- sort tile t (its payloads and digits are in registers) ----
+        // the next tile's bases are fetched now: in flight during the sort, consumed right after it (so they
+        // do not occupy registers while the interleaved phase below needs them most)
+        const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j)
+            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
+        __syncthreads();
+        block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
+        {
+            uint32_t rs[CHUNK];
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j) {
+                const uint32_t slot = tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)RTILE;
+                s_stage[slot] = pay[j];
+                s_pid[slot] = (uint16_t)(tag[j] >> 16);
+            }
+        }
+        {  // lane tid places partition tid's run: the rest of its current chunk, then fresh chunks
+            const uint32_t c = s_cnt[tid], lo = s_lofs[tid];
+            const uint32_t space = CHUNK_PAY - fill;
+            ChunkDst d;
+            d.a = cur * CHUNK_PAY + fill - lo;
+            d.b = 0;
+            if (c > space) {
+                const uint32_t r = c - space;
+                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
+                u64 first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
+                if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
+                if (first + nnew > pool_chunks) {  // cannot happen with the host's pool sizing; never write past it
+                    lost += r;
+                    first = 0;
+                    d.b = CHUNK_DST_DROP;
+                } else {
+                    for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
+                    d.b = first * CHUNK_PAY - space - lo;
+                    cur = first + nnew - 1;
+                    fill = r - (nnew - 1) * CHUNK_PAY;
+                    have_chunk = true;
+                }
+            } else {
+                fill += c;
+            }
+            s_dst[tid] = d;
+            s_meta[tid] = lo | (space << 16);
+        }
+        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
+        __syncthreads();
+        s_cnt[tid] = 0;  // (the next rank atomics come after the barriers below)
+        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next tile
+            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+            s_priv_end = s_priv_next + POOL_GRAB;
+        }
+        // ---- write-out of tile t, interleaved with the extraction of tile t + 1 ----
+        const bool more = t + 1 < te;  // (uniform)
+        Roller roll;
+        if (more) {
+            buf ^= 1;
+            const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
+            roll.init(w, k, wlo);
+        }
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)j * PART_NT;
+            const bool on = i < total;
+            const uint32_t ic = on ? i : 0u;  // (clamped: the loads below are unconditional, only the store is predicated)
+            const uint32_t p = s_pid[ic];
+            const uint32_t v = s_stage[ic];
+            const uint32_t meta = s_meta[p];
+            const ChunkDst d = s_dst[p];
+            if (more) window(roll, j, pay[j], tag[j]);
+            const uint32_t e = i - (meta & 0xFFFFu);
+            const bool first_part = e < (meta >> 16);
+            const u64 dst = (first_part ? d.a : d.b) + i;
+            if (on && (first_part || d.b != CHUNK_DST_DROP)) pool[dst] = v;
+        }
+        __syncthreads();  // every lane is done reading s_stage / s_pid / s_dst / s_meta of tile t
     }
     if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
     const u64 l = wave_sum((u64)lost);
@@ -1049,16 +1215,48 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         uint32_t nk = 0;
         if ((u64)tid < rem) nk = (uint32_t)((rem - tid + REGION_NT - 1) / REGION_NT);
         if (nk > REGION_RK) nk = REGION_RK;
+        uint32_t pj[REGION_RK];
 #pragma unroll
-        for (int j = 0; j < REGION_RK; ++j) s_q[j][tid] = kbuf[j];
+        for (int j = 0; j < REGION_RK; ++j) pj[j] = kbuf[j];
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) {  // next round's payloads in flight during the probing
             const u64 i64 = base + (u64)(REGION_RK + j) * REGION_NT + tid;
             kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
         }
-        if (hot) region32_probe_round<true>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
-        else if (may_special) region32_probe_round<false>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
-        else region32_probe_lean(nk, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
+        if (hot || may_special || !FRESH) {
+            // (the pass over a filled table keeps the old slots in registers; the straight-line first probe below
+            // would push it over the 64 registers that two workgroups per CU allow)
+#pragma unroll
+            for (int j = 0; j < REGION_RK; ++j) s_q[j][tid] = pj[j];
+            if (hot) region32_probe_round<true>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
+            else if (may_special) region32_probe_round<false>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
+            else region32_probe_lean(nk, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
+        } else {
+            // First probe of all eight payloads as straight-line code: the eight slot reads are in flight
+            // together and a payload that finds its key right there (most of them: a key comes ~12 times, and at
+            // load 0.5 two thirds of the keys sit in their home slot) costs a compare and a no-return ds_add --
+            // no loop, no ballot.  A slot only ever goes FREE -> payload once, so an equal value is final; a
+            // stale FREE or a different payload sends the item to the probing loop, which starts over at the
+            // home slot.
+            constexpr int FP = REGION_RK;
+            uint32_t r = 0;  // items left for the loop, compacted into the lane's queue
+#pragma unroll
+            for (int h = 0; h < REGION_RK; h += FP) {
+                uint32_t oj[FP], cj[FP];
+#pragma unroll
+                for (int j = 0; j < FP; ++j) oj[j] = (pj[h + j] >> sshift) & REGION_MASK;
+#pragma unroll
+                for (int j = 0; j < FP; ++j) cj[j] = s_pay[oj[j]];
+#pragma unroll
+                for (int j = 0; j < FP; ++j) {
+                    const bool valid = (uint32_t)(h + j) < nk;
+                    const bool hit = valid && cj[j] == pj[h + j];
+                    if (hit) atomicAdd(&s_add[oj[j]], 1u);  // no-return ds_add_u32
+                    if (valid && !hit) s_q[r++][tid] = pj[h + j];
+                }
+            }
+            region32_probe_lean(r, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
+        }
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);

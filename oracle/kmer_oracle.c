@@ -6,12 +6,14 @@
  * (tests/test_oracle_golden.py); the reference itself (Rust) cannot be built
  * in this image, so there is no oracle/_ref binary.
  */
+#define _GNU_SOURCE /* PTHREAD_MUTEX_ADAPTIVE_NP */
 #include "kmer_oracle.h"
 
 #include <pthread.h>
 #include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ======================================================================== */
 /* src/kmer.rs                                                              */
@@ -380,8 +382,13 @@ uint32_t ko_crc32(const uint8_t *data, size_t n) {
 /* ======================================================================== */
 
 typedef struct {
-    atomic_flag lock; /* DashMap's per-shard RwLock spins before it parks; a spinlock stands in */
+    /* DashMap 5.5.3 guards every shard with a RwLock that spins briefly and then PARKS the thread
+     * (parking_lot style).  A pthread mutex does the same through a futex; a pure test-and-set spinlock --
+     * what stood here in round 1 -- burns the cgroup's CPU quota in the waiters and made this port ~12x
+     * slower than it should be on a box that shows 256 CPUs but grants 16. */
+    pthread_mutex_t lock;
     ko_map map;
+    uint64_t contended, wait_ns; /* updated under the lock */
     char pad[64];
 } shard_t;
 
@@ -391,6 +398,12 @@ typedef struct {
     unsigned shift;
 } sharded_t;
 
+static inline uint64_t now_ns(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ULL + (uint64_t)ts.tv_nsec;
+}
+
 static void emit_to_shards(void *ctx, uint64_t key) {
     /* DashMap: hash -> shard index from the high bits, then lock + upsert
      * (run.rs:565-571).  FxHash is a multiplicative hash; any well-mixed hash
@@ -398,9 +411,14 @@ static void emit_to_shards(void *ctx, uint64_t key) {
     sharded_t *s = (sharded_t *)ctx;
     uint64_t h = key * 0x517cc1b727220a95ULL; /* Fx-style multiply */
     shard_t *sh = &s->shards[(h >> s->shift) & (s->nshards - 1)];
-    while (atomic_flag_test_and_set_explicit(&sh->lock, memory_order_acquire)) __builtin_ia32_pause();
+    if (pthread_mutex_trylock(&sh->lock) != 0) { /* contended: time the wait (the uncontended path pays nothing) */
+        uint64_t t0 = now_ns();
+        pthread_mutex_lock(&sh->lock);
+        sh->contended++;
+        sh->wait_ns += now_ns() - t0;
+    }
     ko_map_add(&sh->map, key, 1);
-    atomic_flag_clear_explicit(&sh->lock, memory_order_release);
+    pthread_mutex_unlock(&sh->lock);
 }
 
 typedef struct {
@@ -432,9 +450,14 @@ static void *worker_main(void *arg) {
     return NULL;
 }
 
-uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
-                             const uint64_t *off, const uint32_t *lens,
-                             uint64_t nrec, size_t k, int min_quality, int nthreads) {
+/* expect_distinct > 0: every shard's table is sized for its share up front, so that no thread ever rehashes
+ * while holding a shard lock (hashbrown inside DashMap amortises its growth; a doubling under the lock of a
+ * hot shard is not what a steady-state krust run looks like).  stats (optional, 4 entries): contended lock
+ * acquisitions, nanoseconds spent waiting for locks (summed over threads), upserts, rehashes under a lock. */
+uint64_t ko_count_records_mt2(ko_map *m, const uint8_t *seq, const uint8_t *qual,
+                              const uint64_t *off, const uint32_t *lens,
+                              uint64_t nrec, size_t k, int min_quality, int nthreads,
+                              uint64_t expect_distinct, uint64_t *stats) {
     if (nthreads < 1) nthreads = 1;
     sharded_t sh;
     uint64_t ns = 1;
@@ -445,10 +468,20 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
     sh.shift = 64 - bits; /* ns >= 4, so bits >= 2 */
     sh.shards = (shard_t *)calloc(ns, sizeof(shard_t));
     if (!sh.shards) abort();
-    for (uint64_t i = 0; i < ns; i++) {
-        atomic_flag_clear(&sh.shards[i].lock);
-        map_alloc(&sh.shards[i].map, 1024);
+    uint64_t cap0 = 1024;
+    if (expect_distinct) {
+        uint64_t per = expect_distinct / ns + 1;
+        while (cap0 * 6 < per * 10 + 16) cap0 <<= 1; /* stays under ko_map_add's 0.6 load limit */
+        cap0 <<= 1;                                  /* and the shards are not perfectly even */
     }
+    pthread_mutexattr_t attr; /* spin briefly, then park: what parking_lot's lock under DashMap does */
+    pthread_mutexattr_init(&attr);
+    pthread_mutexattr_settype(&attr, PTHREAD_MUTEX_ADAPTIVE_NP);
+    for (uint64_t i = 0; i < ns; i++) {
+        pthread_mutex_init(&sh.shards[i].lock, &attr);
+        map_alloc(&sh.shards[i].map, cap0);
+    }
+    pthread_mutexattr_destroy(&attr);
     atomic_ullong next;
     atomic_init(&next, 0);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
@@ -463,14 +496,26 @@ uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
         pthread_join(th[t], NULL);
         counted += ws[t].counted;
     }
+    uint64_t contended = 0, wait_ns = 0, grown = 0;
     for (uint64_t i = 0; i < ns; i++) {
         ko_map *sm = &sh.shards[i].map;
+        contended += sh.shards[i].contended;
+        wait_ns += sh.shards[i].wait_ns;
+        for (uint64_t c = cap0; c < sm->cap; c <<= 1) grown++;
         for (uint64_t j = 0; j < sm->cap; j++)
             if (sm->e[j].val) ko_map_add(m, sm->e[j].key, sm->e[j].val);
         free(sm->e);
+        pthread_mutex_destroy(&sh.shards[i].lock);
     }
+    if (stats) { stats[0] = contended; stats[1] = wait_ns; stats[2] = counted; stats[3] = grown; }
     free(sh.shards); free(th); free(ws);
     return counted;
+}
+
+uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
+                             const uint64_t *off, const uint32_t *lens,
+                             uint64_t nrec, size_t k, int min_quality, int nthreads) {
+    return ko_count_records_mt2(m, seq, qual, off, lens, nrec, k, min_quality, nthreads, 0, NULL);
 }
 
 /* ======================================================================== */

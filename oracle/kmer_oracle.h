@@ -110,13 +110,22 @@ uint32_t ko_crc32(const uint8_t *data, size_t n);
 /* KmerMap::build / build_with_quality, src/run.rs:500-520: one task per record
  * on nthreads threads (rayon for_each over records), each running the literal
  * per-window algorithm above and upserting into a sharded lock-per-shard map
- * (DashMap 5.5.3: shards = 4*nthreads rounded up to a power of two).
+ * (DashMap 5.5.3: shards = 4*nthreads rounded up to a power of two; the lock is a
+ * parking mutex, as DashMap's RwLock parks its waiters).
  * Records are given as offsets into one flat buffer: record i is
  * seq[off[i] .. off[i]+lens[i]).  qual may be NULL.  Results are merged into m.
  * Returns the number of k-mers counted. */
 uint64_t ko_count_records_mt(ko_map *m, const uint8_t *seq, const uint8_t *qual,
                              const uint64_t *off, const uint32_t *lens,
                              uint64_t nrec, size_t k, int min_quality, int nthreads);
+
+/* The same with every shard's table sized up front for its share of expect_distinct keys (0 = start small and
+ * grow under the lock, as above), and lock statistics: stats[0] contended acquisitions, stats[1] nanoseconds
+ * spent waiting for shard locks (summed over threads), stats[2] upserts, stats[3] rehashes that still happened. */
+uint64_t ko_count_records_mt2(ko_map *m, const uint8_t *seq, const uint8_t *qual,
+                              const uint64_t *off, const uint32_t *lens,
+                              uint64_t nrec, size_t k, int min_quality, int nthreads,
+                              uint64_t expect_distinct, uint64_t *stats);
 
 /* Optimised CPU formulation, reported beside the krust-equivalent port so that the GPU figure is
  * not flattered by the port's allocations and locks (implementation B): rolling

@@ -49,6 +49,9 @@ def _load():
     lib.ko_count_records_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_uint64, C.c_size_t, C.c_int, C.c_int]
     lib.ko_count_records_mt.restype = C.c_uint64
+    lib.ko_count_records_mt2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_uint64, C.c_size_t, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
+    lib.ko_count_records_mt2.restype = C.c_uint64
     lib.ko_scan_flat_sampled_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
                                             C.c_uint64, C.c_int]
     lib.ko_scan_flat_sampled_mt.restype = C.c_uint64
@@ -155,14 +158,19 @@ class OracleMap:
     def digest(self):
         return int(lib().ko_map_digest(self._m))
 
-    def count_records_mt(self, seq, offs, lens, k, qual=None, min_quality=None, nthreads=1):
+    def count_records_mt(self, seq, offs, lens, k, qual=None, min_quality=None, nthreads=1, expect_distinct=0, stats=None):
+        """krust-equivalent threaded count.  stats: a dict that receives the lock statistics."""
         sp, _, _ks = _buf(seq)
         qp, _, _kq = _buf(qual)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
-        return int(lib().ko_count_records_mt(self._m, sp, qp, offs.ctypes.data, lens.ctypes.data,
-                                             len(offs), k, -1 if min_quality is None else int(min_quality),
-                                             nthreads))
+        st = np.zeros(4, dtype=np.uint64)
+        n = int(lib().ko_count_records_mt2(self._m, sp, qp, offs.ctypes.data, lens.ctypes.data,
+                                           len(offs), k, -1 if min_quality is None else int(min_quality),
+                                           nthreads, int(expect_distinct), st.ctypes.data))
+        if stats is not None:
+            stats.update(contended=int(st[0]), wait_ns=int(st[1]), upserts=int(st[2]), rehashes_under_lock=int(st[3]))
+        return n
 
 
 def count_records(records, k, quals=None, min_quality=None, rolling=False):

@@ -115,12 +115,13 @@ def test_group_of_ranks_sharing_the_device(K, monkeypatch, world, k, pieces, exp
             assert np.array_equal(keys, fk[sel]) and np.array_equal(cnts, fc[sel]), f"shard {r} differs from the oracle"
             assert info["owned_distinct"] == int(sel.sum())
             assert np.array_equal(dc.lookup(keys[:1000]), cnts[:1000])      # lookups use the sharded placement
-            with pytest.raises(K.KmerHipError) as e:                         # a shard refuses reads until reset,
-                dc.push(b"ACGTACGTACGTACGTACGTACGTACGTACGT\n")
-            assert e.value.status == K.native.KH_ERR_STATE
-            with pytest.raises(K.KmerHipError) as e:                         # and a second merge
-                dc.merge_across()
-            assert e.value.status == K.native.KH_ERR_STATE
+            if expect.startswith("regions"):      # (the pairs route leaves an ordinary table that holds the rank's keys)
+                with pytest.raises(K.KmerHipError) as e:                     # a hash-range shard refuses reads until reset,
+                    dc.push(b"ACGTACGTACGTACGTACGTACGTACGTACGT\n")
+                assert e.value.status == K.native.KH_ERR_STATE
+                with pytest.raises(K.KmerHipError) as e:                     # and a second merge
+                    dc.merge_across()
+                assert e.value.status == K.native.KH_ERR_STATE
             total_sent += info["sent_units"]
         assert total_sent > 0
         # second round on the same group: reset, count again, merge again (dirty tables, same communicators)
