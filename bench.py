@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--verify", action="store_true", help="check a 1/1024 key sample against the CPU oracle")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the end-to-end (host buffers in, results out) figures and the configs[1..2] sub-results")
     return ap.parse_args()
 
 
@@ -136,6 +138,81 @@ def cpu_baseline(host_bases, k, target_seconds):
                 "The radix formulation rolls the window in registers and counts partitions in private tables: no locks, "
                 "cache-sized working sets.")}
     return out
+
+
+def roofline_of(st, nbytes_in, kernel_ms, stage_ms, k):
+    """HBM roofline of one step: algorithmic bytes (every input byte once +
+    24 B per valid k-mer + 8 B per distinct key) over the HIP-event time of the step's counting kernels."""
+    alg = nbytes_in + 24 * st["kmers"] + 8 * st["distinct"]
+    achieved = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "alg_bytes_per_step": alg, "kernel_ms_per_step": kernel_ms,
+            "stages_ms": {n: v for n, v in stage_ms.items() if v > 0}}
+
+
+def sub_config(krust_amd, torch, dev, local_rank, name, reads, k, min_quality):
+    """One BASELINE.json configuration as a sub-result: its own reads, its own context, one warm-up and one
+    timed step (reset + push_device + finish), with its own roofline."""
+    stride = READ_LEN + 1
+    nbytes = reads * stride
+    with_qual = min_quality is not None
+    tb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    tq = torch.empty(nbytes, dtype=torch.uint8, device=dev) if with_qual else None
+    krust_amd.synth_reads_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, SEED, GENOME_LEN, READ_LEN, 0, reads,
+                                 device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    dc = krust_amd.DeviceCounter(k, min_quality=min_quality, capacity_hint=estimate_distinct(reads, k, 1, with_qual), device=local_rank)
+    try:
+        for rep in range(2):
+            dc.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dc.push_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, nbytes)
+            st = dc.finish()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        rf = roofline_of(st, nbytes * (2 if with_qual else 1), st["count_kernel_ms"], st["stage_ms"], k)
+        return {"workload": name, "k": k, "reads": reads, "min_quality": min_quality, "value": st["kmers"] / dt, "unit": "k-mers/s",
+                "ms_per_step": dt * 1e3, "steps": 1, "kmers_per_step": int(st["kmers"]), "distinct": int(st["distinct"]),
+                "table_slots": int(st["table_slots"]), "table_grows": int(st["grows"]), "dtype": "u64", "roofline": rf}
+    finally:
+        dc.close()
+        del tb, tq
+        torch.cuda.empty_cache()
+
+
+def end_to_end(dc, tb, torch, k):
+    """host buffers on both sides, never `value`.  The rank's reads as PAGEABLE host memory ->
+    kh_push (pinned staging, H2D on a copy stream overlapped with counting) -> kh_finish, then the two result
+    forms: every (key, count) pair copied back into fresh host arrays (kh_result_copy), or the count-of-counts
+    histogram computed on the device (kh_histogram) -- what `kmerust --format histogram` needs."""
+    import numpy as np
+    t0 = time.perf_counter()
+    host = tb.cpu().numpy()  # (setting the stage, not timed: a host application HAS its reads in host memory)
+    t_stage = time.perf_counter() - t0
+    dc.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dc.push(host)
+    st = dc.finish()
+    t_push = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hist = dc.histogram()
+    t_hist = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    keys, cnts = dc.result(sort=False)
+    t_pairs = time.perf_counter() - t0
+    ok = bool(int(cnts.sum(dtype=np.uint64)) == st["kmers"] == sum(c * f for c, f in hist) and keys.size == st["distinct"])
+    kmers = int(st["kmers"])
+    return {"what": "pageable host bases -> kh_push -> kh_finish -> results on the host; reads resident in HBM is `value`, not this",
+            "bytes_in": int(host.size), "push_finish_s": t_push, "push_GBps": host.size / t_push / 1e9,
+            "h2d_ms": st["h2d_ms"], "count_kernel_ms": st["count_kernel_ms"],
+            "pairs_out": int(keys.size), "result_copy_s": t_pairs, "result_copy_GBps": 16.0 * keys.size / t_pairs / 1e9,
+            "histogram_s": t_hist, "histogram_lines": len(hist),
+            "kmers_per_s_push_only": kmers / t_push,
+            "kmers_per_s_histogram_out": kmers / (t_push + t_hist),
+            "kmers_per_s_pairs_out": kmers / (t_push + t_pairs),
+            "consistent": ok, "staging_copy_s_untimed": t_stage}
 
 
 def main():
@@ -283,16 +360,17 @@ def main():
                        "p2_count": pay * st["kmers"], "p2_scatter": 2 * pay * st["kmers"],
                        "region": pay * st["kmers"] + 16 * st["table_slots"]}
         dom = max((n for n in stages if n in stage_bytes), key=lambda n: stages[n], default=None)
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):  # measured in separate rocprofv3 --pmc passes (profiles/README.md)
+        if os.path.exists(tpath):  # measured in separate rocprofv3 --pmc passes (profiles/README.md), not in this run
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("reads_per_gpu") == reads and tj.get("k") == k:
+                if tj.get("reads_per_gpu") == reads and tj.get("k") == k and not with_qual:
                     traffic = tj.get("bytes_per_step")
+                    traffic_source = f"profiles/{tj.get('tag')}_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; not re-measured in this run)"
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
         out = {
             "metric": "canonical k-mers/s at k=21, 100M x 150bp reads; bit-exact vs krust CPU",
             "value": total_kmers * args.steps / elapsed,
@@ -314,7 +392,7 @@ def main():
                        "table_grows": int(st["grows"]),
                        "parallelism": f"reads sharded x{world}" + ("; RCCL all-to-all table merge" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_measured_copy_peak": achieved / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s copy
                          "kernel": "partitioned pipeline: part1_scatter_chunked (single-pass level 1) + part2_count + part2_scatter + "
                                    "region_count, one launch each per batch"
@@ -336,6 +414,25 @@ def main():
             sample_reads = min(reads, 6_000_000)
             host = tb[: sample_reads * stride].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host, k, args.cpu_seconds)
+            del host
+        if world == 1 and not args.no_extras:
+            try:
+                out["end_to_end"] = end_to_end(dc, tb, torch, k)
+            except Exception as e:  # (never lose the headline line over an extra)
+                out["end_to_end"] = {"error": repr(e)}
+            dc.close()
+            del tb, tq
+            torch.cuda.empty_cache()
+            subs = []
+            for name, n, kk, mq in (("configs[1] S10M: 10 M x 150 bp, k=21", 10_000_000, 21, None),
+                                    ("configs[2] S100M: 100 M x 150 bp, k=31, -Q 20", 100_000_000, 31, 20)):
+                if reads < 100_000_000 and n > reads:
+                    continue  # (a reduced --reads run: keep the extras proportionate)
+                try:
+                    subs.append(sub_config(krust_amd, torch, dev, local_rank, name, n, kk, mq))
+                except Exception as e:
+                    subs.append({"workload": name, "error": repr(e)})
+            out["configs"] = subs
         print(json.dumps(out), flush=True)
 
     dc.close()

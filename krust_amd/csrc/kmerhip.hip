@@ -595,22 +595,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const bool fast = sizeof(PT) == 4 && kh::p1_fast_ok(g);
             // the BASELINE configurations get kernels compiled for their k (KMERHIP_GENERIC_K=1: the generic form, for A/B)
             static const bool generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
-            // 32-bit payloads: the software-pipelined kernel (KMERHIP_P1_PIPE=0: the plain one, for A/B)
-            static const bool pipe32 = [] { const char *e = getenv("KMERHIP_P1_PIPE"); return !(e && e[0] == '0'); }();
-#define KH_P1_PIPE(QUAL, MODE, FAST, KT) \
-    hipLaunchKernelGGL((kh::part1_pipe32_kernel<QUAL, MODE, FAST, KT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
-                       ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
-                       c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
-            // (without quality masking only: with it the interleaved form spills ~120 registers per lane, the
-            //  masked windows' branches do not mix with the write-out; those inputs keep the plain kernel)
-            if (sizeof(PT) == 4 && pipe32 && !ra.use_qual) {
-                const bool k21 = !generic_k && c->k == 21 && fast && g.p1_bits == 10;
-                if (k21) KH_P1_PIPE(false, KH_MUL_24, true, 21);
-                else if (m24 && fast) KH_P1_PIPE(false, KH_MUL_24, true, 0);
-                else if (m24) KH_P1_PIPE(false, KH_MUL_24, false, 0);
-                else if (fast) KH_P1_PIPE(false, KH_MUL_32, true, 0);
-                else KH_P1_PIPE(false, KH_MUL_32, false, 0);
-            } else if (!generic_k && c->k == 21 && sizeof(PT) == 4 && fast && g.p1_bits == 10) {
+            if (!generic_k && c->k == 21 && sizeof(PT) == 4 && fast && g.p1_bits == 10) {
                 if (ra.use_qual) KH_P1_LAUNCH(true, KH_MUL_24, true, 21);
                 else KH_P1_LAUNCH(false, KH_MUL_24, true, 21);
             } else if (!generic_k && c->k == 31 && sizeof(PT) == 8) {
@@ -620,10 +605,15 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             else if (ra.use_qual) KH_P1_LAUNCH2(true, KH_MUL_32);
             else if (m24) KH_P1_LAUNCH2(false, KH_MUL_24);
             else KH_P1_LAUNCH2(false, KH_MUL_32);
-#undef KH_P1_PIPE
 #undef KH_P1_LAUNCH2
 #undef KH_P1_LAUNCH
         }
+#if KH_ABL
+        if (getenv("KMERHIP_STOP_AFTER_P1")) {  // ablation builds only: time level 1 alone (its output is garbage)
+            HIP_TRY(c, hipGetLastError());
+            return sync_counters(c);
+        }
+#endif
         {
             StageTimer t(c, ST_MISC);
             hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
@@ -654,6 +644,12 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 1024>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
                                (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
     }
+#if KH_ABL2
+    if (getenv("KMERHIP_STOP_AFTER_P2")) {  // ablation builds only: time level 2 alone (its output is garbage)
+        HIP_TRY(c, hipGetLastError());
+        return sync_counters(c);
+    }
+#endif
     {
         StageTimer t(c, ST_MISC);
         hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((nregions + 256) / 256)), dim3(256), 0, c->stream,

@@ -28,6 +28,13 @@
 #pragma once
 #include "kernels.hip.h"
 
+#ifndef KH_ABL2
+#define KH_ABL2 0  // the same for part2_scatter_kernel
+#endif
+#ifndef KH_ABL
+#define KH_ABL 0  // ablation bits for timing experiments on part1_scatter_chunked_kernel (tools/p1_ablation.sh); 0 in any product build
+#endif
+
 namespace kh {
 
 constexpr int PART_NT = 1024;                    // lanes per workgroup in the partition kernels
@@ -276,7 +283,12 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
 #pragma unroll
             for (int j = 0; j < WPR; ++j) {
                 u64 key;
+#if KH_ABL & 8  /* timing experiment: no window extraction */
+                key = (u64)roll.code * (2 * j + 1) + tid;
+                const bool ok = true;
+#else
                 const bool ok = roll.next(h * WPR + j, key);
+#endif
                 uint32_t p1 = 0;
                 // Without quality masking nearly every window is valid (N is rare): hashing unconditionally
                 // is cheaper than an exec-mask region per window.  With -Q ~40 % of the windows are masked,
@@ -288,7 +300,12 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
                         p1 = p1_of_hash(H, g);
                     } else if (FAST) {
                         uint32_t pw;
+#if KH_ABL & 1  /* timing experiment: no hash */
+                        p1 = (uint32_t)key & 1023u;
+                        pw = (uint32_t)(key >> 10);
+#else
                         hash_p1_pay32<MODE>(k, p1b, key, p1, pw);
+#endif
                         pay[j] = (PT)pw;
                     } else {
                         const u64 H = part_hash<MODE>(g, key);
@@ -301,7 +318,11 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
             // ranks in a second sweep: all LDS atomics in flight instead of one wait per window
 #pragma unroll
             for (int j = 0; j < WPR; ++j)
+#if KH_ABL & 16  /* timing experiment: no rank atomics (everything then collapses to an empty sort) */
+                tag[j] &= 0xFFFF0000u;
+#else
                 if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
+#endif
             __syncthreads();
             block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
             // Branch-free staging: every lane reads its run starts back to back (one wait instead of an
@@ -353,179 +374,25 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
             // next tile's bases are fetched while this tile's last runs are written out
             if (h == ROUNDS - 1)
                 raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+#if !(KH_ABL & 4)  /* timing experiment: no write-out */
 #pragma unroll 2
             for (uint32_t i = tid; i < total; i += PART_NT) {
                 const uint32_t p = s_pid[i];
                 const uint32_t meta = s_meta[p];
                 const ChunkDst d = s_dst[p];
                 const uint32_t e = i - (meta & 0xFFFFu);
+#if KH_ABL & 2  /* timing experiment: LDS side of the write-out only, no global stores */
+                if (s_stage[i] == 0x12345678u && e == 77 && d.a == 5) pool[0] = 1;
+#else
                 if (e < (meta >> 16)) pool[d.a + i] = s_stage[i];
                 else if (d.b != CHUNK_DST_DROP) pool[d.b + i] = s_stage[i];
+#endif
             }
+#endif
             // s_stage / s_dst / s_meta are rewritten only after the next round's / tile's barriers; the
             // counters, though, are hit by the next round's atomics right away
             if (h + 1 < ROUNDS) __syncthreads();
         }
-    }
-    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
-    const u64 l = wave_sum((u64)lost);
-    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 1 for 32-bit payloads, software-pipelined: the write-out of tile t runs INTERLEAVED with the
-// extraction of tile t + 1.
-// ---------------------------------------------------------------------------------------------
-// The kernel above does, per tile, [extract + hash: ~50 VALU instructions per window, no LDS] then [rank, scan,
-// stage, write-out: LDS round trips with little arithmetic between them], one 1024-lane workgroup per CU
-// (134 KB of LDS), so the VALU and the LDS pipe take turns: 30 ms of VALU issue + 15 ms of LDS activity
-// = the 45 ms it takes (profiles/r01f).  The extraction needs no staging memory, though -- its results live
-// in registers until the rank step -- so here window j of the NEXT tile is computed between the LDS reads and
-// the global store of write-out iteration j of THIS tile: one wave keeps both pipes busy, without a second
-// workgroup (which the LDS could not hold at this tile size).  Same results, same chunk pool layout.
-template <bool QUAL, int MODE, bool FAST, int KT>
-__global__ __launch_bounds__(PART_NT) void part1_pipe32_kernel(
-    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
-    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
-    Counters *ctr) {
-    constexpr int RTILE = PART_NT * CHUNK;  // 16384 staged payloads per tile
-    __shared__ uint32_t s_code[2][PART_NT + 2];
-    __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ uint32_t s_stage[RTILE + 2];     // 64 KiB (+ a trash slot for windows without a key)
-    __shared__ uint16_t s_pid[RTILE + 2];       // 32 KiB
-    __shared__ uint32_t s_cnt[MAX_P1];
-    __shared__ uint32_t s_meta[MAX_P1];         // lofs | split << 16
-    __shared__ ChunkDst s_dst[MAX_P1];          // 16 KiB
-    __shared__ uint32_t s_wsum[4];
-    __shared__ uint16_t s_lofs[MAX_P1];
-    __shared__ u64 s_priv_next, s_priv_end;     // the workgroup's private range of chunk ids
-    const int tid = threadIdx.x;
-    if (KT) k = KT;
-    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
-    s_cnt[tid] = 0;
-    if (tid == 0) {
-        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-        s_priv_end = s_priv_next + POOL_GRAB;
-    }
-    u64 cur = 0;                // lane tid owns partition tid: its current chunk and how full it is
-    uint32_t fill = CHUNK_PAY;  // "full": the first payload takes a chunk
-    bool have_chunk = false;
-    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
-    u64 te = tb + tiles_per_block;
-    if (te > tile0 + ntiles) te = tile0 + ntiles;
-    uint32_t lost = 0;
-    __syncthreads();
-    if (tb >= te) return;  // (uniform)
-
-    // one window of a tile: canonical key -> level-1 digit + payload
-    auto window = [&](Roller &roll, int j, uint32_t &pay, uint32_t &tag) {
-        u64 key;
-        const bool ok = roll.next(j, key);
-        uint32_t p1 = 0;
-        pay = 0;
-        if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
-            if (FAST) {
-                hash_p1_pay32<MODE>(k, p1b, key, p1, pay);
-            } else {
-                const u64 H = part_hash<MODE>(g, key);
-                pay = Pay<uint32_t>::make(key, H, g);
-                p1 = p1_of_hash(H, g);
-            }
-        }
-        tag = ok ? (p1 << 16) : 0xFFFFFFFFu;
-    };
-
-    uint32_t pay[CHUNK], tag[CHUNK];
-    int buf = 0;
-    {  // prologue: the first tile's windows
-        const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, vend);
-        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
-        Roller roll;
-        roll.init(w, k, wlo);
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j) window(roll, j, pay[j], tag[j]);
-    }
-    for (u64 t = tb; t < te; ++t) {
-        // ---- sort tile t (its payloads and digits are in registers) ----
-        // the next tile's bases are fetched now: in flight during the sort, consumed right after it (so they
-        // do not occupy registers while the interleaved phase below needs them most)
-        const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
-        __syncthreads();
-        block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
-        {
-            uint32_t rs[CHUNK];
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j) {
-                const uint32_t slot = tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)RTILE;
-                s_stage[slot] = pay[j];
-                s_pid[slot] = (uint16_t)(tag[j] >> 16);
-            }
-        }
-        {  // lane tid places partition tid's run: the rest of its current chunk, then fresh chunks
-            const uint32_t c = s_cnt[tid], lo = s_lofs[tid];
-            const uint32_t space = CHUNK_PAY - fill;
-            ChunkDst d;
-            d.a = cur * CHUNK_PAY + fill - lo;
-            d.b = 0;
-            if (c > space) {
-                const uint32_t r = c - space;
-                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
-                u64 first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
-                if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
-                if (first + nnew > pool_chunks) {  // cannot happen with the host's pool sizing; never write past it
-                    lost += r;
-                    first = 0;
-                    d.b = CHUNK_DST_DROP;
-                } else {
-                    for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
-                    d.b = first * CHUNK_PAY - space - lo;
-                    cur = first + nnew - 1;
-                    fill = r - (nnew - 1) * CHUNK_PAY;
-                    have_chunk = true;
-                }
-            } else {
-                fill += c;
-            }
-            s_dst[tid] = d;
-            s_meta[tid] = lo | (space << 16);
-        }
-        const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
-        __syncthreads();
-        s_cnt[tid] = 0;  // (the next rank atomics come after the barriers below)
-        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next tile
-            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-            s_priv_end = s_priv_next + POOL_GRAB;
-        }
-        // ---- write-out of tile t, interleaved with the extraction of tile t + 1 ----
-        const bool more = t + 1 < te;  // (uniform)
-        Roller roll;
-        if (more) {
-            buf ^= 1;
-            const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
-            roll.init(w, k, wlo);
-        }
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)j * PART_NT;
-            const bool on = i < total;
-            const uint32_t ic = on ? i : 0u;  // (clamped: the loads below are unconditional, only the store is predicated)
-            const uint32_t p = s_pid[ic];
-            const uint32_t v = s_stage[ic];
-            const uint32_t meta = s_meta[p];
-            const ChunkDst d = s_dst[p];
-            if (more) window(roll, j, pay[j], tag[j]);
-            const uint32_t e = i - (meta & 0xFFFFu);
-            const bool first_part = e < (meta >> 16);
-            const u64 dst = (first_part ? d.a : d.b) + i;
-            if (on && (first_part || d.b != CHUNK_DST_DROP)) pool[dst] = v;
-        }
-        __syncthreads();  // every lane is done reading s_stage / s_pid / s_dst / s_meta of tile t
     }
     if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
     const u64 l = wave_sum((u64)lost);
@@ -834,7 +701,13 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
 #pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART2_NT) {
             const PT v = s_stage[i];
+#if KH_ABL2 & 1   /* timing experiment: LDS side only, no global stores */
+            if (v == (PT)0x12345678u && s_dst[Pay<PT>::p2(v, g)] == 5) out[0] = v;
+#elif KH_ABL2 & 2 /* timing experiment: the same bytes written densely (batch after batch) instead of scattered */
+            out[(u64)blockIdx.x * (CPB * CHUNK_PAY) + base + i + (s_dst[Pay<PT>::p2(v, g)] & 0)] = v;
+#else
             out[s_dst[Pay<PT>::p2(v, g)] + i] = v;  // consecutive lanes -> consecutive addresses inside a run
+#endif
         }
         __syncthreads();
     }
