@@ -595,7 +595,25 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const bool fast = sizeof(PT) == 4 && kh::p1_fast_ok(g);
             // the BASELINE configurations get kernels compiled for their k (KMERHIP_GENERIC_K=1: the generic form, for A/B)
             static const bool generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
-            if (!generic_k && c->k == 21 && sizeof(PT) == 4 && fast && g.p1_bits == 10) {
+            // 32-bit payloads: the kernel with the 16-byte write-out (KMERHIP_P1_VEC=0: the per-payload one, for A/B)
+            static const bool vec32 = [] { const char *e = getenv("KMERHIP_P1_VEC"); return !(e && e[0] == '0'); }();
+#define KH_P1_VEC(QUAL, MODE, FAST, KT) \
+    hipLaunchKernelGGL((kh::part1_vec32_kernel<QUAL, MODE, FAST, KT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
+                       ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
+                       c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
+            if (sizeof(PT) == 4 && vec32) {
+                const bool k21 = !generic_k && c->k == 21 && fast && g.p1_bits == 10;
+                if (k21 && ra.use_qual) KH_P1_VEC(true, KH_MUL_24, true, 21);
+                else if (k21) KH_P1_VEC(false, KH_MUL_24, true, 21);
+                else if (ra.use_qual && m24 && fast) KH_P1_VEC(true, KH_MUL_24, true, 0);
+                else if (ra.use_qual && m24) KH_P1_VEC(true, KH_MUL_24, false, 0);
+                else if (ra.use_qual && fast) KH_P1_VEC(true, KH_MUL_32, true, 0);
+                else if (ra.use_qual) KH_P1_VEC(true, KH_MUL_32, false, 0);
+                else if (m24 && fast) KH_P1_VEC(false, KH_MUL_24, true, 0);
+                else if (m24) KH_P1_VEC(false, KH_MUL_24, false, 0);
+                else if (fast) KH_P1_VEC(false, KH_MUL_32, true, 0);
+                else KH_P1_VEC(false, KH_MUL_32, false, 0);
+            } else if (!generic_k && c->k == 21 && sizeof(PT) == 4 && fast && g.p1_bits == 10) {
                 if (ra.use_qual) KH_P1_LAUNCH(true, KH_MUL_24, true, 21);
                 else KH_P1_LAUNCH(false, KH_MUL_24, true, 21);
             } else if (!generic_k && c->k == 31 && sizeof(PT) == 8) {
@@ -605,6 +623,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             else if (ra.use_qual) KH_P1_LAUNCH2(true, KH_MUL_32);
             else if (m24) KH_P1_LAUNCH2(false, KH_MUL_24);
             else KH_P1_LAUNCH2(false, KH_MUL_32);
+#undef KH_P1_VEC
 #undef KH_P1_LAUNCH2
 #undef KH_P1_LAUNCH
         }

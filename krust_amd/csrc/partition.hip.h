@@ -399,6 +399,197 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
 }
 
+// ---------------------------------------------------------------------------------------------
+// level 1 for 32-bit payloads with a VECTOR write-out: four payloads (16 bytes) per lane and store
+// ---------------------------------------------------------------------------------------------
+// Timing experiments on the kernel above (tools/p1_ablation.sh, S100M): of its 42 ms the write-out costs 9.6
+// (5.5 the global stores -- 64 lanes x 4 bytes into four or five different lines per instruction --, 4.1 its
+// LDS reads: payload, partition id, split point, 16-byte destination pair PER PAYLOAD).  Here every partition's
+// run is written in units of four payloads: the <= 3 that do not fill a unit stay behind in LDS (s_res) and
+// lead the partition's next run, so chunk fill levels are multiples of four, every store is an aligned
+// global_store_dwordx4 fed by one ds_read_b128, and the per-run lookups happen once per unit.  The sorted tile
+// keeps every partition's region 16-byte aligned (regions are padded to whole units: s_stage grows from 64 to
+// 88 KB, paid for by dropping the per-payload partition ids for per-unit ones).  What a workgroup still holds at
+// the end goes out payload by payload.  Same chunk pool, same reader: level 2 is unchanged.
+constexpr int P1V_SCAP = PART_NT * CHUNK + 6 * (int)MAX_P1;  // sorted tile: payloads + residues (<= 3) + padding (<= 3) per partition
+
+template <bool QUAL, int MODE, bool FAST, int KT>
+__global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
+    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
+    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
+    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
+    Counters *ctr) {
+    __shared__ uint32_t s_code[2][PART_NT + 2];
+    __shared__ uint16_t s_val[2][PART_NT + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[P1V_SCAP + 4];  // 88 KiB (+ a trash unit)
+    __shared__ uint16_t s_vpid[P1V_SCAP / 4 + 1];  // owner partition of every whole unit, 0xFFFF = not to be written
+    __shared__ uint32_t s_cnt[MAX_P1];
+    __shared__ uint16_t s_lofv[MAX_P1];            // first unit of the partition's region
+    __shared__ uint32_t s_meta[MAX_P1];            // lofv | units that still go to the current chunk << 16
+    __shared__ ChunkDst s_dst[MAX_P1];             // 16 KiB: pool index of a payload slot = a (or b) + slot
+    __shared__ uint32_t s_res[3][MAX_P1];          // the <= 3 payloads carried to the partition's next run
+    __shared__ uint32_t s_wsum[PART_NT / 64];
+    __shared__ uint32_t s_vtot;
+    __shared__ u64 s_priv_next, s_priv_end;        // the workgroup's private range of chunk ids
+    const int tid = threadIdx.x;
+    if (KT) k = KT;
+    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
+    s_cnt[tid] = 0;
+    if (tid == 0) {
+        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+        s_priv_end = s_priv_next + POOL_GRAB;
+    }
+    // lane tid owns partition tid: its current chunk, how full it is (a multiple of 4), its carried payloads
+    u64 cur = 0;
+    uint32_t fill = CHUNK_PAY;  // "full": the first unit takes a chunk
+    uint32_t res = 0;
+    bool have_chunk = false;
+    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
+    u64 te = tb + tiles_per_block;
+    if (te > tile0 + ntiles) te = tile0 + ntiles;
+    int buf = 0;
+    uint32_t lost = 0;
+    __syncthreads();
+    // takes `nnew` consecutive chunk ids for this lane's partition; false if the pool is exhausted
+    auto take_chunks = [&](uint32_t nnew, u64 &first) -> bool {
+        first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
+        if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
+        if (first + nnew > pool_chunks) return false;  // cannot happen with the host's pool sizing; never write past it
+        for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
+        return true;
+    };
+    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
+    for (u64 t = tb; t < te; ++t, buf ^= 1) {
+        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
+        Roller roll;
+        roll.init(w, k, wlo);
+        uint32_t pay[CHUNK], tag[CHUNK];  // tag = (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            u64 key;
+            const bool ok = roll.next(j, key);
+            uint32_t p1 = 0;
+            pay[j] = 0;
+            if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
+                if (FAST) {
+                    hash_p1_pay32<MODE>(k, p1b, key, p1, pay[j]);
+                } else {
+                    const u64 H = part_hash<MODE>(g, key);
+                    pay[j] = Pay<uint32_t>::make(key, H, g);
+                    p1 = p1_of_hash(H, g);
+                }
+            }
+            tag[j] = ok ? (p1 << 16) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j)
+            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
+        __syncthreads();
+        // regions in whole units: exclusive scan of ceil((new + carried) / 4) over the 1024 partitions
+        const uint32_t c = s_cnt[tid];
+        const uint32_t tot = c + res;
+        const uint32_t szv = (tot + 3u) >> 2;
+        uint32_t incl = szv;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t nb = __shfl_up(incl, off, 64);
+            if ((tid & 63) >= off) incl += nb;
+        }
+        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t lofv = incl - szv;
+        for (int q = 0; q < (tid >> 6); ++q) lofv += s_wsum[q];
+        s_lofv[tid] = (uint16_t)lofv;
+        if (tid == PART_NT - 1) s_vtot = lofv + szv;
+        __syncthreads();
+        {  // branch-free staging: every lane reads its region starts back to back, then stores
+            uint32_t rs[CHUNK];
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j) rs[j] = 4u * (uint32_t)s_lofv[(tag[j] >> 16) & (MAX_P1 - 1)];
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j)
+                s_stage[tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)P1V_SCAP] = pay[j];
+        }
+        const uint32_t nvec = tot >> 2;  // whole units of this partition in this tile
+        {  // lane tid places partition tid's run
+#pragma unroll
+            for (uint32_t i = 0; i < 3; ++i)  // the carried payloads follow the new ones
+                if (i < res) s_stage[4u * lofv + c + i] = s_res[i][tid];
+            for (uint32_t i = 0; i < szv; ++i) s_vpid[lofv + i] = i < nvec ? (uint16_t)tid : (uint16_t)0xFFFFu;
+            const uint32_t space = CHUNK_PAY - fill;  // multiple of 4
+            const uint32_t n4 = 4u * nvec;
+            ChunkDst d;
+            d.a = cur * CHUNK_PAY + fill - 4u * lofv;
+            d.b = 0;
+            if (n4 > space) {
+                const uint32_t r = n4 - space;
+                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
+                u64 first;
+                if (!take_chunks(nnew, first)) {
+                    lost += r;
+                    d.b = CHUNK_DST_DROP;  // marks "drop" for the write-out
+                } else {
+                    d.b = first * CHUNK_PAY - space - 4u * lofv;
+                    cur = first + nnew - 1;
+                    fill = r - (nnew - 1) * CHUNK_PAY;
+                    have_chunk = true;
+                }
+            } else {
+                fill += n4;
+            }
+            s_dst[tid] = d;
+            s_meta[tid] = lofv | ((space >> 2) << 16);
+        }
+        __syncthreads();
+        s_cnt[tid] = 0;  // ordered before the next atomics by the next tile's stage_tile() barrier
+        res = tot & 3u;
+#pragma unroll
+        for (uint32_t i = 0; i < 3; ++i)  // what does not fill a unit waits for the next tile
+            if (i < res) s_res[i][tid] = s_stage[4u * (lofv + nvec) + i];
+        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next tile
+            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+            s_priv_end = s_priv_next + POOL_GRAB;
+        }
+        // next tile's bases are fetched while this tile's runs are written out
+        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+        const uint32_t vtot = s_vtot;
+#pragma unroll 2
+        for (uint32_t v = tid; v < vtot; v += PART_NT) {
+            const uint32_t p = s_vpid[v];
+            if (p == 0xFFFFu) continue;
+            const uint32_t meta = s_meta[p];
+            const ChunkDst d = s_dst[p];
+            const uint4 x = *reinterpret_cast<const uint4 *>(&s_stage[4u * v]);
+            const bool first_part = v - (meta & 0xFFFFu) < (meta >> 16);
+            if (first_part) *reinterpret_cast<uint4 *>(pool + (d.a + 4u * v)) = x;
+            else if (d.b != CHUNK_DST_DROP) *reinterpret_cast<uint4 *>(pool + (d.b + 4u * v)) = x;
+        }
+        // (s_stage / s_vpid / s_dst / s_meta / s_res are rewritten only after the next tile's barriers)
+    }
+    // the payloads still carried: one by one into the partition's chunk
+    if (res) {
+        bool room = true;
+        if (fill + res > CHUNK_PAY) {  // (fill is a multiple of 4, so this means fill == 256: a fresh chunk)
+            u64 first;
+            room = take_chunks(1u, first);
+            if (room) {
+                cur = first;
+                fill = 0;
+                have_chunk = true;
+            } else {
+                lost += res;
+            }
+        }
+        if (room) {
+            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = s_res[i][tid];
+            fill += res;
+        }
+    }
+    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
+    const u64 l = wave_sum((u64)lost);
+    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
+}
+
 // ---- chunk list: chunk ids ordered by partition ---------------------------------------------------
 // pcount[p] += chunks owned by partition p among ids [0, nchunks)
 __global__ __launch_bounds__(1024) void chunk_hist_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
@@ -698,6 +889,13 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
 #pragma unroll
         for (int j = 0; j < P2_PER; ++j)
             have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + PART2_TILE + (uint32_t)j * PART2_NT + tid, n, pay[j]) << j;
+#if KH_ABL2 & 4   /* timing experiment: the same scatter pattern and byte volume, but every write one whole aligned 128-byte line */
+        for (uint32_t i = tid; i < (uint32_t)PART2_TILE; i += PART2_NT) {
+            constexpr uint32_t LP = 128 / sizeof(PT);
+            const uint32_t b = (i / LP) & (uint32_t)(P2 - 1);
+            out[((s_dst[b] + s_lofs[b]) & ~(u64)(LP - 1)) + (i % LP)] = s_stage[i];
+        }
+#else
 #pragma unroll 2
         for (uint32_t i = tid; i < total; i += PART2_NT) {
             const PT v = s_stage[i];
@@ -709,6 +907,7 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
             out[s_dst[Pay<PT>::p2(v, g)] + i] = v;  // consecutive lanes -> consecutive addresses inside a run
 #endif
         }
+#endif
         __syncthreads();
     }
 }
