@@ -125,6 +125,7 @@ struct kh_ctx {
     u64 *bstart = nullptr;
     uint8_t *rfail = nullptr;
     uint32_t *rnew = nullptr;
+    uint32_t *rreal = nullptr;       // k-mers per bucket (its size minus the line-padding sentinels)
     uint32_t *rheads = nullptr;      // exchange heads per region, left by a FRESH region pass
     bool rheads_valid = false;       // ... and still describing the table (nothing else touched it since)
     bool rheads_wide = false;
@@ -479,10 +480,10 @@ void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot)
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
     else
         hipLaunchKernelGGL(kh::region_count_kernel64<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty);
+                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
 }
 template <>
 void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot) {
@@ -492,11 +493,11 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel32<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
                            (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty,
-                           c->rheads_cb, c->rheads, c->d_ctr);
+                           c->rheads_cb, c->rheads, c->d_ctr, c->rreal);
     else
         hipLaunchKernelGGL(kh::region_count_kernel32<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
                            (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, 0u, 0u,
-                           (uint32_t *)nullptr, c->d_ctr);
+                           (uint32_t *)nullptr, c->d_ctr, c->rreal);
 }
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
@@ -545,6 +546,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->rnew, &z, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
         z = c->rheads ? c->region_cap : 0;
         if ((rc = ensure_buf(c, &c->rheads, &z, nregions, "hipMalloc(rheads)")) != KH_OK) return rc;
+        z = c->rreal ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rreal, &z, nregions, "hipMalloc(rreal)")) != KH_OK) return rc;
         c->region_cap = nregions;
     }
     if (c->pool_cap < pool_chunks) {
@@ -556,8 +559,14 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->plist, &z, pool_chunks, "hipMalloc(plist)")) != KH_OK) return rc;
         c->pool_cap = pool_chunks;
     }
+    // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
+    // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
+    static const bool lines_on = [] { const char *e = getenv("KMERHIP_P2_LINES"); return !(e && e[0] == '0'); }();
+    const bool lines = lines_on && sizeof(PT) == 4 && g.p2_bits >= 1 && g.p2_bits <= 9;
+    const uint32_t force_wide = [] { const char *e = getenv("KMERHIP_P2_FORCE_WIDE"); return (e && e[0] == '1') ? 1u : 0u; }();
     const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
-    const u64 key_bytes = std::max(a_bytes, n_ub * (u64)sizeof(PT));
+    const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L_LINE - 1) : 0;  // sentinels at the segment ends
+    const u64 key_bytes = std::max(a_bytes, (n_ub + pad_ub) * (u64)sizeof(PT));
     if (c->key_cap < key_bytes) {  // key_cap is in BYTES per buffer
         u64 z = c->keysA ? c->key_cap : 0;
         if ((rc = ensure_buf(c, &c->keysA, &z, key_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
@@ -639,7 +648,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
                                (const u64 *)c->pool_next, pool_chunks, c->pcount);
             if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
             hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
-                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount);
+                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide);
             hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
                                (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
             HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
@@ -648,7 +657,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     {
         StageTimer t(c, ST_P2_COUNT);
         hipLaunchKernelGGL((kh::part2_count_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA, cs,
-                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2);
+                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2, lines ? (uint32_t)kh::P2L_LINE : 1u);
     }
     {
         StageTimer t(c, ST_MISC);
@@ -656,14 +665,19 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     }
     {
         StageTimer t(c, ST_P2_SCATTER);
+        const uint32_t fallback = lines ? 1u : 0u;  // behind the unit kernel the unaligned one runs only where that stood down
+        if (lines)  // whole aligned 64-byte units only (32-bit payloads, 2..512 buckets per partition)
+            hipLaunchKernelGGL((kh::part2_scatter_lines_kernel<CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::P2L_NT), 0, c->stream,
+                               (const uint32_t *)c->keysA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2,
+                               (uint32_t *)c->keysB);
         if (g.p2_bits <= 9)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
             hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 512>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB, fallback);
         else
             hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 1024>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB, fallback);
     }
-#if KH_ABL2
+#if KH_ABL2 || KH_ABL3
     if (getenv("KMERHIP_STOP_AFTER_P2")) {  // ablation builds only: time level 2 alone (its output is garbage)
         HIP_TRY(c, hipGetLastError());
         return sync_counters(c);
@@ -684,7 +698,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     {
         StageTimer t(c, ST_MISC);
         hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
-                           (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (u64)nregions, c->d_ctr);
+                           (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const uint32_t *)c->rreal, (u64)nregions, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
@@ -1078,7 +1092,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->rfail, c->rnew, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->bstart, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)

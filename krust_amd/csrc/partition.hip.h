@@ -28,6 +28,9 @@
 #pragma once
 #include "kernels.hip.h"
 
+#ifndef KH_ABL3
+#define KH_ABL3 0  // the same for part2_scatter_lines_kernel
+#endif
 #ifndef KH_ABL2
 #define KH_ABL2 0  // the same for part2_scatter_kernel
 #endif
@@ -646,7 +649,8 @@ __global__ __launch_bounds__(1024) void chunk_list_kernel(const uint16_t *__rest
 __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__restrict__ pstart, PartGeom g,
                                                                   Part2Block *__restrict__ blocks, u64 max_blocks,
                                                                   u64 *__restrict__ moff, uint32_t *__restrict__ nch,
-                                                                  u64 *__restrict__ info, uint32_t *__restrict__ cursors) {
+                                                                  u64 *__restrict__ info, uint32_t *__restrict__ cursors,
+                                                                  uint32_t force_wide) {
     __shared__ u64 s_bbase[MAX_P1 + 1];
     const int tid = threadIdx.x;
     const int P1 = 1 << g.p1_bits;
@@ -661,6 +665,16 @@ __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__r
         info[0] = b;
         info[1] = b << g.p2_bits;
         info[2] = 0;
+        // info[3]: some partition's level-2 output (payloads + unit padding) does not fit 32-bit offsets -- only
+        // when > 4 G k-mers of one batch share a level-1 digit.  The unit-writing level-2 kernel then stands
+        // down for the whole batch and the unaligned one runs (both are launched, each checks this word).
+        u64 wide = force_wide;  // (KMERHIP_P2_FORCE_WIDE=1: tests exercise the stand-down without 4 G k-mers)
+        for (int p = 0; p < P1; ++p) {
+            const u64 nchunks = pstart[p + 1] - pstart[p];
+            const u64 nblocks = (nchunks + CPB - 1) / CPB;
+            if (nchunks * CHUNK_PAY + nblocks * 1024ull * 64ull >= (1ull << 32)) wide = 1;
+        }
+        info[3] = wide;
     }
     __syncthreads();
     if (tid < P1) {
@@ -770,11 +784,13 @@ __global__ __launch_bounds__(SCAN_NT) void scan_apply_kernel(const uint32_t *__r
 // ---------------------------------------------------------------------------------------------
 // level 2, pass A: histogram of bucket ids (p2) per workgroup.  H2 must be zero-filled.
 // ---------------------------------------------------------------------------------------------
+// pad: every (bucket, workgroup) count is rounded up to a multiple of `pad` payloads (1 = exact), so that the
+// exclusive scan puts every segment of the level-2 output on a line boundary (part2_scatter_lines_kernel).
 template <typename PT, bool CHUNKED>
 __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restrict__ pays, ChunkSrc cs,
                                                               const Part2Block *__restrict__ blocks,
                                                               const u64 *__restrict__ info, PartGeom g,
-                                                              uint32_t *__restrict__ H2) {
+                                                              uint32_t *__restrict__ H2, uint32_t pad) {
     __shared__ uint32_t s_hist[1u << MAX_P2_BITS];
     __shared__ uint32_t s_chk[CHUNKED ? CPB : 1];
     __shared__ uint16_t s_cfill[CHUNKED ? CPB : 1];
@@ -797,7 +813,8 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restri
             if (ok & (1u << j)) atomicAdd(&s_hist[Pay<PT>::p2(v[j], g)], 1u);
     }
     __syncthreads();
-    if (tid < (1 << g.p2_bits)) H2[pb.mbase + (u64)tid * pb.mstride] = s_hist[tid];
+    if (pad > 1 && info[3]) pad = 1;  // (the unit-writing kernel stands down for this batch: no padding)
+    if (tid < (1 << g.p2_bits)) H2[pb.mbase + (u64)tid * pb.mstride] = (s_hist[tid] + pad - 1) / pad * pad;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -825,7 +842,7 @@ constexpr int P2_PER = PART2_TILE / PART2_NT;   // payloads per lane per batch
 template <typename PT, bool CHUNKED, int NBK>
 __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) void part2_scatter_kernel(
     const PT *__restrict__ pays, ChunkSrc cs, const Part2Block *__restrict__ blocks, const u64 *__restrict__ info, PartGeom g,
-    const u64 *__restrict__ O2, PT *__restrict__ out) {
+    const u64 *__restrict__ O2, PT *__restrict__ out, uint32_t only_if_wide) {
     constexpr int OWN = NBK / PART2_NT;         // buckets whose output cursor a lane keeps in registers
     __shared__ PT s_stage[PART2_TILE + 1];      // 64 KiB (u32) / 128 KiB (u64), + a trash slot
     __shared__ uint32_t s_cnt[NBK];
@@ -835,6 +852,7 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
     __shared__ uint32_t s_chk[CHUNKED ? CPB : 1];
     __shared__ uint16_t s_cfill[CHUNKED ? CPB : 1];
     if ((u64)blockIdx.x >= info[0]) return;
+    if (only_if_wide && !info[3]) return;  // launched behind part2_scatter_lines_kernel: runs only where that one stood down
     const Part2Block pb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
     const int P2 = 1 << g.p2_bits;
@@ -889,9 +907,9 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
 #pragma unroll
         for (int j = 0; j < P2_PER; ++j)
             have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + PART2_TILE + (uint32_t)j * PART2_NT + tid, n, pay[j]) << j;
-#if KH_ABL2 & 4   /* timing experiment: the same scatter pattern and byte volume, but every write one whole aligned 128-byte line */
+#if KH_ABL2 & 28  /* timing experiment: the same scatter pattern and byte volume, but every write one whole aligned 128 / 64 / 32-byte unit */
         for (uint32_t i = tid; i < (uint32_t)PART2_TILE; i += PART2_NT) {
-            constexpr uint32_t LP = 128 / sizeof(PT);
+            constexpr uint32_t LP = ((KH_ABL2 & 4) ? 128 : (KH_ABL2 & 8) ? 64 : 32) / sizeof(PT);
             const uint32_t b = (i / LP) & (uint32_t)(P2 - 1);
             out[((s_dst[b] + s_lofs[b]) & ~(u64)(LP - 1)) + (i % LP)] = s_stage[i];
         }
@@ -909,6 +927,167 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
         }
 #endif
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 2, pass B writing whole aligned 64-byte units only (32-bit payloads, <= 512 buckets per partition)
+// ---------------------------------------------------------------------------------------------
+// Timing experiments on the kernel above (KH_ABL2, S100M: 36.4 ms): loads + LDS sort 18.2 ms; the same bytes
+// stored densely +2.7; stored to the same scattered places but as whole aligned 128-byte lines +3.8, as whole
+// aligned 64-byte units +5.2, 32-byte units +12; stored as today -- one 128-byte run per bucket and batch,
+// starting wherever the previous run ended, i.e. partly written sectors at both ends -- +18.  The memory
+// system has to merge or read-modify-write every partly written sector; whole ones it just takes.  So here
+// nothing but whole aligned 64-byte units (UNIT = 16 payloads) ever leaves the workgroup:
+//   * every (bucket, workgroup) segment of the output starts on a unit boundary: the count pass pads the
+//     counts to multiples of UNIT, and the pad is filled with SENTINELS at the end of the segment (payloads
+//     whose level-2 digit is not the bucket's: the region pass skips them);
+//   * per bucket the <= UNIT - 1 payloads that do not fill a unit stay in LDS until the bucket's next payloads
+//     complete it.  They never get copied: the counting sort knows, before it stores anything, how many of a
+//     bucket's new payloads complete units (those go to the sorted stage) and which are the new tail (those go
+//     straight to the bucket's slot of the residue array of the NEXT batch -- two residue arrays, by parity);
+//   * the units that became complete are enumerated (s_unit: output offset, where in the stage the unit
+//     starts, how many of its first payloads come from the carried residue) and written by 16 lanes each.
+// 1024 lanes x 16 payloads per batch: with the stores cheap the kernel is bound by its own instruction stream
+// (one workgroup per CU: 152 KB of LDS), and sixteen waves hide the LDS round trips better than eight.
+constexpr int P2L_NBK = 512;   // buckets per partition this kernel handles
+constexpr int P2L_LINE = 16;   // payloads per unit (64 bytes)
+constexpr int P2L_NT = 1024;   // lanes per workgroup
+constexpr int P2L_PER = PART2_TILE / P2L_NT;
+
+// sentinel of bucket `digit`: a payload carrying ANOTHER level-2 digit (needs p2_bits >= 1)
+__device__ __forceinline__ uint32_t p2_sentinel(uint32_t digit, uint32_t p2_bits) { return (digit ^ 1u) << (32 - p2_bits); }
+
+template <bool CHUNKED>
+__global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint32_t *__restrict__ pays, ChunkSrc cs,
+                                                                     const Part2Block *__restrict__ blocks,
+                                                                     const u64 *__restrict__ info, PartGeom g,
+                                                                     const u64 *__restrict__ O2, uint32_t *__restrict__ out) {
+    typedef uint32_t PT;
+    constexpr int NBK = P2L_NBK, UNIT = P2L_LINE, NT = P2L_NT, PER = P2L_PER;
+    constexpr int MAXU = PART2_TILE / UNIT + NBK;       // units one batch can complete
+    constexpr uint32_t RES0 = PART2_TILE + 1;           // s_buf: [sorted stage | trash | residues (even) | residues (odd)]
+    constexpr uint32_t RES_SZ = NBK * UNIT;
+    __shared__ PT s_buf[PART2_TILE + 1 + 2 * NBK * UNIT];
+    __shared__ uint32_t s_cnt[NBK];
+    __shared__ uint2 s_ofs[NBK];        // x: stage start of the bucket's run | payloads that go to the stage << 16
+                                        // y: s_buf index of the new tail's payload of rank 0 (biased by those payloads)
+    __shared__ uint2 s_unit[MAXU];      // x: output offset of the unit (payloads, from the block's base position)
+                                        // y: (stage index of unit position 0) + UNIT | carried payloads at its front << 16 | bucket << 20
+    __shared__ uint32_t s_wsum[NBK / 64];
+    __shared__ uint32_t s_nu;
+    __shared__ uint32_t s_chk[CHUNKED ? CPB : 1];
+    __shared__ uint16_t s_cfill[CHUNKED ? CPB : 1];
+    if ((u64)blockIdx.x >= info[0] || info[3]) return;  // info[3]: a partition too large for 32-bit offsets (see the plan kernel)
+    const Part2Block pb = blocks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int P2 = 1 << g.p2_bits;
+    p2_stage_chunks<CHUNKED>(cs, pb, s_chk, s_cfill, tid, NT);
+    // lane b < 512 owns bucket b: its output cursor (always on a unit boundary, relative to the block's base
+    // position = bucket 0's segment: the segments of the higher buckets lie above it) and its carried count
+    const u64 gbase = O2[pb.mbase];
+    uint32_t gdone = (tid < P2) ? (uint32_t)(O2[pb.mbase + (u64)tid * pb.mstride] - gbase) : 0u;
+    uint32_t res = 0;
+    uint32_t par = 0;  // residues of this batch are read from array `par`, new tails go to array `par ^ 1`
+    if (tid < NBK) s_cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t n = p2_count_of<CHUNKED>(pb);
+    PT pay[PER];
+    uint32_t have = 0;  // bit j: pay[j] holds a payload
+#pragma unroll
+    for (int j = 0; j < PER; ++j)  // lane-contiguous: coalesced loads
+        have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, (uint32_t)j * NT + tid, n, pay[j]) << j;
+    for (uint32_t base = 0; base < n; base += PART2_TILE, par ^= 1u) {
+        const uint32_t res_old = RES0 + par * RES_SZ, res_new = RES0 + (par ^ 1u) * RES_SZ;
+        uint32_t tag[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) tag[j] = (have & (1u << j)) ? (Pay<PT>::p2(pay[j], g) << 16) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)  // all LDS rank atomics in flight before the first is consumed
+            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
+        __syncthreads();
+        // owner lanes: how the bucket's new payloads split into completed units and the new tail
+        uint32_t c = 0, nu = 0, thr = 0, packed = 0, incl = 0;
+        if (tid < NBK) {
+            c = s_cnt[tid];
+            nu = (res + c) / UNIT;                  // units completing in this batch
+            thr = nu ? nu * UNIT - res : 0u;        // new payloads that go to the stage (<= c)
+            packed = thr | (nu << 16);              // one scan for both: sums <= 16384 payloads, <= 1536 units
+            incl = packed;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t nb = __shfl_up(incl, off, 64);
+                if ((tid & 63) >= off) incl += nb;
+            }
+            if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+        }
+        __syncthreads();
+        if (tid < NBK) {
+            uint32_t excl = incl - packed;
+            for (int q = 0; q < (tid >> 6); ++q) excl += s_wsum[q];
+            const uint32_t lofs = excl & 0xFFFFu, uofs = excl >> 16;
+            const uint32_t dst0 = nu ? 0u : res;    // where the new tail starts in the bucket's residue slot
+            s_ofs[tid] = make_uint2(lofs | (thr << 16), res_new + (uint32_t)tid * UNIT + dst0 - thr);
+            for (uint32_t l = 0; l < nu; ++l)
+                s_unit[uofs + l] = make_uint2(gdone + l * UNIT,
+                                              (lofs + l * UNIT - res + UNIT) | ((l == 0 ? res : 0u) << 16) | ((uint32_t)tid << 20));
+            if (!nu && res)  // no unit completes: the carried payloads move on to the next batch's array
+                for (uint32_t i = 0; i < res; ++i) s_buf[res_new + tid * UNIT + i] = s_buf[res_old + tid * UNIT + i];
+            if (tid == NBK - 1) s_nu = uofs + nu;
+            gdone += nu * UNIT;
+            res = (res + c) % UNIT;
+        }
+        __syncthreads();
+        {  // branch-free staging: all offsets first, then the stores (stage for unit payloads, residue array for tails)
+            uint2 o[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) o[j] = s_ofs[(tag[j] >> 16) & (NBK - 1)];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t rank = tag[j] & 0xFFFFu;
+                uint32_t addr = rank < (o[j].x >> 16) ? (o[j].x & 0xFFFFu) + rank : o[j].y + rank;
+                if (tag[j] == 0xFFFFFFFFu) addr = (uint32_t)PART2_TILE;  // trash slot
+                s_buf[addr] = pay[j];
+            }
+        }
+        __syncthreads();
+        if (tid < NBK) s_cnt[tid] = 0;
+        // next batch's payloads are fetched while this batch's units are written out
+        have = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + PART2_TILE + (uint32_t)j * NT + tid, n, pay[j]) << j;
+        // the completed units: 16 lanes per unit, carried payloads first, then the sorted run
+#if KH_ABL3 & 2  /* timing experiment: no write-out */
+        const uint32_t nslots = 0;
+#else
+        const uint32_t nslots = s_nu * UNIT;
+#endif
+        uint32_t *__restrict__ obase = out + gbase;
+#pragma unroll 4
+        for (uint32_t x = tid; x < nslots; x += NT) {
+            const uint2 u = s_unit[x / UNIT];
+            const uint32_t i = x % UNIT;
+            const uint32_t nres = (u.y >> 16) & 0xFu, b = u.y >> 20;
+            const uint32_t idx = i < nres ? res_old + b * UNIT + i : (u.y & 0xFFFFu) - UNIT + i;
+#if KH_ABL3 & 1  /* timing experiment: LDS side of the write-out only */
+            if (s_buf[idx] == 0x12345678u && u.x == 77u) out[0] = 1;
+#else
+            obase[u.x + i] = s_buf[idx];
+#endif
+        }
+        // (the next batch's barriers order everything: its owner lanes rewrite s_ofs / s_unit after two of them,
+        //  its tails go to the array this batch has just finished reading)
+    }
+    // the last, incomplete unit of every bucket: padded with sentinels (the count pass reserved the room)
+    __syncthreads();
+    if (tid < NBK) s_ofs[tid] = make_uint2(res, gdone);
+    __syncthreads();
+    const uint32_t res_fin = RES0 + par * RES_SZ;
+    for (uint32_t x = tid; x < (uint32_t)NBK * UNIT; x += NT) {
+        const uint32_t b = x / UNIT, i = x % UNIT;
+        const uint2 m = s_ofs[b];
+        if (m.x && b < (uint32_t)P2) out[gbase + m.y + i] = i < m.x ? s_buf[res_fin + b * UNIT + i] : p2_sentinel(b, g.p2_bits);
     }
 }
 
@@ -951,7 +1130,8 @@ __device__ __forceinline__ void write_empty_region(Slot *reg, int tid) {
 template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
-                                                                   uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty) {
+                                                                   uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
+                                                                   uint32_t *__restrict__ rreal) {
     __shared__ u64 s_key[REGION_SLOTS];
     __shared__ u64 s_cnt[REGION_SLOTS];
     __shared__ uint32_t s_fail;
@@ -962,7 +1142,10 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     Slot *reg = tg.table + r * REGION_SLOTS;
     if (lo == hi) {  // nothing new for this region
         if (FRESH && dirty) write_empty_region(reg, tid);
-        if (tid == 0) rnew[r] = 0;
+        if (tid == 0) {
+            rnew[r] = 0;
+            rreal[r] = 0;
+        }
         return;
     }
     // branch-free loads: bucket-relative index clamped to the last valid key, validity folded into the
@@ -1059,7 +1242,10 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
         const u64 kk = s_key[i], cc = s_cnt[i];
         o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
     }
-    if (tid == 0) rnew[r] = s_new;
+    if (tid == 0) {
+        rnew[r] = s_new;
+        rreal[r] = (uint32_t)(n < 0xFFFFFFFFull ? n : 0xFFFFFFFFull);  // 64-bit payloads carry no sentinels: every payload is a k-mer
+    }
 }
 
 constexpr int R32_SLOTS_PER_LANE = REGION_SLOTS / REGION_NT;
@@ -1189,7 +1375,10 @@ template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
-                                                                   uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr) {
+                                                                   uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr,
+                                                                   uint32_t *__restrict__ rreal) {
+    // rreal[r] = payloads of the bucket that are k-mers (the bucket may hold SENTINELS, payloads with another
+    // level-2 digit that pad its segments to whole lines: part2_scatter_lines_kernel; they are skipped here)
     // head_cb != 0 (FRESH only): also leave in rheads[r] the number of 32-bit exchange heads the region
     // will need (shard.hip.h heads_of), so that a multi-GPU export right after this pass can skip its
     // counting pass over the table.
@@ -1197,7 +1386,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     __shared__ uint32_t s_add[REGION_SLOTS];
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
-    __shared__ uint32_t s_special, s_sp_off, s_sp_new, s_heads;
+    __shared__ uint32_t s_special, s_sp_off, s_sp_new, s_heads, s_real;
     __shared__ uint32_t s_q[REGION_RK][REGION_NT];  // per-lane payload queues (32 KiB)
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
@@ -1206,6 +1395,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         if (FRESH && dirty) write_empty_region(tg.table + r * REGION_SLOTS, tid);
         if (tid == 0) {
             rnew[r] = 0;
+            rreal[r] = 0;
             if (head_cb) rheads[r] = 0;
         }
         return;
@@ -1229,6 +1419,10 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     // can a payload of this region equal the free marker 0xFFFFFFFF?  Only if its level-2 digit is all ones.
     const uint32_t p2mask = (1u << g.p2_bits) - 1u;
     const bool may_special = g.p2_bits == 0 || ((uint32_t)r & p2mask) == p2mask;
+    const uint32_t dshift = g.p2_bits ? 32 - g.p2_bits : 0;   // a real payload has the region's own digit on top
+    const uint32_t digit = g.p2_bits ? ((uint32_t)r & p2mask) : 0u;
+    const uint32_t dmask = g.p2_bits ? 0xFFFFFFFFu : 0u;      // (no level-2 digit: nothing to check, no sentinels exist)
+    uint32_t nreal = 0;
     uint32_t kbuf[REGION_RK];
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {  // branch-free: clamped index
@@ -1272,6 +1466,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         s_new = 0;
         s_special = 0;
         s_heads = 0;
+        s_real = 0;
     }
     __syncthreads();
     if (unrepresentable) s_fail = 1;
@@ -1298,11 +1493,14 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         if (hot || may_special || !FRESH) {
             // (the pass over a filled table keeps the old slots in registers; the straight-line first probe below
             // would push it over the 64 registers that two workgroups per CU allow)
+            uint32_t rq = 0;  // real payloads, compacted into the lane's queue (sentinels dropped)
 #pragma unroll
-            for (int j = 0; j < REGION_RK; ++j) s_q[j][tid] = pj[j];
-            if (hot) region32_probe_round<true>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
-            else if (may_special) region32_probe_round<false>(nk, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
-            else region32_probe_lean(nk, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
+            for (int j = 0; j < REGION_RK; ++j)
+                if ((uint32_t)j < nk && (((pj[j] >> dshift) ^ digit) & dmask) == 0) s_q[rq++][tid] = pj[j];
+            nreal += rq;
+            if (hot) region32_probe_round<true>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
+            else if (may_special) region32_probe_round<false>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
+            else region32_probe_lean(rq, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
         } else {
             // First probe of all eight payloads as straight-line code: the eight slot reads are in flight
             // together and a payload that finds its key right there (most of them: a key comes ~12 times, and at
@@ -1321,7 +1519,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
                 for (int j = 0; j < FP; ++j) cj[j] = s_pay[oj[j]];
 #pragma unroll
                 for (int j = 0; j < FP; ++j) {
-                    const bool valid = (uint32_t)(h + j) < nk;
+                    const bool valid = (uint32_t)(h + j) < nk && (((pj[h + j] >> dshift) ^ digit) & dmask) == 0;
+                    nreal += valid;
                     const bool hit = valid && cj[j] == pj[h + j];
                     if (hit) atomicAdd(&s_add[oj[j]], 1u);  // no-return ds_add_u32
                     if (valid && !hit) s_q[r++][tid] = pj[h + j];
@@ -1332,6 +1531,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
+    const uint32_t rw = (uint32_t)wave_sum((u64)nreal);
+    if ((tid & 63) == 0 && rw) atomicAdd(&s_real, rw);
     __syncthreads();
     if (s_special && tid == 0 && !s_fail) {
         // The payload equal to the free marker was only counted.  One lane places it now by plain
@@ -1388,7 +1589,10 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             too_wide |= cc > (64ull << head_cb);
         }
     }
-    if (tid == 0) rnew[r] = s_new;
+    if (tid == 0) {
+        rnew[r] = s_new;
+        rreal[r] = s_real;
+    }
     if (FRESH && head_cb) {
         const uint32_t hw = (uint32_t)wave_sum((u64)nheads);
         if ((tid & 63) == 0 && hw) atomicAdd(&s_heads, hw);
@@ -1400,7 +1604,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
 
 // Folds the per-region results of one region_count pass into the context counters.
 __global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restrict__ bstart, const uint8_t *__restrict__ rfail,
-                                                              const uint32_t *__restrict__ rnew, u64 nregions, Counters *ctr) {
+                                                              const uint32_t *__restrict__ rnew, const uint32_t *__restrict__ rreal,
+                                                              u64 nregions, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     u64 d = 0, km = 0, nf = 0;
     for (u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x; r < nregions; r += stride) {
@@ -1408,7 +1613,10 @@ __global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restr
             ++nf;
         } else {
             d += rnew[r];
-            km += bstart[r + 1] - bstart[r];
+            // k-mers of the bucket: its size, minus the sentinels the 32-bit region pass skipped (a bucket of
+            // >= 2^32 payloads fails the 32-bit pass, and the 64-bit one holds no sentinels)
+            const u64 sz = bstart[r + 1] - bstart[r];
+            km += sz >= 0xFFFFFFFFull ? sz : (u64)rreal[r];
         }
     }
     d = wave_sum(d);
@@ -1433,13 +1641,20 @@ __global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(TableGeom 
     const u64 lo = bstart[r], hi = bstart[r + 1];
     const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
     uint32_t nd = 0, nf = 0;
-    for (u64 i = lo + threadIdx.x; i < hi; i += BLOCK) upsert(tg, Pay<PT>::key(pays[i], p1, g), 1ull, nd, nf);
-    const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    u64 real = 0;
+    for (u64 i = lo + threadIdx.x; i < hi; i += BLOCK) {
+        const PT v = pays[i];
+        // 32-bit payloads: a payload with another level-2 digit is a sentinel (line padding), not a k-mer
+        if (sizeof(PT) == 4 && g.p2_bits && (uint32_t)((u64)v >> (32 - g.p2_bits)) != ((uint32_t)r & ((1u << g.p2_bits) - 1u))) continue;
+        ++real;
+        upsert(tg, Pay<PT>::key(v, p1, g), 1ull, nd, nf);
+    }
+    const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf), km = wave_sum(real);
     if (lane_id() == 0) {  // rare path (only regions that overflowed): plain counter atomics are fine
         if (d) atomicAdd(&ctr->distinct, d);
         if (f) atomicAdd(&ctr->failed, f);
+        if (km) atomicAdd(&ctr->kmers, km);
     }
-    if (threadIdx.x == 0) atomicAdd(&ctr->kmers, hi - lo);
 }
 
 }  // namespace kh

@@ -991,3 +991,34 @@ def test_full_map_digest_10M_reads(K, k, minq):
     with np.errstate(over="ignore"):
         got = int(_np_mix64(keys ^ _np_mix64(cnts)).sum(dtype=np.uint64))
     assert got == digest
+
+
+@pytest.mark.parametrize("mode", ["units", "stand-down", "unaligned"])
+@pytest.mark.parametrize("k,hint", [(21, 3_000_000), (21, 40_000_000), (19, 8_000_000), (15, 2_000_000), (21, 0)],
+                         ids=["k21-2buckets", "k21-64buckets", "k19", "k15", "k21-unhinted"])
+def test_level2_unit_writer_and_its_stand_down(K, monkeypatch, mode, k, hint):
+    """Level 2 with 32-bit payloads writes whole aligned 64-byte units (segments padded with sentinels that the
+    region pass skips, tails carried in LDS); a partition too large for its 32-bit offsets makes it stand down for
+    the batch in favour of the unaligned kernel (forced here by KMERHIP_P2_FORCE_WIDE: the real condition needs
+    > 4 G k-mers with one level-1 digit); KMERHIP_P2_LINES=0 is the unaligned kernel alone.  All three must give
+    the oracle's map, over several batches into one table (non-fresh region passes see the sentinels too)."""
+    if mode == "stand-down":
+        monkeypatch.setenv("KMERHIP_P2_FORCE_WIDE", "1")
+    elif mode == "unaligned":
+        monkeypatch.setenv("KMERHIP_P2_LINES", "0")
+    n_reads = 70_000
+    bases, _ = O.synth_reads(SEED, 1 << 19, 150, 0, n_reads, with_qual=False)
+    m = O.OracleMap()
+    m.scan_flat(bases, k, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    import torch
+    tb = torch.from_numpy(bases).cuda()
+    torch.cuda.synchronize()
+    with K.DeviceCounter(k, capacity_hint=hint, path="partition") as dc:
+        cut = [0, 20_000 * 151, 20_001 * 151, 45_000 * 151, n_reads * 151]  # batches of very different sizes
+        for a, b in zip(cut, cut[1:]):
+            dc.push_device(tb.data_ptr() + a, None, b - a)  # (every push_device is a batch of its own)
+        st = dc.finish()
+        assert st["kmers"] == m.total() and st["part_batches"] >= 3
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
