@@ -994,9 +994,29 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint3
     const uint32_t n = p2_count_of<CHUNKED>(pb);
     PT pay[PER];
     uint32_t have = 0;  // bit j: pay[j] holds a payload
+    // Element e = first + j * NT + tid of the block's input lies in chunk (e >> 8) of its chunk list, and a wave's
+    // 64 lanes always share that chunk (NT and the wave's first lane are multiples of 64, chunks hold 256): chunk
+    // id and fill level are wave-uniform -- read once, kept in scalar registers, the address is base + lane offset.
+    const uint32_t nchk = CHUNKED ? (uint32_t)(pb.hi - pb.lo) : 0u;
+    const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
+    auto load_batch = [&](uint32_t first) {
+        have = 0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j)  // lane-contiguous: coalesced loads
-        have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, (uint32_t)j * NT + tid, n, pay[j]) << j;
+        for (int j = 0; j < PER; ++j) {
+            if (CHUNKED) {
+                const uint32_t ci = __builtin_amdgcn_readfirstlane((first >> 8) + (uint32_t)j * (NT / CHUNK_PAY) + ((uint32_t)tid >> 8));
+                const uint32_t cc = ci < nchk ? ci : nchk - 1;  // (clamped: the load below is unconditional)
+                const uint32_t chunk = __builtin_amdgcn_readfirstlane(s_chk[cc]);
+                const uint32_t fillc = __builtin_amdgcn_readfirstlane((uint32_t)s_cfill[cc]);
+                const bool ok = ci < nchk && woff < fillc;
+                pay[j] = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (ok ? woff : 0u)];
+                have |= (uint32_t)ok << j;
+            } else {
+                have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, first + (uint32_t)j * NT + tid, n, pay[j]) << j;
+            }
+        }
+    };
+    load_batch(0);
     for (uint32_t base = 0; base < n; base += PART2_TILE, par ^= 1u) {
         const uint32_t res_old = RES0 + par * RES_SZ, res_new = RES0 + (par ^ 1u) * RES_SZ;
         uint32_t tag[PER];
@@ -1053,10 +1073,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint3
         __syncthreads();
         if (tid < NBK) s_cnt[tid] = 0;
         // next batch's payloads are fetched while this batch's units are written out
-        have = 0;
-#pragma unroll
-        for (int j = 0; j < PER; ++j)
-            have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + PART2_TILE + (uint32_t)j * NT + tid, n, pay[j]) << j;
+        load_batch(base + PART2_TILE);
         // the completed units: 16 lanes per unit, carried payloads first, then the sorted run
 #if KH_ABL3 & 2  /* timing experiment: no write-out */
         const uint32_t nslots = 0;
@@ -1383,11 +1400,11 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     // will need (shard.hip.h heads_of), so that a multi-GPU export right after this pass can skip its
     // counting pass over the table.
     __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
-    __shared__ uint32_t s_add[REGION_SLOTS];
+    __shared__ uint32_t s_add[REGION_SLOTS + (FRESH ? REGION_NT : 0)];  // (+ one dummy word per lane for predicated adds)
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
     __shared__ uint32_t s_special, s_sp_off, s_sp_new, s_heads, s_real;
-    __shared__ uint32_t s_q[REGION_RK][REGION_NT];  // per-lane payload queues (32 KiB)
+    __shared__ uint32_t s_q[REGION_RK + (FRESH ? 1 : 0)][REGION_NT];  // per-lane payload queues (32 KiB; + a dummy row for predicated stores)
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bstart[r + 1];
@@ -1519,11 +1536,15 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
                 for (int j = 0; j < FP; ++j) cj[j] = s_pay[oj[j]];
 #pragma unroll
                 for (int j = 0; j < FP; ++j) {
+                    // (predicated, not branched: the exec-mask bookkeeping of sixteen small branches per round cost
+                    //  as many scalar instructions as the kernel has vector ones)
                     const bool valid = (uint32_t)(h + j) < nk && (((pj[h + j] >> dshift) ^ digit) & dmask) == 0;
                     nreal += valid;
                     const bool hit = valid && cj[j] == pj[h + j];
-                    if (hit) atomicAdd(&s_add[oj[j]], 1u);  // no-return ds_add_u32
-                    if (valid && !hit) s_q[r++][tid] = pj[h + j];
+                    atomicAdd(&s_add[hit ? oj[j] : REGION_SLOTS + (uint32_t)tid], 1u);  // no-return ds_add_u32; misses add to a private dummy word
+                    const bool queue = valid && !hit;
+                    s_q[queue ? r : (uint32_t)REGION_RK][tid] = pj[h + j];             // (row REGION_RK is a dummy row)
+                    r += queue;
                 }
             }
             region32_probe_lean(r, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
