@@ -1400,11 +1400,11 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     // will need (shard.hip.h heads_of), so that a multi-GPU export right after this pass can skip its
     // counting pass over the table.
     __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
-    __shared__ uint32_t s_add[REGION_SLOTS + (FRESH ? REGION_NT : 0)];  // (+ one dummy word per lane for predicated adds)
+    __shared__ uint32_t s_add[REGION_SLOTS + REGION_NT];  // (+ one dummy word per lane for predicated adds)
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
     __shared__ uint32_t s_special, s_sp_off, s_sp_new, s_heads, s_real;
-    __shared__ uint32_t s_q[REGION_RK + (FRESH ? 1 : 0)][REGION_NT];  // per-lane payload queues (32 KiB; + a dummy row for predicated stores)
+    __shared__ uint32_t s_q[REGION_RK + 1][REGION_NT];  // per-lane payload queues (32 KiB; + a dummy row for predicated stores)
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bstart[r + 1];
