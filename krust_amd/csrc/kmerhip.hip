@@ -125,7 +125,7 @@ struct kh_ctx {
     u64 *bstart = nullptr;
     uint8_t *rfail = nullptr;
     uint32_t *rnew = nullptr;
-    uint32_t *rreal = nullptr;       // k-mers per bucket (its size minus the line-padding sentinels)
+    u64 *rreal = nullptr;            // k-mers per bucket (its size minus the unit-padding sentinels)
     uint32_t *rheads = nullptr;      // exchange heads per region, left by a FRESH region pass
     bool rheads_valid = false;       // ... and still describing the table (nothing else touched it since)
     bool rheads_wide = false;
@@ -428,6 +428,12 @@ GeomChoice make_geom(const kh_ctx *c, u64 cap) {
         p1 = (uint32_t)need;
         p2 = rbits - p1;
     }
+    // 64-bit payloads are free in the split: with >= 2^11 regions give level 1 its full 1024 partitions, so that level 2
+    // has <= 512 buckets per partition up to 2^19 regions (the unit-writing level-2 kernel handles 512)
+    if (!((hbits - (int)p1) <= 32 && c->pay_mode != 64) && rbits > kh::MAX_P1_BITS) {
+        p1 = kh::MAX_P1_BITS;
+        p2 = rbits - p1;
+    }
     gc.g.rbits = rbits;
     gc.g.p1_bits = p1;
     gc.g.p2_bits = p2;
@@ -562,10 +568,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
     // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
     static const bool lines_on = [] { const char *e = getenv("KMERHIP_P2_LINES"); return !(e && e[0] == '0'); }();
-    const bool lines = lines_on && sizeof(PT) == 4 && g.p2_bits >= 1 && g.p2_bits <= 9;
+    const bool lines = lines_on && g.p2_bits >= 1 && g.p2_bits <= 9;
     const uint32_t force_wide = [] { const char *e = getenv("KMERHIP_P2_FORCE_WIDE"); return (e && e[0] == '1') ? 1u : 0u; }();
     const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
-    const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L_LINE - 1) : 0;  // sentinels at the segment ends
+    const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
     const u64 key_bytes = std::max(a_bytes, (n_ub + pad_ub) * (u64)sizeof(PT));
     if (c->key_cap < key_bytes) {  // key_cap is in BYTES per buffer
         u64 z = c->keysA ? c->key_cap : 0;
@@ -657,7 +663,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     {
         StageTimer t(c, ST_P2_COUNT);
         hipLaunchKernelGGL((kh::part2_count_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA, cs,
-                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2, lines ? (uint32_t)kh::P2L_LINE : 1u);
+                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2, lines ? (uint32_t)kh::P2L<PT>::UNIT : 1u);
     }
     {
         StageTimer t(c, ST_MISC);
@@ -667,9 +673,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         StageTimer t(c, ST_P2_SCATTER);
         const uint32_t fallback = lines ? 1u : 0u;  // behind the unit kernel the unaligned one runs only where that stood down
         if (lines)  // whole aligned 64-byte units only (32-bit payloads, 2..512 buckets per partition)
-            hipLaunchKernelGGL((kh::part2_scatter_lines_kernel<CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::P2L_NT), 0, c->stream,
-                               (const uint32_t *)c->keysA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2,
-                               (uint32_t *)c->keysB);
+            hipLaunchKernelGGL((kh::part2_scatter_lines_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::P2L_NT), 0, c->stream,
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
         if (g.p2_bits <= 9)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
             hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 512>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
                                (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB, fallback);
@@ -698,7 +703,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     {
         StageTimer t(c, ST_MISC);
         hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
-                           (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const uint32_t *)c->rreal, (u64)nregions, c->d_ctr);
+                           (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const u64 *)c->rreal, (u64)nregions, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;

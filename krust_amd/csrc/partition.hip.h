@@ -950,25 +950,35 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
 //     starts, how many of its first payloads come from the carried residue) and written by 16 lanes each.
 // 1024 lanes x 16 payloads per batch: with the stores cheap the kernel is bound by its own instruction stream
 // (one workgroup per CU: 152 KB of LDS), and sixteen waves hide the LDS round trips better than eight.
+// 64-bit payloads (k >= 22): the same kernel with 8 payloads per unit and batches of 8192 (same LDS bytes); the
+// sentinel there is KH_EMPTY_KEY, which the 64-bit region pass skips anyway.
 constexpr int P2L_NBK = 512;   // buckets per partition this kernel handles
-constexpr int P2L_LINE = 16;   // payloads per unit (64 bytes)
 constexpr int P2L_NT = 1024;   // lanes per workgroup
-constexpr int P2L_PER = PART2_TILE / P2L_NT;
+template <typename PT>
+struct P2L {
+    static constexpr int UNIT = 64 / (int)sizeof(PT);                                  // payloads per unit (64 bytes)
+    static constexpr int TILE = sizeof(PT) == 4 ? PART2_TILE : PART2_TILE / 2;         // payloads per batch
+    static constexpr int PER = TILE / P2L_NT;
+};
 
-// sentinel of bucket `digit`: a payload carrying ANOTHER level-2 digit (needs p2_bits >= 1)
-__device__ __forceinline__ uint32_t p2_sentinel(uint32_t digit, uint32_t p2_bits) { return (digit ^ 1u) << (32 - p2_bits); }
+// sentinel of bucket `digit`: 32-bit payloads -- a payload carrying ANOTHER level-2 digit (needs p2_bits >= 1);
+// 64-bit payloads (keys) -- the empty key
+template <typename PT>
+__device__ __forceinline__ PT p2_sentinel(uint32_t digit, uint32_t p2_bits) {
+    if (sizeof(PT) == 8) return (PT)KH_EMPTY_KEY;
+    return (PT)((digit ^ 1u) << (32 - p2_bits));
+}
 
-template <bool CHUNKED>
-__global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint32_t *__restrict__ pays, ChunkSrc cs,
+template <typename PT, bool CHUNKED>
+__global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *__restrict__ pays, ChunkSrc cs,
                                                                      const Part2Block *__restrict__ blocks,
                                                                      const u64 *__restrict__ info, PartGeom g,
-                                                                     const u64 *__restrict__ O2, uint32_t *__restrict__ out) {
-    typedef uint32_t PT;
-    constexpr int NBK = P2L_NBK, UNIT = P2L_LINE, NT = P2L_NT, PER = P2L_PER;
-    constexpr int MAXU = PART2_TILE / UNIT + NBK;       // units one batch can complete
-    constexpr uint32_t RES0 = PART2_TILE + 1;           // s_buf: [sorted stage | trash | residues (even) | residues (odd)]
+                                                                     const u64 *__restrict__ O2, PT *__restrict__ out) {
+    constexpr int NBK = P2L_NBK, UNIT = P2L<PT>::UNIT, NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
+    constexpr int MAXU = TILE / UNIT + NBK;             // units one batch can complete
+    constexpr uint32_t RES0 = TILE + 1;                 // s_buf: [sorted stage | trash | residues (even) | residues (odd)]
     constexpr uint32_t RES_SZ = NBK * UNIT;
-    __shared__ PT s_buf[PART2_TILE + 1 + 2 * NBK * UNIT];
+    __shared__ PT s_buf[TILE + 1 + 2 * NBK * UNIT];
     __shared__ uint32_t s_cnt[NBK];
     __shared__ uint2 s_ofs[NBK];        // x: stage start of the bucket's run | payloads that go to the stage << 16
                                         // y: s_buf index of the new tail's payload of rank 0 (biased by those payloads)
@@ -1017,7 +1027,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint3
         }
     };
     load_batch(0);
-    for (uint32_t base = 0; base < n; base += PART2_TILE, par ^= 1u) {
+    for (uint32_t base = 0; base < n; base += TILE, par ^= 1u) {
         const uint32_t res_old = RES0 + par * RES_SZ, res_new = RES0 + (par ^ 1u) * RES_SZ;
         uint32_t tag[PER];
 #pragma unroll
@@ -1066,21 +1076,21 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint3
             for (int j = 0; j < PER; ++j) {
                 const uint32_t rank = tag[j] & 0xFFFFu;
                 uint32_t addr = rank < (o[j].x >> 16) ? (o[j].x & 0xFFFFu) + rank : o[j].y + rank;
-                if (tag[j] == 0xFFFFFFFFu) addr = (uint32_t)PART2_TILE;  // trash slot
+                if (tag[j] == 0xFFFFFFFFu) addr = (uint32_t)TILE;  // trash slot
                 s_buf[addr] = pay[j];
             }
         }
         __syncthreads();
         if (tid < NBK) s_cnt[tid] = 0;
         // next batch's payloads are fetched while this batch's units are written out
-        load_batch(base + PART2_TILE);
+        load_batch(base + TILE);
         // the completed units: 16 lanes per unit, carried payloads first, then the sorted run
 #if KH_ABL3 & 2  /* timing experiment: no write-out */
         const uint32_t nslots = 0;
 #else
         const uint32_t nslots = s_nu * UNIT;
 #endif
-        uint32_t *__restrict__ obase = out + gbase;
+        PT *__restrict__ obase = out + gbase;
 #pragma unroll 4
         for (uint32_t x = tid; x < nslots; x += NT) {
             const uint2 u = s_unit[x / UNIT];
@@ -1088,7 +1098,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint3
             const uint32_t nres = (u.y >> 16) & 0xFu, b = u.y >> 20;
             const uint32_t idx = i < nres ? res_old + b * UNIT + i : (u.y & 0xFFFFu) - UNIT + i;
 #if KH_ABL3 & 1  /* timing experiment: LDS side of the write-out only */
-            if (s_buf[idx] == 0x12345678u && u.x == 77u) out[0] = 1;
+            if (s_buf[idx] == (PT)0x12345678u && u.x == 77u) out[0] = 1;
 #else
             obase[u.x + i] = s_buf[idx];
 #endif
@@ -1104,7 +1114,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const uint3
     for (uint32_t x = tid; x < (uint32_t)NBK * UNIT; x += NT) {
         const uint32_t b = x / UNIT, i = x % UNIT;
         const uint2 m = s_ofs[b];
-        if (m.x && b < (uint32_t)P2) out[gbase + m.y + i] = i < m.x ? s_buf[res_fin + b * UNIT + i] : p2_sentinel(b, g.p2_bits);
+        if (m.x && b < (uint32_t)P2) out[gbase + m.y + i] = i < m.x ? s_buf[res_fin + b * UNIT + i] : p2_sentinel<PT>(b, g.p2_bits);
     }
 }
 
@@ -1148,11 +1158,12 @@ template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
-                                                                   uint32_t *__restrict__ rreal) {
+                                                                   u64 *__restrict__ rreal) {
     __shared__ u64 s_key[REGION_SLOTS];
     __shared__ u64 s_cnt[REGION_SLOTS];
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
+    __shared__ u64 s_real;
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bstart[r + 1];
@@ -1171,11 +1182,13 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     const u64 n = hi - lo;
     const bool hot = n > hot_threshold;  // far above the mean bucket: skewed keys likely (see region32_probe_round)
     u64 kbuf[REGION_RK];  // first round of keys: in flight while the region image is loaded
+    u64 nreal = 0;  // keys of the bucket that are k-mers (KH_EMPTY_KEY pads its segments to whole units)
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {
         const u64 i = (u64)j * REGION_NT + tid;
         const u64 v = src[i < n ? i : n - 1];
         kbuf[j] = i < n ? v : KH_EMPTY_KEY;
+        nreal += kbuf[j] != KH_EMPTY_KEY;
     }
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
 #pragma unroll
@@ -1192,6 +1205,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     if (tid == 0) {
         s_fail = 0;
         s_new = 0;
+        s_real = 0;
     }
     __syncthreads();
     uint32_t nd = 0;
@@ -1202,6 +1216,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
             const u64 i = base + (u64)(REGION_RK + j) * REGION_NT + tid;
             const u64 v = src[i < n ? i : n - 1];
             nbuf[j] = i < n ? v : KH_EMPTY_KEY;
+            nreal += nbuf[j] != KH_EMPTY_KEY;
         }
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) {
@@ -1244,6 +1259,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);  // LDS
+    const u64 rw = wave_sum(nreal);
+    if ((tid & 63) == 0 && rw) atomicAdd(&s_real, rw);  // LDS, 64-bit: a hot bucket may hold >= 2^32 keys
     __syncthreads();
     if (s_fail) {
         if (FRESH && dirty) write_empty_region(reg, tid);
@@ -1261,7 +1278,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     }
     if (tid == 0) {
         rnew[r] = s_new;
-        rreal[r] = (uint32_t)(n < 0xFFFFFFFFull ? n : 0xFFFFFFFFull);  // 64-bit payloads carry no sentinels: every payload is a k-mer
+        rreal[r] = s_real;
     }
 }
 
@@ -1393,7 +1410,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr,
-                                                                   uint32_t *__restrict__ rreal) {
+                                                                   u64 *__restrict__ rreal) {
     // rreal[r] = payloads of the bucket that are k-mers (the bucket may hold SENTINELS, payloads with another
     // level-2 digit that pad its segments to whole lines: part2_scatter_lines_kernel; they are skipped here)
     // head_cb != 0 (FRESH only): also leave in rheads[r] the number of 32-bit exchange heads the region
@@ -1625,7 +1642,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
 
 // Folds the per-region results of one region_count pass into the context counters.
 __global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restrict__ bstart, const uint8_t *__restrict__ rfail,
-                                                              const uint32_t *__restrict__ rnew, const uint32_t *__restrict__ rreal,
+                                                              const uint32_t *__restrict__ rnew, const u64 *__restrict__ rreal,
                                                               u64 nregions, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     u64 d = 0, km = 0, nf = 0;
@@ -1634,10 +1651,7 @@ __global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restr
             ++nf;
         } else {
             d += rnew[r];
-            // k-mers of the bucket: its size, minus the sentinels the 32-bit region pass skipped (a bucket of
-            // >= 2^32 payloads fails the 32-bit pass, and the 64-bit one holds no sentinels)
-            const u64 sz = bstart[r + 1] - bstart[r];
-            km += sz >= 0xFFFFFFFFull ? sz : (u64)rreal[r];
+            km += rreal[r];  // k-mers of the bucket: its size minus the sentinels that pad its segments to whole units
         }
     }
     d = wave_sum(d);
@@ -1667,6 +1681,7 @@ __global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(TableGeom 
         const PT v = pays[i];
         // 32-bit payloads: a payload with another level-2 digit is a sentinel (line padding), not a k-mer
         if (sizeof(PT) == 4 && g.p2_bits && (uint32_t)((u64)v >> (32 - g.p2_bits)) != ((uint32_t)r & ((1u << g.p2_bits) - 1u))) continue;
+        if (sizeof(PT) == 8 && (u64)v == KH_EMPTY_KEY) continue;  // 64-bit payloads: the empty key pads the segments
         ++real;
         upsert(tg, Pay<PT>::key(v, p1, g), 1ull, nd, nf);
     }
