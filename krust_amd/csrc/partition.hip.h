@@ -1011,14 +1011,21 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
     const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
     auto load_batch = [&](uint32_t first) {
         have = 0;
+        // lane (l mod PER) of the wave fetches the metadata of the wave's j-th chunk: ONE LDS read per wave and array
+        // instead of PER; v_readlane hands every lane the j-th pair
+        uint32_t mychunk = 0, myfill = 0;
+        if (CHUNKED) {
+            const uint32_t myci = (first >> 8) + ((uint32_t)tid & (PER - 1)) * (NT / CHUNK_PAY) + ((uint32_t)tid >> 8);
+            const uint32_t mycc = myci < nchk ? myci : nchk - 1;  // (clamped: the loads below are unconditional)
+            mychunk = s_chk[mycc];
+            myfill = myci < nchk ? (uint32_t)s_cfill[mycc] : 0u;  // (no such chunk: no payload is valid)
+        }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             if (CHUNKED) {
-                const uint32_t ci = __builtin_amdgcn_readfirstlane((first >> 8) + (uint32_t)j * (NT / CHUNK_PAY) + ((uint32_t)tid >> 8));
-                const uint32_t cc = ci < nchk ? ci : nchk - 1;  // (clamped: the load below is unconditional)
-                const uint32_t chunk = __builtin_amdgcn_readfirstlane(s_chk[cc]);
-                const uint32_t fillc = __builtin_amdgcn_readfirstlane((uint32_t)s_cfill[cc]);
-                const bool ok = ci < nchk && woff < fillc;
+                const uint32_t chunk = __builtin_amdgcn_readlane(mychunk, j);
+                const uint32_t fillc = __builtin_amdgcn_readlane(myfill, j);
+                const bool ok = woff < fillc;
                 pay[j] = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (ok ? woff : 0u)];
                 have |= (uint32_t)ok << j;
             } else {
