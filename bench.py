@@ -266,10 +266,20 @@ def main():
     # backend of the 1-GPU tests, where ranks share a device and RCCL cannot be used) selects the
     # torch.distributed harness krust_amd/distributed.py instead; both leave identical shard tables.
     merge_impl = os.environ.get("BENCH_MERGE", "c" if backend == "nccl" else "python")
+    merge_note = None
     if world > 1 and merge_impl == "c":
-        box = [krust_amd.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        dc.comm_init(world, rank, box[0])
+        ok = 1
+        try:
+            box = [krust_amd.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            dc.comm_init(world, rank, box[0])
+        except Exception as e:  # (an RCCL failure inside the library: every rank falls back together, and says so)
+            ok, merge_note = 0, f"kh_comm_init failed on rank {rank}: {e!r}"
+        flag = torch.tensor([ok], dtype=torch.int64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            merge_impl = "python"
+            merge_note = merge_note or "kh_comm_init failed on another rank"
 
     def merge():
         if merge_impl == "c":
@@ -279,7 +289,10 @@ def main():
                     "owned_distinct": mi["owned_distinct"],
                     "phase_ms": {"export": mi["export_ms"], "exchange_wait": mi["wait_ms"], "merge": mi["merge_ms"],
                                  "total": mi["total_ms"], "pieces": mi["pieces"]}}
-        return dict(merge_across_ranks(dc, phase_times=True), impl="krust_amd.distributed (torch.distributed)")
+        out = dict(merge_across_ranks(dc, phase_times=True), impl="krust_amd.distributed (torch.distributed)")
+        if merge_note:
+            out["fallback_from_c_abi"] = merge_note
+        return out
 
     def step():
         dc.reset()
