@@ -403,18 +403,27 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// level 1 for 32-bit payloads with a VECTOR write-out: four payloads (16 bytes) per lane and store
+// level 1 for 32-bit payloads with a VECTOR write-out: four payloads (16 bytes) per store
 // ---------------------------------------------------------------------------------------------
 // Timing experiments on the kernel above (tools/p1_ablation.sh, S100M): of its 42 ms the write-out costs 9.6
 // (5.5 the global stores -- 64 lanes x 4 bytes into four or five different lines per instruction --, 4.1 its
-// LDS reads: payload, partition id, split point, 16-byte destination pair PER PAYLOAD).  Here every partition's
-// run is written in units of four payloads: the <= 3 that do not fill a unit stay behind in LDS (s_res) and
-// lead the partition's next run, so chunk fill levels are multiples of four, every store is an aligned
-// global_store_dwordx4 fed by one ds_read_b128, and the per-run lookups happen once per unit.  The sorted tile
-// keeps every partition's region 16-byte aligned (regions are padded to whole units: s_stage grows from 64 to
-// 88 KB, paid for by dropping the per-payload partition ids for per-unit ones).  What a workgroup still holds at
-// the end goes out payload by payload.  Same chunk pool, same reader: level 2 is unchanged.
+// LDS reads: payload, partition id, split point, 16-byte destination pair PER PAYLOAD) and the rank atomics 5.4
+// (every ds_add_rtn in its own exec-masked block, i.e. sixteen serialised LDS round trips per tile).  Here
+//   * the ranks are taken branch-free when there is no quality masking: a window without a key bumps one of 64
+//     waste counters (one per lane of a wave, so they never pile up on one address), and the sixteen atomics of
+//     a lane go out back to back with a single wait;
+//   * every partition's run is written in units of four payloads: the <= 3 that do not fill a unit stay behind
+//     in LDS (s_res) and lead the partition's next run, so chunk fill levels are multiples of four and every
+//     store is an aligned global_store_dwordx4 fed by one ds_read_b128;
+//   * the write-out is done BY THE LANE THAT OWNS THE PARTITION (lane tid <-> partition tid): where the run
+//     lies in the sorted tile, how many whole units it has, the current chunk and the freshly taken ones are
+//     all in that lane's registers, so the loop is ds_read_b128 + global_store_dwordx4 and nothing else (the
+//     unit -> partition map, the split points and the destination pairs of the earlier form, and their
+//     ~36 instructions per unit, are gone).  A run is ~3.5 units, the loop runs to the wave's longest (~7).
+// The sorted tile keeps every partition's region 16-byte aligned (regions are padded to whole units: 88 KB).
+// What a workgroup still holds at the end goes out payload by payload.  Same chunk pool, same reader.
 constexpr int P1V_SCAP = PART_NT * CHUNK + 6 * (int)MAX_P1;  // sorted tile: payloads + residues (<= 3) + padding (<= 3) per partition
+constexpr uint32_t P1V_NOKEY = (uint32_t)MAX_P1 << 16;       // tags from here up: window without a key
 
 template <bool QUAL, int MODE, bool FAST, int KT>
 __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
@@ -425,19 +434,16 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
     __shared__ uint32_t s_code[2][PART_NT + 2];
     __shared__ uint16_t s_val[2][PART_NT + 2];
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[P1V_SCAP + 4];  // 88 KiB (+ a trash unit)
-    __shared__ uint16_t s_vpid[P1V_SCAP / 4 + 1];  // owner partition of every whole unit, 0xFFFF = not to be written
-    __shared__ uint32_t s_cnt[MAX_P1];
+    __shared__ uint32_t s_cnt[MAX_P1 + 64];        // + the waste counters
     __shared__ uint16_t s_lofv[MAX_P1];            // first unit of the partition's region
-    __shared__ uint32_t s_meta[MAX_P1];            // lofv | units that still go to the current chunk << 16
-    __shared__ ChunkDst s_dst[MAX_P1];             // 16 KiB: pool index of a payload slot = a (or b) + slot
     __shared__ uint32_t s_res[3][MAX_P1];          // the <= 3 payloads carried to the partition's next run
     __shared__ uint32_t s_wsum[PART_NT / 64];
-    __shared__ uint32_t s_vtot;
     __shared__ u64 s_priv_next, s_priv_end;        // the workgroup's private range of chunk ids
     const int tid = threadIdx.x;
     if (KT) k = KT;
     const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
     s_cnt[tid] = 0;
+    if (tid < 64) s_cnt[MAX_P1 + tid] = 0;
     if (tid == 0) {
         s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
         s_priv_end = s_priv_next + POOL_GRAB;
@@ -452,6 +458,7 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
     if (te > tile0 + ntiles) te = tile0 + ntiles;
     int buf = 0;
     uint32_t lost = 0;
+    const uint32_t nokey = P1V_NOKEY + ((uint32_t)(tid & 63) << 16);
     __syncthreads();
     // takes `nnew` consecutive chunk ids for this lane's partition; false if the pool is exhausted
     auto take_chunks = [&](uint32_t nnew, u64 &first) -> bool {
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
         const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
         Roller roll;
         roll.init(w, k, wlo);
-        uint32_t pay[CHUNK], tag[CHUNK];  // tag = (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
+        uint32_t pay[CHUNK], tag[CHUNK];  // tag = (p1 << 16) | rank-in-partition; >= P1V_NOKEY: no key
 #pragma unroll
         for (int j = 0; j < CHUNK; ++j) {
             u64 key;
@@ -482,11 +489,11 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
                     p1 = p1_of_hash(H, g);
                 }
             }
-            tag[j] = ok ? (p1 << 16) : 0xFFFFFFFFu;
+            tag[j] = ok ? (p1 << 16) : nokey;
         }
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j)
-            if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
+        for (int j = 0; j < CHUNK; ++j)  // with -Q ~40 % of the windows have no key: there the branch pays
+            if (!QUAL || tag[j] < P1V_NOKEY) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
         // regions in whole units: exclusive scan of ceil((new + carried) / 4) over the 1024 partitions
         const uint32_t c = s_cnt[tid];
@@ -503,7 +510,8 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
         uint32_t lofv = incl - szv;
         for (int q = 0; q < (tid >> 6); ++q) lofv += s_wsum[q];
         s_lofv[tid] = (uint16_t)lofv;
-        if (tid == PART_NT - 1) s_vtot = lofv + szv;
+        s_cnt[tid] = 0;  // (everybody has read its count; the next atomics come after the next tile's barriers)
+        if (!QUAL && tid < 64) s_cnt[MAX_P1 + tid] = 0;
         __syncthreads();
         {  // branch-free staging: every lane reads its region starts back to back, then stores
             uint32_t rs[CHUNK];
@@ -511,40 +519,35 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
             for (int j = 0; j < CHUNK; ++j) rs[j] = 4u * (uint32_t)s_lofv[(tag[j] >> 16) & (MAX_P1 - 1)];
 #pragma unroll
             for (int j = 0; j < CHUNK; ++j)
-                s_stage[tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)P1V_SCAP] = pay[j];
+                s_stage[tag[j] < P1V_NOKEY ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)P1V_SCAP] = pay[j];
         }
-        const uint32_t nvec = tot >> 2;  // whole units of this partition in this tile
-        {  // lane tid places partition tid's run
+        // lane tid places partition tid's run: nvec whole units, the first `spacev` of them into the current chunk
+        // at pool index ia, the others into freshly taken, consecutive chunks at pool index ib
+        const uint32_t nvec = tot >> 2;
+        uint32_t nout = nvec;
+        const uint32_t spacev = (CHUNK_PAY - fill) >> 2;
+        const u64 ia = cur * CHUNK_PAY + fill;
+        u64 ib = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 3; ++i)  // the carried payloads follow the new ones
-                if (i < res) s_stage[4u * lofv + c + i] = s_res[i][tid];
-            for (uint32_t i = 0; i < szv; ++i) s_vpid[lofv + i] = i < nvec ? (uint16_t)tid : (uint16_t)0xFFFFu;
-            const uint32_t space = CHUNK_PAY - fill;  // multiple of 4
-            const uint32_t n4 = 4u * nvec;
-            ChunkDst d;
-            d.a = cur * CHUNK_PAY + fill - 4u * lofv;
-            d.b = 0;
-            if (n4 > space) {
-                const uint32_t r = n4 - space;
-                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
-                u64 first;
-                if (!take_chunks(nnew, first)) {
-                    lost += r;
-                    d.b = CHUNK_DST_DROP;  // marks "drop" for the write-out
-                } else {
-                    d.b = first * CHUNK_PAY - space - 4u * lofv;
-                    cur = first + nnew - 1;
-                    fill = r - (nnew - 1) * CHUNK_PAY;
-                    have_chunk = true;
-                }
+        for (uint32_t i = 0; i < 3; ++i)  // the carried payloads follow the new ones
+            if (i < res) s_stage[4u * lofv + c + i] = s_res[i][tid];
+        if (nvec > spacev) {
+            const uint32_t r = 4u * (nvec - spacev);
+            const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
+            u64 first;
+            if (!take_chunks(nnew, first)) {
+                lost += r;
+                nout = spacev;
             } else {
-                fill += n4;
+                ib = first * CHUNK_PAY;
+                cur = first + nnew - 1;
+                fill = r - (nnew - 1) * CHUNK_PAY;
+                have_chunk = true;
             }
-            s_dst[tid] = d;
-            s_meta[tid] = lofv | ((space >> 2) << 16);
+        } else {
+            fill += 4u * nvec;
         }
         __syncthreads();
-        s_cnt[tid] = 0;  // ordered before the next atomics by the next tile's stage_tile() barrier
         res = tot & 3u;
 #pragma unroll
         for (uint32_t i = 0; i < 3; ++i)  // what does not fill a unit waits for the next tile
@@ -555,19 +558,13 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
         }
         // next tile's bases are fetched while this tile's runs are written out
         raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        const uint32_t vtot = s_vtot;
-#pragma unroll 2
-        for (uint32_t v = tid; v < vtot; v += PART_NT) {
-            const uint32_t p = s_vpid[v];
-            if (p == 0xFFFFu) continue;
-            const uint32_t meta = s_meta[p];
-            const ChunkDst d = s_dst[p];
-            const uint4 x = *reinterpret_cast<const uint4 *>(&s_stage[4u * v]);
-            const bool first_part = v - (meta & 0xFFFFu) < (meta >> 16);
-            if (first_part) *reinterpret_cast<uint4 *>(pool + (d.a + 4u * v)) = x;
-            else if (d.b != CHUNK_DST_DROP) *reinterpret_cast<uint4 *>(pool + (d.b + 4u * v)) = x;
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(&s_stage[4u * lofv]);
+            uint4 *da = reinterpret_cast<uint4 *>(pool + ia);
+            uint4 *db = reinterpret_cast<uint4 *>(pool + ib) - spacev;
+            for (uint32_t i = 0; i < nout; ++i) (i < spacev ? da : db)[i] = src[i];
         }
-        // (s_stage / s_vpid / s_dst / s_meta / s_res are rewritten only after the next tile's barriers)
+        // (s_stage / s_res are rewritten only after the next tile's barriers)
     }
     // the payloads still carried: one by one into the partition's chunk
     if (res) {
