@@ -613,10 +613,16 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             static const bool generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
             // 32-bit payloads: the kernel with the 16-byte write-out (KMERHIP_P1_VEC=0: the per-payload one, for A/B)
             static const bool vec32 = [] { const char *e = getenv("KMERHIP_P1_VEC"); return !(e && e[0] == '0'); }();
-#define KH_P1_VEC(QUAL, MODE, FAST, KT) \
-    hipLaunchKernelGGL((kh::part1_vec32_kernel<QUAL, MODE, FAST, KT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
+            // ... of those, the one with fixed per-partition bins in LDS (KMERHIP_P1_BINS=0: the tile-sorting one, for A/B)
+            static const bool bins32 = [] { const char *e = getenv("KMERHIP_P1_BINS"); return !(e && e[0] == '0'); }();
+#define KH_P1_VECK(KERNEL, QUAL, MODE, FAST, KT) \
+    hipLaunchKernelGGL((kh::KERNEL<QUAL, MODE, FAST, KT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
                        ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
                        c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
+// (with quality masking the bins kernel runs out of registers -- 20-odd VGPRs spilled -- and loses to the tile-sorting
+// one, 44.7 vs 41.1 ms on S100M -Q 20: it is not instantiated for that)
+#define KH_P1_VEC(QUAL, MODE, FAST, KT) \
+    do { if (bins32 && !QUAL) KH_P1_VECK(part1_bins32_kernel, false, MODE, FAST, KT); else KH_P1_VECK(part1_vec32_kernel, QUAL, MODE, FAST, KT); } while (0)
             if (sizeof(PT) == 4 && vec32) {
                 const bool k21 = !generic_k && c->k == 21 && fast && g.p1_bits == 10;
                 if (k21 && ra.use_qual) KH_P1_VEC(true, KH_MUL_24, true, 21);

@@ -590,6 +590,238 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
     if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
 }
 
+// ---------------------------------------------------------------------------------------------
+// level 1 for 32-bit payloads with DIRECT BINS: rank, store, flush -- two barriers per tile
+// ---------------------------------------------------------------------------------------------
+// The kernel above sorts every tile in LDS: rank atomics, barrier, scan of the 1024 counts (two more barriers),
+// a lookup of the region start per payload, barrier, write-out.  Its SQ counters (profiles/README.md r02a) say the
+// VALU issue (65 % of the tile time) and the LDS pipeline (34 %) do not overlap, and a fifth of both is that
+// bookkeeping.  Here every partition has a FIXED bin of P1B_CAP = 32 payloads (eight 16-byte units; 128 KiB for
+// the 1024 partitions, which is what LDS there is): a payload's place is bin(p) + rank, known the moment the rank
+// atomic returns, so there is no scan, no region table, no second pass over the tags:
+//     B0  (inside stage_tile_raw: the tile's 2-bit codes are in LDS)
+//     extraction + hash; rank = atomicAdd(&s_cnt[p], 1); s_bin[p][rank] = payload
+//     B1
+//     lane p (owner of partition p): whole units of its bin -> the partition's chunk (ds_read_b128 +
+//     global_store_dwordx4); the <= 3 payloads left over move to the front of the bin; s_cnt[p] = that count
+// A tile brings 13.8 payloads per partition on average, so with the carried <= 3 a bin overflows about once in
+// 10^4 partition-tiles on well-mixed input -- and always on skewed input (a homopolymer run sends 16384 payloads
+// of a tile to ONE partition).  Overflow is exact, not a fallback to another kernel: a rank >= 32 raises s_flag;
+// after B1 the owner, which sees the partition's full count c, reserves room for all c >> 2 units in the
+// partition's chunk sequence as usual, flushes the bin's 8 units, and leaves in the (now free) bin where the
+// others go; one more barrier (B2, taken only in such tiles), then the payloads whose rank was >= 32 store
+// themselves, 4 bytes each.  They do not keep payload and rank in registers across the flush (that is 32 VGPRs of
+// a 128-VGPR budget, for a path well-mixed input never takes): a lane remembers WHICH of its windows they were
+// (16 bits), rolls over its windows again, and takes a second rank from the same counter, which the owner has
+// restarted at -(whole units' worth of them): a negative rank is a position in the run, 0..2 a carried payload's
+// bin slot, and the counter ends at c & 3 as it must.  Chunk fill levels stay multiples of four: same pool
+// format, same reader.
+// Bank spread: the units of bin p are rotated by p & 7 (payload r sits at word (r + 4 (p & 7)) mod 32), so
+// equal ranks of different partitions do not pile up on one bank.
+constexpr uint32_t P1B_CAP = 32;
+constexpr uint32_t P1B_WORDS = MAX_P1 * P1B_CAP;
+__device__ __forceinline__ uint32_t p1b_slot(uint32_t p, uint32_t r) {
+    return p * P1B_CAP + ((r + 4u * (p & 7u)) & (P1B_CAP - 1u));
+}
+
+template <bool QUAL, int MODE, bool FAST, int KT>
+__global__ __launch_bounds__(PART_NT) void part1_bins32_kernel(
+    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
+    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
+    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
+    Counters *ctr) {
+    __shared__ uint32_t s_code[2][PART_NT + 2];
+    __shared__ uint16_t s_val[2][PART_NT + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_bin[P1B_WORDS + 4];  // 128 KiB (+ a trash unit)
+    __shared__ uint32_t s_cnt[MAX_P1 + 64];  // payloads in the bin; + one waste counter per lane of a wave (windows without a key)
+    __shared__ uint32_t s_flag;              // some rank of this tile did not fit its bin
+    __shared__ u64 s_priv_next, s_priv_end;  // the workgroup's private range of chunk ids
+    const int tid = threadIdx.x;
+    if (KT) k = KT;
+    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
+    s_cnt[tid] = 0;
+    if (tid < 64) s_cnt[MAX_P1 + tid] = 0;
+    if (tid == 0) {
+        s_flag = 0;
+        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+        s_priv_end = s_priv_next + POOL_GRAB;
+    }
+    // lane tid owns partition tid: its current chunk and how full it is (a multiple of 4)
+    u64 cur = 0;
+    uint32_t fill = CHUNK_PAY;  // "full": the first unit takes a chunk
+    uint32_t res = 0;           // payloads carried in the bin (== s_cnt[tid] between tiles)
+    bool have_chunk = false;
+    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
+    u64 te = tb + tiles_per_block;
+    if (te > tile0 + ntiles) te = tile0 + ntiles;
+    int buf = 0;
+    uint32_t lost = 0;
+    const uint32_t nokey = (uint32_t)(MAX_P1 + (tid & 63)) << 16;
+    const uint32_t rot = (uint32_t)tid & 7u;
+    __syncthreads();
+    auto take_chunks = [&](uint32_t nnew, u64 &first) -> bool {
+        first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
+        if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
+        if (first + nnew > pool_chunks) return false;  // cannot happen with the host's pool sizing; never write past it
+        for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
+        return true;
+    };
+    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
+    for (u64 t = tb; t < te; ++t, buf ^= 1) {
+        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
+        // (past B0 every lane has finished the previous tile's flush: nobody is taking chunks right now)
+        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for this tile's flush
+            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+            s_priv_end = s_priv_next + POOL_GRAB;
+        }
+        Roller roll;
+        roll.init(w, k, wlo);
+        uint32_t pay[CHUNK], tag[CHUNK];  // tag = (p1 << 16) | rank; p1 >= MAX_P1: no key
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            u64 key;
+            const bool ok = roll.next(j, key);
+            uint32_t p1 = 0;
+            pay[j] = 0;
+            if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
+                if (FAST) {
+                    hash_p1_pay32<MODE>(k, p1b, key, p1, pay[j]);
+                } else {
+                    const u64 H = part_hash<MODE>(g, key);
+                    pay[j] = Pay<uint32_t>::make(key, H, g);
+                    p1 = p1_of_hash(H, g);
+                }
+            }
+            tag[j] = ok ? (p1 << 16) : nokey;
+        }
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j)  // with -Q ~40 % of the windows have no key: there the branch pays
+            if (!QUAL || tag[j] < P1V_NOKEY) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
+        uint32_t rmax = 0, omask = 0;  // omask bit j: window j has a key and its rank did not fit the bin
+#pragma unroll
+        for (int j = 0; j < CHUNK; ++j) {
+            const uint32_t r = tag[j] & 0xFFFFu;
+            const bool valid = tag[j] < P1V_NOKEY;
+            s_bin[valid && r < P1B_CAP ? p1b_slot(tag[j] >> 16, r) : P1B_WORDS] = pay[j];
+            rmax = max(rmax, valid ? r : 0u);
+        }
+        if (rmax >= P1B_CAP) {
+            s_flag = 1u;
+#pragma unroll
+            for (int j = 0; j < CHUNK; ++j)
+                if (tag[j] < P1V_NOKEY && (tag[j] & 0xFFFFu) >= P1B_CAP) omask |= 1u << j;
+        }
+        __syncthreads();  // B1
+        const bool slow = s_flag != 0u;  // uniform
+        // next tile's bases are fetched while this tile's bins are flushed
+        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+        {   // lane tid flushes partition tid
+            const uint32_t c = s_cnt[tid];  // carried + new
+            const uint32_t nvt = c >> 2;    // whole units of the partition's run, the first min(nvt, 8) of them in the bin
+            const uint32_t binv = min(nvt, P1B_CAP / 4u);
+            uint32_t nout = nvt;
+            const uint32_t spacev = (CHUNK_PAY - fill) >> 2;
+            const u64 ia = cur * CHUNK_PAY + fill;
+            u64 ib = 0;
+            if (nvt > spacev) {
+                const uint32_t r = 4u * (nvt - spacev);
+                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
+                u64 first;
+                if (!take_chunks(nnew, first)) {
+                    lost += r;
+                    nout = spacev;
+                } else {
+                    ib = first * CHUNK_PAY;
+                    cur = first + nnew - 1;
+                    fill = r - (nnew - 1) * CHUNK_PAY;
+                    have_chunk = true;
+                }
+            } else {
+                fill += 4u * nvt;
+            }
+            uint4 *da = reinterpret_cast<uint4 *>(pool + ia);
+            uint4 *db = reinterpret_cast<uint4 *>(pool + ib) - spacev;
+            const uint32_t nb = min(binv, nout);
+            for (uint32_t u = 0; u < nb; ++u)
+                (u < spacev ? da : db)[u] = *reinterpret_cast<const uint4 *>(&s_bin[(uint32_t)tid * P1B_CAP + 4u * ((u + rot) & 7u)]);
+            res = c & 3u;
+            if (c <= P1B_CAP) {
+                if (binv)  // the payloads that do not fill a unit move to the front of the bin
+                    for (uint32_t i = 0; i < res; ++i) s_bin[p1b_slot(tid, i)] = s_bin[p1b_slot(tid, 4u * binv + i)];
+            } else {  // where the payloads that did not fit go: left in units 2 and 3 of the emptied bin
+                const u64 a = ia, b2 = ib - 4u * spacev;
+                s_bin[p1b_slot(tid, 8)] = (uint32_t)a;
+                s_bin[p1b_slot(tid, 9)] = (uint32_t)(a >> 32);
+                s_bin[p1b_slot(tid, 10)] = (uint32_t)b2;
+                s_bin[p1b_slot(tid, 11)] = (uint32_t)(b2 >> 32);
+                s_bin[p1b_slot(tid, 12)] = 4u * spacev;  // run positions before this one go to a + e, the others to b2 + e
+                s_bin[p1b_slot(tid, 13)] = 4u * nout;    // ... if below this (less than 4 nvt only when the pool ran out)
+                s_bin[p1b_slot(tid, 14)] = 4u * nvt;     // end of the run's whole units
+            }
+            // Those payloads take a second rank in the slow path below, counted from -(their share of whole units):
+            // negative = run position 4 nvt + rank, 0..2 = carried in bin slot rank; and the counter ends at c & 3.
+            s_cnt[tid] = c <= P1B_CAP ? res : res - (c - P1B_CAP);
+        }
+        if (slow) {
+            __syncthreads();  // B2
+            if (omask) {  // the registers of the fast path are gone: roll over the lane's windows again
+                Roller again;
+                again.init(w, k, wlo);
+#pragma unroll
+                for (int j = 0; j < CHUNK; ++j) {
+                    u64 key;
+                    again.next(j, key);
+                    if ((omask >> j) & 1u) {
+                        uint32_t p, pv;
+                        if (FAST) {
+                            hash_p1_pay32<MODE>(k, p1b, key, p, pv);
+                        } else {
+                            const u64 H = part_hash<MODE>(g, key);
+                            pv = Pay<uint32_t>::make(key, H, g);
+                            p = p1_of_hash(H, g);
+                        }
+                        const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 1u);
+                        if (r2 >= 0) {
+                            s_bin[p1b_slot(p, (uint32_t)r2)] = pv;
+                        } else {
+                            const u64 a = ((u64)s_bin[p1b_slot(p, 9)] << 32) | s_bin[p1b_slot(p, 8)];
+                            const u64 b2 = ((u64)s_bin[p1b_slot(p, 11)] << 32) | s_bin[p1b_slot(p, 10)];
+                            const uint32_t split = s_bin[p1b_slot(p, 12)], lim = s_bin[p1b_slot(p, 13)];
+                            const uint32_t e = s_bin[p1b_slot(p, 14)] + (uint32_t)r2;
+                            if (e < lim) pool[(e < split ? a : b2) + e] = pv;
+                        }
+                    }
+                }
+            }
+            if (tid == 0) s_flag = 0u;  // (everybody read it before B2; the next tile sets it after its B0)
+        }
+        // (bins, counts and flag are touched again only after the next tile's B0)
+    }
+    __syncthreads();  // (the last tile's slow path may have left carried payloads in other lanes' bins)
+    // the payloads still carried: one by one into the partition's chunk
+    if (res) {
+        bool room = true;
+        if (fill + res > CHUNK_PAY) {  // (fill is a multiple of 4, so this means fill == 256: a fresh chunk)
+            u64 first;
+            room = take_chunks(1u, first);
+            if (room) {
+                cur = first;
+                fill = 0;
+                have_chunk = true;
+            } else {
+                lost += res;
+            }
+        }
+        if (room) {
+            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = s_bin[p1b_slot(tid, i)];
+            fill += res;
+        }
+    }
+    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
+    const u64 l = wave_sum((u64)lost);
+    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
+}
+
 // ---- chunk list: chunk ids ordered by partition ---------------------------------------------------
 // pcount[p] += chunks owned by partition p among ids [0, nchunks)
 __global__ __launch_bounds__(1024) void chunk_hist_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
