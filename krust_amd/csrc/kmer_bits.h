@@ -89,10 +89,11 @@ KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
     uint32_t t;
     if (MODE == KH_MUL_24 || (MODE == KH_MUL_AUTO && kh_k_uses_mul24(k))) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        // (The compiler turns this into a plain multiply where it can prove both operands 24-bit and re-selects
-        // v_mul_u32_u24 only in half of the rounds of the extraction kernels -- the others come out as
-        // v_mul_lo_u32.  Forcing the instruction with inline asm was measured 1.5 - 12 ms SLOWER on level 1
-        // (S100M, profiles/README.md r02c): the opaque asm costs more in scheduling than the multiplier saves.)
+        // (__umul24() is a masked plain multiply to the compiler, re-selected as v_mul_u32_u24 only where
+        // instruction selection can prove both operands 24-bit: in the extraction kernels two of the four rounds
+        // come out as v_mul_lo_u32.  Forcing v_mul_u32_u24 -- by inline asm, or by the llvm.amdgcn.mul.u24
+        // intrinsic -- was measured SLOWER on level 1 every time (S100M: +1.5 .. +14 ms, the scheduling and
+        // register allocation around it change for the worse), so it stays as written.)
         t = __umul24(r, (c & 0xFFFFFFu) | 1u);
 #else
         t = (uint32_t)((uint64_t)r * ((c & 0xFFFFFFu) | 1u));
