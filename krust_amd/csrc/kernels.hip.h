@@ -160,12 +160,16 @@ __device__ __forceinline__ RawChunk load_raw(const uint8_t *__restrict__ abase, 
     r.w = make_uint4(0, 0, 0, 0);
     r.q = make_uint4(0, 0, 0, 0);
     r.live = !(p0 < 0 || (u64)p0 >= vend);
-    if (!r.live) return r;
-    r.w = *reinterpret_cast<const uint4 *>(abase + p0);
+    // The 16-byte loads are UNCONDITIONAL (a chunk outside the data reads the data's first chunk instead and is
+    // ignored by encode_raw): behind a branch the loaded registers reach the caller through copies at the join,
+    // the compiler waits for the load right there, and the "prefetch" of the next tile stalls every wave for a
+    // memory round trip per tile (s_waitcnt vmcnt(0) straight after the global_load in every level-1 kernel).
+    const int64_t pa = r.live ? p0 : (int64_t)(vbeg & ~(u64)15);
+    r.w = *reinterpret_cast<const uint4 *>(abase + pa);
     if (QUAL) {
         if (qaligned) {
-            r.q = *reinterpret_cast<const uint4 *>(qbase + p0);
-        } else {
+            r.q = *reinterpret_cast<const uint4 *>(qbase + pa);
+        } else if (r.live) {
             uint32_t qq[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < CHUNK; ++j) {
@@ -293,6 +297,43 @@ __device__ __forceinline__ WinCtx stage_tile_raw(uint32_t (*s_code)[NT + 2], uin
     return w;
 }
 
+// The same in two halves, for a kernel that encodes tile t + 1 while it still works on tile t (so that the wait for
+// the prefetched bases is not also a wait for the global stores the kernel has just issued -- one counter, vmcnt,
+// covers both): stage_encode() is everything before the barrier, stage_collect() everything after it.
+template <bool QUAL, int NT>
+__device__ __forceinline__ void stage_encode(uint32_t (*s_code)[NT + 2], uint16_t (*s_val)[NT + 2], int buf, bool first, int tid,
+                                             const RawChunk &raw, const uint8_t *__restrict__ abase,
+                                             const uint8_t *__restrict__ qbase, int qaligned, u64 t, u64 vbeg, u64 vend,
+                                             uint32_t thr) {
+    constexpr int TILE_N = NT * CHUNK;
+    uint32_t code, val;
+    encode_raw<QUAL>(raw, vbeg, vend, thr, code, val);
+    s_code[buf][tid + 2] = code;
+    s_val[buf][tid + 2] = (uint16_t)val;
+    if (first && tid < 2) {
+        uint32_t hc, hv;
+        encode_chunk<QUAL>(abase, qbase, qaligned, (int64_t)(t * TILE_N) - (int64_t)(2 - tid) * CHUNK, vbeg, vend, thr,
+                           hc, hv);
+        s_code[buf][tid] = hc;
+        s_val[buf][tid] = (uint16_t)hv;
+    }
+}
+template <int NT>
+__device__ __forceinline__ WinCtx stage_collect(uint32_t (*s_code)[NT + 2], uint16_t (*s_val)[NT + 2], int buf, int tid, u64 t) {
+    const uint32_t code = s_code[buf][tid + 2];
+    const uint32_t val = s_val[buf][tid + 2];
+    if (tid >= NT - 2) {  // the last two words are the next tile's look-back (that buffer's slots [0,1] are free: see stage_tile_raw)
+        s_code[buf ^ 1][tid - (NT - 2)] = code;
+        s_val[buf ^ 1][tid - (NT - 2)] = (uint16_t)val;
+    }
+    WinCtx w;
+    w.hi = s_code[buf][tid];
+    w.lo64 = ((u64)s_code[buf][tid + 1] << 32) | code;
+    w.V = ((u64)s_val[buf][tid] << 32) | ((u64)s_val[buf][tid + 1] << 16) | (u64)val;
+    w.p0 = (u64)chunk_pos<NT>(t, tid);
+    return w;
+}
+
 template <bool QUAL, int NT>
 __device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_t (*s_val)[NT + 2], int buf, bool first,
                                              int tid, const uint8_t *__restrict__ abase,
@@ -308,6 +349,26 @@ __device__ __forceinline__ WinCtx stage_tile(uint32_t (*s_code)[NT + 2], uint16_
 //   good = bit (15-j): the window ENDING at own base j is countable (k valid bases, inside the
 //          data, ending at or after wlo) -- computed once per lane by eroding the 48 validity bits
 // next(j) must be called for j = 0, 1, ..., 15 in order.
+// bit (15-j): the window ENDING at the lane's own base j is countable (k valid bases, inside the data, ending at
+// or after wlo): G = AND_{i<k} (V >> i) over the lane's 48 validity bits
+__device__ __forceinline__ uint32_t window_good(const WinCtx &w, uint32_t k, u64 wlo) {
+    u64 g = w.V;
+    uint32_t L = 1;
+#pragma unroll
+    for (uint32_t sft = 1; sft <= 16; sft <<= 1)
+        if (2 * sft <= k) {
+            g &= g >> sft;
+            L = 2 * sft;
+        }
+    if (k > L) g &= g >> (k - L);
+    uint32_t good = (uint32_t)g & 0xFFFFu;
+    if (w.p0 < wlo) {  // windows ending before wlo belong to an earlier launch
+        const u64 d = wlo - w.p0;
+        good = d >= 16 ? 0u : (good & (0xFFFFu >> d));
+    }
+    return good;
+}
+
 struct Roller {
     uint32_t flo, fhi, rlo, rhi, code, good;
     uint32_t kmlo, kmhi;  // kh_kmask(k)
@@ -327,21 +388,7 @@ struct Roller {
         const u64 rc = kh_revcomp((((u64)fhi << 32) | flo) & km, k);
         rlo = (uint32_t)rc;
         rhi = (uint32_t)(rc >> 32);
-        // G = AND_{i<k} (V >> i): bit (15-j) set iff bases j-k+1..j are all countable
-        u64 g = w.V;
-        uint32_t L = 1;
-#pragma unroll
-        for (uint32_t sft = 1; sft <= 16; sft <<= 1)
-            if (2 * sft <= k) {
-                g &= g >> sft;
-                L = 2 * sft;
-            }
-        if (k > L) g &= g >> (k - L);
-        good = (uint32_t)g & 0xFFFFu;
-        if (w.p0 < wlo) {  // windows ending before wlo belong to an earlier launch
-            const u64 d = wlo - w.p0;
-            good = d >= 16 ? 0u : (good & (0xFFFFu >> d));
-        }
+        good = window_good(w, k, wlo);
     }
 
     __device__ __forceinline__ bool next(int j, u64 &key) {

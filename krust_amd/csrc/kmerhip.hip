@@ -625,7 +625,16 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     do { if (bins32 && !QUAL) KH_P1_VECK(part1_bins32_kernel, false, MODE, FAST, KT); else KH_P1_VECK(part1_vec32_kernel, QUAL, MODE, FAST, KT); } while (0)
             if (sizeof(PT) == 4 && vec32) {
                 const bool k21 = !generic_k && c->k == 21 && fast && g.p1_bits == 10;
-                if (k21 && ra.use_qual) KH_P1_VEC(true, KH_MUL_24, true, 21);
+                // k = 21 at the headline geometry: the kernel with the hand-written window sequence (KMERHIP_P1_K21=0: off, for A/B)
+                static const bool k21asm = [] { const char *e = getenv("KMERHIP_P1_K21"); return !(e && e[0] == '0'); }();
+#define KH_P1_K21(QUAL) \
+    hipLaunchKernelGGL((kh::part1_k21_kernel<QUAL>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg, ra.vend, \
+                       ra.wlo, tile0, ntiles, tpb, thr, (uint32_t *)c->keysA, c->chunk_part, c->fill8, c->pool_next, \
+                       pool_chunks, c->d_ctr)
+                if (k21 && k21asm && bins32 && g.shard_shift == 0) {
+                    if (ra.use_qual) KH_P1_K21(true);
+                    else KH_P1_K21(false);
+                } else if (k21 && ra.use_qual) KH_P1_VEC(true, KH_MUL_24, true, 21);
                 else if (k21) KH_P1_VEC(false, KH_MUL_24, true, 21);
                 else if (ra.use_qual && m24 && fast) KH_P1_VEC(true, KH_MUL_24, true, 0);
                 else if (ra.use_qual && m24) KH_P1_VEC(true, KH_MUL_24, false, 0);

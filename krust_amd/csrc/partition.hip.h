@@ -618,6 +618,9 @@ __global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
 // format, same reader.
 // Bank spread: the units of bin p are rotated by p & 7 (payload r sits at word (r + 4 (p & 7)) mod 32), so
 // equal ranks of different partitions do not pile up on one bank (37.3 vs 37.6 ms without).
+#ifndef KH_P1B_GROUP
+#define KH_P1B_GROUP 4
+#endif
 constexpr uint32_t P1B_CAP = 32;
 constexpr uint32_t P1B_WORDS = MAX_P1 * P1B_CAP;
 __device__ __forceinline__ uint32_t p1b_slot(uint32_t p, uint32_t r) {
@@ -676,35 +679,46 @@ __global__ __launch_bounds__(PART_NT) void part1_bins32_kernel(
         }
         Roller roll;
         roll.init(w, k, wlo);
+        // In groups of KH_P1B_GROUP windows: hash a group, send its rank atomics, and only then store the previous
+        // group's payloads -- whose ranks have come back while this group was being hashed.
         uint32_t pay[CHUNK], tag[CHUNK];  // tag = (p1 << 16) | rank; p1 >= MAX_P1: no key
+        uint32_t rk[CHUNK];               // (kept apart from the tag until the store: nothing waits for the atomic before that)
+        uint32_t rmax = 0, omask = 0;     // omask bit j: window j has a key and its rank did not fit the bin
+        auto store_group = [&](int j0) {
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            u64 key;
-            const bool ok = roll.next(j, key);
-            uint32_t p1 = 0;
-            pay[j] = 0;
-            if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
-                if (FAST) {
-                    hash_p1_pay32<MODE>(k, p1b, key, p1, pay[j]);
-                } else {
-                    const u64 H = part_hash<MODE>(g, key);
-                    pay[j] = Pay<uint32_t>::make(key, H, g);
-                    p1 = p1_of_hash(H, g);
-                }
+            for (int j = j0; j < j0 + KH_P1B_GROUP; ++j) {
+                const uint32_t r = rk[j];
+                const bool valid = tag[j] < P1V_NOKEY;
+                s_bin[valid && r < P1B_CAP ? p1b_slot(tag[j] >> 16, r) : P1B_WORDS] = pay[j];
+                rmax = max(rmax, valid ? r : 0u);
+                tag[j] |= r;
             }
-            tag[j] = ok ? (p1 << 16) : nokey;
-        }
+        };
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j)  // with -Q ~40 % of the windows have no key: there the branch pays
-            if (!QUAL || tag[j] < P1V_NOKEY) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
-        uint32_t rmax = 0, omask = 0;  // omask bit j: window j has a key and its rank did not fit the bin
+        for (int j0 = 0; j0 < CHUNK; j0 += KH_P1B_GROUP) {
 #pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            const uint32_t r = tag[j] & 0xFFFFu;
-            const bool valid = tag[j] < P1V_NOKEY;
-            s_bin[valid && r < P1B_CAP ? p1b_slot(tag[j] >> 16, r) : P1B_WORDS] = pay[j];
-            rmax = max(rmax, valid ? r : 0u);
+            for (int j = j0; j < j0 + KH_P1B_GROUP; ++j) {
+                u64 key;
+                const bool ok = roll.next(j, key);
+                uint32_t p1 = 0;
+                pay[j] = 0;
+                if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
+                    if (FAST) {
+                        hash_p1_pay32<MODE>(k, p1b, key, p1, pay[j]);
+                    } else {
+                        const u64 H = part_hash<MODE>(g, key);
+                        pay[j] = Pay<uint32_t>::make(key, H, g);
+                        p1 = p1_of_hash(H, g);
+                    }
+                }
+                tag[j] = ok ? (p1 << 16) : nokey;
+            }
+#pragma unroll
+            for (int j = j0; j < j0 + KH_P1B_GROUP; ++j)  // with -Q ~40 % of the windows have no key: there the branch pays
+                rk[j] = (!QUAL || tag[j] < P1V_NOKEY) ? atomicAdd(&s_cnt[tag[j] >> 16], 1u) : 0u;
+            if (j0) store_group(j0 - KH_P1B_GROUP);
         }
+        store_group(CHUNK - KH_P1B_GROUP);
         if (rmax >= P1B_CAP) {
             s_flag = 1u;
 #pragma unroll
@@ -814,6 +828,319 @@ __global__ __launch_bounds__(PART_NT) void part1_bins32_kernel(
         }
         if (room) {
             for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = s_bin[p1b_slot(tid, i)];
+            fill += res;
+        }
+    }
+    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
+    const u64 l = wave_sum((u64)lost);
+    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 1 for k = 21 at the headline geometry (1024 partitions, 32-bit payloads): the bins kernel with the
+// per-window instruction sequence WRITTEN OUT
+// ---------------------------------------------------------------------------------------------
+// tools/ubench/valu_rates.hip measured what gfx950's VALU instructions cost per wave (cycles at 2.4 GHz, 4 waves
+// per SIMD): v_xor/and/or/add/sub/lshrrev/mov/not and v_bitop3 ~2.9; v_lshlrev, v_min/max, v_bfe, v_alignbit, every
+// fused three-operand form, every multiply (24- and 32-bit alike) ~4.9; v_cmp ~5.5; a v_cndmask on a mask in an SGPR
+// pair ~3.4; and a v_cndmask reading a VCC that the instruction before it did not just write ~20 (so the usual
+// "v_cmp_lt_u64 vcc; v_cndmask; v_cndmask" of a 64-bit min costs 27).  The compiler's code for a window of the
+// bins kernel adds up to ~215 such cycles, ~60 instructions: rolling both strands through registers, a second
+// VCC read in the canonical choice, left shifts and compares for tags and slot addresses.  Here the window is
+// ~27 instructions, ~105 cycles, in one asm statement per window (the compiler schedules the sixteen as units
+// and allocates everything but eight scratch registers):
+//   * no rolling state: the lane's 48 bases are three words (w2:w1:w0, first base in the top bits) and their
+//     reverse complements three more (c2:c1:c0 = 2-bit groups reversed and inverted, made once per tile), and
+//     BOTH strands of window J are 42-bit fields of those at fixed offsets: v_alignbit + v_bfe each;
+//   * canonical choice: v_cmp_lt_u64 into an SGPR pair, two v_cndmask on it;
+//   * Feistel rounds of v_mul_u32_u24, v_lshrrev, v_xor -- no masks (21-bit halves stay 21-bit), no copies
+//     (the halves swap by name);
+//   * outputs are what the LDS instructions need, derived from the left half L by shift-right + and: the counter's
+//     byte address (L >> 9) & 0xFFC, the bin's (L >> 4) & 0x1FF80, payload (L << 21) | R; a window without a key
+//     gets the lane's waste counter by a sign-extended v_bfe of its validity bit + v_bitop3, no compare.
+// The waste counters start every tile at 0x8000: the rank they return fails the "< 32" test that guards the store
+// by itself, and "some real rank did not fit" is (OR of all ranks) & 0x7FE0.  Same bins, same flush, same overflow
+// path, same pool format as part1_bins32_kernel; the bins are not rotated (the address is then one v_lshl_add).
+// Window J of 16: forward field at bit 2 (15 - J) of w2:w1:w0, reverse-complement field at bit 2 (J + 12) of c2:c1:c0.
+#define KH_W21_HASH_AND_OUT \
+    "v_cmp_lt_u64_e64 s[98:99], v[120:121], v[122:123]\n" \
+    "v_cndmask_b32_e64 v120, v122, v120, s[98:99]\n" \
+    "v_cndmask_b32_e64 v121, v123, v121, s[98:99]\n" \
+    "v_alignbit_b32 v122, v121, v120, 21\n"        /* L */ \
+    "v_and_b32 v123, 0x1fffff, v120\n"             /* R */ \
+    "v_mul_u32_u24 v124, 0x3779b1, v123\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v122, v124, v122\n" \
+    "v_mul_u32_u24 v124, 0xebca77, v122\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v123, v124, v123\n" \
+    "v_mul_u32_u24 v124, 0xb2ae3d, v123\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v122, v124, v122\n" \
+    "v_mul_u32_u24 v124, 0xd4eb2f, v122\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v123, v124, v123\n" \
+    "v_lshl_or_b32 %[pay], v122, 21, v123\n"       /* L = v122, R = v123 */ \
+    "v_lshrrev_b32 v124, 9, v122\n v_and_b32 v124, 0xffc, v124\n" \
+    "v_bfe_i32 v120, %[good], %[gb], 1\n" \
+    "v_bitop3_b32 %[cnta], v120, v124, %[waste] bitop3:0xca\n" \
+    "v_lshrrev_b32 v124, 4, v122\n v_and_b32 %[binb], 0x1ff80, v124\n"
+#define KH_W21_OPERANDS \
+    : [pay] "=&v"(pay), [cnta] "=&v"(cnta), [binb] "=&v"(binb) \
+    : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [good] "v"(good), [waste] "v"(waste), \
+      [sf] "n"(SF), [sr] "n"(SR & 31), [gb] "n"(15 - J) \
+    : "v120", "v121", "v122", "v123", "v124", "s98", "s99"
+template <int J>
+__device__ __forceinline__ void p1_window21(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t c0, uint32_t c1, uint32_t c2,
+                                            uint32_t good, uint32_t waste, uint32_t &pay, uint32_t &cnta, uint32_t &binb) {
+    constexpr int SF = 2 * (15 - J), SR = 2 * (J + 12);
+    if constexpr (J <= 3) {  // both fields straddle two words at their top end
+        asm("v_alignbit_b32 v120, %[w1], %[w0], %[sf]\n v_alignbit_b32 v121, %[w2], %[w1], %[sf]\n v_and_b32 v121, 0x3ff, v121\n"
+            "v_alignbit_b32 v122, %[c1], %[c0], %[sr]\n v_alignbit_b32 v123, %[c2], %[c1], %[sr]\n v_and_b32 v123, 0x3ff, v123\n"
+            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
+    } else if constexpr (J == 4) {  // the reverse-complement field starts on a word boundary
+        asm("v_alignbit_b32 v120, %[w1], %[w0], %[sf]\n v_bfe_u32 v121, %[w1], %[sf], 10\n"
+            "v_mov_b32 v122, %[c1]\n v_and_b32 v123, 0x3ff, %[c2]\n"
+            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
+    } else if constexpr (J <= 14) {
+        asm("v_alignbit_b32 v120, %[w1], %[w0], %[sf]\n v_bfe_u32 v121, %[w1], %[sf], 10\n"
+            "v_alignbit_b32 v122, %[c2], %[c1], %[sr]\n v_bfe_u32 v123, %[c2], %[sr], 10\n"
+            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
+    } else {  // the forward field starts on a word boundary
+        asm("v_mov_b32 v120, %[w0]\n v_and_b32 v121, 0x3ff, %[w1]\n"
+            "v_alignbit_b32 v122, %[c2], %[c1], %[sr]\n v_bfe_u32 v123, %[c2], %[sr], 10\n"
+            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
+    }
+}
+// 2-bit groups of x reversed and complemented: base m of a code word (bits 31-2m..30-2m) lands, complemented, at bits 2m..2m+1
+__device__ __forceinline__ uint32_t rev2_complement(uint32_t x) {
+    const uint32_t y = __builtin_bitreverse32(~x);
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+}
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+constexpr uint32_t K21_CNT_OFF = 0;                                // 1024 counters + 64 waste counters
+constexpr uint32_t K21_BIN_OFF = (MAX_P1 + 64) * 4;                // the bins, 128 KiB
+constexpr uint32_t K21_TRASH_OFF = K21_BIN_OFF + P1B_WORDS * 4;    // one unit nobody reads
+constexpr uint32_t K21_WASTE0 = 0x8000u;
+
+template <bool QUAL>
+__global__ __launch_bounds__(PART_NT) void part1_k21_kernel(
+    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
+    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t thr, uint32_t *__restrict__ pool,
+    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
+    Counters *ctr) {
+    constexpr uint32_t k = 21, p1b = 10;
+    constexpr int HALF = CHUNK / 2;          // windows per lane per flush
+    constexpr uint32_t SEG = 16;             // payloads per 64-byte segment: what a flush writes is whole segments
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[(K21_TRASH_OFF + 16) / 4];
+    __shared__ uint32_t s_code[2][PART_NT + 2];
+    __shared__ uint16_t s_val[2][PART_NT + 2];
+    __shared__ uint32_t s_flag;              // some rank of this half-tile did not fit its bin
+    __shared__ u64 s_priv_next, s_priv_end;  // the workgroup's private range of chunk ids
+    uint32_t *const s_cnt = s_mem + K21_CNT_OFF / 4;
+    uint32_t *const s_bin = s_mem + K21_BIN_OFF / 4;
+    __attribute__((address_space(3))) char *const lds = (__attribute__((address_space(3))) char *)s_mem;
+    const int tid = threadIdx.x;
+    s_cnt[tid] = 0;
+    if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
+    if (tid == 0) {
+        s_flag = 0;
+        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
+        s_priv_end = s_priv_next + POOL_GRAB;
+    }
+    // lane tid owns partition tid: its current chunk and how full it is (a multiple of 16 until the very end)
+    u64 cur = 0;
+    uint32_t fill = CHUNK_PAY;  // "full": the first segment takes a chunk
+    uint32_t res = 0;           // payloads carried in the bin (== s_cnt[tid] between flushes)
+    bool have_chunk = false;
+    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
+    u64 te = tb + tiles_per_block;
+    if (te > tile0 + ntiles) te = tile0 + ntiles;
+    int buf = 0;
+    uint32_t lost = 0;
+    const uint32_t waste = K21_CNT_OFF + 4u * (MAX_P1 + ((uint32_t)tid & 63u));
+    uint32_t *const bin = s_bin + (uint32_t)tid * P1B_CAP;
+    __syncthreads();
+    auto take_chunk = [&](u64 &first) -> bool {
+        first = atomicAdd(&s_priv_next, 1ull);  // LDS
+        if (first + 1 > s_priv_end) first = atomicAdd(pool_next, 1ull);  // private range ran out (rare)
+        if (first + 1 > pool_chunks) return false;  // cannot happen with the host's pool sizing; never write past it
+        chunk_part[first] = (uint16_t)tid;
+        return true;
+    };
+    // Lane tid flushes partition tid, in WHOLE ALIGNED 64-BYTE SEGMENTS: tools/ubench/scatter_runs.hip measures
+    // what the memory system takes from 256 K lanes each appending to its own stream of 1-KiB chunks: 1.3 TB/s in
+    // runs of 48 bytes, 2.8 TB/s in runs of one aligned 64-byte segment (3.6 in 128-byte lines) -- and the
+    // 56-byte runs of a flush of every whole 16-byte unit, 52 GB of them per S100M batch, were the whole 37 ms of
+    // this kernel, whatever the instruction stream did.  So a partition keeps up to 15 payloads back; to have room
+    // for them in a 32-payload bin the bins are flushed twice per tile, after 8 windows per lane each (6.9
+    // arrivals per partition on average; a bin overflows once in ~10^4 partition-flushes on well-mixed input).
+    // c = what the bin's counter says (carried + new, possibly more than fit).  Returns the carried count.
+    auto flush = [&](uint32_t c) -> uint32_t {
+        const uint32_t nseg = c / SEG;                        // whole segments of the partition's run ...
+        const uint32_t bseg = min(nseg, P1B_CAP / SEG);       // ... of which in the bin (the others: slow path)
+        const uint32_t r = c % SEG;
+        uint32_t nout = nseg;                                 // segments that find room in the pool
+        u64 dst[P1B_CAP / SEG];                               // pool index of the bin's segments
+        const uint32_t space = (CHUNK_PAY - fill) / SEG;      // segments left in the current chunk
+        u64 ib = 0;                                           // first fresh chunk taken, if any (they are consecutive only
+        uint32_t ntaken = 0;                                  //   when taken by one call: here one chunk at a time)
+        // the run's segments fill the current chunk, then fresh chunks one after the other
+        u64 run_a = cur * CHUNK_PAY + fill, run_b = 0;        // run position e < 16 space goes to run_a + e, else run_b + e
+        if (nseg > space) {
+            const uint32_t need = nseg - space;               // segments beyond the current chunk
+            const uint32_t nnew = (need * SEG + CHUNK_PAY - 1) / CHUNK_PAY;
+            u64 first = 0;
+            bool ok = true;
+            if (nnew == 1) ok = take_chunk(first);
+            else {  // only a skewed batch does this: several consecutive chunks at once
+                first = atomicAdd(pool_next, (u64)nnew);
+                ok = first + nnew <= pool_chunks;
+                if (ok) for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
+            }
+            if (!ok) {
+                lost += need * SEG;
+                nout = space;
+            } else {
+                ib = first;
+                ntaken = nnew;
+                run_b = first * CHUNK_PAY - (u64)space * SEG;
+                cur = first + nnew - 1;
+                fill = need * SEG - (nnew - 1) * CHUNK_PAY;
+                have_chunk = true;
+            }
+        } else {
+            fill += nseg * SEG;
+        }
+        (void)ib; (void)ntaken;
+#pragma unroll
+        for (uint32_t sg = 0; sg < P1B_CAP / SEG; ++sg) dst[sg] = (sg < space ? run_a : run_b) + (u64)sg * SEG;
+        const uint32_t nb = min(bseg, nout);
+#pragma unroll
+        for (uint32_t sg = 0; sg < P1B_CAP / SEG; ++sg)
+            if (sg < nb) {
+                uint4 *d = reinterpret_cast<uint4 *>(pool + dst[sg]);
+                const uint4 *src = reinterpret_cast<const uint4 *>(bin + sg * SEG);
+                const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+                d[0] = x0; d[1] = x1; d[2] = x2; d[3] = x3;
+            }
+        if (c <= P1B_CAP) {
+            if (bseg) {  // what does not fill a segment moves to the front of the bin, 16 bytes at a time
+                const uint4 *src = reinterpret_cast<const uint4 *>(bin + bseg * SEG);
+                uint4 *d = reinterpret_cast<uint4 *>(bin);
+                const uint32_t nu = (r + 3u) / 4u;
+                for (uint32_t i = 0; i < nu; ++i) d[i] = src[i];
+            }
+            s_cnt[tid] = r;
+        } else {  // where the payloads that did not fit go: left in the second half of the emptied bin
+            bin[16] = (uint32_t)run_a;
+            bin[17] = (uint32_t)(run_a >> 32);
+            bin[18] = (uint32_t)run_b;
+            bin[19] = (uint32_t)(run_b >> 32);
+            bin[20] = space * SEG;  // run positions before this one go to run_a + e, the others to run_b + e
+            bin[21] = nout * SEG;   // ... if below this (less than the next only when the pool ran out)
+            bin[22] = nseg * SEG;   // end of the run's whole segments
+            // Those payloads take a second rank in the slow path, counted from -(their share of whole segments):
+            // negative = run position 16 nseg + rank, 0..14 = carried in bin slot rank; the counter ends at c % 16.
+            s_cnt[tid] = r - (c - P1B_CAP);
+        }
+        if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
+        return r;
+    };
+    // The bases are fetched and encoded ONE tile ahead, between B0 and the first flush: vmcnt counts loads and
+    // stores alike, so a wait for the prefetched bases placed after a flush (where the compiler puts it if the tile
+    // is staged at the top of the loop, or if the loaded registers are carried around the loop: it copies them at
+    // the back edge) is a wait for the acknowledgement of every store the flush has just issued.
+    {
+        const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
+        stage_encode<QUAL, PART_NT>(s_code, s_val, 0, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
+    }
+    for (u64 t = tb; t < te; ++t, buf ^= 1) {
+        __syncthreads();  // B0: tile t's codes are in s_code[buf], the previous flush is over
+        const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+        const WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
+        const uint32_t good = window_good(w, k, wlo);
+        const uint32_t w0 = (uint32_t)w.lo64, w1 = (uint32_t)(w.lo64 >> 32), w2 = w.hi;
+        const uint32_t c0 = rev2_complement(w2), c1 = rev2_complement(w1), c2 = rev2_complement(w0);
+#define KH_W21(J)                                                                                            \
+    {                                                                                                        \
+        uint32_t cnta;                                                                                       \
+        p1_window21<J>(w0, w1, w2, c0, c1, c2, good, waste, pay[(J) % HALF], cnta, binb[(J) % HALF]);        \
+        rk[(J) % HALF] = __hip_atomic_fetch_add((lds_u32 *)(lds + cnta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t omask = 0;  // bit j: window h * 8 + j has a key and its rank did not fit the bin
+            {
+                uint32_t pay[HALF], binb[HALF], rk[HALF];
+                if (h == 0) { KH_W21(0) KH_W21(1) KH_W21(2) KH_W21(3) KH_W21(4) KH_W21(5) KH_W21(6) KH_W21(7) }
+                else { KH_W21(8) KH_W21(9) KH_W21(10) KH_W21(11) KH_W21(12) KH_W21(13) KH_W21(14) KH_W21(15) }
+                uint32_t racc = 0;
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) {
+                    const uint32_t r = rk[j];
+                    *(lds_u32 *)(lds + K21_BIN_OFF + (r < P1B_CAP ? binb[j] + 4u * r : K21_TRASH_OFF - K21_BIN_OFF)) = pay[j];
+                    racc |= r;
+                }
+                if (racc & (K21_WASTE0 - P1B_CAP)) {  // a real rank (< 0x8000) of 32 or more
+                    s_flag = 1u;
+#pragma unroll
+                    for (int j = 0; j < HALF; ++j)
+                        if (rk[j] >= P1B_CAP && rk[j] < K21_WASTE0) omask |= 1u << j;
+                }
+            }
+            if (h == 1 && tid == 0 && s_priv_next + 2 * POOL_LOW > s_priv_end) {  // refill the private range (nobody takes
+                s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);               // chunks between a B0/B2 and the next B1;
+                s_priv_end = s_priv_next + POOL_GRAB;                             // a vmcnt wait here finds only old stores)
+            }
+            __syncthreads();  // B1
+            const bool slow = s_flag != 0u;  // uniform
+            if (h == 0)  // tile t + 1's codes -> the other buffer (its bases were requested at B0)
+                stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
+            res = flush(s_cnt[tid]);
+            if (slow) {
+                __syncthreads();  // B2'
+                if (omask) {  // the registers of the fast path are gone: roll over the lane's windows again
+                    Roller again;
+                    again.init(w, k, wlo);
+#pragma unroll
+                    for (int j = 0; j < CHUNK; ++j) {
+                        u64 key;
+                        again.next(j, key);
+                        if (j / HALF == h && ((omask >> (j % HALF)) & 1u)) {
+                            uint32_t p, pv;
+                            hash_p1_pay32<KH_MUL_24>(k, p1b, key, p, pv);
+                            uint32_t *const pbin = s_bin + p * P1B_CAP;
+                            const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 1u);
+                            if (r2 >= 0) {
+                                pbin[r2] = pv;
+                            } else {
+                                const u64 ra = ((u64)pbin[17] << 32) | pbin[16];
+                                const u64 rb = ((u64)pbin[19] << 32) | pbin[18];
+                                const uint32_t split = pbin[20], lim = pbin[21];
+                                const uint32_t e = pbin[22] + (uint32_t)r2;
+                                if (e < lim) pool[(e < split ? ra : rb) + e] = pv;
+                            }
+                        }
+                    }
+                }
+                if (tid == 0) s_flag = 0u;  // (everybody read it before B2'; it is set again after the next barrier)
+            }
+            if (h == 0) __syncthreads();  // B2: the first flush is over (after the second one: the next tile's B0)
+        }
+#undef KH_W21
+    }
+    __syncthreads();  // (the last slow path may have left carried payloads in other lanes' bins)
+    res = s_cnt[tid];
+    // the payloads still carried: one by one into the partition's chunk
+    if (res) {
+        bool room = true;
+        if (fill + res > CHUNK_PAY) {  // (fill is a multiple of 16, so this means fill == 256: a fresh chunk)
+            u64 first;
+            room = take_chunk(first);
+            if (room) {
+                cur = first;
+                fill = 0;
+                have_chunk = true;
+            } else {
+                lost += res;
+            }
+        }
+        if (room) {
+            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = bin[i];
             fill += res;
         }
     }
