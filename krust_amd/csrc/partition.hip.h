@@ -1558,14 +1558,12 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
     if (tid < NBK) s_cnt[tid] = 0;
     __syncthreads();
     const uint32_t n = p2_count_of<CHUNKED>(pb);
-    PT pay[PER];
-    uint32_t have = 0;  // bit j: pay[j] holds a payload
     // Element e = first + j * NT + tid of the block's input lies in chunk (e >> 8) of its chunk list, and a wave's
     // 64 lanes always share that chunk (NT and the wave's first lane are multiples of 64, chunks hold 256): chunk
     // id and fill level are wave-uniform -- read once, kept in scalar registers, the address is base + lane offset.
     const uint32_t nchk = CHUNKED ? (uint32_t)(pb.hi - pb.lo) : 0u;
     const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
-    auto load_batch = [&](uint32_t first) {
+    auto load_batch = [&](uint32_t first, PT (&pay)[PER], uint32_t &have) {  // have: bit j = pay[j] holds a payload
         have = 0;
         // lane (l mod PER) of the wave fetches the metadata of the wave's j-th chunk: ONE LDS read per wave and array
         // instead of PER; v_readlane hands every lane the j-th pair
@@ -1589,8 +1587,12 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
             }
         }
     };
-    load_batch(0);
-    for (uint32_t base = 0; base < n; base += TILE, par ^= 1u) {
+    // One batch.  `pay` holds its payloads; the NEXT batch's are requested into `nxt` after the first barrier and
+    // awaited right BEFORE this batch's units are stored: vmcnt counts loads and stores alike, so a wait for loaded
+    // payloads placed after the stores (at the top of the next batch, as it used to be) is a wait for the
+    // acknowledgement of every store just issued -- a memory round trip per batch.  Hence two register sets, used
+    // alternately.
+    auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
         const uint32_t res_old = RES0 + par * RES_SZ, res_new = RES0 + (par ^ 1u) * RES_SZ;
         uint32_t tag[PER];
 #pragma unroll
@@ -1599,6 +1601,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
         for (int j = 0; j < PER; ++j)  // all LDS rank atomics in flight before the first is consumed
             if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
         __syncthreads();
+        load_batch(base + TILE, nxt, have_nxt);
         // owner lanes: how the bucket's new payloads split into completed units and the new tail
         uint32_t c = 0, nu = 0, thr = 0, packed = 0, incl = 0;
         if (tid < NBK) {
@@ -1645,8 +1648,9 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
         }
         __syncthreads();
         if (tid < NBK) s_cnt[tid] = 0;
-        // next batch's payloads are fetched while this batch's units are written out
-        load_batch(base + TILE);
+        // (the wait for the next batch's payloads goes HERE, before the stores)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) asm volatile("" : "+v"(nxt[j]));
         // the completed units: 16 lanes per unit, carried payloads first, then the sorted run
 #if KH_ABL3 & 2  /* timing experiment: no write-out */
         const uint32_t nslots = 0;
@@ -1666,8 +1670,18 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
             obase[u.x + i] = s_buf[idx];
 #endif
         }
+        par ^= 1u;
         // (the next batch's barriers order everything: its owner lanes rewrite s_ofs / s_unit after two of them,
         //  its tails go to the array this batch has just finished reading)
+    };
+    PT payA[PER], payB[PER];
+    uint32_t haveA = 0, haveB = 0;
+    load_batch(0, payA, haveA);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) asm volatile("" : "+v"(payA[j]));  // (waited for here, so that the loop's top does not wait: it would wait for stores)
+    for (uint32_t base = 0; base < n; base += 2 * TILE) {
+        batch(base, payA, haveA, payB, haveB);
+        if (base + TILE < n) batch(base + TILE, payB, haveB, payA, haveA);
     }
     // the last, incomplete unit of every bucket: padded with sentinels (the count pass reserved the room)
     __syncthreads();
