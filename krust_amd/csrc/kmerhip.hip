@@ -611,39 +611,25 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const bool fast = sizeof(PT) == 4 && kh::p1_fast_ok(g);
             // the BASELINE configurations get kernels compiled for their k (KMERHIP_GENERIC_K=1: the generic form, for A/B)
             static const bool generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
-            // 32-bit payloads: the kernel with the 16-byte write-out (KMERHIP_P1_VEC=0: the per-payload one, for A/B)
-            static const bool vec32 = [] { const char *e = getenv("KMERHIP_P1_VEC"); return !(e && e[0] == '0'); }();
-            // ... of those, the one with fixed per-partition bins in LDS (KMERHIP_P1_BINS=0: the tile-sorting one, for A/B)
+            // 32-bit payloads: the bins kernel (KMERHIP_P1_BINS=0: the tile-sorting, per-payload-storing one, for A/B);
+            // k = 21 at the headline geometry gets the written-out window (KMERHIP_GENERIC_K=1: the C++ window)
             static const bool bins32 = [] { const char *e = getenv("KMERHIP_P1_BINS"); return !(e && e[0] == '0'); }();
-#define KH_P1_VECK(KERNEL, QUAL, MODE, FAST, KT) \
-    hipLaunchKernelGGL((kh::KERNEL<QUAL, MODE, FAST, KT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
+#define KH_P1_BINS(QUAL, MODE, FAST, ASM21) \
+    hipLaunchKernelGGL((kh::part1_bins_kernel<QUAL, MODE, FAST, ASM21>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
                        ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
                        c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
-// (with quality masking the bins kernel runs out of registers -- 20-odd VGPRs spilled -- and loses to the tile-sorting
-// one, 44.7 vs 41.1 ms on S100M -Q 20: it is not instantiated for that)
-#define KH_P1_VEC(QUAL, MODE, FAST, KT) \
-    do { if (bins32 && !QUAL) KH_P1_VECK(part1_bins32_kernel, false, MODE, FAST, KT); else KH_P1_VECK(part1_vec32_kernel, QUAL, MODE, FAST, KT); } while (0)
-            if (sizeof(PT) == 4 && vec32) {
+            if (sizeof(PT) == 4 && bins32) {
                 const bool k21 = !generic_k && c->k == 21 && fast && g.p1_bits == 10;
-                // k = 21 at the headline geometry: the kernel with the hand-written window sequence (KMERHIP_P1_K21=0: off, for A/B)
-                static const bool k21asm = [] { const char *e = getenv("KMERHIP_P1_K21"); return !(e && e[0] == '0'); }();
-#define KH_P1_K21(QUAL) \
-    hipLaunchKernelGGL((kh::part1_k21_kernel<QUAL>), g1, b1, 0, c->stream, ra.abase, ra.qbase, ra.qaligned, ra.vbeg, ra.vend, \
-                       ra.wlo, tile0, ntiles, tpb, thr, (uint32_t *)c->keysA, c->chunk_part, c->fill8, c->pool_next, \
-                       pool_chunks, c->d_ctr)
-                if (k21 && k21asm && bins32 && g.shard_shift == 0) {
-                    if (ra.use_qual) KH_P1_K21(true);
-                    else KH_P1_K21(false);
-                } else if (k21 && ra.use_qual) KH_P1_VEC(true, KH_MUL_24, true, 21);
-                else if (k21) KH_P1_VEC(false, KH_MUL_24, true, 21);
-                else if (ra.use_qual && m24 && fast) KH_P1_VEC(true, KH_MUL_24, true, 0);
-                else if (ra.use_qual && m24) KH_P1_VEC(true, KH_MUL_24, false, 0);
-                else if (ra.use_qual && fast) KH_P1_VEC(true, KH_MUL_32, true, 0);
-                else if (ra.use_qual) KH_P1_VEC(true, KH_MUL_32, false, 0);
-                else if (m24 && fast) KH_P1_VEC(false, KH_MUL_24, true, 0);
-                else if (m24) KH_P1_VEC(false, KH_MUL_24, false, 0);
-                else if (fast) KH_P1_VEC(false, KH_MUL_32, true, 0);
-                else KH_P1_VEC(false, KH_MUL_32, false, 0);
+                if (k21 && ra.use_qual) KH_P1_BINS(true, KH_MUL_24, true, true);
+                else if (k21) KH_P1_BINS(false, KH_MUL_24, true, true);
+                else if (ra.use_qual && m24 && fast) KH_P1_BINS(true, KH_MUL_24, true, false);
+                else if (ra.use_qual && m24) KH_P1_BINS(true, KH_MUL_24, false, false);
+                else if (ra.use_qual && fast) KH_P1_BINS(true, KH_MUL_32, true, false);
+                else if (ra.use_qual) KH_P1_BINS(true, KH_MUL_32, false, false);
+                else if (m24 && fast) KH_P1_BINS(false, KH_MUL_24, true, false);
+                else if (m24) KH_P1_BINS(false, KH_MUL_24, false, false);
+                else if (fast) KH_P1_BINS(false, KH_MUL_32, true, false);
+                else KH_P1_BINS(false, KH_MUL_32, false, false);
             } else if (!generic_k && c->k == 21 && sizeof(PT) == 4 && fast && g.p1_bits == 10) {
                 if (ra.use_qual) KH_P1_LAUNCH(true, KH_MUL_24, true, 21);
                 else KH_P1_LAUNCH(false, KH_MUL_24, true, 21);
@@ -654,7 +640,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             else if (ra.use_qual) KH_P1_LAUNCH2(true, KH_MUL_32);
             else if (m24) KH_P1_LAUNCH2(false, KH_MUL_24);
             else KH_P1_LAUNCH2(false, KH_MUL_32);
-#undef KH_P1_VEC
+#undef KH_P1_BINS
 #undef KH_P1_LAUNCH2
 #undef KH_P1_LAUNCH
         }

@@ -402,466 +402,66 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
 }
 
-// ---------------------------------------------------------------------------------------------
-// level 1 for 32-bit payloads with a VECTOR write-out: four payloads (16 bytes) per store
-// ---------------------------------------------------------------------------------------------
-// Timing experiments on the kernel above (tools/p1_ablation.sh, S100M): of its 42 ms the write-out costs 9.6
-// (5.5 the global stores -- 64 lanes x 4 bytes into four or five different lines per instruction --, 4.1 its
-// LDS reads: payload, partition id, split point, 16-byte destination pair PER PAYLOAD) and the rank atomics 5.4
-// (every ds_add_rtn in its own exec-masked block, i.e. sixteen serialised LDS round trips per tile).  Here
-//   * the ranks are taken branch-free when there is no quality masking: a window without a key bumps one of 64
-//     waste counters (one per lane of a wave, so they never pile up on one address), and the sixteen atomics of
-//     a lane go out back to back with a single wait;
-//   * every partition's run is written in units of four payloads: the <= 3 that do not fill a unit stay behind
-//     in LDS (s_res) and lead the partition's next run, so chunk fill levels are multiples of four and every
-//     store is an aligned global_store_dwordx4 fed by one ds_read_b128;
-//   * the write-out is done BY THE LANE THAT OWNS THE PARTITION (lane tid <-> partition tid): where the run
-//     lies in the sorted tile, how many whole units it has, the current chunk and the freshly taken ones are
-//     all in that lane's registers, so the loop is ds_read_b128 + global_store_dwordx4 and nothing else (the
-//     unit -> partition map, the split points and the destination pairs of the earlier form, and their
-//     ~36 instructions per unit, are gone).  A run is ~3.5 units, the loop runs to the wave's longest (~7).
-// The sorted tile keeps every partition's region 16-byte aligned (regions are padded to whole units: 88 KB).
-// What a workgroup still holds at the end goes out payload by payload.  Same chunk pool, same reader.
-constexpr int P1V_SCAP = PART_NT * CHUNK + 6 * (int)MAX_P1;  // sorted tile: payloads + residues (<= 3) + padding (<= 3) per partition
-constexpr uint32_t P1V_NOKEY = (uint32_t)MAX_P1 << 16;       // tags from here up: window without a key
-
-template <bool QUAL, int MODE, bool FAST, int KT>
-__global__ __launch_bounds__(PART_NT) void part1_vec32_kernel(
-    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
-    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
-    Counters *ctr) {
-    __shared__ uint32_t s_code[2][PART_NT + 2];
-    __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[P1V_SCAP + 4];  // 88 KiB (+ a trash unit)
-    __shared__ uint32_t s_cnt[MAX_P1 + 64];        // + the waste counters
-    __shared__ uint16_t s_lofv[MAX_P1];            // first unit of the partition's region
-    __shared__ uint32_t s_res[3][MAX_P1];          // the <= 3 payloads carried to the partition's next run
-    __shared__ uint32_t s_wsum[PART_NT / 64];
-    __shared__ u64 s_priv_next, s_priv_end;        // the workgroup's private range of chunk ids
-    const int tid = threadIdx.x;
-    if (KT) k = KT;
-    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
-    s_cnt[tid] = 0;
-    if (tid < 64) s_cnt[MAX_P1 + tid] = 0;
-    if (tid == 0) {
-        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-        s_priv_end = s_priv_next + POOL_GRAB;
-    }
-    // lane tid owns partition tid: its current chunk, how full it is (a multiple of 4), its carried payloads
-    u64 cur = 0;
-    uint32_t fill = CHUNK_PAY;  // "full": the first unit takes a chunk
-    uint32_t res = 0;
-    bool have_chunk = false;
-    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
-    u64 te = tb + tiles_per_block;
-    if (te > tile0 + ntiles) te = tile0 + ntiles;
-    int buf = 0;
-    uint32_t lost = 0;
-    const uint32_t nokey = P1V_NOKEY + ((uint32_t)(tid & 63) << 16);
-    __syncthreads();
-    // takes `nnew` consecutive chunk ids for this lane's partition; false if the pool is exhausted
-    auto take_chunks = [&](uint32_t nnew, u64 &first) -> bool {
-        first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
-        if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
-        if (first + nnew > pool_chunks) return false;  // cannot happen with the host's pool sizing; never write past it
-        for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
-        return true;
-    };
-    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
-    for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
-        Roller roll;
-        roll.init(w, k, wlo);
-        uint32_t pay[CHUNK], tag[CHUNK];  // tag = (p1 << 16) | rank-in-partition; >= P1V_NOKEY: no key
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j) {
-            u64 key;
-            const bool ok = roll.next(j, key);
-            uint32_t p1 = 0;
-            pay[j] = 0;
-            if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
-                if (FAST) {
-                    hash_p1_pay32<MODE>(k, p1b, key, p1, pay[j]);
-                } else {
-                    const u64 H = part_hash<MODE>(g, key);
-                    pay[j] = Pay<uint32_t>::make(key, H, g);
-                    p1 = p1_of_hash(H, g);
-                }
-            }
-            tag[j] = ok ? (p1 << 16) : nokey;
-        }
-#pragma unroll
-        for (int j = 0; j < CHUNK; ++j)  // with -Q ~40 % of the windows have no key: there the branch pays
-            if (!QUAL || tag[j] < P1V_NOKEY) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
-        __syncthreads();
-        // regions in whole units: exclusive scan of ceil((new + carried) / 4) over the 1024 partitions
-        const uint32_t c = s_cnt[tid];
-        const uint32_t tot = c + res;
-        const uint32_t szv = (tot + 3u) >> 2;
-        uint32_t incl = szv;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t nb = __shfl_up(incl, off, 64);
-            if ((tid & 63) >= off) incl += nb;
-        }
-        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t lofv = incl - szv;
-        for (int q = 0; q < (tid >> 6); ++q) lofv += s_wsum[q];
-        s_lofv[tid] = (uint16_t)lofv;
-        s_cnt[tid] = 0;  // (everybody has read its count; the next atomics come after the next tile's barriers)
-        if (!QUAL && tid < 64) s_cnt[MAX_P1 + tid] = 0;
-        __syncthreads();
-        {  // branch-free staging: every lane reads its region starts back to back, then stores
-            uint32_t rs[CHUNK];
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j) rs[j] = 4u * (uint32_t)s_lofv[(tag[j] >> 16) & (MAX_P1 - 1)];
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j)
-                s_stage[tag[j] < P1V_NOKEY ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)P1V_SCAP] = pay[j];
-        }
-        // lane tid places partition tid's run: nvec whole units, the first `spacev` of them into the current chunk
-        // at pool index ia, the others into freshly taken, consecutive chunks at pool index ib
-        const uint32_t nvec = tot >> 2;
-        uint32_t nout = nvec;
-        const uint32_t spacev = (CHUNK_PAY - fill) >> 2;
-        const u64 ia = cur * CHUNK_PAY + fill;
-        u64 ib = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 3; ++i)  // the carried payloads follow the new ones
-            if (i < res) s_stage[4u * lofv + c + i] = s_res[i][tid];
-        if (nvec > spacev) {
-            const uint32_t r = 4u * (nvec - spacev);
-            const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
-            u64 first;
-            if (!take_chunks(nnew, first)) {
-                lost += r;
-                nout = spacev;
-            } else {
-                ib = first * CHUNK_PAY;
-                cur = first + nnew - 1;
-                fill = r - (nnew - 1) * CHUNK_PAY;
-                have_chunk = true;
-            }
-        } else {
-            fill += 4u * nvec;
-        }
-        __syncthreads();
-        res = tot & 3u;
-#pragma unroll
-        for (uint32_t i = 0; i < 3; ++i)  // what does not fill a unit waits for the next tile
-            if (i < res) s_res[i][tid] = s_stage[4u * (lofv + nvec) + i];
-        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next tile
-            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-            s_priv_end = s_priv_next + POOL_GRAB;
-        }
-        // next tile's bases are fetched while this tile's runs are written out
-        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(&s_stage[4u * lofv]);
-            uint4 *da = reinterpret_cast<uint4 *>(pool + ia);
-            uint4 *db = reinterpret_cast<uint4 *>(pool + ib) - spacev;
-            for (uint32_t i = 0; i < nout; ++i) (i < spacev ? da : db)[i] = src[i];
-        }
-        // (s_stage / s_res are rewritten only after the next tile's barriers)
-    }
-    // the payloads still carried: one by one into the partition's chunk
-    if (res) {
-        bool room = true;
-        if (fill + res > CHUNK_PAY) {  // (fill is a multiple of 4, so this means fill == 256: a fresh chunk)
-            u64 first;
-            room = take_chunks(1u, first);
-            if (room) {
-                cur = first;
-                fill = 0;
-                have_chunk = true;
-            } else {
-                lost += res;
-            }
-        }
-        if (room) {
-            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = s_res[i][tid];
-            fill += res;
-        }
-    }
-    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
-    const u64 l = wave_sum((u64)lost);
-    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
-}
+constexpr uint32_t P1B_CAP = 32;                 // payloads per partition bin
+constexpr uint32_t P1B_WORDS = MAX_P1 * P1B_CAP;   // 128 KiB
 
 // ---------------------------------------------------------------------------------------------
-// level 1 for 32-bit payloads with DIRECT BINS: rank, store, flush -- two barriers per tile
+// level 1 for 32-bit payloads: per-partition BINS in LDS, flushed in whole aligned 64-byte segments
 // ---------------------------------------------------------------------------------------------
-// The kernel above sorts every tile in LDS: rank atomics, barrier, scan of the 1024 counts (two more barriers),
-// a lookup of the region start per payload, barrier, write-out.  Its SQ counters (profiles/README.md r02a) say the
-// VALU issue (65 % of the tile time) and the LDS pipeline (34 %) do not overlap, and a fifth of both is that
-// bookkeeping.  Here every partition has a FIXED bin of P1B_CAP = 32 payloads (eight 16-byte units; 128 KiB for
-// the 1024 partitions, which is what LDS there is): a payload's place is bin(p) + rank, known the moment the rank
-// atomic returns, so there is no scan, no region table, no second pass over the tags:
-//     B0  (inside stage_tile_raw: the tile's 2-bit codes are in LDS)
-//     extraction + hash; rank = atomicAdd(&s_cnt[p], 1); s_bin[p][rank] = payload
-//     B1
-//     lane p (owner of partition p): whole units of its bin -> the partition's chunk (ds_read_b128 +
-//     global_store_dwordx4); the <= 3 payloads left over move to the front of the bin; s_cnt[p] = that count
-// A tile brings 13.8 payloads per partition on average, so with the carried <= 3 a bin overflows about once in
-// 10^4 partition-tiles on well-mixed input -- and always on skewed input (a homopolymer run sends 16384 payloads
-// of a tile to ONE partition).  Overflow is exact, not a fallback to another kernel: a rank >= 32 raises s_flag;
-// after B1 the owner, which sees the partition's full count c, reserves room for all c >> 2 units in the
-// partition's chunk sequence as usual, flushes the bin's 8 units, and leaves in the (now free) bin where the
-// others go; one more barrier (B2, taken only in such tiles), then the payloads whose rank was >= 32 store
-// themselves, 4 bytes each.  They do not keep payload and rank in registers across the flush (that is 32 VGPRs of
-// a 128-VGPR budget, for a path well-mixed input never takes): a lane remembers WHICH of its windows they were
-// (16 bits), rolls over its windows again, and takes a second rank from the same counter, which the owner has
-// restarted at -(whole units' worth of them): a negative rank is a position in the run, 0..2 a carried payload's
-// bin slot, and the counter ends at c & 3 as it must.  Chunk fill levels stay multiples of four: same pool
-// format, same reader.
-// Bank spread: the units of bin p are rotated by p & 7 (payload r sits at word (r + 4 (p & 7)) mod 32), so
-// equal ranks of different partitions do not pile up on one bank (37.3 vs 37.6 ms without).
-#ifndef KH_P1B_GROUP
-#define KH_P1B_GROUP 4
-#endif
-constexpr uint32_t P1B_CAP = 32;
-constexpr uint32_t P1B_WORDS = MAX_P1 * P1B_CAP;
-__device__ __forceinline__ uint32_t p1b_slot(uint32_t p, uint32_t r) {
-    return p * P1B_CAP + ((r + 4u * (p & 7u)) & (P1B_CAP - 1u));
-}
-
-template <bool QUAL, int MODE, bool FAST, int KT>
-__global__ __launch_bounds__(PART_NT) void part1_bins32_kernel(
-    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
-    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
-    Counters *ctr) {
-    __shared__ uint32_t s_code[2][PART_NT + 2];
-    __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ __attribute__((aligned(16))) uint32_t s_bin[P1B_WORDS + 4];  // 128 KiB (+ a trash unit)
-    __shared__ uint32_t s_cnt[MAX_P1 + 64];  // payloads in the bin; + one waste counter per lane of a wave (windows without a key)
-    __shared__ uint32_t s_flag;              // some rank of this tile did not fit its bin
-    __shared__ u64 s_priv_next, s_priv_end;  // the workgroup's private range of chunk ids
-    const int tid = threadIdx.x;
-    if (KT) k = KT;
-    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
-    s_cnt[tid] = 0;
-    if (tid < 64) s_cnt[MAX_P1 + tid] = 0;
-    if (tid == 0) {
-        s_flag = 0;
-        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-        s_priv_end = s_priv_next + POOL_GRAB;
-    }
-    // lane tid owns partition tid: its current chunk and how full it is (a multiple of 4)
-    u64 cur = 0;
-    uint32_t fill = CHUNK_PAY;  // "full": the first unit takes a chunk
-    uint32_t res = 0;           // payloads carried in the bin (== s_cnt[tid] between tiles)
-    bool have_chunk = false;
-    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
-    u64 te = tb + tiles_per_block;
-    if (te > tile0 + ntiles) te = tile0 + ntiles;
-    int buf = 0;
-    uint32_t lost = 0;
-    const uint32_t nokey = (uint32_t)(MAX_P1 + (tid & 63)) << 16;
-    const uint32_t rot = (uint32_t)tid & 7u;
-    __syncthreads();
-    auto take_chunks = [&](uint32_t nnew, u64 &first) -> bool {
-        first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
-        if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
-        if (first + nnew > pool_chunks) return false;  // cannot happen with the host's pool sizing; never write past it
-        for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
-        return true;
-    };
-    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
-    for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
-        // (past B0 every lane has finished the previous tile's flush: nobody is taking chunks right now)
-        if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for this tile's flush
-            s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-            s_priv_end = s_priv_next + POOL_GRAB;
-        }
-        Roller roll;
-        roll.init(w, k, wlo);
-        // In groups of KH_P1B_GROUP windows: hash a group, send its rank atomics, and only then store the previous
-        // group's payloads -- whose ranks have come back while this group was being hashed.
-        uint32_t pay[CHUNK], tag[CHUNK];  // tag = (p1 << 16) | rank; p1 >= MAX_P1: no key
-        uint32_t rk[CHUNK];               // (kept apart from the tag until the store: nothing waits for the atomic before that)
-        uint32_t rmax = 0, omask = 0;     // omask bit j: window j has a key and its rank did not fit the bin
-        auto store_group = [&](int j0) {
-#pragma unroll
-            for (int j = j0; j < j0 + KH_P1B_GROUP; ++j) {
-                const uint32_t r = rk[j];
-                const bool valid = tag[j] < P1V_NOKEY;
-                s_bin[valid && r < P1B_CAP ? p1b_slot(tag[j] >> 16, r) : P1B_WORDS] = pay[j];
-                rmax = max(rmax, valid ? r : 0u);
-                tag[j] |= r;
-            }
-        };
-#pragma unroll
-        for (int j0 = 0; j0 < CHUNK; j0 += KH_P1B_GROUP) {
-#pragma unroll
-            for (int j = j0; j < j0 + KH_P1B_GROUP; ++j) {
-                u64 key;
-                const bool ok = roll.next(j, key);
-                uint32_t p1 = 0;
-                pay[j] = 0;
-                if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
-                    if (FAST) {
-                        hash_p1_pay32<MODE>(k, p1b, key, p1, pay[j]);
-                    } else {
-                        const u64 H = part_hash<MODE>(g, key);
-                        pay[j] = Pay<uint32_t>::make(key, H, g);
-                        p1 = p1_of_hash(H, g);
-                    }
-                }
-                tag[j] = ok ? (p1 << 16) : nokey;
-            }
-#pragma unroll
-            for (int j = j0; j < j0 + KH_P1B_GROUP; ++j)  // with -Q ~40 % of the windows have no key: there the branch pays
-                rk[j] = (!QUAL || tag[j] < P1V_NOKEY) ? atomicAdd(&s_cnt[tag[j] >> 16], 1u) : 0u;
-            if (j0) store_group(j0 - KH_P1B_GROUP);
-        }
-        store_group(CHUNK - KH_P1B_GROUP);
-        if (rmax >= P1B_CAP) {
-            s_flag = 1u;
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j)
-                if (tag[j] < P1V_NOKEY && (tag[j] & 0xFFFFu) >= P1B_CAP) omask |= 1u << j;
-        }
-        __syncthreads();  // B1
-        const bool slow = s_flag != 0u;  // uniform
-        // next tile's bases are fetched while this tile's bins are flushed
-        raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        {   // lane tid flushes partition tid
-            const uint32_t c = s_cnt[tid];  // carried + new
-            const uint32_t nvt = c >> 2;    // whole units of the partition's run, the first min(nvt, 8) of them in the bin
-            const uint32_t binv = min(nvt, P1B_CAP / 4u);
-            uint32_t nout = nvt;
-            const uint32_t spacev = (CHUNK_PAY - fill) >> 2;
-            const u64 ia = cur * CHUNK_PAY + fill;
-            u64 ib = 0;
-            if (nvt > spacev) {
-                const uint32_t r = 4u * (nvt - spacev);
-                const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
-                u64 first;
-                if (!take_chunks(nnew, first)) {
-                    lost += r;
-                    nout = spacev;
-                } else {
-                    ib = first * CHUNK_PAY;
-                    cur = first + nnew - 1;
-                    fill = r - (nnew - 1) * CHUNK_PAY;
-                    have_chunk = true;
-                }
-            } else {
-                fill += 4u * nvt;
-            }
-            uint4 *da = reinterpret_cast<uint4 *>(pool + ia);
-            uint4 *db = reinterpret_cast<uint4 *>(pool + ib) - spacev;
-            const uint32_t nb = min(binv, nout);
-            for (uint32_t u = 0; u < nb; ++u)
-                (u < spacev ? da : db)[u] = *reinterpret_cast<const uint4 *>(&s_bin[(uint32_t)tid * P1B_CAP + 4u * ((u + rot) & 7u)]);
-            res = c & 3u;
-            if (c <= P1B_CAP) {
-                if (binv)  // the payloads that do not fill a unit move to the front of the bin
-                    for (uint32_t i = 0; i < res; ++i) s_bin[p1b_slot(tid, i)] = s_bin[p1b_slot(tid, 4u * binv + i)];
-            } else {  // where the payloads that did not fit go: left in units 2 and 3 of the emptied bin
-                const u64 a = ia, b2 = ib - 4u * spacev;
-                s_bin[p1b_slot(tid, 8)] = (uint32_t)a;
-                s_bin[p1b_slot(tid, 9)] = (uint32_t)(a >> 32);
-                s_bin[p1b_slot(tid, 10)] = (uint32_t)b2;
-                s_bin[p1b_slot(tid, 11)] = (uint32_t)(b2 >> 32);
-                s_bin[p1b_slot(tid, 12)] = 4u * spacev;  // run positions before this one go to a + e, the others to b2 + e
-                s_bin[p1b_slot(tid, 13)] = 4u * nout;    // ... if below this (less than 4 nvt only when the pool ran out)
-                s_bin[p1b_slot(tid, 14)] = 4u * nvt;     // end of the run's whole units
-            }
-            // Those payloads take a second rank in the slow path below, counted from -(their share of whole units):
-            // negative = run position 4 nvt + rank, 0..2 = carried in bin slot rank; and the counter ends at c & 3.
-            s_cnt[tid] = c <= P1B_CAP ? res : res - (c - P1B_CAP);
-        }
-        if (slow) {
-            __syncthreads();  // B2
-            if (omask) {  // the registers of the fast path are gone: roll over the lane's windows again
-                Roller again;
-                again.init(w, k, wlo);
-#pragma unroll
-                for (int j = 0; j < CHUNK; ++j) {
-                    u64 key;
-                    again.next(j, key);
-                    if ((omask >> j) & 1u) {
-                        uint32_t p, pv;
-                        if (FAST) {
-                            hash_p1_pay32<MODE>(k, p1b, key, p, pv);
-                        } else {
-                            const u64 H = part_hash<MODE>(g, key);
-                            pv = Pay<uint32_t>::make(key, H, g);
-                            p = p1_of_hash(H, g);
-                        }
-                        const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 1u);
-                        if (r2 >= 0) {
-                            s_bin[p1b_slot(p, (uint32_t)r2)] = pv;
-                        } else {
-                            const u64 a = ((u64)s_bin[p1b_slot(p, 9)] << 32) | s_bin[p1b_slot(p, 8)];
-                            const u64 b2 = ((u64)s_bin[p1b_slot(p, 11)] << 32) | s_bin[p1b_slot(p, 10)];
-                            const uint32_t split = s_bin[p1b_slot(p, 12)], lim = s_bin[p1b_slot(p, 13)];
-                            const uint32_t e = s_bin[p1b_slot(p, 14)] + (uint32_t)r2;
-                            if (e < lim) pool[(e < split ? a : b2) + e] = pv;
-                        }
-                    }
-                }
-            }
-            if (tid == 0) s_flag = 0u;  // (everybody read it before B2; the next tile sets it after its B0)
-        }
-        // (bins, counts and flag are touched again only after the next tile's B0)
-    }
-    __syncthreads();  // (the last tile's slow path may have left carried payloads in other lanes' bins)
-    // the payloads still carried: one by one into the partition's chunk
-    if (res) {
-        bool room = true;
-        if (fill + res > CHUNK_PAY) {  // (fill is a multiple of 4, so this means fill == 256: a fresh chunk)
-            u64 first;
-            room = take_chunks(1u, first);
-            if (room) {
-                cur = first;
-                fill = 0;
-                have_chunk = true;
-            } else {
-                lost += res;
-            }
-        }
-        if (room) {
-            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = s_bin[p1b_slot(tid, i)];
-            fill += res;
-        }
-    }
-    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
-    const u64 l = wave_sum((u64)lost);
-    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 1 for k = 21 at the headline geometry (1024 partitions, 32-bit payloads): the bins kernel with the
-// per-window instruction sequence WRITTEN OUT
-// ---------------------------------------------------------------------------------------------
-// tools/ubench/valu_rates.hip measured what gfx950's VALU instructions cost per wave (cycles at 2.4 GHz, 4 waves
-// per SIMD): v_xor/and/or/add/sub/lshrrev/mov/not and v_bitop3 ~2.9; v_lshlrev, v_min/max, v_bfe, v_alignbit, every
-// fused three-operand form, every multiply (24- and 32-bit alike) ~4.9; v_cmp ~5.5; a v_cndmask on a mask in an SGPR
-// pair ~3.4; and a v_cndmask reading a VCC that the instruction before it did not just write ~20 (so the usual
-// "v_cmp_lt_u64 vcc; v_cndmask; v_cndmask" of a 64-bit min costs 27).  The compiler's code for a window of the
-// bins kernel adds up to ~215 such cycles, ~60 instructions: rolling both strands through registers, a second
-// VCC read in the canonical choice, left shifts and compares for tags and slot addresses.  Here the window is
-// ~27 instructions, ~105 cycles, in one asm statement per window (the compiler schedules the sixteen as units
-// and allocates everything but eight scratch registers):
-//   * no rolling state: the lane's 48 bases are three words (w2:w1:w0, first base in the top bits) and their
-//     reverse complements three more (c2:c1:c0 = 2-bit groups reversed and inverted, made once per tile), and
-//     BOTH strands of window J are 42-bit fields of those at fixed offsets: v_alignbit + v_bfe each;
-//   * canonical choice: v_cmp_lt_u64 into an SGPR pair, two v_cndmask on it;
-//   * Feistel rounds of v_mul_u32_u24, v_lshrrev, v_xor -- no masks (21-bit halves stay 21-bit), no copies
-//     (the halves swap by name);
-//   * outputs are what the LDS instructions need, derived from the left half L by shift-right + and: the counter's
-//     byte address (L >> 9) & 0xFFC, the bin's (L >> 4) & 0x1FF80, payload (L << 21) | R; a window without a key
-//     gets the lane's waste counter by a sign-extended v_bfe of its validity bit + v_bitop3, no compare.
-// The waste counters start every tile at 0x8000: the rank they return fails the "< 32" test that guards the store
-// by itself, and "some real rank did not fit" is (OR of all ranks) & 0x7FE0.  Same bins, same flush, same overflow
-// path, same pool format as part1_bins32_kernel; the bins are not rotated (the address is then one v_lshl_add).
-// Window J of 16: forward field at bit 2 (15 - J) of w2:w1:w0, reverse-complement field at bit 2 (J + 12) of c2:c1:c0.
+// What this kernel is shaped by was measured, not assumed (profiles/README.md r02c; tools/ubench/):
+//  (1) THE STORE PATTERN.  scatter_runs.hip: 256 K lanes each appending to its own stream of 1-KiB pool chunks reach
+//      1.3 TB/s in runs of 48 bytes and 2.8 TB/s in runs of one ALIGNED 64-BYTE SEGMENT (3.6 in 128-byte lines).  The
+//      earlier level-1 kernels flushed every whole 16-byte unit of a partition every tile -- runs of ~56 bytes, 52 GB
+//      of them per S100M batch: that was their whole 37 ms, whatever the instruction stream did.  Here a partition's
+//      payloads collect in a 32-payload bin (128 KiB for 1024 partitions, which is what LDS there is), a flush writes
+//      whole segments (16 payloads) and keeps up to 15 back, and to leave room for those the bins are flushed TWICE
+//      per tile, after 8 windows per lane each (6.9 arrivals per partition on average: a bin overflows once in ~10^4
+//      partition-flushes on well-mixed input).
+//  (2) vmcnt COUNTS LOADS AND STORES ALIKE.  A wait for prefetched bases that sits after the flush -- where the
+//      compiler puts it when the tile is staged at the top of the loop, or when the loaded registers are carried
+//      around the loop (it copies them at the back edge) -- is a wait for the acknowledgement of every store just
+//      issued.  So the next tile's bases are requested right after B0 and encoded into the other code buffer right
+//      after the first B1 of the same iteration, before any store of it.
+//  (3) No sorting pass: a payload's place is bin(p) + rank, known when the rank atomic returns -- no scan of the
+//      1024 counts, no region table, two barriers per flush:
+//          B0/B2  (codes staged / previous flush over)
+//          8 windows: hash; rank = atomicAdd(&s_cnt[p], 1); s_bin[p][rank] = payload
+//          B1
+//          lane p (owner of partition p): whole segments of its bin -> the partition's chunk; the <= 15 payloads left
+//          over move to the front of the bin; s_cnt[p] = that count
+//      A window without a key bumps one of 64 waste counters (one per lane of a wave) that start every flush at
+//      0x8000: the rank they return fails the "< 32" test that guards the store by itself, and "some real rank did
+//      not fit" is (OR of all ranks) & 0x7FE0.
+//  (4) Overflow is exact, not a fallback to another kernel -- and it is the normal case on skewed input (a
+//      homopolymer run sends a tile's 16384 payloads to ONE partition): a real rank >= 32 raises s_flag; after B1 the
+//      owner, which sees the partition's full count c, reserves room for all c / 16 segments in the partition's chunk
+//      sequence as usual, flushes the bin's two, and leaves in the (now free) bin where the others go; one more
+//      barrier (taken only then), and the payloads that did not fit store themselves, 4 bytes each.  They do not keep
+//      payload and rank in registers across the flush: a lane remembers WHICH of its windows they were, rolls over its
+//      windows again and takes a second rank from the same counter, which the owner has restarted at -(whole
+//      segments' worth of them): a negative rank is a position in the run, 0..14 a carried payload's bin slot, and
+//      the counter ends at c % 16 as it must.  Chunk fill levels stay multiples of 16 until the end of the kernel:
+//      same pool format, same reader.
+//  (5) THE INSTRUCTION STREAM, for k = 21 at the headline geometry (1024 partitions).  valu_rates.hip: per wave, at
+//      4 waves per SIMD, v_xor/and/or/add/sub/lshrrev/mov/not and v_bitop3 cost ~2.9 cycles; v_lshlrev, v_min/max,
+//      v_bfe, v_alignbit, every fused three-operand form and every multiply (24- and 32-bit alike) ~4.9; v_cmp ~5.5;
+//      a v_cndmask on a mask in an SGPR pair ~3.4; a v_cndmask reading a VCC that the instruction before it did not
+//      just write ~20 (the usual "v_cmp_lt_u64 vcc; v_cndmask; v_cndmask" of a 64-bit min: 27).  The compiler's code
+//      for a window adds up to ~215 such cycles, ~60 instructions (both strands rolled through registers, a second VCC
+//      read in the canonical choice, left shifts and compares for tags and addresses).  Written out it is ~27
+//      instructions, ~105 cycles, one asm statement per window (the compiler schedules the sixteen as units and
+//      allocates everything but five scratch registers):
+//        * no rolling state: the lane's 48 bases are three words (w2:w1:w0, first base in the top bits) and their
+//          reverse complements three more (c2:c1:c0 = 2-bit groups reversed and inverted, made once per tile); BOTH
+//          strands of window J are 42-bit fields of those at fixed offsets (forward: bit 2 (15 - J); reverse
+//          complement: bit 2 (J + 12)): v_alignbit + v_bfe each;
+//        * canonical choice: v_cmp_lt_u64 into an SGPR pair, two v_cndmask on it;
+//        * Feistel rounds of v_mul_u32_u24, v_lshrrev, v_xor: no masks (21-bit halves stay 21-bit), no copies (the
+//          halves swap by name);
+//        * outputs are what the LDS instructions need, derived from the left half L by shift-right + and: the
+//          counter's byte address (L >> 9) & 0xFFC, the bin's (L >> 4) & 0x1FF80, payload (L << 21) | R; a window
+//          without a key gets the lane's waste counter by a sign-extended v_bfe of its validity bit + v_bitop3.
+//      Other k / other geometries take the same kernel with the window in C++ (Roller + hash_p1_pay32).
 #define KH_W21_HASH_AND_OUT \
     "v_cmp_lt_u64_e64 s[98:99], v[120:121], v[122:123]\n" \
     "v_cndmask_b32_e64 v120, v122, v120, s[98:99]\n" \
@@ -916,13 +516,15 @@ constexpr uint32_t K21_BIN_OFF = (MAX_P1 + 64) * 4;                // the bins, 
 constexpr uint32_t K21_TRASH_OFF = K21_BIN_OFF + P1B_WORDS * 4;    // one unit nobody reads
 constexpr uint32_t K21_WASTE0 = 0x8000u;
 
-template <bool QUAL>
-__global__ __launch_bounds__(PART_NT) void part1_k21_kernel(
+// ASM21: the written-out window (k = 21, 1024 partitions, no shard shift); otherwise MODE / FAST as in
+// part1_scatter_chunked_kernel, k and the geometry are run-time values.
+template <bool QUAL, int MODE, bool FAST, bool ASM21>
+__global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
     const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t thr, uint32_t *__restrict__ pool,
+    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k_rt, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
     uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
     Counters *ctr) {
-    constexpr uint32_t k = 21, p1b = 10;
+    const uint32_t k = ASM21 ? 21u : k_rt, p1b = ASM21 ? 10u : g.p1_bits;
     constexpr int HALF = CHUNK / 2;          // windows per lane per flush
     constexpr uint32_t SEG = 16;             // payloads per 64-byte segment: what a flush writes is whole segments
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[(K21_TRASH_OFF + 16) / 4];
@@ -1054,11 +656,32 @@ __global__ __launch_bounds__(PART_NT) void part1_k21_kernel(
         const WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
         const uint32_t good = window_good(w, k, wlo);
         const uint32_t w0 = (uint32_t)w.lo64, w1 = (uint32_t)(w.lo64 >> 32), w2 = w.hi;
-        const uint32_t c0 = rev2_complement(w2), c1 = rev2_complement(w1), c2 = rev2_complement(w0);
+        const uint32_t c0 = ASM21 ? rev2_complement(w2) : 0u, c1 = ASM21 ? rev2_complement(w1) : 0u, c2 = ASM21 ? rev2_complement(w0) : 0u;
+        Roller roll;  // (the C++ window rolls through the lane's 16 windows in order, across both halves)
+        if (!ASM21) roll.init(w, k, wlo);
+        // the C++ window: same outputs as p1_window21 (payload, byte address of the counter, byte offset of the bin)
+        auto window = [&](int j, uint32_t &pay, uint32_t &cnta, uint32_t &binb) {
+            u64 key;
+            const bool ok = roll.next(j, key);
+            uint32_t p1 = 0;
+            pay = 0;
+            if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
+                if (FAST) {
+                    hash_p1_pay32<MODE>(k, p1b, key, p1, pay);
+                } else {
+                    const u64 H = part_hash<MODE>(g, key);
+                    pay = Pay<uint32_t>::make(key, H, g);
+                    p1 = p1_of_hash(H, g);
+                }
+            }
+            cnta = ok ? K21_CNT_OFF + 4u * p1 : waste;
+            binb = p1 * (P1B_CAP * 4u);
+        };
 #define KH_W21(J)                                                                                            \
     {                                                                                                        \
         uint32_t cnta;                                                                                       \
-        p1_window21<J>(w0, w1, w2, c0, c1, c2, good, waste, pay[(J) % HALF], cnta, binb[(J) % HALF]);        \
+        if constexpr (ASM21) p1_window21<J>(w0, w1, w2, c0, c1, c2, good, waste, pay[(J) % HALF], cnta, binb[(J) % HALF]); \
+        else window(J, pay[(J) % HALF], cnta, binb[(J) % HALF]);                                             \
         rk[(J) % HALF] = __hip_atomic_fetch_add((lds_u32 *)(lds + cnta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }
 #pragma unroll
@@ -1102,7 +725,13 @@ __global__ __launch_bounds__(PART_NT) void part1_k21_kernel(
                         again.next(j, key);
                         if (j / HALF == h && ((omask >> (j % HALF)) & 1u)) {
                             uint32_t p, pv;
-                            hash_p1_pay32<KH_MUL_24>(k, p1b, key, p, pv);
+                            if (FAST) {
+                                hash_p1_pay32<MODE>(k, p1b, key, p, pv);
+                            } else {
+                                const u64 H = part_hash<MODE>(g, key);
+                                pv = Pay<uint32_t>::make(key, H, g);
+                                p = p1_of_hash(H, g);
+                            }
                             uint32_t *const pbin = s_bin + p * P1B_CAP;
                             const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 1u);
                             if (r2 >= 0) {

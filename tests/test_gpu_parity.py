@@ -1022,3 +1022,61 @@ def test_level2_unit_writer_and_its_stand_down(K, monkeypatch, mode, k, hint):
         assert st["kmers"] == m.total() and st["part_batches"] >= 3
         keys, cnts = dc.result()
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
+
+
+@pytest.mark.parametrize("minq", [None, 20], ids=["noqual", "q20"])
+@pytest.mark.parametrize("k,hint,generic", [(21, 6_000_000, False), (21, 6_000_000, True), (21, 40_000_000, False),
+                                            (20, 6_000_000, False), (17, 3_000_000, False)],
+                         ids=["k21-written-out", "k21-c++window", "k21-64buckets", "k20", "k17"])
+def test_level1_bins_kernel_overflow_and_masks(K, monkeypatch, k, hint, generic, minq):
+    """Level 1 with 32-bit payloads: per-partition bins in LDS, flushed in whole 64-byte segments twice per tile
+    (part1_bins_kernel: the hand-written k = 21 window and the C++ one).  The input is made to hit everything the
+    kernel treats specially: 12 % of the reads are homopolymers / dinucleotide repeats (thousands of payloads of one
+    tile for ONE bin: the overflow path, second ranks, descriptors in the emptied bin), N runs and lower case
+    (windows without a key: the waste counters), reads of every length mod 16 (tile seams), and quality masking.
+    Several batches of very different sizes into one table; against the oracle."""
+    if generic:
+        monkeypatch.setenv("KMERHIP_GENERIC_K", "1")
+    rng = np.random.default_rng(4242 + k)
+    n_reads = 60_000
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1 << 18)
+    recs, quals = [], []
+    for i in range(n_reads):
+        n = int(rng.integers(30, 260))
+        u = rng.random()
+        if u < 0.05:
+            s = np.full(n, ord("A") if i % 2 else ord("T"), dtype=np.uint8)
+        elif u < 0.09:
+            s = np.resize(np.frombuffer(b"AC" if i % 2 else b"GT", dtype=np.uint8), n).copy()
+        elif u < 0.12:
+            s = np.resize(np.frombuffer(b"ACGTTGCA", dtype=np.uint8), n).copy()
+        else:
+            o = int(rng.integers(0, genome.size - n))
+            s = genome[o:o + n].copy()
+            if u > 0.9:
+                a = int(rng.integers(0, n))
+                s[a:a + int(rng.integers(1, 6))] = ord("N")
+            if u > 0.97:
+                s = np.frombuffer(s.tobytes().lower(), dtype=np.uint8).copy()
+        recs.append(s.tobytes())
+        quals.append(rng.choice(np.frombuffer(b"#+5?I", dtype=np.uint8), size=n).astype(np.uint8).tobytes())
+    flat = b"\n".join(recs) + b"\n"
+    qflat = b"\n".join(quals) + b"\n"
+    bases = np.frombuffer(flat, dtype=np.uint8)
+    qual = np.frombuffer(qflat, dtype=np.uint8)
+    m = O.OracleMap()
+    m.scan_flat(bases, k, qual=qual if minq is not None else None, min_quality=minq, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    import torch
+    tb = torch.from_numpy(bases.copy()).cuda()
+    tq = torch.from_numpy(qual.copy()).cuda() if minq is not None else None
+    torch.cuda.synchronize()
+    ends = np.flatnonzero(bases == 10) + 1  # record ends: batches are cut at record boundaries
+    cut = [0, int(ends[999]), int(ends[1000]), int(ends[30_000]), bases.size]
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=hint, path="partition") as dc:
+        for a, b in zip(cut, cut[1:]):
+            dc.push_device(tb.data_ptr() + a, tq.data_ptr() + a if tq is not None else None, b - a)
+        st = dc.finish()
+        assert st["kmers"] == m.total() and st["part_batches"] >= 3
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
