@@ -68,15 +68,16 @@ KH_HD uint64_t kh_canonical_bits(uint64_t fwd, uint32_t k) {
 // ---- table hash: a BIJECTION on the 2k-bit key space, left-aligned in 64 bits -----------------
 // Four Feistel rounds over the two k-bit halves of the packed k-mer; the round function is a
 // 32-bit multiply, keeping the top k bits of the low word.  Everything is 32-bit arithmetic (a 64-bit
-// multiply costs four quarter-rate 32-bit multiplies on gfx950, this costs four in total), and
+// multiply is four 32-bit ones, this costs four in total), and
 // being a bijection it lets the partitioned path carry 32-bit payloads instead of 64-bit keys
 // whenever 2k minus the level-1 partition bits fits in 32 (k <= 21 at the headline table size):
 // the bits of H that a partition level has consumed are implied by where the payload is stored,
 // and the key is recovered with kh_unhash_n().  Quality (chi-square of region / in-region start
 // occupancy on genomic, sequential, low-complexity and strided keys) matches splitmix64.
-// For 16 <= k <= 24 the half fits 24 bits and the product uses the FULL-RATE 24-bit multiplier
-// (v_mul_u32_u24; a 32-bit v_mul_lo_u32 is quarter rate) with the constant's low 24 bits; both
-// variants pass the same occupancy tests.  The choice depends only on k, so it is one function.
+// For 16 <= k <= 24 the half fits 24 bits and the product uses the 24-bit multiplier (v_mul_u32_u24) with
+// the constant's low 24 bits; both variants pass the same occupancy tests.  The choice depends only on k,
+// so it is one function.  (Chosen on the assumption that v_mul_lo_u32 is quarter rate; measured on gfx950,
+// tools/ubench/valu_rates.hip, both cost ~5 cycles per wave.  It stays because it is part of the table format.)
 // MODE: which multiplier.  KH_MUL_AUTO decides from k at run time (one uniform branch per round: fine
 // for cold code, but in the extraction kernels it splits every window into a dozen basic blocks and
 // blocks instruction scheduling), so the hot kernels are instantiated for KH_MUL_24 / KH_MUL_32 and

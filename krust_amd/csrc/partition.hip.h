@@ -274,9 +274,17 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
     int buf = 0;
     uint32_t lost = 0;
     __syncthreads();
-    RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
+    // The next tile's bases are requested right after this tile's first barrier and encoded into the other code buffer
+    // BEFORE this tile's first write-out: a wait for them placed after stores is a wait for the stores' acknowledgement
+    // (vmcnt counts both; see part1_bins_kernel).
+    {
+        const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
+        stage_encode<QUAL, PART_NT>(s_code, s_val, 0, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
+    }
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        const WinCtx w = stage_tile_raw<QUAL, PART_NT>(s_code, s_val, buf, t == tb, tid, raw, abase, qbase, qaligned, t, vbeg, vend, thr);
+        __syncthreads();
+        const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+        const WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
         Roller roll;
         roll.init(w, k, wlo);
 #pragma unroll
@@ -374,9 +382,8 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
                 s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
                 s_priv_end = s_priv_next + POOL_GRAB;
             }
-            // next tile's bases are fetched while this tile's last runs are written out
-            if (h == ROUNDS - 1)
-                raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
+            if (h == 0)  // tile t + 1's codes -> the other buffer, before any store of this tile
+                stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
 #if !(KH_ABL & 4)  /* timing experiment: no write-out */
 #pragma unroll 2
             for (uint32_t i = tid; i < total; i += PART_NT) {
