@@ -34,6 +34,9 @@
 #ifndef KH_ABL2
 #define KH_ABL2 0  // the same for part2_scatter_kernel
 #endif
+#ifndef KH_ABLR
+#define KH_ABLR 0  // the same for region_count_kernel32
+#endif
 #ifndef KH_ABL
 #define KH_ABL 0  // ablation bits for timing experiments on part1_scatter_chunked_kernel (tools/p1_ablation.sh); 0 in any product build
 #endif
@@ -1755,8 +1758,14 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             // no loop, no ballot.  A slot only ever goes FREE -> payload once, so an equal value is final; a
             // stale FREE or a different payload sends the item to the probing loop, which starts over at the
             // home slot.
+            // What the first probe does not settle goes to the probing loop -- through a queue shared by the WAVE, not the
+            // lane's own: the loop runs until the wave's busiest lane is done (ablation: the loop is 8.9 of the
+            // kernel's 24.9 ms), and with private queues that lane has twice the average work.  The wave's items are
+            // numbered by ballot + mbcnt and item n goes to row n / 64, column n % 64 of the wave's 8 x 64 corner of s_q:
+            // every lane then takes rows 0 .. of its own column, one item more or less than its neighbours.
             constexpr int FP = REGION_RK;
-            uint32_t r = 0;  // items left for the loop, compacted into the lane's queue
+            uint32_t wrun = 0;  // items queued by the wave so far (wave-uniform)
+            const uint32_t lane = (uint32_t)tid & 63u, wbase = (uint32_t)tid & ~63u;
 #pragma unroll
             for (int h = 0; h < REGION_RK; h += FP) {
                 uint32_t oj[FP], cj[FP];
@@ -1771,13 +1780,20 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
                     const bool valid = (uint32_t)(h + j) < nk && (((pj[h + j] >> dshift) ^ digit) & dmask) == 0;
                     nreal += valid;
                     const bool hit = valid && cj[j] == pj[h + j];
+#if !(KH_ABLR & 2)  /* timing experiment otherwise: no count updates in the first probe */
                     atomicAdd(&s_add[hit ? oj[j] : REGION_SLOTS + (uint32_t)tid], 1u);  // no-return ds_add_u32; misses add to a private dummy word
+#endif
                     const bool queue = valid && !hit;
-                    s_q[queue ? r : (uint32_t)REGION_RK][tid] = pj[h + j];             // (row REGION_RK is a dummy row)
-                    r += queue;
+                    const u64 qm = __ballot(queue);
+                    const uint32_t pos = wrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                    s_q[queue ? (pos >> 6) : (uint32_t)REGION_RK][wbase + (queue ? (pos & 63u) : lane)] = pj[h + j];  // (row REGION_RK is a dummy row)
+                    wrun += (uint32_t)__builtin_popcountll(qm);
                 }
             }
+            const uint32_t r = wrun > lane ? (wrun - lane + 63u) >> 6 : 0u;  // this lane's share: rows 0 .. r-1 of its column
+#if !(KH_ABLR & 1)  /* timing experiment otherwise: no probing loop behind the straight-line first probe */
             region32_probe_lean(r, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
+#endif
         }
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
@@ -1827,7 +1843,11 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         u64 kk = old[q].key, cc = old[q].count;
         const uint32_t delta = s_add[i];
         if (delta) {
+#if KH_ABLR & 4  /* timing experiment: no inverse hash in the write-back */
+            if (kk == KH_EMPTY_KEY) kk = s_pay[i];
+#else
             if (kk == KH_EMPTY_KEY) kk = Pay<uint32_t>::key(s_pay[i], p1, g);  // new key: invert the hash
+#endif
             cc += delta;
         }
         if (i == sp_off) {
