@@ -131,6 +131,13 @@ struct kh_ctx {
     bool rheads_valid = false;       // ... and still describing the table (nothing else touched it since)
     bool rheads_wide = false;
     uint32_t rheads_cb = 0;
+    u64 *bend = nullptr;             // arena path: end of every region's data (the exact path uses bstart + 1)
+    u64 *ptotal = nullptr;           // [MAX_P1] payloads per level-1 partition
+    uint32_t *pcap = nullptr;        // [MAX_P1] arena capacity of that partition's buckets
+    u64 *ovf = nullptr;              // [2] overflow list: entries handed out, "list full" flag
+    kh::OvfEntry *ovf_list = nullptr;
+    u64 ovf_cap = 0;
+    u64 ovf_pending = 0;             // entries of the overflow list still to be inserted (this batch)
     uint16_t *chunk_part = nullptr;  // chunk pool metadata (32-bit payload path)
     uint8_t *fill8 = nullptr;
     uint32_t *plist = nullptr;
@@ -481,29 +488,29 @@ int head_count_bits(const kh_ctx *c, u64 regions) {
 
 // region rebuild launch, by payload type
 template <typename PT>
-void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot);
+void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend);
 template <>
-void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot) {
+void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
+                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
     else
         hipLaunchKernelGGL(kh::region_count_kernel64<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
+                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
 }
 template <>
-void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot) {
+void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
     c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel32<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty,
+                           (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty,
                            c->rheads_cb, c->rheads, c->d_ctr, c->rreal);
     else
         hipLaunchKernelGGL(kh::region_count_kernel32<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, (const u64 *)c->bstart, c->rfail, c->rnew, hot, 0u, 0u,
+                           (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, 0u, 0u,
                            (uint32_t *)nullptr, c->d_ctr, c->rreal);
 }
 
@@ -555,6 +562,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->rheads, &z, nregions, "hipMalloc(rheads)")) != KH_OK) return rc;
         z = c->rreal ? c->region_cap : 0;
         if ((rc = ensure_buf(c, &c->rreal, &z, nregions, "hipMalloc(rreal)")) != KH_OK) return rc;
+        z = c->bend ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->bend, &z, nregions, "hipMalloc(bend)")) != KH_OK) return rc;
         c->region_cap = nregions;
     }
     if (c->pool_cap < pool_chunks) {
@@ -568,12 +577,18 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     }
     // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
     // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
-    static const bool lines_on = [] { const char *e = getenv("KMERHIP_P2_LINES"); return !(e && e[0] == '0'); }();
+    const bool lines_on = [] { const char *e = getenv("KMERHIP_P2_LINES"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
     const bool lines = lines_on && g.p2_bits >= 1 && g.p2_bits <= 9;
     const uint32_t force_wide = [] { const char *e = getenv("KMERHIP_P2_FORCE_WIDE"); return (e && e[0] == '1') ? 1u : 0u; }();
+    // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
+    // each), 2..512 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
+    const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
+    const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 1 && g.p2_bits <= 9;
+    const u64 arena_pay = arena ? (n_ub + nregions) + ((n_ub + nregions) >> 2) + 1040ull * nregions : 0;  // upper bound of arena_plan_kernel's total
+    const u64 ovf_need = arena ? n_ub / 16 + (2ull << 20) : 0;
     const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
     const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
-    const u64 key_bytes = std::max(a_bytes, (n_ub + pad_ub) * (u64)sizeof(PT));
+    const u64 key_bytes = std::max(std::max(a_bytes, (n_ub + pad_ub) * (u64)sizeof(PT)), arena_pay * (u64)sizeof(PT));
     if (c->key_cap < key_bytes) {  // key_cap is in BYTES per buffer
         u64 z = c->keysA ? c->key_cap : 0;
         if ((rc = ensure_buf(c, &c->keysA, &z, key_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
@@ -582,6 +597,21 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         c->key_cap = key_bytes;
     }
     PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);
+    if (arena) {
+        if (!c->ptotal) {
+            u64 z = 0;
+            if ((rc = ensure_buf(c, &c->ptotal, &z, (u64)kh::MAX_P1, "hipMalloc(ptotal)")) != KH_OK) return rc;
+            z = 0;
+            if ((rc = ensure_buf(c, &c->pcap, &z, (u64)kh::MAX_P1, "hipMalloc(pcap)")) != KH_OK) return rc;
+            z = 0;
+            if ((rc = ensure_buf(c, &c->ovf, &z, 2, "hipMalloc(ovf)")) != KH_OK) return rc;
+        }
+        if (c->ovf_cap < ovf_need) {
+            u64 z = c->ovf_list ? c->ovf_cap : 0;
+            if ((rc = ensure_buf(c, &c->ovf_list, &z, ovf_need, "hipMalloc(ovf_list)")) != KH_OK) return rc;
+            c->ovf_cap = ovf_need;
+        }
+    }
 
     const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
     const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
@@ -610,10 +640,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const bool m24 = kh_k_uses_mul24(c->k);  // the Feistel multiplier is a compile-time choice in the hot kernel
             const bool fast = sizeof(PT) == 4 && kh::p1_fast_ok(g);
             // the BASELINE configurations get kernels compiled for their k (KMERHIP_GENERIC_K=1: the generic form, for A/B)
-            static const bool generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
+            const bool generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
             // 32-bit payloads: the bins kernel (KMERHIP_P1_BINS=0: the tile-sorting, per-payload-storing one, for A/B);
             // k = 21 at the headline geometry gets the written-out window (KMERHIP_GENERIC_K=1: the C++ window)
-            static const bool bins32 = [] { const char *e = getenv("KMERHIP_P1_BINS"); return !(e && e[0] == '0'); }();
+            const bool bins32 = [] { const char *e = getenv("KMERHIP_P1_BINS"); return !(e && e[0] == '0'); }();
 #define KH_P1_BINS(QUAL, MODE, FAST, ASM21) \
     hipLaunchKernelGGL((kh::part1_bins_kernel<QUAL, MODE, FAST, ASM21>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
                        ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
@@ -652,8 +682,9 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 #endif
         {
             StageTimer t(c, ST_MISC);
+            if (arena) HIP_TRY(c, hipMemsetAsync(c->ptotal, 0, kh::MAX_P1 * sizeof(u64), c->stream));
             hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
-                               (const u64 *)c->pool_next, pool_chunks, c->pcount);
+                               (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, arena ? c->ptotal : (u64 *)nullptr);
             if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
             hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
                                c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide);
@@ -662,6 +693,35 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
         }
     }
+    const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
+    bool arena_done = false;
+    const u64 ovf_test_cap = [] { const char *e = getenv("KMERHIP_L2_OVF_CAP"); return e ? (u64)strtoull(e, nullptr, 10) : ~0ull; }();
+    const u64 ovf_lim = std::min(c->ovf_cap, ovf_test_cap);
+    if (arena) {
+        {
+            StageTimer t(c, ST_P2_SCATTER);
+            // (test knobs: KMERHIP_L2_SKEW_X = how many times the mean a partition may hold, 0 = no limit; KMERHIP_L2_OVF_CAP =
+            //  entries the overflow list may take)
+            const uint32_t skew_x = [] { const char *e = getenv("KMERHIP_L2_SKEW_X"); return e ? (uint32_t)atoi(e) : 2u; }();
+            hipLaunchKernelGGL(kh::arena_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
+                               c->ovf, skew_x);
+            hipLaunchKernelGGL((kh::part2_arena_kernel<PT>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
+                               (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
+        }
+        u64 hov[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(hov, c->ovf, sizeof(hov), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (hov[1] == 0) {
+            arena_done = true;
+            bend = c->bend;
+            c->ovf_pending = hov[0];
+            HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
+        } else if (c->trace) {
+            fprintf(stderr, hov[1] == 2 ? "[kmerhip] level-1 partitions too uneven for one workgroup each: this batch takes the exact level-2 path\n"
+                                        : "[kmerhip] level-2 overflow list full (%llu entries): this batch takes the exact path\n", (u64)hov[0]);
+        }
+    }
+    if (!arena_done) {
     {
         StageTimer t(c, ST_P2_COUNT);
         hipLaunchKernelGGL((kh::part2_count_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA, cs,
@@ -696,16 +756,21 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
                            (const u64 *)c->O2, (u64)n2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, c->bstart);
         HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
     }
+    c->ovf_pending = 0;
+    }  // !arena_done
     const bool was_empty = c->table_empty;
     {
         StageTimer t(c, ST_REGION);
         // buckets more than 4x the mean (upper bound) take the skew-guarded probing loop
-        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096);
+        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend);
     }
     {
         StageTimer t(c, ST_MISC);
         hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
                            (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const u64 *)c->rreal, (u64)nregions, c->d_ctr);
+        if (c->ovf_pending)  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
+            hipLaunchKernelGGL(kh::ovf_insert_kernel<PT>, dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream,
+                               table_geom(c, c->table, c->cap), g, (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
@@ -718,18 +783,19 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     if (rc != KH_OK) return rc;
     // the per-region exchange-head counts of a FRESH 32-bit pass describe the whole table until
     // anything else touches it
-    c->rheads_valid = was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->h_ctr->part_failed == 0;
+    c->rheads_valid = was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->h_ctr->part_failed == 0 && c->ovf_pending == 0;
     c->rheads_wide = c->h_ctr->heads_wide != 0;
     if (c->h_ctr->part_failed) {
         // some regions overflowed: they were left untouched; grow, then insert their buckets directly.
         // Worst case every key of a failed bucket is new: size the grown table for that.
         std::vector<uint8_t> hf(nregions);
-        std::vector<u64> hb(nregions + 1);
+        std::vector<u64> hb(nregions), he(nregions);
         HIP_TRY(c, hipMemcpy(hf.data(), c->rfail, nregions, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(hb.data(), c->bstart, (nregions + 1) * sizeof(u64), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(hb.data(), c->bstart, nregions * sizeof(u64), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(he.data(), bend, nregions * sizeof(u64), hipMemcpyDeviceToHost));
         u64 failed_keys = 0;
         for (u64 r = 0; r < nregions; ++r)
-            if (hf[r]) failed_keys += hb[r + 1] - hb[r];
+            if (hf[r]) failed_keys += he[r] - hb[r];
         u64 newcap = c->cap * 2;
         while ((double)(c->distinct_known + failed_keys) > LOAD_HARD * (double)newcap ||
                (double)c->distinct_known > LOAD_TARGET * (double)newcap)
@@ -743,7 +809,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             rc = grow_to(c, newcap);
             if (rc != KH_OK) return rc;
             hipLaunchKernelGGL(kh::failed_buckets_insert_kernel<PT>, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                               table_geom(c, c->table, c->cap), g, (const PT *)bufB, (const u64 *)c->bstart,
+                               table_geom(c, c->table, c->cap), g, (const PT *)bufB, (const u64 *)c->bstart, bend,
                                (const uint8_t *)c->rfail, c->d_ctr);
             HIP_TRY(c, hipMemsetAsync(&c->d_ctr->part_failed, 0, sizeof(u64), c->stream));
         }
@@ -1122,7 +1188,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->bstart, c->bend, c->ptotal, c->pcap, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)

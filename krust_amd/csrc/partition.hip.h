@@ -790,21 +790,29 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
 
 // ---- chunk list: chunk ids ordered by partition ---------------------------------------------------
 // pcount[p] += chunks owned by partition p among ids [0, nchunks)
+// ptotal (optional): ptotal[p] += payloads in those chunks
 __global__ __launch_bounds__(1024) void chunk_hist_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
-                                                          u64 pool_chunks, uint32_t *__restrict__ pcount) {
+                                                          u64 pool_chunks, uint32_t *__restrict__ pcount,
+                                                          const uint8_t *__restrict__ fill8, u64 *__restrict__ ptotal) {
     __shared__ uint32_t s_h[MAX_P1];
+    __shared__ uint32_t s_f[MAX_P1];
     const int tid = threadIdx.x;
     s_h[tid] = 0;
+    s_f[tid] = 0;
     __syncthreads();
     u64 n = *pool_next;
     if (n > pool_chunks) n = pool_chunks;
     const u64 stride = (u64)gridDim.x * 1024;
-    for (u64 i = (u64)blockIdx.x * 1024 + tid; i < n; i += stride) {
+    for (u64 i = (u64)blockIdx.x * 1024 + tid; i < n; i += stride) {  // (<= 2^32 / 256 chunks per workgroup here: the sums fit 32 bits)
         const uint16_t p = chunk_part[i];
-        if (p != PART_NONE) atomicAdd(&s_h[p], 1u);
+        if (p != PART_NONE) {
+            atomicAdd(&s_h[p], 1u);
+            if (ptotal) atomicAdd(&s_f[p], (uint32_t)fill8[i] + 1u);
+        }
     }
     __syncthreads();
     if (s_h[tid]) atomicAdd(&pcount[tid], s_h[tid]);
+    if (ptotal && s_f[tid]) atomicAdd(&ptotal[tid], (u64)s_f[tid]);
 }
 
 // plist[pstart[p] + rank] = chunk id.  cursors[] starts as a copy of pstart[] (low 32 bits suffice:
@@ -1334,6 +1342,302 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// level 2 WITHOUT a counting pass: per-bucket arenas sized from the level-1 partition totals
+// ---------------------------------------------------------------------------------------------
+// The count pass exists to give every (bucket, workgroup) segment of the level-2 output its exact offset; it reads all
+// 51 GB of level-1 output for that (9.6 of the step's 89 ms on S100M).  Level 1 already knows how many payloads each
+// of its partitions holds (chunk fill levels), and a partition's buckets are equally likely: bucket (p, b) gets an ARENA
+// of n_p / P2 payloads plus a quarter plus 1024 (the counts of coverage-deep data spread ~3.6 x wider than a
+// multinomial's, sigma ~ 570 around 24.8 K on S100M), ONE workgroup handles a whole partition -- so a bucket's write
+// position lives in its owner lane's registers, no atomics -- and whatever does not fit its arena (a heavy hitter's
+// copies, essentially) goes to an overflow list of (region, payload) pairs that is inserted through the direct path
+// after the region pass.  The region pass reads [bstart[r], bend[r]); the gaps are address space, not traffic.
+// The workgroup sorts through per-bucket bins in LDS as level 1 does (bin = four 64-byte units, rank atomic -> bin,
+// flush of whole units after half a batch); a payload whose rank does not fit its bin goes to the overflow list too.
+// If the list itself would overflow (ovf[1] set), the host runs the exact count -> scan -> scatter path for the batch.
+
+// bstart[r] for r = (p, b): arenas of cap_p = align16(ceil(n_p / P2) * 5 / 4 + 1024) payloads, partition after partition
+// ovf[1] = 2 if some partition holds more than skew_x times the mean (one workgroup handles a whole partition: a
+// partition that heavy -- a homopolymer's, say -- would be the whole pass; the exact path splits partitions into blocks)
+__global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict__ ptotal, PartGeom g, u64 *__restrict__ bstart,
+                                                          uint32_t *__restrict__ pcap, u64 *__restrict__ ovf, uint32_t skew_x) {
+    __shared__ u64 s_base[MAX_P1 + 1];
+    __shared__ uint32_t s_cap[MAX_P1];
+    const int tid = threadIdx.x;
+    const int P1 = 1 << g.p1_bits;
+    const uint32_t P2 = 1u << g.p2_bits;
+    if (tid < P1) {
+        const u64 m = (ptotal[tid] + P2 - 1) / P2;
+        s_cap[tid] = (uint32_t)((m + (m >> 2) + 1024 + 15) & ~15ull);
+        pcap[tid] = s_cap[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u64 b = 0, tot = 0, mx = 0;
+        for (int p = 0; p < P1; ++p) {
+            s_base[p] = b;
+            b += (u64)s_cap[p] * P2;
+            tot += ptotal[p];
+            mx = max(mx, ptotal[p]);
+        }
+        s_base[P1] = b;
+        ovf[0] = 0;
+        ovf[1] = (skew_x && mx > (u64)skew_x * (tot / P1) + (1u << 20)) ? 2 : 0;
+    }
+    __syncthreads();
+    for (int p = 0; p < P1; ++p)
+        for (uint32_t b = tid; b < P2; b += 1024) bstart[(u64)p * P2 + b] = s_base[p] + (u64)b * s_cap[p];
+    if (tid == 0) bstart[(u64)P1 * P2] = s_base[P1];
+}
+
+struct OvfEntry {
+    uint32_t region;
+    uint32_t pad;
+    u64 pay;
+};
+
+template <typename PT>
+__global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
+                                                             const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
+                                                             PT *__restrict__ out, u64 *__restrict__ bend,
+                                                             OvfEntry *__restrict__ ovf_list, u64 *__restrict__ ovf, u64 ovf_cap) {
+    constexpr int NBK = P2L_NBK, UNIT = P2L<PT>::UNIT, NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
+    constexpr int HALF = PER / 2;
+    constexpr uint32_t CAP = 4 * UNIT;                        // payloads per bin (256 bytes)
+    constexpr uint32_t UW = UNIT * sizeof(PT) / 16;           // 16-byte words per unit (4)
+    __shared__ __attribute__((aligned(16))) PT s_bin[NBK * CAP + UNIT];  // 128 KiB (+ a trash unit)
+    __shared__ uint32_t s_cnt[NBK];
+    __shared__ uint32_t s_chk[CPB];
+    __shared__ uint16_t s_cfill[CPB];
+    __shared__ u64 s_ovf_next, s_ovf_end;  // the workgroup's private segment of the overflow list (none to begin with)
+    __shared__ uint32_t s_ovf_want;
+    constexpr u64 OVF_SEG = 65536, OVF_LOW = 24576;  // (one flush appends < 17 K entries)
+    if (ovf[1]) return;  // (the plan found the batch too skewed for one workgroup per partition: the host takes the exact path)
+    const uint32_t p = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t P2 = 1u << g.p2_bits;
+    if (tid == 0) {
+        s_ovf_next = 0;
+        s_ovf_end = 0;
+        s_ovf_want = 0;
+    }
+    // lane b < P2 owns bucket b: its arena and how much of it is written (a multiple of UNIT until the end)
+    const u64 abase = tid < (int)P2 ? bstart[(u64)p * P2 + tid] : 0;
+    const uint32_t acap = pcap[p];
+    uint32_t apos = 0;
+    if (tid < NBK) s_cnt[tid] = 0;
+    const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
+    uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + (uint32_t)(tid < NBK ? tid : 0) * CAP);
+    // Appends k entries of this lane to the overflow list; false if the list is full (the host then redoes the batch).
+    // On skewed input MANY lanes of MANY workgroups do this: the list is handed out in private segments (one global
+    // atomic per OVF_SEG entries and workgroup, LDS atomics inside), a request that finds the segment short takes its
+    // entries straight from the global cursor, the unused tail of a segment is marked invalid (region = ~0).
+    auto ovf_take = [&](uint32_t k, u64 &at) -> bool {
+        at = atomicAdd(&s_ovf_next, (u64)k);  // LDS
+        if (at + k > s_ovf_end) {
+            s_ovf_want = 1u;
+            at = atomicAdd(&ovf[0], (u64)k);
+        }
+        if (at + k > ovf_cap) {
+            ovf[1] = 1;
+            return false;
+        }
+        return true;
+    };
+    // (between barriers, nobody appending) a fresh segment when one was missed or the current one runs low
+    auto ovf_refill = [&]() {
+        if (!s_ovf_want && s_ovf_next + OVF_LOW <= s_ovf_end) return;  // uniform: read after a barrier
+        const u64 tail0 = s_ovf_next, tail1 = s_ovf_end;
+        for (u64 i = tail0 + tid; i < tail1 && i < ovf_cap; i += NT) ovf_list[i].region = 0xFFFFFFFFu;
+        __syncthreads();
+        if (tid == 0) {
+            s_ovf_next = atomicAdd(&ovf[0], (u64)OVF_SEG);
+            s_ovf_end = s_ovf_next + OVF_SEG;
+            s_ovf_want = 0u;
+        }
+        __syncthreads();
+    };
+    for (u64 blo = pstart[p]; blo < pstart[p + 1]; blo += CPB) {
+        Part2Block pb;
+        pb.lo = blo;
+        pb.hi = min(blo + (u64)CPB, pstart[p + 1]);
+        __syncthreads();  // (the previous block's batches are done with s_chk / s_cfill)
+        p2_stage_chunks<true>(cs, pb, s_chk, s_cfill, tid, NT);
+        __syncthreads();
+        const uint32_t nchk = (uint32_t)(pb.hi - pb.lo);
+        const uint32_t n = nchk * CHUNK_PAY;
+        auto load_batch = [&](uint32_t first, PT (&pay)[PER], uint32_t &have) {  // (as in part2_scatter_lines_kernel)
+            have = 0;
+            const uint32_t myci = (first >> 8) + ((uint32_t)tid & (PER - 1)) * (NT / CHUNK_PAY) + ((uint32_t)tid >> 8);
+            const uint32_t mycc = myci < nchk ? myci : nchk - 1;
+            const uint32_t mychunk = s_chk[mycc];
+            const uint32_t myfill = myci < nchk ? (uint32_t)s_cfill[mycc] : 0u;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const uint32_t chunk = __builtin_amdgcn_readlane(mychunk, j);
+                const uint32_t fillc = __builtin_amdgcn_readlane(myfill, j);
+                const bool ok = woff < fillc;
+                pay[j] = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (ok ? woff : 0u)];
+                have |= (uint32_t)ok << j;
+            }
+        };
+        // lane b writes the whole units of bucket b's bin to its arena (or, the arena full, to the overflow list)
+        auto flush = [&]() {
+            if (tid >= NBK) return;
+            const uint32_t c = min(s_cnt[tid], CAP);  // (ranks beyond the bin went to the overflow list)
+            const uint32_t nun = c / UNIT, r = c % UNIT;
+#pragma unroll
+            for (uint32_t u = 0; u < CAP / UNIT; ++u)
+                if (u < nun) {
+                    uint4 x[UW];
+#pragma unroll
+                    for (uint32_t q = 0; q < UW; ++q) x[q] = bin4[UW * u + q];
+                    if (apos + UNIT <= acap) {
+                        uint4 *d = reinterpret_cast<uint4 *>(out + abase + apos);
+#pragma unroll
+                        for (uint32_t q = 0; q < UW; ++q) d[q] = x[q];
+                        apos += UNIT;
+                    } else {
+                        u64 at;
+                        if (ovf_take(UNIT, at)) {
+                            const PT *e = reinterpret_cast<const PT *>(x);
+                            for (uint32_t q = 0; q < (uint32_t)UNIT; ++q) {
+                                OvfEntry oe;
+                                oe.region = p * P2 + (uint32_t)tid;
+                                oe.pad = 0;
+                                oe.pay = (u64)e[q];
+                                ovf_list[at + q] = oe;
+                            }
+                        }
+                    }
+                }
+            if (nun) {
+                const uint32_t nw = (r * (uint32_t)sizeof(PT) + 15u) / 16u;
+                for (uint32_t i = 0; i < nw; ++i) bin4[i] = bin4[UW * nun + i];
+            }
+            s_cnt[tid] = r;
+        };
+        auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
+            load_batch(base + TILE, nxt, have_nxt);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t rk[HALF], dg[HALF];
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) {
+                    const bool ok = (have >> (h * HALF + j)) & 1u;
+                    dg[j] = Pay<PT>::p2(pay[h * HALF + j], g);
+                    rk[j] = ok ? atomicAdd(&s_cnt[dg[j]], 1u) : 0xFFFFFFFFu;
+                }
+                uint32_t omask = 0;
+#pragma unroll
+                for (int j = 0; j < HALF; ++j) {
+                    const uint32_t r = rk[j];
+                    s_bin[r < CAP ? dg[j] * CAP + r : (uint32_t)(NBK * CAP)] = pay[h * HALF + j];
+                    omask |= (r != 0xFFFFFFFFu && r >= CAP) ? (1u << j) : 0u;
+                }
+                if (__any(omask != 0)) {  // ranks that did not fit their bins (a heavy bucket): straight to the overflow list
+                    const uint32_t k = (uint32_t)__builtin_popcount(omask);
+                    u64 at = 0;
+                    if (k && ovf_take(k, at)) {
+                        uint32_t q = 0;
+#pragma unroll
+                        for (int j = 0; j < HALF; ++j)
+                            if ((omask >> j) & 1u) {
+                                OvfEntry oe;
+                                oe.region = p * P2 + dg[j];
+                                oe.pad = 0;
+                                oe.pay = (u64)pay[h * HALF + j];
+                                ovf_list[at + q++] = oe;
+                            }
+                    }
+                }
+                __syncthreads();  // B1
+                if (h == 0) {  // the wait for the next batch's payloads goes HERE, before the first store (vmcnt: see part1_bins_kernel)
+#pragma unroll
+                    for (int j = 0; j < PER; ++j) asm volatile("" : "+v"(nxt[j]));
+                }
+                flush();
+                __syncthreads();  // B2
+                if (s_ovf_want || s_ovf_end) ovf_refill();  // (uniform; skipped entirely while nothing has overflowed)
+            }
+        };
+        PT payA[PER], payB[PER];
+        uint32_t haveA = 0, haveB = 0;
+        load_batch(0, payA, haveA);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) asm volatile("" : "+v"(payA[j]));
+        for (uint32_t base = 0; base < n; base += 2 * TILE) {
+            batch(base, payA, haveA, payB, haveB);
+            if (base + TILE < n) batch(base + TILE, payB, haveB, payA, haveA);
+        }
+    }
+    // what is left in the bins (< UNIT payloads per bucket), one by one; then the bucket's end
+    if (tid < (int)P2) {
+        const uint32_t r = s_cnt[tid];
+        const PT *bin = s_bin + (uint32_t)tid * CAP;
+        if (r) {
+            if (apos + r <= acap) {
+                for (uint32_t i = 0; i < r; ++i) out[abase + apos + i] = bin[i];
+                apos += r;
+            } else {
+                u64 at;
+                if (ovf_take(r, at))
+                    for (uint32_t i = 0; i < r; ++i) {
+                        OvfEntry oe;
+                        oe.region = p * P2 + (uint32_t)tid;
+                        oe.pad = 0;
+                        oe.pay = (u64)bin[i];
+                        ovf_list[at + i] = oe;
+                    }
+            }
+        }
+        bend[(u64)p * P2 + tid] = abase + apos;
+    }
+    __syncthreads();
+    for (u64 i = s_ovf_next + tid; i < s_ovf_end && i < ovf_cap; i += NT) ovf_list[i].region = 0xFFFFFFFFu;
+}
+
+// the overflow list through the direct path (after the region pass: the table then holds the batch's other k-mers)
+template <typename PT>
+__global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeom g, const OvfEntry *__restrict__ list,
+                                                           const u64 *__restrict__ ovf, Counters *ctr) {
+    const u64 n = ovf[0];
+    uint32_t nd = 0, nf = 0;
+    u64 km = 0;
+    const u64 nround = (n + BLOCK - 1) / BLOCK * BLOCK;  // (whole waves take part in the ballots)
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < nround; i += (u64)gridDim.x * BLOCK) {
+        OvfEntry e;
+        e.region = 0xFFFFFFFFu;
+        e.pay = 0;
+        if (i < n) e = list[i];
+        bool mine = e.region != 0xFFFFFFFFu;
+        km += mine;
+        const u64 key = mine ? Pay<PT>::key((PT)e.pay, e.region >> g.p2_bits, g) : 0ull;
+        // skew guard as in count_direct_kernel: an overflow list is mostly copies of a few heavy keys
+        u64 weight = 1;
+        const u64 vmask = __ballot(mine);
+        if (vmask) {
+            const int first = __builtin_ctzll(vmask);
+            const u64 lead = __shfl(key, first, 64);
+            const bool same = mine && key == lead;
+            const u64 smask = __ballot(same);
+            if (__builtin_popcountll(smask) > 1) {
+                if ((int)lane_id() == first) weight = (u64)__builtin_popcountll(smask);
+                else if (same) mine = false;
+            }
+        }
+        if (mine) upsert(tg, key, weight, nd, nf);
+    }
+    const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    km = wave_sum(km);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (f) atomicAdd(&ctr->failed, f);
+        if (km) atomicAdd(&ctr->kmers, km);
+    }
+}
+
 // bstart[r] = first payload of region r's bucket in the level-2 output, r in [0, R]; bstart[R] = total
 __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restrict__ O2, u64 o2_total_index,
                                                             const u64 *__restrict__ moff, const uint32_t *__restrict__ nch,
@@ -1371,7 +1675,7 @@ __device__ __forceinline__ void write_empty_region(Slot *reg, int tid) {
 }
 
 template <bool FRESH>
-__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys,
+__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    u64 *__restrict__ rreal) {
@@ -1382,7 +1686,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     __shared__ u64 s_real;
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
-    const u64 lo = bstart[r], hi = bstart[r + 1];
+    const u64 lo = bstart[r], hi = bend[r];
     Slot *reg = tg.table + r * REGION_SLOTS;
     if (lo == hi) {  // nothing new for this region
         if (FRESH && dirty) write_empty_region(reg, tid);
@@ -1622,7 +1926,7 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
 // A failed region is left untouched in HBM; its bucket then goes through the direct path.
 
 template <bool FRESH>
-__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays,
+__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr,
@@ -1640,7 +1944,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     __shared__ uint32_t s_q[REGION_RK + 1][REGION_NT];  // per-lane payload queues (32 KiB; + a dummy row for predicated stores)
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
-    const u64 lo = bstart[r], hi = bstart[r + 1];
+    const u64 lo = bstart[r], hi = bend[r];
     if (lo == hi) {
         if (FRESH && dirty) write_empty_region(tg.table + r * REGION_SLOTS, tid);
         if (tid == 0) {
@@ -1902,11 +2206,11 @@ __global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restr
 // built with, `tg` to the grown table.
 template <typename PT>
 __global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(TableGeom tg, PartGeom g, const PT *__restrict__ pays,
-                                                                      const u64 *__restrict__ bstart,
+                                                                      const u64 *__restrict__ bstart, const u64 *__restrict__ bend,
                                                                       const uint8_t *__restrict__ rfail, Counters *ctr) {
     const u64 r = blockIdx.x;
     if (!rfail[r]) return;
-    const u64 lo = bstart[r], hi = bstart[r + 1];
+    const u64 lo = bstart[r], hi = bend[r];
     const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
     uint32_t nd = 0, nf = 0;
     u64 real = 0;

@@ -1080,3 +1080,47 @@ def test_level1_bins_kernel_overflow_and_masks(K, monkeypatch, k, hint, generic,
         assert st["kmers"] == m.total() and st["part_batches"] >= 3
         keys, cnts = dc.result()
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
+
+
+@pytest.mark.parametrize("mode", ["arena", "exact", "list-full", "no-skew-limit", "unaligned-exact"])
+@pytest.mark.parametrize("k,skewed", [(21, False), (21, True), (31, True), (19, False)], ids=["k21", "k21-skewed", "k31-skewed", "k19"])
+def test_level2_arena_path_and_its_fallbacks(K, monkeypatch, mode, k, skewed):
+    """Level 2 without a counting pass (part2_arena_kernel: per-bucket arenas sized from the level-1 partition totals,
+    one workgroup per partition, what does not fit goes to an overflow list inserted through the direct path after the
+    region pass) against the oracle, and every way it can step aside: switched off (`exact`), the overflow list
+    declared full after a few entries (`list-full`: the batch is redone through the exact path), no limit on how uneven
+    the partitions may be (`no-skew-limit`: on skewed input the heavy buckets then really go through the list), and the
+    exact path with the unaligned scatter.  Skewed input: a fifth of the reads are copies of four short repeats."""
+    if mode == "exact":
+        monkeypatch.setenv("KMERHIP_L2_ARENA", "0")
+    elif mode == "list-full":
+        monkeypatch.setenv("KMERHIP_L2_OVF_CAP", "64")
+        monkeypatch.setenv("KMERHIP_L2_SKEW_X", "0")
+    elif mode == "no-skew-limit":
+        monkeypatch.setenv("KMERHIP_L2_SKEW_X", "0")
+    elif mode == "unaligned-exact":
+        monkeypatch.setenv("KMERHIP_L2_ARENA", "0")
+        monkeypatch.setenv("KMERHIP_P2_LINES", "0")
+    rng = np.random.default_rng(900 + k)
+    n_reads = 80_000
+    bases, _ = O.synth_reads(SEED + k, 1 << 19, 150, 0, n_reads, with_qual=False)
+    bases = bases.copy()
+    if skewed:
+        v = bases.reshape(n_reads, 151)
+        reps = [np.resize(np.frombuffer(r, dtype=np.uint8), 150) for r in (b"A", b"AC", b"ACGTTGCA", b"GATTACA")]
+        for i in rng.choice(n_reads, size=n_reads // 5, replace=False):
+            v[i, :150] = reps[i % 4]
+    m = O.OracleMap()
+    m.scan_flat(bases, k, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    import torch
+    tb = torch.from_numpy(bases).cuda()
+    torch.cuda.synchronize()
+    with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:
+        cut = [0, 30_000 * 151, 30_001 * 151, n_reads * 151]
+        for a, b in zip(cut, cut[1:]):
+            dc.push_device(tb.data_ptr() + a, None, b - a)
+        st = dc.finish()
+        assert st["kmers"] == m.total()
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
