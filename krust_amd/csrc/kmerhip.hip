@@ -114,7 +114,7 @@ struct kh_ctx {
     u64 merge_off_cap = 0;
     u64 part_budget = 0;       // bytes for the two key buffers (0 = decide at first use)
     uint8_t *keysA = nullptr, *keysB = nullptr;  // partition ping-pong buffers
-    u64 key_cap = 0;           // bytes per buffer
+    u64 key_cap = 0, keyb_cap = 0;  // bytes of keysA / keysB
     kh::Part2Block *blocks = nullptr;
     u64 blocks_cap = 0;
     u64 *moff = nullptr;
@@ -584,17 +584,21 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     // each), 2..512 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
     const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
     const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 1 && g.p2_bits <= 9;
-    const u64 arena_pay = arena ? (n_ub + nregions) + ((n_ub + nregions) >> 2) + 1040ull * nregions : 0;  // upper bound of arena_plan_kernel's total
+    const u64 arena_pay = arena ? (n_ub + nregions) + ((n_ub + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
     const u64 ovf_need = arena ? n_ub / 16 + (2ull << 20) : 0;
     const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
     const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
-    const u64 key_bytes = std::max(std::max(a_bytes, (n_ub + pad_ub) * (u64)sizeof(PT)), arena_pay * (u64)sizeof(PT));
-    if (c->key_cap < key_bytes) {  // key_cap is in BYTES per buffer
+    // A: the level-1 pool.  B: the level-2 output -- exact path: every payload + sentinel padding; arenas: a quarter more
+    const u64 b_bytes = std::max((n_ub + pad_ub) * (u64)sizeof(PT), arena_pay * (u64)sizeof(PT));
+    if (c->key_cap < a_bytes) {  // (capacities in BYTES)
         u64 z = c->keysA ? c->key_cap : 0;
-        if ((rc = ensure_buf(c, &c->keysA, &z, key_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
-        z = c->keysB ? c->key_cap : 0;
-        if ((rc = ensure_buf(c, &c->keysB, &z, key_bytes, "hipMalloc(keysB)")) != KH_OK) return rc;
-        c->key_cap = key_bytes;
+        if ((rc = ensure_buf(c, &c->keysA, &z, a_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
+        c->key_cap = a_bytes;
+    }
+    if (c->keyb_cap < b_bytes) {
+        u64 z = c->keysB ? c->keyb_cap : 0;
+        if ((rc = ensure_buf(c, &c->keysB, &z, b_bytes, "hipMalloc(keysB)")) != KH_OK) return rc;
+        c->keyb_cap = b_bytes;
     }
     PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);
     if (arena) {
@@ -705,7 +709,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const uint32_t skew_x = [] { const char *e = getenv("KMERHIP_L2_SKEW_X"); return e ? (uint32_t)atoi(e) : 2u; }();
             hipLaunchKernelGGL(kh::arena_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
                                c->ovf, skew_x);
-            hipLaunchKernelGGL((kh::part2_arena_kernel<PT>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
+            hipLaunchKernelGGL((kh::part2_arena_kernel<PT, sizeof(PT) == 4 ? 128 : 64>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
                                (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
         }
         u64 hov[2] = {0, 0};
@@ -933,7 +937,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     if (!c->part_budget) {
         size_t fr = 0, tot = 0;
         u64 budget = 160ull << 30;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap * 2) * 0.75));
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * 0.75));
         const char *e = getenv("KMERHIP_PART_BUDGET_GB");
         if (e && atof(e) > 0) budget = (u64)(atof(e) * (double)(1ull << 30));
         c->part_budget = std::max<u64>(budget, 64ull << 20);
@@ -943,7 +947,8 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     for (u64 t = first_tile; t < end_tile;) {
         const GeomChoice gc = make_geom(c, c->cap);  // re-evaluated per batch: the table may have grown
         if (!gc.ok) return direct_range(c, ra, t * (kh::PART_TILE / kh::TILE), (ra.vend + kh::TILE - 1) / kh::TILE);
-        const u64 per_key = gc.use32 ? 8 : 16;  // two buffers
+        // bytes per key over the two buffers and the overflow list: pool (1.04 x payload) + arenas (1.25 x + 1) + 1
+        const u64 per_key = gc.use32 ? 11 : 20;
         u64 batch_tiles = std::max<u64>(1, c->part_budget / per_key / kh::PART_TILE);
         const u64 left = end_tile - t;
         const u64 nb = (left + batch_tiles - 1) / batch_tiles;  // equal-sized batches

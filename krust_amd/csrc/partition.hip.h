@@ -1357,7 +1357,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
 // flush of whole units after half a batch); a payload whose rank does not fit its bin goes to the overflow list too.
 // If the list itself would overflow (ovf[1] set), the host runs the exact count -> scan -> scatter path for the batch.
 
-// bstart[r] for r = (p, b): arenas of cap_p = align16(ceil(n_p / P2) * 5 / 4 + 1024) payloads, partition after partition
+// bstart[r] for r = (p, b): arenas of cap_p = align32(ceil(n_p / P2) * 5 / 4 + 1024) payloads, partition after partition
 // ovf[1] = 2 if some partition holds more than skew_x times the mean (one workgroup handles a whole partition: a
 // partition that heavy -- a homopolymer's, say -- would be the whole pass; the exact path splits partitions into blocks)
 __global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict__ ptotal, PartGeom g, u64 *__restrict__ bstart,
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict_
     const uint32_t P2 = 1u << g.p2_bits;
     if (tid < P1) {
         const u64 m = (ptotal[tid] + P2 - 1) / P2;
-        s_cap[tid] = (uint32_t)((m + (m >> 2) + 1024 + 15) & ~15ull);
+        s_cap[tid] = (uint32_t)((m + (m >> 2) + 1024 + 31) & ~31ull);
         pcap[tid] = s_cap[tid];
     }
     __syncthreads();
@@ -1397,22 +1397,25 @@ struct OvfEntry {
     u64 pay;
 };
 
-template <typename PT>
+// UNITB: bytes a flush writes at a time -- 128 (whole lines: 3.6 instead of 2.8 TB/s for such appends,
+// tools/ubench/scatter_runs.hip) for 4-byte payloads, 64 for 8-byte ones (a bin is 256 bytes either way, and what a
+// flush keeps back has to leave room for a half batch's arrivals).  Lanes 2b and 2b + 1 flush bucket b together.
+template <typename PT, int UNITB>
 __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
                                                              const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
                                                              PT *__restrict__ out, u64 *__restrict__ bend,
                                                              OvfEntry *__restrict__ ovf_list, u64 *__restrict__ ovf, u64 ovf_cap) {
-    constexpr int NBK = P2L_NBK, UNIT = P2L<PT>::UNIT, NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
+    constexpr int NBK = P2L_NBK, UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
     constexpr int HALF = PER / 2;
-    constexpr uint32_t CAP = 4 * UNIT;                        // payloads per bin (256 bytes)
-    constexpr uint32_t UW = UNIT * sizeof(PT) / 16;           // 16-byte words per unit (4)
+    constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin (256 bytes)
+    constexpr uint32_t UW = UNITB / 16;                       // 16-byte words per unit
     __shared__ __attribute__((aligned(16))) PT s_bin[NBK * CAP + UNIT];  // 128 KiB (+ a trash unit)
     __shared__ uint32_t s_cnt[NBK];
     __shared__ uint32_t s_chk[CPB];
     __shared__ uint16_t s_cfill[CPB];
     __shared__ u64 s_ovf_next, s_ovf_end;  // the workgroup's private segment of the overflow list (none to begin with)
     __shared__ uint32_t s_ovf_want;
-    constexpr u64 OVF_SEG = 65536, OVF_LOW = 24576;  // (one flush appends < 17 K entries)
+    constexpr u64 OVF_SEG = 8192, OVF_LOW = 2048;  // (a request that finds the segment short is served from the global cursor)
     if (ovf[1]) return;  // (the plan found the batch too skewed for one workgroup per partition: the host takes the exact path)
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1422,13 +1425,15 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         s_ovf_end = 0;
         s_ovf_want = 0;
     }
-    // lane b < P2 owns bucket b: its arena and how much of it is written (a multiple of UNIT until the end)
-    const u64 abase = tid < (int)P2 ? bstart[(u64)p * P2 + tid] : 0;
+    // lanes 2b and 2b + 1 own bucket b < P2 together: both keep its arena and how much of it is written (a multiple of
+    // UNIT until the end); of every unit lane i moves the 16-byte words i, i + 2, ...
+    const uint32_t ob = (uint32_t)tid >> 1, oi = (uint32_t)tid & 1u;
+    const u64 abase = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
     const uint32_t acap = pcap[p];
     uint32_t apos = 0;
     if (tid < NBK) s_cnt[tid] = 0;
     const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
-    uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + (uint32_t)(tid < NBK ? tid : 0) * CAP);
+    uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + ob * CAP);
     // Appends k entries of this lane to the overflow list; false if the list is full (the host then redoes the batch).
     // On skewed input MANY lanes of MANY workgroups do this: the list is handed out in private segments (one global
     // atomic per OVF_SEG entries and workgroup, LDS atomics inside), a request that finds the segment short takes its
@@ -1482,29 +1487,28 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 have |= (uint32_t)ok << j;
             }
         };
-        // lane b writes the whole units of bucket b's bin to its arena (or, the arena full, to the overflow list)
+        // lanes 2b, 2b + 1 write the whole units of bucket b's bin to its arena (or, the arena full, lane 2b to the overflow list)
         auto flush = [&]() {
-            if (tid >= NBK) return;
-            const uint32_t c = min(s_cnt[tid], CAP);  // (ranks beyond the bin went to the overflow list)
+            const uint32_t c = min(s_cnt[ob], CAP);  // (ranks beyond the bin went to the overflow list)
             const uint32_t nun = c / UNIT, r = c % UNIT;
 #pragma unroll
             for (uint32_t u = 0; u < CAP / UNIT; ++u)
                 if (u < nun) {
-                    uint4 x[UW];
-#pragma unroll
-                    for (uint32_t q = 0; q < UW; ++q) x[q] = bin4[UW * u + q];
                     if (apos + UNIT <= acap) {
+                        uint4 x[UW / 2];
+#pragma unroll
+                        for (uint32_t q = 0; q < UW / 2; ++q) x[q] = bin4[UW * u + oi + 2 * q];
                         uint4 *d = reinterpret_cast<uint4 *>(out + abase + apos);
 #pragma unroll
-                        for (uint32_t q = 0; q < UW; ++q) d[q] = x[q];
+                        for (uint32_t q = 0; q < UW / 2; ++q) d[oi + 2 * q] = x[q];
                         apos += UNIT;
-                    } else {
+                    } else if (oi == 0) {
                         u64 at;
                         if (ovf_take(UNIT, at)) {
-                            const PT *e = reinterpret_cast<const PT *>(x);
+                            const PT *e = s_bin + ob * CAP + u * UNIT;
                             for (uint32_t q = 0; q < (uint32_t)UNIT; ++q) {
                                 OvfEntry oe;
-                                oe.region = p * P2 + (uint32_t)tid;
+                                oe.region = p * P2 + ob;
                                 oe.pad = 0;
                                 oe.pay = (u64)e[q];
                                 ovf_list[at + q] = oe;
@@ -1512,11 +1516,17 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                         }
                     }
                 }
+            __builtin_amdgcn_wave_barrier();
             if (nun) {
                 const uint32_t nw = (r * (uint32_t)sizeof(PT) + 15u) / 16u;
-                for (uint32_t i = 0; i < nw; ++i) bin4[i] = bin4[UW * nun + i];
+                uint4 m[UW / 2];
+#pragma unroll
+                for (uint32_t q = 0; q < UW / 2; ++q) m[q] = oi + 2 * q < nw ? bin4[UW * nun + oi + 2 * q] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (uint32_t q = 0; q < UW / 2; ++q)
+                    if (oi + 2 * q < nw) bin4[oi + 2 * q] = m[q];
             }
-            s_cnt[tid] = r;
+            if (oi == 0) s_cnt[ob] = r;
         };
         auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
             load_batch(base + TILE, nxt, have_nxt);
@@ -1573,9 +1583,9 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         }
     }
     // what is left in the bins (< UNIT payloads per bucket), one by one; then the bucket's end
-    if (tid < (int)P2) {
-        const uint32_t r = s_cnt[tid];
-        const PT *bin = s_bin + (uint32_t)tid * CAP;
+    if (oi == 0 && ob < P2) {
+        const uint32_t r = s_cnt[ob];
+        const PT *bin = s_bin + ob * CAP;
         if (r) {
             if (apos + r <= acap) {
                 for (uint32_t i = 0; i < r; ++i) out[abase + apos + i] = bin[i];
@@ -1585,14 +1595,14 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 if (ovf_take(r, at))
                     for (uint32_t i = 0; i < r; ++i) {
                         OvfEntry oe;
-                        oe.region = p * P2 + (uint32_t)tid;
+                        oe.region = p * P2 + ob;
                         oe.pad = 0;
                         oe.pay = (u64)bin[i];
                         ovf_list[at + i] = oe;
                     }
             }
         }
-        bend[(u64)p * P2 + tid] = abase + apos;
+        bend[(u64)p * P2 + ob] = abase + apos;
     }
     __syncthreads();
     for (u64 i = s_ovf_next + tid; i < s_ovf_end && i < ovf_cap; i += NT) ovf_list[i].region = 0xFFFFFFFFu;
