@@ -1441,6 +1441,9 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     auto ovf_take = [&](uint32_t k, u64 &at) -> bool {
         at = atomicAdd(&s_ovf_next, (u64)k);  // LDS
         if (at + k > s_ovf_end) {
+            // (the request that crosses the segment's end leaves [at, end) unused: nobody else will write or mark those
+            //  entries -- the cursor is past them -- and they may hold an earlier batch's entries)
+            for (u64 i = at; i < s_ovf_end && i < ovf_cap; ++i) ovf_list[i].region = 0xFFFFFFFFu;
             s_ovf_want = 1u;
             at = atomicAdd(&ovf[0], (u64)k);
         }
