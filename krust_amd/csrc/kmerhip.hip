@@ -581,9 +581,9 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     const bool lines = lines_on && g.p2_bits >= 1 && g.p2_bits <= 9;
     const uint32_t force_wide = [] { const char *e = getenv("KMERHIP_P2_FORCE_WIDE"); return (e && e[0] == '1') ? 1u : 0u; }();
     // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
-    // each), 2..512 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
+    // each), 32..512 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
     const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
-    const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 1 && g.p2_bits <= 9;
+    const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 5 && g.p2_bits <= 9;
     const u64 arena_pay = arena ? (n_ub + nregions) + ((n_ub + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
     const u64 ovf_need = arena ? n_ub / 16 + (2ull << 20) : 0;
     const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);

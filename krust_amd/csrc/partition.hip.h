@@ -1399,7 +1399,7 @@ struct OvfEntry {
 
 // UNITB: bytes a flush writes at a time -- 128 (whole lines: 3.6 instead of 2.8 TB/s for such appends,
 // tools/ubench/scatter_runs.hip) for 4-byte payloads, 64 for 8-byte ones (a bin is 256 bytes either way, and what a
-// flush keeps back has to leave room for a half batch's arrivals).  Lanes 2b and 2b + 1 flush bucket b together.
+// flush keeps back has to leave room for a half batch's arrivals).  Lanes 2b and 2b + 1 flush bucket b together, half a unit each.
 template <typename PT, int UNITB>
 __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
                                                              const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
@@ -1420,20 +1420,21 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x;
     const uint32_t P2 = 1u << g.p2_bits;
+    const uint32_t capr = CAP << (9u - g.p2_bits);  // payloads per bin: the 128 KiB are shared out among the P2 <= 512 buckets
     if (tid == 0) {
         s_ovf_next = 0;
         s_ovf_end = 0;
         s_ovf_want = 0;
     }
     // lanes 2b and 2b + 1 own bucket b < P2 together: both keep its arena and how much of it is written (a multiple of
-    // UNIT until the end); of every unit lane i moves the 16-byte words i, i + 2, ...
+    // UNIT until the end); of every unit lane i moves the i-th half
     const uint32_t ob = (uint32_t)tid >> 1, oi = (uint32_t)tid & 1u;
     const u64 abase = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
     const uint32_t acap = pcap[p];
     uint32_t apos = 0;
     if (tid < NBK) s_cnt[tid] = 0;
     const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
-    uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + ob * CAP);
+    uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + (ob < P2 ? ob : 0u) * capr);
     // Appends k entries of this lane to the overflow list; false if the list is full (the host then redoes the batch).
     // On skewed input MANY lanes of MANY workgroups do this: the list is handed out in private segments (one global
     // atomic per OVF_SEG entries and workgroup, LDS atomics inside), a request that finds the segment short takes its
@@ -1492,23 +1493,25 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         };
         // lanes 2b, 2b + 1 write the whole units of bucket b's bin to its arena (or, the arena full, lane 2b to the overflow list)
         auto flush = [&]() {
-            const uint32_t c = min(s_cnt[ob], CAP);  // (ranks beyond the bin went to the overflow list)
+            if (ob >= P2) return;
+            const uint32_t c = min(s_cnt[ob], capr);  // (ranks beyond the bin went to the overflow list)
             const uint32_t nun = c / UNIT, r = c % UNIT;
-#pragma unroll
-            for (uint32_t u = 0; u < CAP / UNIT; ++u)
-                if (u < nun) {
+            for (uint32_t u = 0; u < nun; ++u) {
+                {
                     if (apos + UNIT <= acap) {
+                        // lane i moves the i-th HALF of the unit (consecutive 16-byte words: with the words interleaved between
+                        // the two lanes the memory side saw 2.2 x as many write requests -- TCC_EA0_WRREQ, r02f)
                         uint4 x[UW / 2];
 #pragma unroll
-                        for (uint32_t q = 0; q < UW / 2; ++q) x[q] = bin4[UW * u + oi + 2 * q];
+                        for (uint32_t q = 0; q < UW / 2; ++q) x[q] = bin4[UW * u + (UW / 2) * oi + q];
                         uint4 *d = reinterpret_cast<uint4 *>(out + abase + apos);
 #pragma unroll
-                        for (uint32_t q = 0; q < UW / 2; ++q) d[oi + 2 * q] = x[q];
+                        for (uint32_t q = 0; q < UW / 2; ++q) d[(UW / 2) * oi + q] = x[q];
                         apos += UNIT;
                     } else if (oi == 0) {
                         u64 at;
                         if (ovf_take(UNIT, at)) {
-                            const PT *e = s_bin + ob * CAP + u * UNIT;
+                            const PT *e = s_bin + ob * capr + u * UNIT;
                             for (uint32_t q = 0; q < (uint32_t)UNIT; ++q) {
                                 OvfEntry oe;
                                 oe.region = p * P2 + ob;
@@ -1519,6 +1522,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                         }
                     }
                 }
+            }
             __builtin_amdgcn_wave_barrier();
             if (nun) {
                 const uint32_t nw = (r * (uint32_t)sizeof(PT) + 15u) / 16u;
@@ -1546,8 +1550,8 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
                     const uint32_t r = rk[j];
-                    s_bin[r < CAP ? dg[j] * CAP + r : (uint32_t)(NBK * CAP)] = pay[h * HALF + j];
-                    omask |= (r != 0xFFFFFFFFu && r >= CAP) ? (1u << j) : 0u;
+                    s_bin[r < capr ? dg[j] * capr + r : (uint32_t)(NBK * CAP)] = pay[h * HALF + j];
+                    omask |= (r != 0xFFFFFFFFu && r >= capr) ? (1u << j) : 0u;
                 }
                 if (__any(omask != 0)) {  // ranks that did not fit their bins (a heavy bucket): straight to the overflow list
                     const uint32_t k = (uint32_t)__builtin_popcount(omask);
@@ -1588,7 +1592,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     // what is left in the bins (< UNIT payloads per bucket), one by one; then the bucket's end
     if (oi == 0 && ob < P2) {
         const uint32_t r = s_cnt[ob];
-        const PT *bin = s_bin + ob * CAP;
+        const PT *bin = s_bin + ob * capr;
         if (r) {
             if (apos + r <= acap) {
                 for (uint32_t i = 0; i < r; ++i) out[abase + apos + i] = bin[i];
