@@ -40,6 +40,9 @@ constexpr u64 ACC_MAX = 2ull << 30;        // device accumulation buffer of kh_p
 constexpr u64 ACC_MIN = 1ull << 20;
 constexpr u64 HALO = 32;                   // >= k-1 bytes re-sent in front of every staged chunk
 constexpr int GRID_CAP = 256 * 8;          // 256 CUs x 8 resident workgroups of 256 threads
+#ifndef KH_ARENA_UNITB
+#define KH_ARENA_UNITB 128  // bytes per flushed unit of the arena level 2, 4-byte payloads (64: A/B builds)
+#endif
 #ifndef KH_PART_G1
 #define KH_PART_G1 512
 #endif
@@ -709,7 +712,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const uint32_t skew_x = [] { const char *e = getenv("KMERHIP_L2_SKEW_X"); return e ? (uint32_t)atoi(e) : 2u; }();
             hipLaunchKernelGGL(kh::arena_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
                                c->ovf, skew_x);
-            hipLaunchKernelGGL((kh::part2_arena_kernel<PT, sizeof(PT) == 4 ? 128 : 64>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
+            hipLaunchKernelGGL((kh::part2_arena_kernel<PT, sizeof(PT) == 4 ? KH_ARENA_UNITB : 64>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
                                (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
         }
         u64 hov[2] = {0, 0};

@@ -50,6 +50,9 @@ constexpr uint32_t MAX_P1_BITS = 10;
 constexpr uint32_t MAX_P2_BITS = 10;             // <= 1024 regions per level-1 partition
 constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // payloads per level-2 workgroup (262144)
 constexpr int REGION_NT = 1024;                  // lanes per workgroup in region_count_kernel
+#ifndef KH_ARENA_LANES
+#define KH_ARENA_LANES 4  // lanes that flush a bucket of the arena level 2 together (1, 2, 8: A/B builds)
+#endif
 #ifndef KH_REGION_RK
 #define KH_REGION_RK 8
 #endif
@@ -1399,7 +1402,7 @@ struct OvfEntry {
 
 // UNITB: bytes a flush writes at a time -- 128 (whole lines: 3.6 instead of 2.8 TB/s for such appends,
 // tools/ubench/scatter_runs.hip) for 4-byte payloads, 64 for 8-byte ones (a bin is 256 bytes either way, and what a
-// flush keeps back has to leave room for a half batch's arrivals).  Lanes 2b and 2b + 1 flush bucket b together, half a unit each.
+// flush keeps back has to leave room for a half batch's arrivals).
 template <typename PT, int UNITB>
 __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
                                                              const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
@@ -1426,15 +1429,25 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         s_ovf_end = 0;
         s_ovf_want = 0;
     }
-    // lanes 2b and 2b + 1 own bucket b < P2 together: both keep its arena and how much of it is written (a multiple of
-    // UNIT until the end); of every unit lane i moves the i-th half
-    const uint32_t ob = (uint32_t)tid >> 1, oi = (uint32_t)tid & 1u;
-    const u64 abase = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
+    // LP consecutive lanes own a bucket together: all keep its arena and how much of it is written (a multiple of UNIT
+    // until the end); of every unit lane i stores the 16-byte words i, i + LP, ... -- so that ONE store instruction covers
+    // LP x 16 contiguous bytes (measured, profiles/README.md r02g: the more of a unit one instruction stores, the fewer
+    // write requests the memory side sees and the faster the kernel; one lane per unit: 152 GB written and 54 ms, two: 120 GB
+    // and 27.6 ms).  1024 lanes / LP < 512 buckets: a lane group owns NB buckets, LP apart... NT / LP apart.
+    constexpr uint32_t LP = KH_ARENA_LANES < UW ? KH_ARENA_LANES : UW;
+    constexpr uint32_t NB = (NBK * LP + NT - 1) / NT;  // buckets per lane group
+    const uint32_t og = (uint32_t)tid / LP, oi = (uint32_t)tid % LP;
+    u64 abase[NB];
+    uint32_t apos[NB];
+#pragma unroll
+    for (uint32_t it = 0; it < NB; ++it) {
+        const uint32_t ob = og + it * (NT / LP);
+        abase[it] = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
+        apos[it] = 0;
+    }
     const uint32_t acap = pcap[p];
-    uint32_t apos = 0;
     if (tid < NBK) s_cnt[tid] = 0;
     const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
-    uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + (ob < P2 ? ob : 0u) * capr);
     // Appends k entries of this lane to the overflow list; false if the list is full (the host then redoes the batch).
     // On skewed input MANY lanes of MANY workgroups do this: the list is handed out in private segments (one global
     // atomic per OVF_SEG entries and workgroup, LDS atomics inside), a request that finds the segment short takes its
@@ -1491,23 +1504,24 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 have |= (uint32_t)ok << j;
             }
         };
-        // lanes 2b, 2b + 1 write the whole units of bucket b's bin to its arena (or, the arena full, lane 2b to the overflow list)
+        // the lane group writes the whole units of its buckets' bins to their arenas (or, an arena full, its first lane to the overflow list)
         auto flush = [&]() {
-            if (ob >= P2) return;
-            const uint32_t c = min(s_cnt[ob], capr);  // (ranks beyond the bin went to the overflow list)
-            const uint32_t nun = c / UNIT, r = c % UNIT;
-            for (uint32_t u = 0; u < nun; ++u) {
-                {
-                    if (apos + UNIT <= acap) {
-                        // lane i moves the i-th HALF of the unit (consecutive 16-byte words: with the words interleaved between
-                        // the two lanes the memory side saw 2.2 x as many write requests -- TCC_EA0_WRREQ, r02f)
-                        uint4 x[UW / 2];
 #pragma unroll
-                        for (uint32_t q = 0; q < UW / 2; ++q) x[q] = bin4[UW * u + (UW / 2) * oi + q];
-                        uint4 *d = reinterpret_cast<uint4 *>(out + abase + apos);
+            for (uint32_t it = 0; it < NB; ++it) {
+                const uint32_t ob = og + it * (NT / LP);
+                if (ob >= P2) continue;
+                uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + ob * capr);
+                const uint32_t c = min(s_cnt[ob], capr);  // (ranks beyond the bin went to the overflow list)
+                const uint32_t nun = c / UNIT, r = c % UNIT;
+                for (uint32_t u = 0; u < nun; ++u) {
+                    if (apos[it] + UNIT <= acap) {
+                        uint4 x[UW / LP];
 #pragma unroll
-                        for (uint32_t q = 0; q < UW / 2; ++q) d[(UW / 2) * oi + q] = x[q];
-                        apos += UNIT;
+                        for (uint32_t q = 0; q < UW / LP; ++q) x[q] = bin4[UW * u + oi + LP * q];
+                        uint4 *d = reinterpret_cast<uint4 *>(out + abase[it] + apos[it]);
+#pragma unroll
+                        for (uint32_t q = 0; q < UW / LP; ++q) d[oi + LP * q] = x[q];
+                        apos[it] += UNIT;
                     } else if (oi == 0) {
                         u64 at;
                         if (ovf_take(UNIT, at)) {
@@ -1522,18 +1536,18 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                         }
                     }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (nun) {
-                const uint32_t nw = (r * (uint32_t)sizeof(PT) + 15u) / 16u;
-                uint4 m[UW / 2];
+                __builtin_amdgcn_wave_barrier();
+                if (nun) {
+                    const uint32_t nw = (r * (uint32_t)sizeof(PT) + 15u) / 16u;
+                    uint4 m[UW / LP];
 #pragma unroll
-                for (uint32_t q = 0; q < UW / 2; ++q) m[q] = oi + 2 * q < nw ? bin4[UW * nun + oi + 2 * q] : make_uint4(0, 0, 0, 0);
+                    for (uint32_t q = 0; q < UW / LP; ++q) m[q] = oi + LP * q < nw ? bin4[UW * nun + oi + LP * q] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-                for (uint32_t q = 0; q < UW / 2; ++q)
-                    if (oi + 2 * q < nw) bin4[oi + 2 * q] = m[q];
+                    for (uint32_t q = 0; q < UW / LP; ++q)
+                        if (oi + LP * q < nw) bin4[oi + LP * q] = m[q];
+                }
+                if (oi == 0) s_cnt[ob] = r;
             }
-            if (oi == 0) s_cnt[ob] = r;
         };
         auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
             load_batch(base + TILE, nxt, have_nxt);
@@ -1590,13 +1604,16 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         }
     }
     // what is left in the bins (< UNIT payloads per bucket), one by one; then the bucket's end
-    if (oi == 0 && ob < P2) {
+#pragma unroll
+    for (uint32_t it = 0; it < NB; ++it) {
+        const uint32_t ob = og + it * (NT / LP);
+        if (oi != 0 || ob >= P2) continue;
         const uint32_t r = s_cnt[ob];
         const PT *bin = s_bin + ob * capr;
         if (r) {
-            if (apos + r <= acap) {
-                for (uint32_t i = 0; i < r; ++i) out[abase + apos + i] = bin[i];
-                apos += r;
+            if (apos[it] + r <= acap) {
+                for (uint32_t i = 0; i < r; ++i) out[abase[it] + apos[it] + i] = bin[i];
+                apos[it] += r;
             } else {
                 u64 at;
                 if (ovf_take(r, at))
@@ -1609,7 +1626,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                     }
             }
         }
-        bend[(u64)p * P2 + ob] = abase + apos;
+        bend[(u64)p * P2 + ob] = abase[it] + apos[it];
     }
     __syncthreads();
     for (u64 i = s_ovf_next + tid; i < s_ovf_end && i < ovf_cap; i += NT) ovf_list[i].region = 0xFFFFFFFFu;
