@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     // until the end); of every unit lane i stores the 16-byte words i, i + LP, ... -- so that ONE store instruction covers
     // LP x 16 contiguous bytes (measured, profiles/README.md r02g: the more of a unit one instruction stores, the fewer
     // write requests the memory side sees and the faster the kernel; one lane per unit: 152 GB written and 54 ms, two: 120 GB
-    // and 27.6 ms).  1024 lanes / LP < 512 buckets: a lane group owns NB buckets, LP apart... NT / LP apart.
+    // and 27.6 ms, four: 65 GB and 21.7 ms).  1024 lanes / LP < 512 buckets: a lane group owns NB buckets, NT / LP apart.
     constexpr uint32_t LP = KH_ARENA_LANES < UW ? KH_ARENA_LANES : UW;
     constexpr uint32_t NB = (NBK * LP + NT - 1) / NT;  // buckets per lane group
     const uint32_t og = (uint32_t)tid / LP, oi = (uint32_t)tid % LP;
