@@ -997,11 +997,12 @@ def test_full_map_digest_10M_reads(K, k, minq):
 @pytest.mark.parametrize("k,hint", [(21, 3_000_000), (21, 40_000_000), (19, 8_000_000), (15, 2_000_000), (21, 0)],
                          ids=["k21-2buckets", "k21-64buckets", "k19", "k15", "k21-unhinted"])
 def test_level2_unit_writer_and_its_stand_down(K, monkeypatch, mode, k, hint):
-    """Level 2 with 32-bit payloads writes whole aligned 64-byte units (segments padded with sentinels that the
+    """The EXACT level 2 (count -> scan -> scatter; what the arena path falls back to) with 32-bit payloads writes whole aligned 64-byte units (segments padded with sentinels that the
     region pass skips, tails carried in LDS); a partition too large for its 32-bit offsets makes it stand down for
     the batch in favour of the unaligned kernel (forced here by KMERHIP_P2_FORCE_WIDE: the real condition needs
     > 4 G k-mers with one level-1 digit); KMERHIP_P2_LINES=0 is the unaligned kernel alone.  All three must give
     the oracle's map, over several batches into one table (non-fresh region passes see the sentinels too)."""
+    monkeypatch.setenv("KMERHIP_L2_ARENA", "0")  # (the exact level 2: the arena path has its own test below)
     if mode == "stand-down":
         monkeypatch.setenv("KMERHIP_P2_FORCE_WIDE", "1")
     elif mode == "unaligned":
