@@ -1,5 +1,5 @@
 #!/bin/bash
-# Where does part1_scatter_chunked_kernel spend its time?  Builds the library with ablation bits (KH_ABL: the
+# Where does part1_scatter_chunked_kernel (the level-1 kernel of 64-bit payloads; 32-bit ones take part1_bins_kernel) spend its time?  Builds the library with ablation bits (KH_ABL: the
 # kernel then produces garbage, so the pipeline stops after level 1) and prints the level-1 stage time of
 # bench.py for each.  Run the build part here (no GPU needed), the timing part through gpurun:
 #   bash tools/p1_ablation.sh build     -> krust_amd/lib/libkmerhip_abl<N>.so
