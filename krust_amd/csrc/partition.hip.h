@@ -1419,9 +1419,15 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     __shared__ u64 s_ovf_next, s_ovf_end;  // the workgroup's private segment of the overflow list (none to begin with)
     __shared__ uint32_t s_ovf_want;
     constexpr u64 OVF_SEG = 8192, OVF_LOW = 2048;  // (a request that finds the segment short is served from the global cursor)
-    if (ovf[1]) return;  // (the plan found the batch too skewed for one workgroup per partition: the host takes the exact path)
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x;
+    // The batch is not for this path (the plan found a partition too heavy), or is lost to it already (another workgroup
+    // found the overflow list full): nothing to do, the host takes the exact path.  Decided by ONE lane for the whole
+    // workgroup -- the flag can change while the lanes are reading it, and a workgroup must not split at a barrier.
+    __shared__ uint32_t s_skip;
+    if (tid == 0) s_skip = ovf[1] != 0;
+    __syncthreads();
+    if (s_skip) return;
     const uint32_t P2 = 1u << g.p2_bits;
     const uint32_t capr = CAP << (9u - g.p2_bits);  // payloads per bin: the 128 KiB are shared out among the P2 <= 512 buckets
     if (tid == 0) {
@@ -1604,6 +1610,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         }
     }
     // what is left in the bins (< UNIT payloads per bucket), one by one; then the bucket's end
+    __syncthreads();  // (a partition without chunks comes here straight from the initialisation of the counters)
 #pragma unroll
     for (uint32_t it = 0; it < NB; ++it) {
         const uint32_t ob = og + it * (NT / LP);
