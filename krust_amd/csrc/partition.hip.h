@@ -1353,11 +1353,12 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
 // of its partitions holds (chunk fill levels), and a partition's buckets are equally likely: bucket (p, b) gets an ARENA
 // of n_p / P2 payloads plus a quarter plus 1024 (the counts of coverage-deep data spread ~3.6 x wider than a
 // multinomial's, sigma ~ 570 around 24.8 K on S100M), ONE workgroup handles a whole partition -- so a bucket's write
-// position lives in its owner lane's registers, no atomics -- and whatever does not fit its arena (a heavy hitter's
+// position lives in its owner lanes' registers, no atomics -- and whatever does not fit its arena (a heavy hitter's
 // copies, essentially) goes to an overflow list of (region, payload) pairs that is inserted through the direct path
 // after the region pass.  The region pass reads [bstart[r], bend[r]); the gaps are address space, not traffic.
-// The workgroup sorts through per-bucket bins in LDS as level 1 does (bin = four 64-byte units, rank atomic -> bin,
-// flush of whole units after half a batch); a payload whose rank does not fit its bin goes to the overflow list too.
+// The workgroup sorts through per-bucket bins in LDS as level 1 does (128 KiB shared out among the partition's P2 <= 512
+// buckets: 256 bytes each at 512; rank atomic -> bin, flush of whole units after half a batch); a payload whose rank
+// does not fit its bin goes to the overflow list too.
 // If the list itself would overflow (ovf[1] set), the host runs the exact count -> scan -> scatter path for the batch.
 
 // bstart[r] for r = (p, b): arenas of cap_p = align32(ceil(n_p / P2) * 5 / 4 + 1024) payloads, partition after partition
