@@ -57,7 +57,9 @@ typedef enum kh_status {
     KH_ERR_RANGE = -8,      /* caller-provided output array too small */
     KH_ERR_FORMAT = -9,     /* kh_push_text*: a record layout the device scanner does not take
                                (nothing was counted; parse on the host and use kh_push) */
-    KH_ERR_RCCL = -10       /* an RCCL call failed (kh_comm_init / kh_merge_across); kh_last_error() has the text */
+    KH_ERR_RCCL = -10,      /* an RCCL call failed or timed out (kh_comm_init / kh_merge_across); kh_last_error() has the text */
+    KH_ERR_PEER = -11       /* kh_merge_across: ANOTHER rank of the collective failed (its own status says why;
+                               kh_last_error() names the rank); every rank leaves the merge together */
 } kh_status;
 
 typedef struct kh_ctx kh_ctx;
@@ -87,13 +89,14 @@ typedef struct kh_config {
 
 /* indices into kh_stats.stage_ms */
 #define KH_NUM_STAGES 8
-#define KH_STAGE_DIRECT 0      /* count_direct_kernel */
+#define KH_STAGE_DIRECT 0      /* count_direct_kernel (the device-atomic path) */
 #define KH_STAGE_P1_COUNT 1    /* (no longer used: level 1 is a single pass; always 0) */
-#define KH_STAGE_P1_SCATTER 2  /* part1_scatter_chunked_kernel */
-#define KH_STAGE_P2_COUNT 3    /* part2_count_kernel */
-#define KH_STAGE_P2_SCATTER 4  /* part2_scatter_kernel */
-#define KH_STAGE_REGION 5      /* region_count_kernel */
-#define KH_STAGE_MISC 6        /* scans, plan, bounds, memsets */
+#define KH_STAGE_P1_SCATTER 2  /* level 1: part1_bins_kernel (4-byte payloads, k <= 21 at >= 1024 regions) /
+                                  part1_bins64_kernel (8-byte payloads) */
+#define KH_STAGE_P2_COUNT 3    /* level 2, exact path only: part2_count_kernel (0 = the batch took the arena path) */
+#define KH_STAGE_P2_SCATTER 4  /* level 2: part2_arena_kernel, or part2_scatter_lines_kernel (+ part2_scatter_kernel) on the exact path */
+#define KH_STAGE_REGION 5      /* region_count_kernel32 / region_count_kernel64 (+ shard_merge_kernel in a merge) */
+#define KH_STAGE_MISC 6        /* scans, plans, chunk lists, bounds, memsets, region_reduce, ovf_insert */
 #define KH_STAGE_GROW 7        /* table growth / rehash */
 
 typedef struct kh_stats {
@@ -260,7 +263,15 @@ int kh_merge_pairs(kh_ctx *ctx, const uint64_t *keys, const uint64_t *counts, ui
  * ncclSend / ncclRecv groups on an own stream -- in KMERHIP_MERGE_PIECES (default 4) pieces, so that the
  * export of piece i + 1 and the LDS merge of piece i - 1 overlap the transfer of piece i -- and leaves this
  * context holding its hash-range shard (kh_set_shard state; kh_reset makes it a full table again).
- * One rank per context; ranks may be processes (one per GPU) or threads of one process (kh_group_*). */
+ * One rank per context; ranks may be processes (one per GPU) or threads of one process (kh_group_*).
+ *
+ * Failure is collective too.  Every small all-gather of the sequence carries each rank's status, no transfer starts
+ * before such a gather has come back clean, and one more closes the merge: a rank that fails on its own (out of
+ * memory for a receive buffer, a kernel error) returns its status, EVERY other rank returns KH_ERR_PEER from the same
+ * call -- nobody is left waiting.  Every wait is bounded by KMERHIP_MERGE_TIMEOUT_S (default 300 s): on expiry, or on
+ * an asynchronous RCCL error, the communicator is aborted (ncclCommAbort) and the call returns KH_ERR_RCCL; that
+ * context's communicator is dead afterwards (kh_merge_across refuses it; make a new context and communicator).
+ * After any failed merge the table's content is unspecified until kh_reset. */
 typedef struct kh_unique_id { char internal[128]; } kh_unique_id;  /* ncclUniqueId, opaque */
 int kh_comm_unique_id(kh_unique_id *out);
 /* Collective over all ranks (it blocks until every rank has called it).  The context must be on the GPU this
@@ -300,7 +311,7 @@ int kh_group_create(kh_group **out, const kh_config *cfg, const int32_t *devices
 kh_ctx *kh_group_ctx(kh_group *g, uint32_t rank);
 uint32_t kh_group_size(const kh_group *g);
 /* kh_merge_across on every context, each on its own host thread; infos: ndevices entries or NULL.
- * Returns the first failing rank's status. */
+ * Returns KH_OK, else the status of a rank that failed itself (before any peer's KH_ERR_PEER). */
 int kh_group_merge(kh_group *g, kh_merge_info *infos);
 void kh_group_destroy(kh_group *g);
 

@@ -18,11 +18,40 @@
 
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
 
+// ---- liveness (round 3) -----------------------------------------------------------------------------
+// kh_merge_across is a collective: a rank that fails on its own (an allocation, an export that does not fit, a
+// kernel error) must not leave its peers blocked in the next all-gather or ncclRecv.  Three rules:
+//   1. STATUS IS PART OF THE PROTOCOL.  Every small all-gather carries the sender's status word in front of its
+//      values (xp_gather).  A rank that failed locally keeps walking to the next gather and reports there; every
+//      rank sees the same gathered words, so all of them leave at the same point: the failing rank with its own
+//      status, the others with KH_ERR_PEER.  No data all-to-all starts before such a gather has come back clean,
+//      and the last act of a merge is one more gather, so that "my merge failed" reaches everybody too.
+//   2. EVERY WAIT IS BOUNDED (KMERHIP_MERGE_TIMEOUT_S, default 300).  Waiting for a transfer is a poll of the event
+//      (hipEventQuery) that also reads ncclCommGetAsyncError; a watchdog thread covers the RCCL calls that can block
+//      inside the library (connection set-up in ncclGroupEnd / the first collective).  Either one, on expiry or on
+//      an asynchronous error, calls ncclCommAbort -- which releases whatever this rank had in flight -- and the merge
+//      returns KH_ERR_RCCL; the communicator is dead from then on (kh_merge_across refuses it), the context is not.
+//   3. A send / recv group that fails half way is still closed (ncclGroupEnd), then the communicator is aborted.
+// The process-local hub follows the same rules with a poison flag in place of the abort: a barrier that times out,
+// or a rank that cannot go on, poisons the hub and every barrier returns at once.
+// KMERHIP_FAULT="rank:point[:status]" (tests) makes `rank` fail at a named point of the sequence.
+
 namespace {
+
+double merge_timeout_s() {
+    const char *e = getenv("KMERHIP_MERGE_TIMEOUT_S");
+    const double v = e ? atof(e) : 300.0;
+    return v > 0 ? v : 300.0;
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // ---- process-local hub: ranks are threads of one process --------------------------------------------
 struct LocalHub {
@@ -31,20 +60,44 @@ struct LocalHub {
     std::condition_variable cv;
     uint32_t arrived = 0;
     u64 generation = 0;
+    bool poisoned = false;                       // a rank gave up: every barrier returns false from now on
     std::vector<const void *> base;              // posted per rank
     std::vector<std::vector<u64>> off, len;      // [rank][peer], bytes
     std::vector<std::vector<u64>> small;         // all-gather postings
-    explicit LocalHub(uint32_t nr) : n(nr), base(nr, nullptr), off(nr), len(nr), small(nr) {}
-    void barrier() {
+    std::vector<hipStream_t> xs;                 // every rank's exchange stream (drained by all on a poisoned exit)
+    explicit LocalHub(uint32_t nr) : n(nr), base(nr, nullptr), off(nr), len(nr), small(nr), xs(nr, nullptr) {}
+    // false: the hub is poisoned (by a time-out here, or by poison())
+    bool barrier() {
         std::unique_lock<std::mutex> lk(m);
+        if (poisoned) return false;
         const u64 gen = generation;
         if (++arrived == n) {
             arrived = 0;
             ++generation;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            return true;
         }
+        const bool woke = cv.wait_for(lk, std::chrono::duration<double>(merge_timeout_s()), [&] { return generation != gen || poisoned; });
+        if (generation != gen) return true;  // (the barrier completed, whatever happened since)
+        if (!woke) {
+            poisoned = true;
+            cv.notify_all();
+        }
+        return false;
+    }
+    void poison() {
+        std::lock_guard<std::mutex> lk(m);
+        poisoned = true;
+        cv.notify_all();
+    }
+    bool is_poisoned() {
+        std::lock_guard<std::mutex> lk(m);
+        return poisoned;
+    }
+    void revive() {  // between merges, with no rank inside one (kh_group_merge)
+        std::lock_guard<std::mutex> lk(m);
+        poisoned = false;
+        arrived = 0;
     }
 };
 
@@ -55,49 +108,157 @@ struct Comm {
     hipStream_t xs = nullptr;    // the exchange stream (transfers overlap the kernels on ctx->stream)
     u64 *d_small = nullptr;      // device staging of the small all-gathers: (1 + nranks) * SMALL_MAX u64
     u64 *h_small = nullptr;      // pinned twin
+    // liveness
+    double timeout_s = 300.0;
+    std::atomic<bool> dead{false};        // aborted: nothing may use `nccl` any more
+    std::atomic<double> busy_since{0.0};  // != 0: this rank is inside an RCCL call that may block (ms clock)
+    std::atomic<bool> stop{false};
+    std::mutex abort_m;
+    std::thread watchdog;
 };
-constexpr uint32_t SMALL_MAX = 128;  // u64 per rank in one small all-gather
+constexpr uint32_t SMALL_MAX = 128;  // u64 per rank in one small all-gather (status word included)
+
+// ncclCommAbort, once.  Safe from the watchdog while the rank's own thread is blocked inside RCCL: that is what the call is for.
+void comm_abort(Comm *cm) {
+    std::lock_guard<std::mutex> lk(cm->abort_m);
+    if (cm->dead.exchange(true)) return;
+    if (cm->nccl) (void)ncclCommAbort(cm->nccl);
+}
 
 int rccl_fail(kh_ctx *c, const char *what, ncclResult_t r) {
     c->last_error = std::string(what) + ": " + ncclGetErrorString(r);
     return KH_ERR_RCCL;
 }
-#define NCCL_TRY(c, call)                                          \
-    do {                                                           \
-        ncclResult_t r_ = (call);                                  \
-        if (r_ != ncclSuccess) return rccl_fail((c), #call, r_);   \
+int rccl_dead(kh_ctx *c, const char *what) {
+    c->last_error = std::string(what) + ": the communicator was aborted (time-out or asynchronous RCCL error; KMERHIP_MERGE_TIMEOUT_S)";
+    return KH_ERR_RCCL;
+}
+// an RCCL call that may block inside the library: the watchdog sees how long it has been in there
+#define NCCL_CALL(cm, res, call)             \
+    do {                                     \
+        (cm)->busy_since.store(now_ms());    \
+        (res) = (call);                      \
+        (cm)->busy_since.store(0.0);         \
+    } while (0)
+// ... and fails the enclosing function (after aborting the communicator: its state is unknown)
+#define NCCL_TRY(c, call)                                                 \
+    do {                                                                  \
+        Comm *cm_ = (c)->comm;                                            \
+        if (cm_->dead.load()) return rccl_dead((c), #call);               \
+        ncclResult_t r_;                                                  \
+        NCCL_CALL(cm_, r_, (call));                                       \
+        if (cm_->dead.load()) return rccl_dead((c), #call);               \
+        if (r_ != ncclSuccess) {                                          \
+            comm_abort(cm_);                                              \
+            return rccl_fail((c), #call, r_);                             \
+        }                                                                 \
     } while (0)
 
-double now_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+// Bounded wait for the exchange stream (ev == nullptr) or an event recorded on it.
+int xp_wait(kh_ctx *c, hipEvent_t ev, const char *what) {
+    Comm *cm = c->comm;
+    const double t_end = now_ms() + cm->timeout_s * 1e3;
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t e = ev ? hipEventQuery(ev) : hipStreamQuery(cm->xs);
+        if (e == hipSuccess) return KH_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorNotReady) return fail(c, KH_ERR_HIP, what, e);
+        if (cm->nccl) {
+            if (cm->dead.load()) return rccl_dead(c, what);
+            if ((spins & 63u) == 63u) {
+                ncclResult_t ar = ncclSuccess;
+                const ncclResult_t qr = ncclCommGetAsyncError(cm->nccl, &ar);
+                if (qr != ncclSuccess || (ar != ncclSuccess && ar != ncclInProgress)) {
+                    comm_abort(cm);
+                    return rccl_fail(c, "asynchronous RCCL error while waiting for the exchange", qr != ncclSuccess ? qr : ar);
+                }
+            }
+        }
+        if (now_ms() > t_end) {
+            if (cm->nccl) comm_abort(cm);
+            if (cm->hub) cm->hub->poison();
+            c->last_error = std::string(what) + ": timed out (KMERHIP_MERGE_TIMEOUT_S)";
+            return KH_ERR_RCCL;
+        }
+        if (spins < 4096) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
-// all-gather of n (<= SMALL_MAX) host integers: all[r * n + i] = rank r's mine[i].  Blocks.
+int hub_fail(kh_ctx *c, const char *what) {
+    c->last_error = std::string(what) + ": another rank of the group gave up (or a barrier timed out)";
+    return KH_ERR_PEER;
+}
+
+// all-gather of n (<= SMALL_MAX) host integers: all[r * n + i] = rank r's mine[i].  Blocks (bounded).
 int xp_allgather(kh_ctx *c, const u64 *mine, uint32_t n, u64 *all) {
     Comm *cm = c->comm;
     if (n > SMALL_MAX) return fail(c, KH_ERR_BAD_ARG, "xp_allgather: too many values");
     if (cm->hub) {
         cm->hub->small[cm->rank].assign(mine, mine + n);
-        cm->hub->barrier();
-        for (uint32_t r = 0; r < cm->nranks; ++r) memcpy(all + (size_t)r * n, cm->hub->small[r].data(), n * sizeof(u64));
-        cm->hub->barrier();  // nobody overwrites its posting before everybody has read it
+        if (!cm->hub->barrier()) return hub_fail(c, "all-gather");
+        for (uint32_t r = 0; r < cm->nranks; ++r) {
+            if (cm->hub->small[r].size() != n) {  // (a protocol bug, not a run-time condition: never read past a posting)
+                cm->hub->poison();
+                return fail(c, KH_ERR_STATE, "local all-gather: the ranks posted different numbers of values");
+            }
+            memcpy(all + (size_t)r * n, cm->hub->small[r].data(), n * sizeof(u64));
+        }
+        if (!cm->hub->barrier()) return hub_fail(c, "all-gather");  // nobody overwrites its posting before everybody has read it
         return KH_OK;
     }
+    if (cm->dead.load()) return rccl_dead(c, "all-gather");
     memcpy(cm->h_small, mine, n * sizeof(u64));
     HIP_TRY(c, hipMemcpyAsync(cm->d_small, cm->h_small, n * sizeof(u64), hipMemcpyHostToDevice, cm->xs));
     NCCL_TRY(c, ncclAllGather(cm->d_small, cm->d_small + SMALL_MAX, n, ncclUint64, cm->nccl, cm->xs));
     HIP_TRY(c, hipMemcpyAsync(cm->h_small + SMALL_MAX, cm->d_small + SMALL_MAX, (size_t)cm->nranks * n * sizeof(u64),
                               hipMemcpyDeviceToHost, cm->xs));
-    HIP_TRY(c, hipStreamSynchronize(cm->xs));
+    const int rc = xp_wait(c, nullptr, "all-gather");
+    if (rc != KH_OK) return rc;
     memcpy(all, cm->h_small + SMALL_MAX, (size_t)cm->nranks * n * sizeof(u64));
+    return KH_OK;
+}
+
+// The gather every step of the sequence goes through: this rank's status `lrc` in front of its n values.
+// all[r * n + i] = rank r's value i.  KH_OK: every rank is fine.  Otherwise every rank returns non-zero from the SAME
+// call: the ranks that failed their own status, the others KH_ERR_PEER (kh_last_error names the first failing rank).
+int xp_gather(kh_ctx *c, int lrc, const u64 *mine, uint32_t n, u64 *all, const char *where) {
+    Comm *cm = c->comm;
+    const uint32_t W = cm->nranks;
+    if (n + 1 > SMALL_MAX) return fail(c, KH_ERR_BAD_ARG, "xp_gather: too many values");
+    std::vector<u64> m(n + 1, 0), g((size_t)W * (n + 1), 0);
+    m[0] = (u64)(int64_t)lrc;
+    if (lrc == KH_OK && n) memcpy(&m[1], mine, n * sizeof(u64));
+    const std::string keep = c->last_error;  // (the text of this rank's own failure survives the gather)
+    const int trc = xp_allgather(c, m.data(), n + 1, g.data());
+    if (trc != KH_OK) return lrc != KH_OK ? (c->last_error = keep, lrc) : trc;
+    int bad_rank = -1, bad_rc = KH_OK;
+    for (uint32_t r = 0; r < W; ++r) {
+        const int s = (int)(int64_t)g[(size_t)r * (n + 1)];
+        if (s != KH_OK && bad_rank < 0) {
+            bad_rank = (int)r;
+            bad_rc = s;
+        }
+        if (all && n) memcpy(all + (size_t)r * n, &g[(size_t)r * (n + 1) + 1], n * sizeof(u64));
+    }
+    if (lrc != KH_OK) {
+        c->last_error = keep;
+        return lrc;
+    }
+    if (bad_rank >= 0) {
+        c->last_error = std::string("rank ") + std::to_string(bad_rank) + " failed with status " + std::to_string(bad_rc) + " (" +
+                        kh_strerror(bad_rc) + ") before " + where + "; every rank leaves the merge";
+        return KH_ERR_PEER;
+    }
     return KH_OK;
 }
 
 // all-to-all of device byte ranges: peer p receives send[soff[p] .. +slen[p]) and this rank receives peer
 // p's range for it at recv + roff[p] (rlen[p] bytes; the caller has exchanged the sizes).  Enqueued on the
-// exchange stream: returns once the transfers are IN FLIGHT; xp_done() records their completion.
+// exchange stream: returns once the transfers are IN FLIGHT; xp_wait() waits for their completion.
 // `send` must be complete in device memory (the export calls block until it is) and stay untouched until
 // the completion event has been waited for -- with the hub also until the closing barrier of the merge.
+// Only called right after a clean xp_gather: every rank is known to arrive.
 int xp_alltoallv(kh_ctx *c, const void *send, const u64 *soff, const u64 *slen, void *recv, const u64 *roff, const u64 *rlen) {
     Comm *cm = c->comm;
     if (cm->hub) {
@@ -105,8 +266,8 @@ int xp_alltoallv(kh_ctx *c, const void *send, const u64 *soff, const u64 *slen, 
         h->base[cm->rank] = send;
         h->off[cm->rank].assign(soff, soff + cm->nranks);
         h->len[cm->rank].assign(slen, slen + cm->nranks);
-        h->barrier();
-        int rc = KH_OK;  // (no return between the two barriers: the other threads would wait for ever)
+        if (!h->barrier()) return hub_fail(c, "local exchange");
+        int rc = KH_OK;  // (no return between the two barriers: the other threads would wait for the time-out)
         for (uint32_t p = 0; p < cm->nranks && rc == KH_OK; ++p) {
             const u64 n = h->len[p][cm->rank];
             if (n != rlen[p]) rc = fail(c, KH_ERR_STATE, "local exchange: announced and posted segment sizes differ");
@@ -114,15 +275,38 @@ int xp_alltoallv(kh_ctx *c, const void *send, const u64 *soff, const u64 *slen, 
                                          cm->xs) != hipSuccess)
                 rc = fail(c, KH_ERR_HIP, "hipMemcpyAsync(local exchange)");
         }
-        h->barrier();  // postings may be replaced (the COPIES are still in flight: buffers stay alive, see above)
+        if (!h->barrier() && rc == KH_OK) rc = hub_fail(c, "local exchange");  // postings may be replaced (the COPIES are still in flight: buffers stay alive, see above)
         return rc;
     }
-    NCCL_TRY(c, ncclGroupStart());
-    for (uint32_t p = 0; p < cm->nranks; ++p) {
-        if (slen[p]) NCCL_TRY(c, ncclSend((const char *)send + soff[p], slen[p], ncclUint8, (int)p, cm->nccl, cm->xs));
-        if (rlen[p]) NCCL_TRY(c, ncclRecv((char *)recv + roff[p], rlen[p], ncclUint8, (int)p, cm->nccl, cm->xs));
+    if (cm->dead.load()) return rccl_dead(c, "all-to-all");
+    // a group that fails half way is still closed; then the communicator (whose state nobody knows) is aborted
+    ncclResult_t r;
+    NCCL_CALL(cm, r, ncclGroupStart());
+    const bool open = r == ncclSuccess;
+    const char *what = "ncclGroupStart";
+    for (uint32_t p = 0; p < cm->nranks && r == ncclSuccess; ++p) {
+        if (slen[p]) {
+            NCCL_CALL(cm, r, ncclSend((const char *)send + soff[p], slen[p], ncclUint8, (int)p, cm->nccl, cm->xs));
+            what = "ncclSend";
+        }
+        if (r == ncclSuccess && rlen[p]) {
+            NCCL_CALL(cm, r, ncclRecv((char *)recv + roff[p], rlen[p], ncclUint8, (int)p, cm->nccl, cm->xs));
+            what = "ncclRecv";
+        }
     }
-    NCCL_TRY(c, ncclGroupEnd());
+    if (open) {
+        ncclResult_t r2;
+        NCCL_CALL(cm, r2, ncclGroupEnd());
+        if (r == ncclSuccess && r2 != ncclSuccess) {
+            r = r2;
+            what = "ncclGroupEnd";
+        }
+    }
+    if (cm->dead.load()) return rccl_dead(c, "all-to-all");
+    if (r != ncclSuccess) {
+        comm_abort(cm);
+        return rccl_fail(c, what, r);
+    }
     return KH_OK;
 }
 
@@ -130,8 +314,7 @@ int xp_allreduce_sum_u64(kh_ctx *c, u64 *d_buf, u64 n) {
     Comm *cm = c->comm;
     if (cm->hub) return fail(c, KH_ERR_STATE, "dense all-reduce is not available on the process-local hub");
     NCCL_TRY(c, ncclAllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, cm->nccl, cm->xs));
-    HIP_TRY(c, hipStreamSynchronize(cm->xs));
-    return KH_OK;
+    return xp_wait(c, nullptr, "all-reduce");
 }
 
 struct DevBuf {  // scratch of one merge; freed when it goes out of scope
@@ -146,7 +329,10 @@ struct DevBuf {  // scratch of one merge; freed when it goes out of scope
         if (e != hipSuccess) {
             (void)hipGetLastError();
             p = nullptr;
-            return fail(c, KH_ERR_OOM, what, e);
+            // (not through fail(): an allocation of exchange scratch that does not fit leaves the table as it was,
+            //  the context stays usable)
+            c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+            return KH_ERR_OOM;
         }
         return KH_OK;
     }
@@ -158,15 +344,26 @@ uint32_t merge_pieces_default() {
     return v >= 1 ? (uint32_t)v : 1u;
 }
 
-// agreement among the ranks on a few integers: true iff every rank's value i equals `mine[i]`... the
-// callers only need min / all-equal, so the raw gather is handed back
-int vote(kh_ctx *c, std::initializer_list<u64> mine, std::vector<u64> &all) {
-    std::vector<u64> m(mine);
-    all.assign((size_t)c->comm->nranks * m.size(), 0);
-    return xp_allgather(c, m.data(), (uint32_t)m.size(), all.data());
-}
+// KMERHIP_FAULT="rank:point[:status]" -- tests: rank `rank` fails at `point` of the merge sequence
+struct Fault {
+    int rank = -1, code = KH_ERR_STATE;
+    std::string point;
+    Fault() {
+        const char *e = getenv("KMERHIP_FAULT");
+        if (!e || !*e) return;
+        const std::string s(e);
+        const size_t a = s.find(':');
+        if (a == std::string::npos) return;
+        const size_t b = s.find(':', a + 1);
+        rank = atoi(s.substr(0, a).c_str());
+        point = s.substr(a + 1, b == std::string::npos ? std::string::npos : b - a - 1);
+        if (b != std::string::npos) code = atoi(s.substr(b + 1).c_str());
+    }
+};
 
 // ---- the merge sequence -----------------------------------------------------------------------------
+// Shape of every stretch below: local, fallible steps accumulate into `lrc` (a failed rank skips the rest of the
+// stretch); the stretch ends in xp_gather, which is where everybody learns about it.
 int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
     Comm *cm = c->comm;
     const uint32_t W = cm->nranks, R = cm->rank;
@@ -176,7 +373,28 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
     memset(&mi, 0, sizeof(mi));
     mi.nranks = W;
     mi.pieces = 1;
+    const Fault flt;
+    auto inject = [&](const char *point) -> int {
+        if ((int)R == flt.rank && flt.point == point) {
+            c->last_error = std::string("injected fault at ") + point;
+            return flt.code;
+        }
+        return KH_OK;
+    };
+    bool transfers = false;  // something may be in flight on the exchange stream (into / out of this merge's buffers)
     auto done = [&](int rc) {
+        if (transfers) {
+            // nothing may still write into (or, hub: read from) buffers about to be freed
+            if (cm->hub && rc != KH_OK) {
+                cm->hub->poison();  // (an error exit does not know where its peers are: nobody waits for anybody any more)
+                for (hipStream_t s : cm->hub->xs)
+                    if (s) (void)hipStreamSynchronize(s);
+            } else if (cm->nccl && !cm->dead.load()) {
+                (void)xp_wait(c, nullptr, "draining the exchange stream");
+            } else if (cm->xs) {
+                (void)hipStreamSynchronize(cm->xs);
+            }
+        }
         (void)kh_set_region_window(c, 0, 1);  // whatever happened: later exports / merges cover the whole range again
         mi.export_ms = t_export;
         mi.wait_ms = t_wait;
@@ -185,34 +403,62 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
         if (info) *info = mi;
         return rc;
     };
-    int rc = kh_finish(c, nullptr);
-    if (rc != KH_OK) return done(rc);
-    const u64 n_local = c->h_ctr->distinct;
+    // gather with timing; `where` names what would have come next
+    std::vector<u64> all;
+    auto gather = [&](int lrc, std::initializer_list<u64> mine, const char *where) -> int {
+        const std::vector<u64> m(mine);
+        all.assign((size_t)W * std::max<size_t>(m.size(), 1), 0);
+        const double t0 = now_ms();
+        const int rc = xp_gather(c, lrc, m.data(), (uint32_t)m.size(), all.data(), where);
+        t_wait += now_ms() - t0;
+        return rc;
+    };
+    // the merge's last act: every rank learns whether every other one got through its merge kernels.  (Hub: also the
+    // closing barrier -- every peer has finished copying out of this rank's send buffer before it is freed.)
+    auto finish = [&](int lrc) -> int {
+        if (cm->hub && transfers && lrc == KH_OK && hipStreamSynchronize(cm->xs) != hipSuccess) lrc = fail(c, KH_ERR_HIP, "hipStreamSynchronize(exchange)");
+        const int rc = gather(lrc, {}, "the end of the merge");
+        if (rc == KH_OK) transfers = false;  // (every rank's copies are complete: see the line above)
+        return done(rc);
+    };
+
+    if (cm->nccl && (int)R == flt.rank && flt.point == "abort") {  // (tests: what a time-out does, without waiting for one)
+        comm_abort(cm);
+        return done(rccl_dead(c, "injected abort"));
+    }
+    int lrc = kh_finish(c, nullptr);
+    if (lrc == KH_OK) lrc = inject("start");
+    const u64 n_local = lrc == KH_OK ? c->h_ctr->distinct : 0;
     const u64 nreg = c->cap / kh::REGION_SLOTS;
     mi.local_distinct = n_local;
-    std::vector<u64> all;
+    int rc;
 
     // ---- small k: the key space as a dense count array IS element-wise reducible ----
-    if (2 * c->k <= 26 && !cm->hub) {
+    if (2 * c->k <= 26 && !cm->hub) {  // (uniform: k and the transport are the same on every rank)
         const u64 n = 1ull << (2 * c->k);
         DevBuf dense;
-        if ((rc = dense.alloc(c, n * sizeof(u64), "hipMalloc(dense)")) != KH_OK) return done(rc);
         double t0 = now_ms();
-        if ((rc = kh_export_dense_device(c, (uint64_t *)dense.p, n)) != KH_OK) return done(rc);  // blocks until complete
+        if (lrc == KH_OK) lrc = dense.alloc(c, n * sizeof(u64), "hipMalloc(dense)");
+        if (lrc == KH_OK) lrc = inject("dense_export");
+        if (lrc == KH_OK) lrc = kh_export_dense_device(c, (uint64_t *)dense.p, n);  // blocks until complete
         t_export += now_ms() - t0;
+        if ((rc = gather(lrc, {}, "the dense all-reduce")) != KH_OK) return done(rc);
         t0 = now_ms();
-        if ((rc = xp_allreduce_sum_u64(c, (u64 *)dense.p, n)) != KH_OK) return done(rc);
+        transfers = true;
+        if ((rc = xp_allreduce_sum_u64(c, (u64 *)dense.p, n)) != KH_OK) return done(rc);  // (transport failure: communicator aborted)
+        transfers = false;
         t_wait += now_ms() - t0;
         t0 = now_ms();
-        if ((rc = kh_reset(c)) != KH_OK) return done(rc);
-        if ((rc = kh_merge_dense_device(c, (const uint64_t *)dense.p, n, R, W)) != KH_OK) return done(rc);
-        if ((rc = kh_finish(c, nullptr)) != KH_OK) return done(rc);
+        lrc = kh_reset(c);
+        if (lrc == KH_OK) lrc = inject("dense_merge");
+        if (lrc == KH_OK) lrc = kh_merge_dense_device(c, (const uint64_t *)dense.p, n, R, W);
+        if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
         t_merge += now_ms() - t0;
         mi.route = KH_ROUTE_DENSE;
         mi.unit_bytes = 8;
         mi.sent_units = mi.recv_units = n;
-        mi.owned_distinct = c->h_ctr->distinct;
-        return done(KH_OK);
+        if (lrc == KH_OK) mi.owned_distinct = c->h_ctr->distinct;
+        return finish(lrc);
     }
 
     const bool pow2 = (W & (W - 1)) == 0;
@@ -224,8 +470,6 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
     // send buffer: heads (2 per key), packed (1 u64 per key) and one array of wide pairs all fit 8 B x n_local
     DevBuf sendbuf, sendcnt, rcnt, counts_all;
     const u64 cap_units64 = std::max<u64>(n_local, 1);
-    if ((rc = sendbuf.alloc(c, cap_units64 * 8, "hipMalloc(exchange send buffer)")) != KH_OK) return done(rc);
-    if ((rc = rcnt.alloc(c, std::max<u64>(nreg, 1) * sizeof(uint32_t), "hipMalloc(region counts)")) != KH_OK) return done(rc);
     std::vector<uint64_t> parts(W, 0);
     uint64_t treg = 0;
     // fmt: 2 heads, 1 packed, 0 = neither fits
@@ -235,65 +479,91 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
         t_export += now_ms() - t0;
         return r;
     };
-    int my_fmt = 0;
-    if (regions_ok) {
-        if (piped && (rc = kh_set_region_window(c, 0, npieces)) != KH_OK) return done(rc);
-        for (int fmt : {2, 1}) {  // speculative: the export itself finds out whether the counts fit
-            rc = export_fmt(fmt, sendbuf.p, fmt == 2 ? 2 * n_local : n_local);
-            if (rc == KH_OK) {
-                my_fmt = fmt;
-                break;
+    // speculative: the export itself finds out whether the counts fit; *fmt_out = 0 when neither narrow unit applies
+    auto export_narrowest = [&](int *fmt_out) -> int {
+        *fmt_out = 0;
+        for (int fmt : {2, 1}) {
+            const int r = export_fmt(fmt, sendbuf.p, fmt == 2 ? 2 * n_local : n_local);
+            if (r == KH_OK) {
+                *fmt_out = fmt;
+                return KH_OK;
             }
-            if (rc != KH_ERR_RANGE) return done(rc);
+            if (r != KH_ERR_RANGE) return r;
+        }
+        return KH_OK;
+    };
+    int my_fmt = 0;
+    if (lrc == KH_OK) lrc = sendbuf.alloc(c, cap_units64 * 8, "hipMalloc(exchange send buffer)");
+    if (lrc == KH_OK) lrc = rcnt.alloc(c, std::max<u64>(nreg, 1) * sizeof(uint32_t), "hipMalloc(region counts)");
+    if (lrc == KH_OK) lrc = inject("export0");
+    if (lrc == KH_OK && regions_ok) {
+        if (piped) lrc = kh_set_region_window(c, 0, npieces);
+        if (lrc == KH_OK) lrc = export_narrowest(&my_fmt);
+        if (lrc == KH_OK && my_fmt == 2 && flt.point == "fmt_packed" && (int)R == flt.rank) {  // (tests: this rank alone needs the wider unit)
+            my_fmt = 0;
+            const int r = export_fmt(1, sendbuf.p, n_local);
+            if (r == KH_OK) my_fmt = 1;
+            else if (r != KH_ERR_RANGE) lrc = r;
         }
     }
-    double t0 = now_ms();
-    if ((rc = vote(c, {nreg, (u64)my_fmt, (u64)piped}, all)) != KH_OK) return done(rc);
-    t_wait += now_ms() - t0;
-    bool same_size = true, all_piped = true;
+    if ((rc = gather(lrc, {nreg, (u64)my_fmt, (u64)piped}, "the format vote")) != KH_OK) return done(rc);
+    // Everything decided from here on is decided from the GATHERED words only, so that every rank decides the same
+    // (round 2 compared `agreed` with this rank's own format: a rank whose format WAS the agreed one stayed in the
+    // pipeline while its peer left it, and their next collectives no longer matched).
+    bool same_size = true, all_piped = true, all_same_fmt = true;
     u64 agreed = 3;
     for (uint32_t r = 0; r < W; ++r) {
-        same_size &= all[3 * r] == nreg;
+        same_size &= all[3 * r] == all[0];
         agreed = std::min(agreed, all[3 * r + 1]);
+        all_same_fmt &= all[3 * r + 1] == all[1];
         all_piped &= all[3 * r + 2] != 0;
     }
-    if (!(regions_ok && same_size)) agreed = 0;
-    if (piped && !(agreed && agreed == (u64)my_fmt && all_piped)) {
-        // some rank cannot run the pipeline in this rank's format: everybody takes the one-shot route
+    if (!(regions_ok && same_size)) agreed = 0;  // (regions_ok depends on W and on nreg: uniform once the sizes are equal)
+    bool redo_export = false;                    // the send buffer does not hold a whole-table export in the agreed unit
+    if (piped && !(same_size && agreed && all_same_fmt && all_piped)) {
+        // some rank cannot run the pipeline, or not in the others' format: everybody takes the one-shot route
         piped = false;
         npieces = 1;
         (void)kh_set_region_window(c, 0, 1);
-        my_fmt = -1;  // the windowed export does not describe the whole table: export again below
+        redo_export = true;  // the windowed export does not describe the whole table
+    } else if (!piped && all_piped) {
+        all_piped = false;  // (cannot happen: `piped` follows from W, nreg and the environment, which the ranks share)
     }
     if (piped) {
         // every piece's size is known before anything is sent: a table needing more units than the send
         // buffer holds is found out HERE, and all ranks leave the pipeline together
         const uint32_t ub = agreed == 2 ? 4 : 8;
-        if ((rc = counts_all.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(unit counts)")) != KH_OK) return done(rc);
-        uint64_t treg2 = 0;
-        t0 = now_ms();
-        rc = kh_region_unit_counts_device(c, ub, (uint32_t *)counts_all.p, nreg, &treg2);
-        t_export += now_ms() - t0;
-        bool fits = rc == KH_OK;
-        if (rc != KH_OK && rc != KH_ERR_RANGE) return done(rc);
+        const u64 cap_total = agreed == 2 ? 2 * n_local : n_local;
         std::vector<uint32_t> hcounts;
-        if (fits) {
-            hcounts.resize(nreg);
-            HIP_TRY(c, hipMemcpy(hcounts.data(), counts_all.p, nreg * sizeof(uint32_t), hipMemcpyDeviceToHost));
-            u64 total = 0;
-            for (uint32_t v : hcounts) total += v;
-            fits = total <= (agreed == 2 ? 2 * n_local : n_local);
+        bool fits = false;
+        {
+            const double t0 = now_ms();
+            lrc = counts_all.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(unit counts)");
+            if (lrc == KH_OK) lrc = inject("unit_counts");
+            if (lrc == KH_OK) {
+                uint64_t treg2 = 0;
+                const int r = kh_region_unit_counts_device(c, ub, (uint32_t *)counts_all.p, nreg, &treg2);
+                if (r == KH_OK) {
+                    hcounts.resize(nreg);
+                    if (hipMemcpy(hcounts.data(), counts_all.p, nreg * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+                        lrc = fail(c, KH_ERR_HIP, "hipMemcpy(unit counts)");
+                    u64 total = 0;
+                    for (uint32_t v : hcounts) total += v;
+                    fits = lrc == KH_OK && total <= cap_total;
+                } else if (r != KH_ERR_RANGE) {
+                    lrc = r;
+                }
+            }
+            t_export += now_ms() - t0;
         }
-        t0 = now_ms();
-        if ((rc = vote(c, {(u64)fits}, all)) != KH_OK) return done(rc);
-        t_wait += now_ms() - t0;
+        if ((rc = gather(lrc, {(u64)fits}, "the piece sizes")) != KH_OK) return done(rc);
         bool all_fit = true;
         for (uint32_t r = 0; r < W; ++r) all_fit &= all[r] != 0;
         if (!all_fit) {
             piped = false;
             npieces = 1;
             (void)kh_set_region_window(c, 0, 1);
-            my_fmt = -1;
+            redo_export = true;
         } else {
             // ---- pipeline over the pieces: [export i+1 | transfer i], then [merge i | transfers > i] ----
             const u64 per = nreg / W, wper = per / npieces;
@@ -307,24 +577,55 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
                     send_mat[(size_t)o * npieces + i] = s;
                 }
             // recv_mat[sender][piece]: what each sender has for ME -- gather everybody's matrix (W * npieces <= 4096
-            // values, in SMALL_MAX slices)
+            // values, in slices)
             {
-                t0 = now_ms();
+                const double t0 = now_ms();
                 std::vector<u64> allm((size_t)W * W * npieces);
-                const uint32_t tot = W * npieces;
-                for (uint32_t b = 0; b < tot; b += SMALL_MAX) {
-                    const uint32_t n = std::min<uint32_t>(SMALL_MAX, tot - b);
+                const uint32_t tot = W * npieces, SL = SMALL_MAX - 1;
+                for (uint32_t b = 0; b < tot; b += SL) {
+                    const uint32_t n = std::min<uint32_t>(SL, tot - b);
                     std::vector<u64> g((size_t)W * n);
-                    if ((rc = xp_allgather(c, send_mat.data() + b, n, g.data())) != KH_OK) return done(rc);
+                    if ((rc = xp_gather(c, KH_OK, send_mat.data() + b, n, g.data(), "the piece sizes")) != KH_OK) return done(rc);
                     for (uint32_t r = 0; r < W; ++r) memcpy(&allm[(size_t)r * tot + b], &g[(size_t)r * n], n * sizeof(u64));
                 }
                 for (uint32_t s = 0; s < W; ++s)
                     for (uint32_t i = 0; i < npieces; ++i) recv_mat[(size_t)s * npieces + i] = allm[(size_t)s * tot + (size_t)R * npieces + i];
                 t_wait += now_ms() - t0;
             }
-            // every sender's unit counts of MY regions: W slices of `per` counts
-            DevBuf rrc_full;
-            if ((rc = rrc_full.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(region counts in)")) != KH_OK) return done(rc);
+            // Every buffer the pipeline needs is allocated BEFORE its first transfer (all of them are alive together
+            // anyway): running out of memory is then something the ranks hear about in the gather below, not a peer
+            // that never posts its receive.
+            struct Flight {
+                DevBuf buf;
+                std::vector<u64> roff;  // byte offsets per sender
+                u64 units = 0;
+                hipEvent_t ev = nullptr;
+            };
+            std::vector<Flight> flights(npieces);
+            struct EvGuard {  // (events are destroyed on every exit)
+                std::vector<Flight> &f;
+                ~EvGuard() {
+                    for (auto &x : f)
+                        if (x.ev) (void)hipEventDestroy(x.ev);
+                }
+            } ev_guard{flights};
+            DevBuf rrc_full, rrc;  // every sender's unit counts of MY regions (W slices of `per`); the same, zero outside a piece
+            lrc = rrc_full.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(region counts in)");
+            if (lrc == KH_OK) lrc = rrc.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(region counts piece)");
+            if (lrc == KH_OK) lrc = inject("alloc_recv");
+            for (uint32_t i = 0; i < npieces && lrc == KH_OK; ++i) {
+                u64 rtot = 0;
+                flights[i].roff.resize(W);
+                for (uint32_t p = 0; p < W; ++p) {
+                    flights[i].roff[p] = rtot * ub;
+                    rtot += recv_mat[(size_t)p * npieces + i];
+                }
+                flights[i].units = rtot;
+                lrc = flights[i].buf.alloc(c, rtot * ub, "hipMalloc(exchange receive buffer)");
+                if (lrc == KH_OK && hipEventCreateWithFlags(&flights[i].ev, hipEventDisableTiming) != hipSuccess)
+                    lrc = fail(c, KH_ERR_HIP, "hipEventCreate(exchange)");
+            }
+            if ((rc = gather(lrc, {}, "the region-count exchange")) != KH_OK) return done(rc);
             {
                 std::vector<u64> so(W), sl(W), ro(W), rl(W);
                 for (uint32_t p = 0; p < W; ++p) {
@@ -333,67 +634,55 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
                     ro[p] = (u64)p * per * 4;
                     rl[p] = per * 4;
                 }
-                t0 = now_ms();
-                if ((rc = xp_alltoallv(c, counts_all.p, so.data(), sl.data(), rrc_full.p, ro.data(), rl.data())) != KH_OK) return done(rc);
-                HIP_TRY(c, hipStreamSynchronize(cm->xs));
+                const double t0 = now_ms();
+                transfers = true;
+                lrc = xp_alltoallv(c, counts_all.p, so.data(), sl.data(), rrc_full.p, ro.data(), rl.data());
+                if (lrc == KH_OK) lrc = xp_wait(c, nullptr, "region-count exchange");
                 t_wait += now_ms() - t0;
             }
-            struct Flight {
-                DevBuf buf;
-                std::vector<u64> roff;  // byte offsets per sender
-                u64 units = 0;
-                hipEvent_t ev = nullptr;
-            };
-            std::vector<Flight> flights(npieces);
             u64 used = 0;  // units of the send buffer in use
-            const u64 cap_total = agreed == 2 ? 2 * n_local : n_local;
-            int frc = KH_OK;
-            for (uint32_t i = 0; i < npieces && frc == KH_OK; ++i) {
+            for (uint32_t i = 0; i < npieces; ++i) {
                 void *dst = (char *)sendbuf.p + used * ub;
-                if (i > 0) {
-                    if ((frc = kh_set_region_window(c, i, npieces)) != KH_OK) break;
-                    if ((frc = export_fmt((int)agreed, dst, cap_total - used)) != KH_OK) break;  // (sizes were checked: cannot be RANGE)
-                }
                 std::vector<u64> so(W), sl(W), rl(W);
-                u64 o = 0, rtot = 0;
-                flights[i].roff.resize(W);
-                for (uint32_t p = 0; p < W; ++p) {
-                    if (parts[p] != send_mat[(size_t)p * npieces + i]) frc = fail(c, KH_ERR_STATE, "piece sizes differ from the announced ones");
+                u64 o = 0;
+                if (lrc == KH_OK && i > 0) {
+                    lrc = kh_set_region_window(c, i, npieces);
+                    if (lrc == KH_OK) lrc = inject("export_piece");
+                    if (lrc == KH_OK) lrc = export_fmt((int)agreed, dst, cap_total - used);  // (sizes were checked: cannot be RANGE)
+                }
+                for (uint32_t p = 0; p < W && lrc == KH_OK; ++p) {
+                    if (parts[p] != send_mat[(size_t)p * npieces + i]) lrc = fail(c, KH_ERR_STATE, "piece sizes differ from the announced ones");
                     so[p] = o * ub;
                     sl[p] = parts[p] * ub;
                     o += parts[p];
-                    flights[i].roff[p] = rtot * ub;
                     rl[p] = recv_mat[(size_t)p * npieces + i] * ub;
-                    rtot += recv_mat[(size_t)p * npieces + i];
                 }
-                if (frc != KH_OK) break;
+                // piece i leaves only when every rank has it ready (the gather queues behind transfer i - 1 on the exchange
+                // stream, which transfer i would do anyway; the export of piece i has overlapped transfer i - 1 by now)
+                if ((rc = gather(lrc, {}, "the transfer of a piece")) != KH_OK) return done(rc);
                 mi.sent_units += o - parts[R];
                 used += o;
-                flights[i].units = rtot;
-                if ((frc = flights[i].buf.alloc(c, rtot * ub, "hipMalloc(exchange receive buffer)")) != KH_OK) break;
-                t0 = now_ms();
-                if ((frc = xp_alltoallv(c, dst, so.data(), sl.data(), flights[i].buf.p, flights[i].roff.data(), rl.data())) != KH_OK) break;
-                if (hipEventCreateWithFlags(&flights[i].ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(flights[i].ev, cm->xs) != hipSuccess)
-                    frc = fail(c, KH_ERR_HIP, "hipEventRecord(exchange)");
+                const double t0 = now_ms();
+                lrc = xp_alltoallv(c, dst, so.data(), sl.data(), flights[i].buf.p, flights[i].roff.data(), rl.data());
+                if (lrc == KH_OK && hipEventRecord(flights[i].ev, cm->xs) != hipSuccess) lrc = fail(c, KH_ERR_HIP, "hipEventRecord(exchange)");
                 t_wait += now_ms() - t0;
+                if (lrc != KH_OK && cm->nccl) return done(lrc);  // (an RCCL failure aborted the communicator: the peers' waits end)
             }
-            if (frc == KH_OK) frc = kh_set_region_window(c, 0, 1);
-            if (frc == KH_OK) frc = kh_reset(c);
-            if (frc == KH_OK) frc = kh_set_shard(c, R, W);
-            // the senders' region counts as the merge of piece i wants them: zero outside the piece
-            DevBuf rrc;
-            if (frc == KH_OK) frc = rrc.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(region counts piece)");
-            for (uint32_t i = 0; i < npieces && frc == KH_OK; ++i) {
-                t0 = now_ms();
-                if (hipMemsetAsync(rrc.p, 0, nreg * sizeof(uint32_t), c->stream) != hipSuccess) frc = fail(c, KH_ERR_HIP, "hipMemsetAsync(rrc)");
-                for (uint32_t s = 0; s < W && frc == KH_OK; ++s) {
+            if (lrc == KH_OK) lrc = kh_set_region_window(c, 0, 1);
+            if (lrc == KH_OK) lrc = kh_reset(c);
+            if (lrc == KH_OK) lrc = kh_set_shard(c, R, W);
+            for (uint32_t i = 0; i < npieces && lrc == KH_OK; ++i) {
+                double t0 = now_ms();
+                // the senders' region counts as the merge of piece i wants them: zero outside the piece
+                if (hipMemsetAsync(rrc.p, 0, nreg * sizeof(uint32_t), c->stream) != hipSuccess) lrc = fail(c, KH_ERR_HIP, "hipMemsetAsync(rrc)");
+                for (uint32_t s = 0; s < W && lrc == KH_OK; ++s) {
                     const u64 o = ((u64)s * per + (u64)i * wper) * 4;
                     if (hipMemcpyAsync((char *)rrc.p + o, (const char *)rrc_full.p + o, wper * 4, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
-                        frc = fail(c, KH_ERR_HIP, "hipMemcpyAsync(rrc)");
+                        lrc = fail(c, KH_ERR_HIP, "hipMemcpyAsync(rrc)");
                 }
-                if (frc == KH_OK && hipEventSynchronize(flights[i].ev) != hipSuccess) frc = fail(c, KH_ERR_HIP, "hipEventSynchronize(exchange)");
+                if (lrc == KH_OK) lrc = xp_wait(c, flights[i].ev, "transfer of a piece");
                 t_wait += now_ms() - t0;
-                if (frc != KH_OK) break;
+                if (lrc != KH_OK) break;
                 t0 = now_ms();
                 std::vector<const void *> kp(W);
                 std::vector<const uint32_t *> rp(W);
@@ -401,62 +690,52 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
                     kp[s] = (const char *)flights[i].buf.p + flights[i].roff[s];
                     rp[s] = (const uint32_t *)rrc.p + (u64)s * per;
                 }
-                if ((frc = kh_set_region_window(c, i, npieces)) != KH_OK) break;
-                frc = merge_regions(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, W, nreg, kp.data(), nullptr, rp.data());
+                lrc = kh_set_region_window(c, i, npieces);
+                if (lrc == KH_OK) lrc = inject("merge_piece");
+                if (lrc == KH_OK) lrc = merge_regions(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, W, nreg, kp.data(), nullptr, rp.data());
                 mi.recv_units += flights[i].units;
                 t_merge += now_ms() - t0;
             }
-            for (auto &f : flights)
-                if (f.ev) {
-                    (void)hipEventSynchronize(f.ev);  // (error paths: nothing may still write into buffers about to be freed)
-                    (void)hipEventDestroy(f.ev);
-                }
-            if (cm->hub) cm->hub->barrier();  // every peer has finished copying out of this rank's send buffer
-            if (frc != KH_OK) return done(frc);
-            (void)kh_set_region_window(c, 0, 1);
-            if ((rc = kh_finish(c, nullptr)) != KH_OK) return done(rc);
+            if (lrc == KH_OK) {
+                (void)kh_set_region_window(c, 0, 1);
+                lrc = kh_finish(c, nullptr);
+            }
             mi.route = agreed == 2 ? KH_ROUTE_REGIONS_HEADS : KH_ROUTE_REGIONS_PACKED;
             mi.pieces = npieces;
             mi.unit_bytes = ub;
-            mi.owned_distinct = c->h_ctr->distinct;
-            return done(KH_OK);
+            if (lrc == KH_OK) mi.owned_distinct = c->h_ctr->distinct;
+            return finish(lrc);  // (flights' buffers are freed after done() has drained the exchange stream)
         }
     }
-    if (my_fmt < 0 && regions_ok) {  // left the pipeline: one shot, whole table, narrowest unit that fits
-        my_fmt = 0;
-        for (int fmt : {2, 1}) {
-            rc = export_fmt(fmt, sendbuf.p, fmt == 2 ? 2 * n_local : n_local);
-            if (rc == KH_OK) {
-                my_fmt = fmt;
-                break;
-            }
-            if (rc != KH_ERR_RANGE) return done(rc);
-        }
-        t0 = now_ms();
-        if ((rc = vote(c, {(u64)my_fmt}, all)) != KH_OK) return done(rc);
-        t_wait += now_ms() - t0;
+    // ---- one shot ----
+    lrc = KH_OK;
+    if (redo_export) {  // left the pipeline: whole table, narrowest unit that fits, and a second vote
+        lrc = inject("oneshot_export");
+        if (lrc == KH_OK) lrc = export_narrowest(&my_fmt);
+        if ((rc = gather(lrc, {(u64)my_fmt}, "the second format vote")) != KH_OK) return done(rc);
         agreed = 3;
         for (uint32_t r = 0; r < W; ++r) agreed = std::min(agreed, all[r]);
-        if (!same_size) agreed = 0;
+        if (!(regions_ok && same_size)) agreed = 0;
     }
-    if (agreed && agreed != (u64)my_fmt) {  // another rank could not go as narrow: redo in the common format
-        rc = export_fmt((int)agreed, sendbuf.p, agreed == 2 ? 2 * n_local : n_local);
-        if (rc != KH_OK) return done(rc);
-    }
+    if (agreed && agreed != (u64)my_fmt)  // another rank could not go as narrow: redo in the common format
+        lrc = export_fmt((int)agreed, sendbuf.p, agreed == 2 ? 2 * n_local : n_local);
 
-    // one all-to-all of per-owner unit counts, then the data; shared by the three one-shot routes below
-    auto exchange_sizes = [&](const std::vector<uint64_t> &send_units_in, std::vector<u64> &recv_units) -> int {
+    // one all-to-all of per-owner unit counts (with the status of whatever came before), then the data
+    auto exchange_sizes = [&](int st, const std::vector<uint64_t> &send_units_in, std::vector<u64> &recv_units) -> int {
         std::vector<u64> send_units(send_units_in.begin(), send_units_in.end());
         std::vector<u64> g;
         recv_units.assign(W, 0);
-        for (uint32_t b = 0; b < W; b += SMALL_MAX) {
-            const uint32_t n = std::min<uint32_t>(SMALL_MAX, W - b);
+        const uint32_t SL = SMALL_MAX - 1;
+        const double t0 = now_ms();
+        for (uint32_t b = 0; b < W; b += SL) {
+            const uint32_t n = std::min<uint32_t>(SL, W - b);
             g.assign((size_t)W * n, 0);
-            int r = xp_allgather(c, send_units.data() + b, n, g.data());
+            const int r = xp_gather(c, st, send_units.data() + b, n, g.data(), "the unit counts");
             if (r != KH_OK) return r;
             if (R >= b && R < b + n)
                 for (uint32_t s = 0; s < W; ++s) recv_units[s] = g[(size_t)s * n + (R - b)];
         }
+        t_wait += now_ms() - t0;
         return KH_OK;
     };
     auto a2a_units = [&](const void *send, const std::vector<uint64_t> &su, const std::vector<u64> &ru, u64 ub, void *recv) -> int {
@@ -477,99 +756,109 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
         const bool wide = !agreed;
         const u64 ub = agreed == 2 ? 4 : 8;
         const u64 per = nreg / W;
-        if (wide) {  // (u64 key, u64 count): two arrays
-            if ((rc = sendcnt.alloc(c, cap_units64 * 8, "hipMalloc(exchange send counts)")) != KH_OK) return done(rc);
-            t0 = now_ms();
-            rc = export_regions(c, XF_WIDE, W, sendbuf.p, (uint64_t *)sendcnt.p, n_local, (uint32_t *)rcnt.p, nreg, parts.data(), &treg);
+        if (wide && lrc == KH_OK) {  // (u64 key, u64 count): two arrays
+            lrc = sendcnt.alloc(c, cap_units64 * 8, "hipMalloc(exchange send counts)");
+            const double t0 = now_ms();
+            if (lrc == KH_OK) lrc = export_regions(c, XF_WIDE, W, sendbuf.p, (uint64_t *)sendcnt.p, n_local, (uint32_t *)rcnt.p, nreg, parts.data(), &treg);
             t_export += now_ms() - t0;
-            if (rc != KH_OK) return done(rc);
         }
+        if (lrc == KH_OK) lrc = inject("oneshot_sizes");
         std::vector<u64> recv_units;
-        t0 = now_ms();
-        if ((rc = exchange_sizes(parts, recv_units)) != KH_OK) return done(rc);
+        if ((rc = exchange_sizes(lrc, parts, recv_units)) != KH_OK) return done(rc);
         u64 rtot = 0;
         for (u64 v : recv_units) rtot += v;
         DevBuf rbuf, rbuf2, rrc;
-        if ((rc = rbuf.alloc(c, rtot * ub, "hipMalloc(exchange receive buffer)")) != KH_OK) return done(rc);
-        if ((rc = rrc.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(region counts in)")) != KH_OK) return done(rc);
-        if ((rc = a2a_units(sendbuf.p, parts, recv_units, ub, rbuf.p)) != KH_OK) return done(rc);
-        if (wide) {
-            if ((rc = rbuf2.alloc(c, rtot * 8, "hipMalloc(exchange receive counts)")) != KH_OK) return done(rc);
-            if ((rc = a2a_units(sendcnt.p, parts, recv_units, 8, rbuf2.p)) != KH_OK) return done(rc);
-        }
-        {
+        lrc = rbuf.alloc(c, rtot * ub, "hipMalloc(exchange receive buffer)");
+        if (lrc == KH_OK) lrc = rrc.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(region counts in)");
+        if (lrc == KH_OK && wide) lrc = rbuf2.alloc(c, rtot * 8, "hipMalloc(exchange receive counts)");
+        if (lrc == KH_OK) lrc = inject("oneshot_alloc");
+        if ((rc = gather(lrc, {}, "the exchange")) != KH_OK) return done(rc);
+        double t0 = now_ms();
+        transfers = true;
+        lrc = a2a_units(sendbuf.p, parts, recv_units, ub, rbuf.p);
+        if (lrc == KH_OK && wide) lrc = a2a_units(sendcnt.p, parts, recv_units, 8, rbuf2.p);
+        if (lrc == KH_OK) {
             std::vector<u64> so(W), sl(W, per * 4);
             for (uint32_t p = 0; p < W; ++p) so[p] = (u64)p * per * 4;
-            if ((rc = xp_alltoallv(c, rcnt.p, so.data(), sl.data(), rrc.p, so.data(), sl.data())) != KH_OK) return done(rc);
+            lrc = xp_alltoallv(c, rcnt.p, so.data(), sl.data(), rrc.p, so.data(), sl.data());
         }
-        HIP_TRY(c, hipStreamSynchronize(cm->xs));  // the merge kernels run on the context's stream
+        if (lrc != KH_OK && cm->nccl) return done(lrc);      // (RCCL failure: communicator aborted, the peers' waits end)
+        if (lrc == KH_OK) lrc = xp_wait(c, nullptr, "exchange");  // the merge kernels run on the context's stream
         t_wait += now_ms() - t0;
         t0 = now_ms();
-        if ((rc = kh_reset(c)) != KH_OK) return done(rc);
-        if ((rc = kh_set_shard(c, R, W)) != KH_OK) return done(rc);
-        std::vector<const void *> kp(W);
-        std::vector<const uint64_t *> cp(W);
-        std::vector<const uint32_t *> rp(W);
-        u64 o = 0;
-        for (uint32_t s = 0; s < W; ++s) {
-            kp[s] = (const char *)rbuf.p + o * ub;
-            cp[s] = wide ? (const uint64_t *)rbuf2.p + o : nullptr;
-            rp[s] = (const uint32_t *)rrc.p + (u64)s * per;
-            o += recv_units[s];
+        if (lrc == KH_OK) lrc = kh_reset(c);
+        if (lrc == KH_OK) lrc = kh_set_shard(c, R, W);
+        if (lrc == KH_OK) lrc = inject("oneshot_merge");
+        if (lrc == KH_OK) {
+            std::vector<const void *> kp(W);
+            std::vector<const uint64_t *> cp(W);
+            std::vector<const uint32_t *> rp(W);
+            u64 o = 0;
+            for (uint32_t s = 0; s < W; ++s) {
+                kp[s] = (const char *)rbuf.p + o * ub;
+                cp[s] = wide ? (const uint64_t *)rbuf2.p + o : nullptr;
+                rp[s] = (const uint32_t *)rrc.p + (u64)s * per;
+                o += recv_units[s];
+            }
+            lrc = merge_regions(c, wide ? XF_WIDE : (agreed == 2 ? XF_HEADS32 : XF_PACKED64), W, nreg, kp.data(), wide ? cp.data() : nullptr, rp.data());
         }
-        rc = merge_regions(c, wide ? XF_WIDE : (agreed == 2 ? XF_HEADS32 : XF_PACKED64), W, nreg, kp.data(), wide ? cp.data() : nullptr, rp.data());
-        if (cm->hub) cm->hub->barrier();
-        if (rc != KH_OK) return done(rc);
-        if ((rc = kh_finish(c, nullptr)) != KH_OK) return done(rc);
+        if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
         t_merge += now_ms() - t0;
         mi.route = wide ? KH_ROUTE_REGIONS_WIDE : (agreed == 2 ? KH_ROUTE_REGIONS_HEADS : KH_ROUTE_REGIONS_PACKED);
         mi.unit_bytes = wide ? 16 : (uint32_t)ub;
         for (uint32_t p = 0; p < W; ++p) mi.sent_units += p == R ? 0 : parts[p];
         mi.recv_units = rtot;
-        mi.owned_distinct = c->h_ctr->distinct;
-        return done(KH_OK);
+        if (lrc == KH_OK) mi.owned_distinct = c->h_ctr->distinct;
+        return finish(lrc);
     }
 
     // ---- generic route: any world size, tables of any size; device-atomic re-insert ----
     {
-        if ((rc = sendcnt.alloc(c, cap_units64 * 8, "hipMalloc(exchange send counts)")) != KH_OK) return done(rc);
-        t0 = now_ms();
-        rc = kh_export_by_owner_device(c, W, (uint64_t *)sendbuf.p, (uint64_t *)sendcnt.p, n_local, parts.data());  // blocks until complete
+        if (lrc == KH_OK) lrc = sendcnt.alloc(c, cap_units64 * 8, "hipMalloc(exchange send counts)");
+        double t0 = now_ms();
+        if (lrc == KH_OK) lrc = inject("generic_export");
+        if (lrc == KH_OK) lrc = kh_export_by_owner_device(c, W, (uint64_t *)sendbuf.p, (uint64_t *)sendcnt.p, n_local, parts.data());  // blocks until complete
         t_export += now_ms() - t0;
-        if (rc != KH_OK) return done(rc);
         std::vector<u64> recv_units;
-        t0 = now_ms();
-        if ((rc = exchange_sizes(parts, recv_units)) != KH_OK) return done(rc);
+        if ((rc = exchange_sizes(lrc, parts, recv_units)) != KH_OK) return done(rc);
         u64 rtot = 0;
         for (u64 v : recv_units) rtot += v;
         DevBuf rk, rcn;
-        if ((rc = rk.alloc(c, rtot * 8, "hipMalloc(exchange receive keys)")) != KH_OK) return done(rc);
-        if ((rc = rcn.alloc(c, rtot * 8, "hipMalloc(exchange receive counts)")) != KH_OK) return done(rc);
-        if ((rc = a2a_units(sendbuf.p, parts, recv_units, 8, rk.p)) != KH_OK) return done(rc);
-        if ((rc = a2a_units(sendcnt.p, parts, recv_units, 8, rcn.p)) != KH_OK) return done(rc);
-        HIP_TRY(c, hipStreamSynchronize(cm->xs));
+        lrc = rk.alloc(c, rtot * 8, "hipMalloc(exchange receive keys)");
+        if (lrc == KH_OK) lrc = rcn.alloc(c, rtot * 8, "hipMalloc(exchange receive counts)");
+        if (lrc == KH_OK) lrc = inject("generic_alloc");
+        if ((rc = gather(lrc, {}, "the exchange")) != KH_OK) return done(rc);
+        t0 = now_ms();
+        transfers = true;
+        lrc = a2a_units(sendbuf.p, parts, recv_units, 8, rk.p);
+        if (lrc == KH_OK) lrc = a2a_units(sendcnt.p, parts, recv_units, 8, rcn.p);
+        if (lrc != KH_OK && cm->nccl) return done(lrc);
+        if (lrc == KH_OK) lrc = xp_wait(c, nullptr, "exchange");
         t_wait += now_ms() - t0;
         t0 = now_ms();
-        if ((rc = kh_reset(c)) != KH_OK) return done(rc);
-        rc = kh_merge_pairs_device(c, (const uint64_t *)rk.p, (const uint64_t *)rcn.p, rtot);
-        if (rc == KH_OK) rc = kh_finish(c, nullptr);  // (also: the kernels are done with rk / rcn before they are freed)
-        if (cm->hub) cm->hub->barrier();
-        if (rc != KH_OK) return done(rc);
+        if (lrc == KH_OK) lrc = kh_reset(c);
+        if (lrc == KH_OK) lrc = inject("generic_merge");
+        if (lrc == KH_OK) lrc = kh_merge_pairs_device(c, (const uint64_t *)rk.p, (const uint64_t *)rcn.p, rtot);
+        if (lrc == KH_OK) lrc = kh_finish(c, nullptr);  // (also: the kernels are done with rk / rcn before they are freed)
+        else (void)hipStreamSynchronize(c->stream);
         t_merge += now_ms() - t0;
         mi.route = KH_ROUTE_PAIRS;
         mi.unit_bytes = 16;
         for (uint32_t p = 0; p < W; ++p) mi.sent_units += p == R ? 0 : parts[p];
         mi.recv_units = rtot;
-        mi.owned_distinct = c->h_ctr->distinct;
-        return done(KH_OK);
+        if (lrc == KH_OK) mi.owned_distinct = c->h_ctr->distinct;
+        return finish(lrc);
     }
 }
 
 void comm_release(kh_ctx *c) {
     Comm *cm = c->comm;
     if (!cm) return;
-    if (cm->xs) (void)hipStreamSynchronize(cm->xs);
-    if (cm->nccl) (void)ncclCommDestroy(cm->nccl);
+    cm->stop.store(true);
+    if (cm->watchdog.joinable()) cm->watchdog.join();
+    if (cm->xs && !cm->dead.load()) (void)hipStreamSynchronize(cm->xs);
+    if (cm->nccl && !cm->dead.load()) (void)ncclCommDestroy(cm->nccl);  // (an aborted communicator is gone already)
+    if (cm->hub && cm->rank < cm->hub->xs.size()) cm->hub->xs[cm->rank] = nullptr;
     if (cm->d_small) (void)hipFree(cm->d_small);
     if (cm->h_small) (void)hipHostFree(cm->h_small);
     if (cm->xs) (void)hipStreamDestroy(cm->xs);
@@ -586,9 +875,11 @@ int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id
     cm->nranks = nranks;
     cm->rank = rank;
     cm->hub = hub;
+    cm->timeout_s = merge_timeout_s();
     c->comm = cm;
     int rc = KH_OK;
     if (hipStreamCreateWithFlags(&cm->xs, hipStreamNonBlocking) != hipSuccess) rc = fail(c, KH_ERR_HIP, "hipStreamCreate(exchange)");
+    if (rc == KH_OK && hub) hub->xs[rank] = cm->xs;
     if (rc == KH_OK && !hub) {
         const size_t n = (size_t)(1 + nranks) * SMALL_MAX * sizeof(u64);
         if (hipMalloc((void **)&cm->d_small, n) != hipSuccess || hipHostMalloc((void **)&cm->h_small, n, hipHostMallocDefault) != hipSuccess) {
@@ -600,6 +891,20 @@ int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id
             if (r != ncclSuccess) {
                 cm->nccl = nullptr;
                 rc = rccl_fail(c, "ncclCommInitRank", r);
+            }
+        }
+        if (rc == KH_OK) {
+            // the watchdog: an RCCL call that has kept this rank inside the library for longer than the time-out is
+            // released by aborting the communicator (a peer that never arrives, a link that never comes up)
+            try {
+                cm->watchdog = std::thread([cm] {
+                    while (!cm->stop.load()) {
+                        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                        const double since = cm->busy_since.load();
+                        if (since != 0.0 && now_ms() - since > cm->timeout_s * 1e3) comm_abort(cm);
+                    }
+                });
+            } catch (...) {  // (no thread: the polls still bound every wait on the stream, only calls blocked inside RCCL are not covered)
             }
         }
     }
@@ -634,6 +939,8 @@ extern "C" int kh_merge_across(kh_ctx *c, kh_merge_info *info) {
     int rc = enter(c);
     if (rc != KH_OK) return rc;
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "the table is already a shard (merged before); kh_reset first");
+    if (c->comm && c->comm->dead.load())
+        return fail(c, KH_ERR_RCCL, "the communicator was aborted by an earlier failed merge; create a new context and communicator");
     if (!c->comm) {  // a lone context is its own world
         if (info) {
             memset(info, 0, sizeof(*info));
@@ -716,9 +1023,12 @@ extern "C" int kh_group_merge(kh_group *g, kh_merge_info *infos) {
     const uint32_t n = (uint32_t)g->ctx.size();
     std::vector<int> rcs(n, KH_OK);
     if (n == 1) return kh_merge_across(g->ctx[0], infos);
+    if (g->hub) g->hub->revive();  // (no rank is inside a merge here: a poisoned hub of an earlier failed merge starts afresh)
     std::vector<std::thread> th;
     for (uint32_t i = 0; i < n; ++i) th.emplace_back([&, i] { rcs[i] = kh_merge_across(g->ctx[i], infos ? infos + i : nullptr); });
     for (auto &t : th) t.join();
+    for (int r : rcs)  // the status of a rank that failed ITSELF says more than its peers' KH_ERR_PEER
+        if (r != KH_OK && r != KH_ERR_PEER) return r;
     for (int r : rcs)
         if (r != KH_OK) return r;
     return KH_OK;

@@ -721,7 +721,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if (hov[1] == 0) {
             arena_done = true;
             bend = c->bend;
-            c->ovf_pending = hov[0];
+            c->ovf_pending = std::min<u64>(hov[0], ovf_lim);  // (the cursor moves in whole segments: it may end beyond the list)
             HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
         } else if (c->trace) {
             fprintf(stderr, hov[1] == 2 ? "[kmerhip] level-1 partitions too uneven for one workgroup each: this batch takes the exact level-2 path\n"
@@ -777,7 +777,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
                            (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const u64 *)c->rreal, (u64)nregions, c->d_ctr);
         if (c->ovf_pending)  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
             hipLaunchKernelGGL(kh::ovf_insert_kernel<PT>, dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream,
-                               table_geom(c, c->table, c->cap), g, (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, c->d_ctr);
+                               table_geom(c, c->table, c->cap), g, (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
@@ -2194,6 +2194,7 @@ extern "C" const char *kh_strerror(int s) {
     case KH_ERR_RANGE: return "output array too small";
     case KH_ERR_FORMAT: return "text layout not accepted by the device record scanner";
     case KH_ERR_RCCL: return "RCCL error";
+    case KH_ERR_PEER: return "another rank of the collective failed";
     default: return "unknown error";
     }
 }

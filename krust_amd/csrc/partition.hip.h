@@ -1643,8 +1643,11 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 // the overflow list through the direct path (after the region pass: the table then holds the batch's other k-mers)
 template <typename PT>
 __global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeom g, const OvfEntry *__restrict__ list,
-                                                           const u64 *__restrict__ ovf, Counters *ctr) {
-    const u64 n = ovf[0];
+                                                           const u64 *__restrict__ ovf, u64 ovf_cap, Counters *ctr) {
+    // ovf[0] is a CURSOR, advanced by whole segments (part2_arena_kernel, ovf_refill): a workgroup's last segment may
+    // straddle or lie beyond the list's end without the "list full" flag ever being raised (nothing was appended there).
+    // Entries are only ever written, and unused ones only ever marked invalid, below ovf_cap: never read past it.
+    const u64 n = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;
     uint32_t nd = 0, nf = 0;
     u64 km = 0;
     const u64 nround = (n + BLOCK - 1) / BLOCK * BLOCK;  // (whole waves take part in the ballots)

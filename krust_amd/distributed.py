@@ -73,6 +73,24 @@ def _gather_ints(values, group=None):
     return [[int(x) for x in v.tolist()] for v in allv]
 
 
+class PeerFailure(RuntimeError):
+    """Another rank of the collective failed; every rank leaves the merge from the same gather (KH_ERR_PEER of the C ABI)."""
+
+
+def _checked_gather(values, err, group, where):
+    """The gather every stretch of the merge ends in (exchange.hip.h, xp_gather): this rank's status in front of its
+    values.  A rank that failed locally (err = its exception) reports here and re-raises; every other rank raises
+    PeerFailure from the SAME call -- nobody walks on into an all-to-all a peer will never post."""
+    vals = [0] * len(values) if err is not None else [int(v) for v in values]
+    rows = _gather_ints([0 if err is None else 1] + vals, group)
+    if err is not None:
+        raise err
+    bad = [r for r, row in enumerate(rows) if row[0]]
+    if bad:
+        raise PeerFailure(f"rank {bad[0]} failed before {where}; every rank leaves the merge")
+    return [row[1:] for row in rows]
+
+
 def _same_everywhere(value, group=None):
     """True iff every rank holds the same integer."""
     return all(v[0] == int(value) for v in _gather_ints([value], group))
@@ -157,55 +175,76 @@ def _merge_pipelined(counter, group, agreed, npieces, exported, counts_all, keys
     t_wait += t1 - t0
     t0 = t1
     flights, used, sent, parts = [], 0, 0, exported[0]
+    # every receive buffer is allocated before the first transfer: running out of memory is something the ranks hear
+    # about in the gather below, not a peer that never posts its receive
+    err, bufs = None, []
+    try:
+        bufs = [torch.empty(int(recv_h[:, i].sum()), dtype=sendbuf.dtype, device=dev) for i in range(npieces)]
+    except Exception as e:
+        err = e
+    _checked_gather([], err, group, "the first transfer")
     for i in range(npieces):
-        if i > 0:
-            counter.set_region_window(i, npieces)
-            ptr = keys.data_ptr() + used * ub
-            if unit32:
-                res = counter.export_regions_heads_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
-            else:
-                res = counter.export_regions_packed_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
-            if res is None:  # (cannot happen: the sizes were checked against the buffer before the first send)
-                raise RuntimeError("a later piece of the table does not fit the exchange format of the first")
-            parts = res[0]
-        send_sizes = [int(x) for x in parts.tolist()]
-        assert send_sizes == [int(x) for x in send_h[:, i]], "piece sizes differ from the announced ones"
-        recv_sizes = [int(x) for x in recv_h[:, i]]
+        err = buf = None
+        send_sizes = recv_sizes = None
+        try:
+            if i > 0:
+                counter.set_region_window(i, npieces)
+                ptr = keys.data_ptr() + used * ub
+                if unit32:
+                    res = counter.export_regions_heads_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
+                else:
+                    res = counter.export_regions_packed_device(world, ptr, cap_total - used, rcnt.data_ptr(), nreg)
+                if res is None:  # (cannot happen: the sizes were checked against the buffer before the first send)
+                    raise RuntimeError("a later piece of the table does not fit the exchange format of the first")
+                parts = res[0]
+            send_sizes = [int(x) for x in parts.tolist()]
+            if send_sizes != [int(x) for x in send_h[:, i]]:
+                raise RuntimeError("piece sizes differ from the announced ones")
+            recv_sizes = [int(x) for x in recv_h[:, i]]
+            buf = sendbuf[used:used + sum(send_sizes)]
+        except Exception as e:
+            err = e
+        # piece i leaves only when every rank has it ready
+        _checked_gather([], err, group, f"the transfer of piece {i}")
         total = sum(send_sizes)
-        buf = sendbuf[used:used + total]
         used += total
         sent += total - send_sizes[rank]
-        rp = torch.empty(sum(recv_sizes), dtype=buf.dtype, device=dev)
+        rp = bufs[i]
         t1 = time.perf_counter()
         t_exp += t1 - t0
         work = _all_to_all_async(rp, buf, recv_sizes, send_sizes, group=group)
         flights.append((rp, recv_sizes, work, buf))  # (buf stays alive while in flight)
         t0 = time.perf_counter()
         t_wait += t0 - t1
-    counter.set_region_window(0, 1)
-    counter.reset()
-    counter.set_shard(rank, world)
-    merge = counter.merge_regions_heads_device if unit32 else counter.merge_regions_packed_device
-    n_recv = 0
-    rrc_v = rrc_full.view(world, npieces, wper)
-    for i, (rp, recv_sizes, work, _) in enumerate(flights):
-        t1 = time.perf_counter()
-        rrc = torch.zeros_like(rrc_v)  # the senders' region counts as the merge of piece i wants them: zero elsewhere
-        rrc[:, i, :] = rrc_v[:, i, :]
-        _wait_all([work])
-        _stream_sync()  # (rrc is written on torch's stream, read on the counter's; NOT a device-wide sync:
-                        #  the later all-to-alls stay in flight)
-        t2 = time.perf_counter()
-        t_wait += t2 - t1
-        offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-        unit = rp.element_size()
-        counter.set_region_window(i, npieces)
-        merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
-              [rrc.data_ptr() + 4 * per * s for s in range(world)])
-        n_recv += rp.numel()
-        t_merge += time.perf_counter() - t2
-    counter.set_region_window(0, 1)
-    st2 = counter.finish()
+    n_recv, st2, err = 0, None, None
+    try:
+        counter.set_region_window(0, 1)
+        counter.reset()
+        counter.set_shard(rank, world)
+        merge = counter.merge_regions_heads_device if unit32 else counter.merge_regions_packed_device
+        rrc_v = rrc_full.view(world, npieces, wper)
+        for i, (rp, recv_sizes, work, _) in enumerate(flights):
+            t1 = time.perf_counter()
+            rrc = torch.zeros_like(rrc_v)  # the senders' region counts as the merge of piece i wants them: zero elsewhere
+            rrc[:, i, :] = rrc_v[:, i, :]
+            _wait_all([work])
+            _stream_sync()  # (rrc is written on torch's stream, read on the counter's; NOT a device-wide sync:
+                            #  the later all-to-alls stay in flight)
+            t2 = time.perf_counter()
+            t_wait += t2 - t1
+            offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
+            unit = rp.element_size()
+            counter.set_region_window(i, npieces)
+            merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
+                  [rrc.data_ptr() + 4 * per * s for s in range(world)])
+            n_recv += rp.numel()
+            t_merge += time.perf_counter() - t2
+        counter.set_region_window(0, 1)
+        st2 = counter.finish()
+    except Exception as e:
+        err = e
+        _wait_all([f[2] for f in flights])  # (nothing may still write into buffers about to be dropped)
+    _checked_gather([], err, group, "the end of the merge")  # "my merge failed" reaches every rank too
     if timing is not None:
         _device_sync()
         timing.update({"export": timing.get("export", 0.0) + t_exp * 1e3, "exchange_wait": t_wait * 1e3, "merge": t_merge * 1e3,
@@ -251,7 +290,24 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    st = counter.finish()
+    # Shape of every stretch below (as in exchange.hip.h): local, fallible steps run under `attempt`, which keeps the
+    # first exception; the stretch ends in _checked_gather, where every rank learns about it and all leave together.
+    err = [None]
+
+    def attempt(fn, *a):
+        if err[0] is not None:
+            return None
+        try:
+            return fn(*a)
+        except Exception as e:  # (reported at the next gather)
+            err[0] = e
+            return None
+
+    def gather(values, where):
+        e, err[0] = err[0], None
+        return _checked_gather(values, e, group, where)
+
+    st = attempt(counter.finish) or {"distinct": 0, "table_slots": 0}
     n_local = int(st["distinct"])
     nreg = int(st["table_slots"]) // 4096
     # (a counter may name the device its buffers live on: the CPU stand-in of tests/test_dist_gloo.py does)
@@ -260,9 +316,10 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         # Small k: the key space itself is a dense array of 4^k counts, and THAT is element-wise
         # reducible: one all-reduce(sum), any world size, then every rank keeps the keys it owns.
         n = 1 << (2 * counter.k)
-        arr = torch.empty(n, dtype=torch.int64, device=dev)
-        counter.export_dense_device(arr.data_ptr(), n)
+        arr = attempt(lambda: torch.empty(n, dtype=torch.int64, device=dev))
+        attempt(lambda: counter.export_dense_device(arr.data_ptr(), n))
         lap("export")
+        gather([], "the dense all-reduce")
         if _host_staged(group):
             h = arr.cpu()
             dist.all_reduce(h, group=group)
@@ -271,19 +328,20 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
             dist.all_reduce(arr, group=group)
         _stream_sync()  # the collective runs on torch's stream, the merge on the counter's own
         lap("all_reduce")
-        counter.reset()
-        counter.merge_dense_device(arr.data_ptr(), n, rank, world)
-        st2 = counter.finish()
+        attempt(counter.reset)
+        attempt(lambda: counter.merge_dense_device(arr.data_ptr(), n, rank, world))
+        st2 = attempt(counter.finish)
         lap("merge")
+        gather([], "the end of the merge")
         if timing is not None and os.environ.get("KMERHIP_MERGE_TIMING"):
             print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
         return {"path": "dense", "local_distinct": n_local, "sent_pairs": n, "recv_pairs": n,
                 "owned_distinct": int(st2["distinct"]), "phase_ms": timing}
-    keys = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
+    keys = attempt(lambda: torch.empty(max(n_local, 1), dtype=torch.int64, device=dev))
     lap("setup")
     pow2 = world & (world - 1) == 0
     regions_ok = pow2 and world <= 64 and nreg >= world
-    rcnt = torch.empty(nreg, dtype=torch.int32, device=dev) if regions_ok else None
+    rcnt = attempt(lambda: torch.empty(nreg, dtype=torch.int32, device=dev)) if regions_ok else None
 
     def export(fmt):
         if fmt == 2:
@@ -292,30 +350,30 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
             return counter.export_regions_packed_device(world, keys.data_ptr(), n_local, rcnt.data_ptr(), nreg)
         return None
 
+    def export_narrowest():  # speculative: the export itself finds out whether the counts fit
+        for fmt in (2, 1):
+            ex = export(fmt)
+            if ex is not None:
+                return ex, fmt
+        return None, 0
+
     npieces = default_pieces() if pieces is None else int(pieces)
     piped = (regions_ok and packed and npieces > 1 and npieces & (npieces - 1) == 0 and npieces <= 64
              and (nreg // world) >= 64 * npieces)
     exported, my_fmt = None, 0
-    if regions_ok and packed:  # speculative: the export itself finds out whether the counts fit
+    if regions_ok and packed:
         if piped:
-            counter.set_region_window(0, npieces)
-        for fmt in (2, 1):
-            exported = export(fmt)
-            if exported is not None:
-                my_fmt = fmt
-                break
+            attempt(counter.set_region_window, 0, npieces)
+        exported, my_fmt = attempt(export_narrowest) or (None, 0)
     lap("export")
-    votes = _gather_ints([nreg, my_fmt, int(piped)], group)
-    same_size = all(v[0] == nreg for v in votes)
+    votes = gather([nreg, my_fmt, int(piped)], "the format vote")
+    # everything decided from here on is decided from the gathered words only: every rank decides the same
+    same_size = all(v[0] == votes[0][0] for v in votes)
     agreed = min(v[1] for v in votes) if (regions_ok and same_size) else 0
-    if piped and not (agreed and agreed == my_fmt and all(v[1] == agreed and v[2] for v in votes)):
-        # some rank cannot run the pipeline in this rank's format: everybody takes the one-shot route
-        piped = False
-        counter.set_region_window(0, 1)
-        exported, my_fmt = None, 0
-    if agreed and agreed != my_fmt:  # another rank could not go as narrow: redo in the common format
-        exported = export(agreed)
-        assert exported is not None
+    redo = False
+    if piped and not (agreed and all(v[1] == agreed and v[2] for v in votes)):
+        # some rank cannot run the pipeline, or not in the others' format: everybody takes the one-shot route
+        piped, redo = False, True
     per = nreg // world if regions_ok else 0
     counts_all = None
     if piped:
@@ -325,76 +383,96 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
         unit32 = agreed == 2
         ub = 4 if unit32 else 8
         cap_total = 2 * n_local if unit32 else n_local
-        counts_all = torch.empty(nreg, dtype=torch.int32, device=dev)
-        fits = counter.region_unit_counts_device(ub, counts_all.data_ptr(), nreg) == nreg
-        if fits:
-            _stream_sync()
-            fits = int(counts_all.sum(dtype=torch.int64)) <= cap_total
-        if not all(v[0] for v in _gather_ints([int(bool(fits))], group)):
-            piped = False
-            counter.set_region_window(0, 1)
-            exported, my_fmt = None, 0
-            for fmt in (2, 1):  # one shot, whole table: the export itself says whether the narrow unit fits
-                exported = export(fmt)
-                if exported is not None:
-                    my_fmt = fmt
-                    break
-            votes = _gather_ints([my_fmt], group)
-            agreed = min(v[0] for v in votes)
-            if agreed and agreed != my_fmt:
-                exported = export(agreed)
-                assert exported is not None
+
+        def unit_counts():
+            ca = torch.empty(nreg, dtype=torch.int32, device=dev)
+            ok = counter.region_unit_counts_device(ub, ca.data_ptr(), nreg) == nreg
+            if ok:
+                _stream_sync()
+                ok = int(ca.sum(dtype=torch.int64)) <= cap_total
+            return ca, ok
+
+        counts_all, fits = attempt(unit_counts) or (None, False)
+        if not all(v[0] for v in gather([int(bool(fits))], "the piece sizes")):
+            piped, redo = False, True
     if piped:
         try:
             return _merge_pipelined(counter, group, agreed, npieces, exported, counts_all, keys, rcnt, nreg, n_local, dev,
                                     timing, t_last)
         finally:
             counter.set_region_window(0, 1)  # whatever happened: later exports / merges cover the whole range again
+    if redo:  # left the pipeline: whole table, narrowest unit that fits, and a second vote
+        attempt(counter.set_region_window, 0, 1)
+        exported, my_fmt = attempt(export_narrowest) or (None, 0)
+        votes = gather([my_fmt], "the second format vote")
+        agreed = min(v[0] for v in votes) if (regions_ok and same_size) else 0
+    if agreed and agreed != my_fmt:  # another rank could not go as narrow: redo in the common format
+        exported = attempt(export, agreed)
+        if err[0] is None and exported is None:
+            err[0] = RuntimeError("the table does not fit the exchange unit the ranks agreed on")
     if agreed:
-        parts, _ = exported
+        parts = exported[0] if exported is not None else np.zeros(world, dtype=np.uint64)
         total = int(parts.sum())
-        buf = keys.view(torch.int32)[:total] if agreed == 2 else keys[:total]
+        buf = attempt(lambda: keys.view(torch.int32)[:total] if agreed == 2 else keys[:total])
         lap("vote")
+        gather([], "the exchange")
         rp, recv_sizes = exchange_segments(buf, parts.tolist(), group=group)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)  # world slices of nreg / world region counts
         _all_to_all(rrc, rcnt, group=group)
         _stream_sync()  # a non-async collective only orders torch's stream; the merge kernels run on the counter's
         lap("all_to_all")
-        counter.reset()
-        counter.set_shard(rank, world)
-        offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-        unit = rp.element_size()
-        merge = counter.merge_regions_heads_device if agreed == 2 else counter.merge_regions_packed_device
-        merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
-              [rrc.data_ptr() + 4 * per * s for s in range(world)])
+
+        def merge_narrow():
+            counter.reset()
+            counter.set_shard(rank, world)
+            offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
+            unit = rp.element_size()
+            merge = counter.merge_regions_heads_device if agreed == 2 else counter.merge_regions_packed_device
+            merge(nreg, [rp.data_ptr() + unit * int(offs[s]) for s in range(world)],
+                  [rrc.data_ptr() + 4 * per * s for s in range(world)])
+
+        attempt(merge_narrow)
         path, n_recv = ("regions-heads" if agreed == 2 else "regions-packed"), rp.numel()
         lap("merge")
     elif regions_ok and same_size:
-        cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
-        parts, nreg2 = counter.export_regions_device(world, keys.data_ptr(), cnts.data_ptr(), n_local, rcnt.data_ptr(), nreg)
-        assert nreg2 == nreg
+        cnts = attempt(lambda: torch.empty(max(n_local, 1), dtype=torch.int64, device=dev))
+        res = attempt(lambda: counter.export_regions_device(world, keys.data_ptr(), cnts.data_ptr(), n_local, rcnt.data_ptr(), nreg))
+        parts = res[0] if res is not None else np.zeros(world, dtype=np.uint64)
+        gather([], "the exchange")
         rk, rc, recv_sizes = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group, return_sizes=True)
         rrc = torch.empty(nreg, dtype=torch.int32, device=dev)
         _all_to_all(rrc, rcnt, group=group)
         _stream_sync()
-        counter.reset()
-        counter.set_shard(rank, world)
-        offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
-        counter.merge_regions_device(nreg,
-                                     [rk.data_ptr() + 8 * int(offs[s]) for s in range(world)],
-                                     [rc.data_ptr() + 8 * int(offs[s]) for s in range(world)],
-                                     [rrc.data_ptr() + 4 * per * s for s in range(world)])
+
+        def merge_wide():
+            counter.reset()
+            counter.set_shard(rank, world)
+            offs = np.concatenate([[0], np.cumsum(recv_sizes)]).astype(np.int64)
+            counter.merge_regions_device(nreg,
+                                         [rk.data_ptr() + 8 * int(offs[s]) for s in range(world)],
+                                         [rc.data_ptr() + 8 * int(offs[s]) for s in range(world)],
+                                         [rrc.data_ptr() + 4 * per * s for s in range(world)])
+
+        attempt(merge_wide)
         path, n_recv = "regions", rk.numel()
     else:
-        cnts = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
-        parts = counter.export_by_owner_device(world, keys.data_ptr(), cnts.data_ptr(), n_local)
+        cnts = attempt(lambda: torch.empty(max(n_local, 1), dtype=torch.int64, device=dev))
+        parts = attempt(lambda: counter.export_by_owner_device(world, keys.data_ptr(), cnts.data_ptr(), n_local))
+        if parts is None:
+            parts = np.zeros(world, dtype=np.uint64)
+        gather([], "the exchange")
         rk, rc = exchange_pairs(keys[:n_local], cnts[:n_local], parts.tolist(), group=group)
         _stream_sync()
-        counter.reset()
-        counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
+
+        def merge_pairs():
+            counter.reset()
+            counter.merge_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
+
+        attempt(merge_pairs)
         path, n_recv = "pairs", rk.numel()
-    st2 = counter.finish()
+    st2 = attempt(counter.finish)
     lap("finish")
+    gather([], "the end of the merge")  # "my merge failed" reaches every rank too
     if timing is not None and os.environ.get("KMERHIP_MERGE_TIMING"):
         print("[merge timing ms]", {k: round(v, 2) for k, v in timing.items()}, flush=True)
     return {"path": path, "local_distinct": n_local, "sent_pairs": int(parts.sum() - parts[rank]),  # in exchange units

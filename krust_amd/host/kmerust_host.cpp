@@ -297,6 +297,7 @@ struct Session {
             std::vector<uint8_t> job;  // whole records handed over by the reader
             bool has_job = false, quit = false;
             int rc = KH_OK;
+            kh_ctx *ctx = nullptr;  // the device context this worker pushes into: its kh_last_error explains `rc`
         };
         std::vector<std::unique_ptr<Worker>> workers;
         const int text_fmt = fastq ? KH_TEXT_FASTQ : KH_TEXT_FASTA;
@@ -305,6 +306,7 @@ struct Session {
                 workers.emplace_back(new Worker());
                 Worker *w = workers.back().get();
                 kh_ctx *c = ctxs[d];
+                w->ctx = c;
                 w->th = std::thread([w, c, text_fmt] {
                     for (;;) {
                         std::unique_lock<std::mutex> lk(w->m);
@@ -319,6 +321,7 @@ struct Session {
                     }
                 });
             }
+        kh_ctx *failed_ctx = nullptr;       // the context whose push failed (the message must be ITS kh_last_error, not device 0's)
         auto stop_workers = [&]() -> int {  // waits for the queued chunks; first error of any device
             int rc = KH_OK;
             for (auto &w : workers) {
@@ -327,7 +330,10 @@ struct Session {
                     w->cv.wait(lk, [&] { return !w->has_job; });
                     w->quit = true;
                     w->cv.notify_all();
-                    if (rc == KH_OK) rc = w->rc;
+                    if (rc == KH_OK && w->rc != KH_OK) {
+                        rc = w->rc;
+                        failed_ctx = w->ctx;
+                    }
                 }
                 w->th.join();
             }
@@ -383,9 +389,10 @@ struct Session {
                 }
                 if (w->rc != KH_OK) {
                     const int rc = w->rc;
+                    kh_ctx *const wc = w->ctx;
                     lk.unlock();
                     (void)stop_workers();
-                    check(rc, "kh_push_text");
+                    check_on(wc, rc, "kh_push_text");
                 }
                 w->job.assign(buf.begin(), buf.begin() + (ptrdiff_t)cut);
                 w->has_job = true;
@@ -400,7 +407,7 @@ struct Session {
             if (pushed) reset_all();
             return false;
         }
-        check(rc, "kh_push_text");
+        check_on(failed_ctx ? failed_ctx : ctx, rc, "kh_push_text");
         return true;
     }
     static size_t text_chunk_bytes() {

@@ -23,6 +23,7 @@ KH_ERR_STATE = -7
 KH_ERR_RANGE = -8
 KH_ERR_FORMAT = -9
 KH_ERR_RCCL = -10
+KH_ERR_PEER = -11
 TEXT_FASTA, TEXT_FASTQ = 1, 2
 
 
@@ -50,7 +51,8 @@ class KhMergeInfo(C.Structure):
 
 
 ROUTES = ("none", "dense", "regions-heads", "regions-packed", "regions", "pairs")  # KH_ROUTE_*
-STAGES = ("direct", "p1_count", "p1_scatter", "p2_count", "p2_scatter", "region", "misc", "grow")
+# names of kh_stats.stage_ms[i] (KH_STAGE_* of the header); bench.py maps them to the kernels that ran
+STAGES = ("direct", "unused", "level1", "level2_count", "level2", "region", "misc", "grow")
 FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION, FLAG_CALLER_STREAM = 1, 2, 4, 8
 
 

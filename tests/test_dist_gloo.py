@@ -186,7 +186,8 @@ class StandIn:
                     key = table_unhash(h, self.k)
                     self.table[key] = self.table.get(key, 0) + (u & ((1 << self.cb) - 1)) + 1
 
-dist.init_process_group("gloo")
+import datetime
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
 rank, world = dist.get_rank(), dist.get_world_size()
 N_READS, K, SEED, RBITS = 4000, 19, 20260130, 11
 lo, hi = shard_range(N_READS, rank, world)
@@ -229,7 +230,52 @@ if rank == 0:
         assert not (set(tab) & set(union))
         union.update(tab)
     assert sum(union.values()) == full.total() + 100 * len(m) and set(union) == set(full.as_dict())
-print("PIPE_OK", world)
+sys.stdout.write(f"PIPE_OK {world}\n"); sys.stdout.flush()
+# ---- liveness: a rank that fails on its own takes EVERY rank out of the same merge, nobody hangs ----
+# (VERDICT r2 next-1c.)  One rank's stand-in raises at a named call -- the export of a later piece (one transfer
+# already in flight), the up-front unit counts, the merge of a piece, the very first finish, the one-shot export --
+# and every rank must come out of merge_across_ranks with an exception: the failing one with its own, the others
+# with PeerFailure naming it.  gloo's collective time-out (60 s) would turn a hang into a failure of this script.
+from krust_amd.distributed import PeerFailure
+import time
+class Boom(RuntimeError):
+    pass
+class Faulty(StandIn):
+    def __init__(self, k, rbits, fail_at, nth=1):
+        super().__init__(k, rbits)
+        self.fail_at, self.nth, self.seen = fail_at, nth, 0
+    def _maybe(self, name):
+        if name == self.fail_at:
+            self.seen += 1
+            if self.seen == self.nth:
+                raise Boom(f"injected failure in {name}")
+for name in ("finish", "region_unit_counts_device", "export_regions_heads_device", "merge_regions_heads_device", "reset", "set_shard"):
+    def wrap(name=name, inner=getattr(StandIn, name)):
+        def f(self, *a, **kw):
+            self._maybe(name)
+            return inner(self, *a, **kw)
+        return f
+    setattr(Faulty, name, wrap())
+bad = world - 1
+for pieces, fail_at, nth in ((None, "export_regions_heads_device", 2), (None, "region_unit_counts_device", 1), (None, "merge_regions_heads_device", 2),
+                             (None, "finish", 1), (1, "export_regions_heads_device", 1), (1, "set_shard", 1), (2, "reset", 1)):
+    c = Faulty(K, RBITS, fail_at if rank == bad else None, nth)
+    c.table = dict(m.as_dict())
+    t0 = time.time()
+    try:
+        merge_across_ranks(c, pieces=pieces)
+        raise SystemExit(f"rank {rank}: the merge returned although rank {bad} failed in {fail_at}")
+    except Boom as e:
+        assert rank == bad, (rank, e)
+    except PeerFailure as e:
+        assert rank != bad and f"rank {bad} failed" in str(e), (rank, e)
+    assert time.time() - t0 < 30
+    dist.barrier()   # every rank is out, and the group still works:
+    c = StandIn(K, RBITS)
+    c.table = dict(m.as_dict())
+    info = merge_across_ranks(c, pieces=pieces)
+    assert all(krust_amd.owner(key, K, world) == rank for key in c.table) and c.win == (0, 1)
+sys.stdout.write(f"FAULT_OK {world}\n"); sys.stdout.flush()
 dist.destroy_process_group()
 '''
 
@@ -245,6 +291,7 @@ def test_gloo_merge_across_ranks_pipeline_with_cpu_standin(world, tmp_path):
                          capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count(f"PIPE_OK {world}") == world
+    assert out.stdout.count(f"FAULT_OK {world}") == world   # the failure-injection leg: every rank out of every failed merge
 
 
 def test_shard_range_partition():

@@ -158,3 +158,162 @@ def test_group_with_large_counts_leaves_the_pipeline_together(K, monkeypatch):
         for r, dc in enumerate(g.counters):
             keys, cnts = dc.result()
             assert np.array_equal(keys, fk[owners == r]) and np.array_equal(cnts, fc[owners == r])
+
+
+# ---- liveness (round 3): failure is collective, every wait is bounded ---------------------------------------------
+def _merge_each_rank_on_its_own_thread(K, g, timeout=120):
+    """kh_merge_across per context from Python threads (what kh_group_merge does inside the library), keeping every
+    rank's own status.  Returns [(status, last_error)] per rank; fails the test if a rank is still inside after `timeout`."""
+    import ctypes as C
+    import threading
+    L = K.lib()
+    out = [None] * len(g)
+
+    def run(i):
+        info = K.native.KhMergeInfo()
+        rc = L.kh_merge_across(g[i]._h, C.byref(info))
+        out[i] = (rc, L.kh_last_error(g[i]._h).decode(), K.native.merge_info_dict(info))
+
+    th = [threading.Thread(target=run, args=(i,), daemon=True) for i in range(len(g))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+    assert all(not t.is_alive() for t in th), "a rank is still inside kh_merge_across: the collective hung"
+    return out
+
+
+def test_one_rank_needs_a_wider_unit_than_the_others(K, monkeypatch):
+    """rank 0 holds a k-mer whose count needs more than 64 heads (> 64 << cb), rank 1 does not, so
+    rank 0 votes `packed` and rank 1 `heads`.  The ranks must leave the pipeline TOGETHER (round 2 compared the agreed
+    unit with each rank's own: the rank whose unit was the agreed one stayed in and the next collectives mismatched)."""
+    monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    k, world, n_reads = 19, 2, 60_000
+    full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
+    full_b = full_b.copy()
+    v = full_b.reshape(n_reads, 151)
+    v[:40, :150] = ord("A")                       # rank 0's half: A^19 5280 times; cb = 5 at 2^11 regions -> 64 << 5 = 2048 is the most heads carry
+    fk, fc = oracle_arrays(full_b, k)
+    assert int(fc.max()) > 2048
+    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    per = n_reads // world
+    with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
+        for r, dc in enumerate(g.counters):
+            dc.push(full_b[r * per * 151: (r + 1) * per * 151])
+        infos = g.merge()
+        assert infos[0]["path"] == infos[1]["path"] and infos[0]["pieces"] == infos[1]["pieces"], infos
+        assert infos[0]["path"] == "regions-packed", infos   # the common unit of a one-shot exchange
+        for r, dc in enumerate(g.counters):
+            keys, cnts = dc.result()
+            assert np.array_equal(keys, fk[owners == r]) and np.array_equal(cnts, fc[owners == r]), f"shard {r}"
+
+
+POINTS_PIPED = ["start", "export0", "unit_counts", "alloc_recv", "export_piece", "merge_piece"]
+POINTS_ONESHOT = ["start", "export0", "oneshot_sizes", "oneshot_alloc", "oneshot_merge"]
+
+
+@pytest.mark.parametrize("world,k,pieces,point,bad", [(2, 19, None, p, 1) for p in POINTS_PIPED] + [(4, 21, "1", p, 2) for p in POINTS_ONESHOT]
+                         + [(4, 19, "2", "export_piece", 0), (3, 21, None, "generic_export", 1), (3, 21, None, "generic_alloc", 2),
+                            (3, 21, None, "generic_merge", 0), (2, 31, None, "oneshot_alloc", 0)])
+def test_a_rank_that_fails_takes_every_rank_out_of_the_merge(K, monkeypatch, world, k, pieces, point, bad):
+    """a rank-local failure anywhere in the sequence (KMERHIP_FAULT injects one at a named point)
+    makes EVERY rank return from the same kh_merge_across -- the failing rank with its own status, the others with
+    KH_ERR_PEER naming it -- instead of leaving the peers in the next all-gather / receive for ever.  Afterwards the
+    same group (reset, counted again) merges correctly."""
+    if pieces is None:
+        monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    else:
+        monkeypatch.setenv("KMERHIP_MERGE_PIECES", pieces)
+    monkeypatch.setenv("KMERHIP_MERGE_TIMEOUT_S", "60")
+    n_reads = 40_000
+    full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
+    fk, fc = oracle_arrays(full_b, k)
+    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    per = n_reads // world
+
+    def count_all(g):
+        for r, dc in enumerate(g.counters):
+            dc.reset()
+            lo, hi = r * per, (n_reads if r == world - 1 else (r + 1) * per)
+            dc.push(full_b[lo * 151: hi * 151])
+
+    import time
+    with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
+        count_all(g)
+        monkeypatch.setenv("KMERHIP_FAULT", f"{bad}:{point}:{K.native.KH_ERR_STATE}")
+        t0 = time.time()
+        res = _merge_each_rank_on_its_own_thread(K, g)
+        assert time.time() - t0 < 30, "the ranks left, but only after a time-out"
+        for r, (rc, err, _) in enumerate(res):
+            if r == bad:
+                assert rc == K.native.KH_ERR_STATE and "injected fault" in err, (r, rc, err)
+            else:
+                assert rc == K.native.KH_ERR_PEER and f"rank {bad} failed" in err, (r, rc, err)
+        monkeypatch.delenv("KMERHIP_FAULT")
+        count_all(g)
+        g.merge()
+        for r, dc in enumerate(g.counters):
+            keys, cnts = dc.result()
+            assert np.array_equal(keys, fk[owners == r]) and np.array_equal(cnts, fc[owners == r]), f"shard {r} after the failed merge"
+
+
+def test_a_rank_that_never_arrives_times_out(K, monkeypatch):
+    """Only rank 0 of a two-rank group calls kh_merge_across: its first gather waits KMERHIP_MERGE_TIMEOUT_S and comes
+    back with an error instead of blocking for ever."""
+    import time
+    monkeypatch.setenv("KMERHIP_MERGE_TIMEOUT_S", "2")
+    bases, _ = O.synth_reads(SEED, 1 << 18, 150, 0, 5000, with_qual=False)
+    with K.DeviceGroup(21, [0, 0], capacity_hint=1_000_000) as g:
+        g[0].push(bases)
+        g[1].push(bases)
+        t0 = time.time()
+        with pytest.raises(K.KmerHipError) as e:
+            g[0].merge_across()
+        assert 1.5 < time.time() - t0 < 20
+        assert e.value.status == K.native.KH_ERR_PEER
+        monkeypatch.setenv("KMERHIP_MERGE_TIMEOUT_S", "60")
+        g[0].reset(); g[1].reset()
+        g[0].push(bases); g[1].push(bases)
+        infos = g.merge()                                  # kh_group_merge starts from a revived hub
+        assert infos[0]["owned_distinct"] + infos[1]["owned_distinct"] == infos[0]["local_distinct"]
+
+
+@pytest.mark.parametrize("point", ["start", "export0", "unit_counts", "alloc_recv", "merge_piece", "dense_export"])
+def test_rccl_world1_local_failures_and_an_aborted_communicator(K, reads, monkeypatch, point):
+    """The same protocol over RCCL (world 1: the gathers, send / recv groups and waits are RCCL's): a local failure is
+    reported through the gather and leaves the communicator usable; an abort (what a time-out does) kills the
+    communicator, not the process: the context says so, is destroyed cleanly, and a new one works."""
+    monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    k = 11 if point == "dense_export" else 19
+    ok, oc = oracle_arrays(reads, k)
+    with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+        dc.comm_init(1, 0, K.comm_unique_id())
+        dc.push(reads)
+        monkeypatch.setenv("KMERHIP_FAULT", f"0:{point}:{K.native.KH_ERR_STATE}")
+        with pytest.raises(K.KmerHipError) as e:
+            dc.merge_across()
+        assert e.value.status == K.native.KH_ERR_STATE and "injected fault" in str(e.value)
+        monkeypatch.delenv("KMERHIP_FAULT")
+        dc.reset()
+        dc.push(reads)
+        info = dc.merge_across()
+        assert info["owned_distinct"] == len(ok)
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
+        if point == "start":
+            dc.reset()
+            dc.push(reads)
+            monkeypatch.setenv("KMERHIP_FAULT", "0:abort")
+            with pytest.raises(K.KmerHipError) as e:
+                dc.merge_across()
+            assert e.value.status == K.native.KH_ERR_RCCL
+            monkeypatch.delenv("KMERHIP_FAULT")
+            with pytest.raises(K.KmerHipError) as e:      # the communicator is gone for good
+                dc.merge_across()
+            assert e.value.status == K.native.KH_ERR_RCCL and "aborted" in str(e.value)
+            keys, cnts = dc.result()                       # ... the context and its table are not
+            assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
+    with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:
+        dc.comm_init(1, 0, K.comm_unique_id())
+        dc.push(reads)
+        assert dc.merge_across()["owned_distinct"] == len(ok)

@@ -1084,14 +1084,20 @@ def test_level1_bins_kernel_overflow_and_masks(K, monkeypatch, k, hint, generic,
 
 
 @pytest.mark.parametrize("mode", ["arena", "exact", "list-full", "no-skew-limit", "unaligned-exact"])
-@pytest.mark.parametrize("k,skewed", [(21, False), (21, True), (31, True), (19, False)], ids=["k21", "k21-skewed", "k31-skewed", "k19"])
+@pytest.mark.parametrize("k,skewed", [(21, False), (21, True), (31, True), (19, False), (21, "many")],
+                         ids=["k21", "k21-skewed", "k31-skewed", "k19", "k21-many-heavy"])
 def test_level2_arena_path_and_its_fallbacks(K, monkeypatch, mode, k, skewed):
     """Level 2 without a counting pass (part2_arena_kernel: per-bucket arenas sized from the level-1 partition totals,
     one workgroup per partition, what does not fit goes to an overflow list inserted through the direct path after the
     region pass) against the oracle, and every way it can step aside: switched off (`exact`), the overflow list
     declared full after a few entries (`list-full`: the batch is redone through the exact path), no limit on how uneven
     the partitions may be (`no-skew-limit`: on skewed input the heavy buckets then really go through the list), and the
-    exact path with the unaligned scatter.  Skewed input: a fifth of the reads are copies of four short repeats."""
+    exact path with the unaligned scatter.  Skewed input: a fifth of the reads are copies of four short repeats;
+    `many-heavy`: twenty reads 2000 times each, i.e. ~2600 k-mers each heavier than a bucket's arena slack, spread over
+    nearly all of the 1024 partitions -- every workgroup takes a private 8192-entry segment of the overflow list, so the
+    list's cursor ends far beyond its capacity without the list being full (the insert kernel must stop at the capacity).
+    The table is sized (hint 50 M -> 2^15 regions) so that the geometry is the arena path's: 1024 partitions x 32 buckets;
+    which path a batch took shows in the stage times (the arena path has no counting pass)."""
     if mode == "exact":
         monkeypatch.setenv("KMERHIP_L2_ARENA", "0")
     elif mode == "list-full":
@@ -1106,7 +1112,12 @@ def test_level2_arena_path_and_its_fallbacks(K, monkeypatch, mode, k, skewed):
     n_reads = 80_000
     bases, _ = O.synth_reads(SEED + k, 1 << 19, 150, 0, n_reads, with_qual=False)
     bases = bases.copy()
-    if skewed:
+    if skewed == "many":
+        v = bases.reshape(n_reads, 151)
+        heavy = v[:20, :150].copy()                      # twenty reads, 2000 copies of each
+        for j, i in enumerate(rng.choice(np.arange(20, n_reads), size=40_000, replace=False)):
+            v[i, :150] = heavy[j % 20]
+    elif skewed:
         v = bases.reshape(n_reads, 151)
         reps = [np.resize(np.frombuffer(r, dtype=np.uint8), 150) for r in (b"A", b"AC", b"ACGTTGCA", b"GATTACA")]
         for i in rng.choice(n_reads, size=n_reads // 5, replace=False):
@@ -1117,11 +1128,16 @@ def test_level2_arena_path_and_its_fallbacks(K, monkeypatch, mode, k, skewed):
     import torch
     tb = torch.from_numpy(bases).cuda()
     torch.cuda.synchronize()
-    with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:
+    with K.DeviceCounter(k, capacity_hint=50_000_000, path="partition") as dc:
         cut = [0, 30_000 * 151, 30_001 * 151, n_reads * 151]
         for a, b in zip(cut, cut[1:]):
             dc.push_device(tb.data_ptr() + a, None, b - a)
         st = dc.finish()
-        assert st["kmers"] == m.total()
+        assert st["kmers"] == m.total() and st["table_slots"] == 1 << 27
+        counted = st["stage_ms"]["level2_count"] > 0          # some batch went through count -> scan -> scatter
+        if mode in ("exact", "unaligned-exact", "list-full"):
+            assert counted or mode == "list-full" and not skewed
+        elif not skewed or mode == "no-skew-limit":
+            assert not counted, "the arena path stepped aside where it should not have"
         keys, cnts = dc.result()
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)

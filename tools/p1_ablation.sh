@@ -15,7 +15,7 @@ else
     KMERHIP_LIB=libkmerhip_abl$b.so python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('KH_ABL=$b', 'p1_scatter_ms', round(d['roofline']['stages_ms'].get('p1_scatter',0),2))" >> gpurun_out/p1_ablation.txt
+print('KH_ABL=$b', 'level1_ms', round(d['roofline']['stages_ms'].get('level1',0),2))" >> gpurun_out/p1_ablation.txt
   done
   cat gpurun_out/p1_ablation.txt
 fi
