@@ -481,6 +481,7 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
     }
 }
 
+#ifndef KH_HELPERS_ONLY  // (the level-1 translation units take the helpers above, not the kernels below: one definition each)
 // ---------------------------------------------------------------------------------------------
 // table maintenance
 // ---------------------------------------------------------------------------------------------
@@ -746,5 +747,7 @@ __global__ __launch_bounds__(BLOCK) void synth_reads_kernel(u64 seed, u64 genome
         }
     }
 }
+
+#endif  // KH_HELPERS_ONLY
 
 }  // namespace kh

@@ -20,6 +20,7 @@
 
 #include "kernels.hip.h"
 #include "partition.hip.h"
+#include "level1_api.h"
 #include "shard.hip.h"
 #include "rawparse.hip.h"
 
@@ -439,9 +440,12 @@ GeomChoice make_geom(const kh_ctx *c, u64 cap) {
         p1 = (uint32_t)need;
         p2 = rbits - p1;
     }
-    // 64-bit payloads are free in the split: with >= 2^11 regions give level 1 its full 1024 partitions, so that level 2
-    // has <= 512 buckets per partition up to 2^19 regions (the unit-writing level-2 kernel handles 512)
-    if (!((hbits - (int)p1) <= 32 && c->pay_mode != 64) && rbits > kh::MAX_P1_BITS) {
+    // With more than 2^10 regions level 1 gets its full 1024 partitions, whatever the payload: the bins kernels are built
+    // around one lane per partition, level 2 then has <= 512 buckets per partition up to 2^19 regions (what the arena
+    // kernel and the unit-writing scatter take), and the written-out windows (window.hip.h) fix the digit at 10 bits.
+    // (Round 2 did this for 64-bit payloads only: k = 19 at the headline size got 512 partitions x 1024 buckets, i.e. the
+    // exact level 2 with the unaligned scatter -- 122 ms per step against k = 21's 75.)
+    if (rbits > kh::MAX_P1_BITS && c->shard_shift == 0 && c->k >= kh::MAX_P1_BITS) {
         p1 = kh::MAX_P1_BITS;
         p2 = rbits - p1;
     }
@@ -622,7 +626,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 
     const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
     const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
-    const dim3 g1(PART_G1), b1(kh::PART_NT);
+    const dim3 b1(kh::PART_NT);
     kh::ChunkSrc cs;
     cs.pay = c->keysA;
     cs.plist = c->plist;
@@ -638,48 +642,34 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         }
         {
             StageTimer t(c, ST_P1_SCATTER);
-#define KH_P1_LAUNCH(QUAL, MODE, FAST, KT) \
-    hipLaunchKernelGGL((kh::part1_scatter_chunked_kernel<QUAL, MODE, FAST, PT, KT>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
-                       ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (PT *)c->keysA, \
-                       c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
-#define KH_P1_LAUNCH2(QUAL, MODE) \
-    do { if (fast) KH_P1_LAUNCH(QUAL, MODE, true, 0); else KH_P1_LAUNCH(QUAL, MODE, false, 0); } while (0)
-            const bool m24 = kh_k_uses_mul24(c->k);  // the Feistel multiplier is a compile-time choice in the hot kernel
-            const bool fast = sizeof(PT) == 4 && kh::p1_fast_ok(g);
-            // the BASELINE configurations get kernels compiled for their k (KMERHIP_GENERIC_K=1: the generic form, for A/B)
-            const bool generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
-            // 32-bit payloads: the bins kernel (KMERHIP_P1_BINS=0: the tile-sorting, per-payload-storing one, for A/B);
-            // k = 21 at the headline geometry gets the written-out window (KMERHIP_GENERIC_K=1: the C++ window)
-            const bool bins32 = [] { const char *e = getenv("KMERHIP_P1_BINS"); return !(e && e[0] == '0'); }();
-#define KH_P1_BINS(QUAL, MODE, FAST, ASM21) \
-    hipLaunchKernelGGL((kh::part1_bins_kernel<QUAL, MODE, FAST, ASM21>), g1, b1, 0, c->stream, ra.abase, ra.qbase, \
-                       ra.qaligned, ra.vbeg, ra.vend, ra.wlo, tile0, ntiles, tpb, c->k, thr, g, (uint32_t *)c->keysA, \
-                       c->chunk_part, c->fill8, c->pool_next, pool_chunks, c->d_ctr)
-            if (sizeof(PT) == 4 && bins32) {
-                const bool k21 = !generic_k && c->k == 21 && fast && g.p1_bits == 10;
-                if (k21 && ra.use_qual) KH_P1_BINS(true, KH_MUL_24, true, true);
-                else if (k21) KH_P1_BINS(false, KH_MUL_24, true, true);
-                else if (ra.use_qual && m24 && fast) KH_P1_BINS(true, KH_MUL_24, true, false);
-                else if (ra.use_qual && m24) KH_P1_BINS(true, KH_MUL_24, false, false);
-                else if (ra.use_qual && fast) KH_P1_BINS(true, KH_MUL_32, true, false);
-                else if (ra.use_qual) KH_P1_BINS(true, KH_MUL_32, false, false);
-                else if (m24 && fast) KH_P1_BINS(false, KH_MUL_24, true, false);
-                else if (m24) KH_P1_BINS(false, KH_MUL_24, false, false);
-                else if (fast) KH_P1_BINS(false, KH_MUL_32, true, false);
-                else KH_P1_BINS(false, KH_MUL_32, false, false);
-            } else if (!generic_k && c->k == 21 && sizeof(PT) == 4 && fast && g.p1_bits == 10) {
-                if (ra.use_qual) KH_P1_LAUNCH(true, KH_MUL_24, true, 21);
-                else KH_P1_LAUNCH(false, KH_MUL_24, true, 21);
-            } else if (!generic_k && c->k == 31 && sizeof(PT) == 8) {
-                if (ra.use_qual) KH_P1_LAUNCH(true, KH_MUL_32, false, 31);
-                else KH_P1_LAUNCH(false, KH_MUL_32, false, 31);
-            } else if (ra.use_qual && m24) KH_P1_LAUNCH2(true, KH_MUL_24);
-            else if (ra.use_qual) KH_P1_LAUNCH2(true, KH_MUL_32);
-            else if (m24) KH_P1_LAUNCH2(false, KH_MUL_24);
-            else KH_P1_LAUNCH2(false, KH_MUL_32);
-#undef KH_P1_BINS
-#undef KH_P1_LAUNCH2
-#undef KH_P1_LAUNCH
+            // level 1 lives in translation units of its own (level1_api.h): one kernel per k for the written-out window
+            kh::L1Launch l1;
+            l1.stream = c->stream;
+            l1.grid = (unsigned)PART_G1;
+            l1.abase = ra.abase;
+            l1.qbase = ra.qbase;
+            l1.qaligned = ra.qaligned;
+            l1.use_qual = ra.use_qual;
+            l1.vbeg = ra.vbeg;
+            l1.vend = ra.vend;
+            l1.wlo = ra.wlo;
+            l1.tile0 = tile0;
+            l1.ntiles = ntiles;
+            l1.tiles_per_block = tpb;
+            l1.k = c->k;
+            l1.thr = thr;
+            l1.g = g;
+            l1.pool = c->keysA;
+            l1.chunk_part = c->chunk_part;
+            l1.fill8 = c->fill8;
+            l1.pool_next = c->pool_next;
+            l1.pool_chunks = pool_chunks;
+            l1.ctr = c->d_ctr;
+            // KMERHIP_GENERIC_K=1: the C++ window where a written-out one exists; KMERHIP_P1_BINS=0: round 1's tile-sorting kernel (both for A/B)
+            l1.generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
+            l1.legacy = [] { const char *e = getenv("KMERHIP_P1_BINS"); return e && e[0] == '0'; }();
+            if (sizeof(PT) == 4) kh::launch_level1_32(l1, nullptr);
+            else kh::launch_level1_64(l1, nullptr);
         }
 #if KH_ABL
         if (getenv("KMERHIP_STOP_AFTER_P1")) {  // ablation builds only: time level 1 alone (its output is garbage)

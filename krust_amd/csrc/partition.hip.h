@@ -26,770 +26,9 @@
 // Reference counterpart: none (the reference is src/run.rs:526-571 + DashMap); results are the
 // same multiset of (key,count) as the direct path.
 #pragma once
-#include "kernels.hip.h"
-
-#ifndef KH_ABL3
-#define KH_ABL3 0  // the same for part2_scatter_lines_kernel
-#endif
-#ifndef KH_ABL2
-#define KH_ABL2 0  // the same for part2_scatter_kernel
-#endif
-#ifndef KH_ABLR
-#define KH_ABLR 0  // the same for region_count_kernel32
-#endif
-#ifndef KH_ABL
-#define KH_ABL 0  // ablation bits for timing experiments on part1_scatter_chunked_kernel (tools/p1_ablation.sh); 0 in any product build
-#endif
+#include "part_common.hip.h"
 
 namespace kh {
-
-constexpr int PART_NT = 1024;                    // lanes per workgroup in the partition kernels
-constexpr int PART_TILE = PART_NT * CHUNK;       // 16384 positions / keys per batch
-constexpr uint32_t MAX_P1 = 1024;
-constexpr uint32_t MAX_P1_BITS = 10;
-constexpr uint32_t MAX_P2_BITS = 10;             // <= 1024 regions per level-1 partition
-constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // payloads per level-2 workgroup (262144)
-constexpr int REGION_NT = 1024;                  // lanes per workgroup in region_count_kernel
-#ifndef KH_ARENA_LANES
-#define KH_ARENA_LANES 4  // lanes that flush a bucket of the arena level 2 together (1, 2, 8: A/B builds)
-#endif
-#ifndef KH_REGION_RK
-#define KH_REGION_RK 8
-#endif
-constexpr int REGION_RK = KH_REGION_RK;                     // keys prefetched per lane per round
-
-struct PartGeom {
-    uint32_t rbits;        // log2(regions) = p1_bits + p2_bits
-    uint32_t p1_bits;      // level-1 partitions = 1 << p1_bits
-    uint32_t p2_bits;      // buckets per level-1 partition = 1 << p2_bits
-    uint32_t k;
-    uint32_t shard_shift;  // as TableGeom: placement hash = kh_table_hash << shard_shift
-    uint32_t shard_index;
-};
-
-template <int MODE = KH_MUL_AUTO>
-__device__ __forceinline__ u64 part_hash(const PartGeom &g, u64 key) { return kh_table_hash<MODE>(key, g.k) << g.shard_shift; }
-// key of a placement hash of this (possibly sharded) table
-__device__ __forceinline__ u64 part_unhash(const PartGeom &g, u64 Hs) {
-    const u64 H = g.shard_shift ? ((Hs >> g.shard_shift) | ((u64)g.shard_index << (64 - g.shard_shift))) : Hs;
-    return kh_table_unhash(H, g.k);
-}
-
-// ---- payload traits ---------------------------------------------------------------------------
-template <typename PT>
-struct Pay;
-
-template <>
-struct Pay<u64> {  // the key itself
-    __device__ static __forceinline__ u64 make(u64 key, u64 H, const PartGeom &g) { return key; }
-    __device__ static __forceinline__ uint32_t p2(u64 pay, const PartGeom &g) {
-        const u64 H = part_hash(g, pay);
-        return g.p2_bits ? (uint32_t)((H << g.p1_bits) >> (64 - g.p2_bits)) : 0u;
-    }
-    __device__ static __forceinline__ u64 key(u64 pay, uint32_t p1, const PartGeom &g) { return pay; }
-};
-
-template <>
-struct Pay<uint32_t> {  // bits [p1_bits, p1_bits+32) of H
-    __device__ static __forceinline__ uint32_t make(u64 key, u64 H, const PartGeom &g) { return (uint32_t)((H << g.p1_bits) >> 32); }
-    __device__ static __forceinline__ uint32_t p2(uint32_t pay, const PartGeom &g) {
-        return g.p2_bits ? (pay >> (32 - g.p2_bits)) : 0u;
-    }
-    __device__ static __forceinline__ u64 hash(uint32_t pay, uint32_t p1, const PartGeom &g) {
-        const u64 top = g.p1_bits ? ((u64)p1 << (64 - g.p1_bits)) : 0ull;
-        return top | ((u64)pay << (32 - g.p1_bits));
-    }
-    __device__ static __forceinline__ u64 key(uint32_t pay, uint32_t p1, const PartGeom &g) {
-        return part_unhash(g, hash(pay, p1, g));
-    }
-};
-
-__device__ __forceinline__ uint32_t p1_of_hash(u64 H, const PartGeom &g) {
-    return g.p1_bits ? (uint32_t)(H >> (64 - g.p1_bits)) : 0u;
-}
-
-// Level-1 digit and 32-bit payload straight from the two k-bit halves of the hash, h = L << k | R:
-// p1 = the top p1_bits of h, payload = the remaining 2k - p1_bits (<= 32) bits, left-aligned.  All
-// 32-bit shifts (the generic form above costs five 64-bit shifts per window).  Valid iff the table is
-// not a shard, p1_bits <= k and 1 <= 2k - p1_bits <= 32 (p1_fast_ok); same values as the generic form.
-__host__ __device__ inline bool p1_fast_ok(const PartGeom &g) {
-    return g.shard_shift == 0 && g.p1_bits <= g.k && 2 * g.k - g.p1_bits >= 1 && 2 * g.k - g.p1_bits <= 32 && g.k < 32;
-}
-template <int MODE>
-__device__ __forceinline__ void hash_p1_pay32(const uint32_t k, const uint32_t p1_bits, u64 key, uint32_t &p1, uint32_t &pay) {
-    const uint32_t mask = (1u << k) - 1u;
-    uint32_t L = (uint32_t)(key >> k) & mask, R = (uint32_t)key & mask, t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC0, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC1, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC2, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC3, k)) & mask; L = R; R = t;
-    p1 = L >> (k - p1_bits);
-    pay = ((L << k) | R) << (32u - (2u * k - p1_bits));  // L's top p1_bits fall off the 32-bit word
-}
-
-// ---- level-2 work unit and the two level-1 output layouts it can read -----------------------------
-struct Part2Block {
-    u64 lo, hi;        // dense source: payload range in the level-1 output;
-                       // chunked source: range of the partition's chunk list (plist indices)
-    u64 mbase;         // H2/O2 index of (p2 = 0, this chunk)
-    uint32_t mstride;  // chunks in this partition: H2 index of p2 is mbase + p2 * mstride
-    uint32_t p1;
-};
-
-// ---- level-1 output as a pool of fixed-size chunks ------------------------------------------------
-// Level 1 can then run in ONE pass: no counting pass is needed to know where a partition's data
-// goes, a workgroup just takes the next free chunk when a partition's current chunk fills up.
-// Chunks are handed out in per-workgroup ranges (one global atomic per POOL_GRAB chunks; a lone
-// pool counter hit once per chunk would serialise at ~6-17 ns per same-address atomic).
-constexpr uint32_t CHUNK_PAY = 256;     // payloads per pool chunk (1 KiB)
-constexpr uint32_t POOL_GRAB = 4096;    // chunks per workgroup grab (4 MiB of payloads)
-constexpr uint32_t POOL_LOW = 72;       // refill the private range below this many free chunks
-constexpr uint32_t CPB = 1024;          // chunks per level-2 workgroup (262144 payloads)
-constexpr uint16_t PART_NONE = 0xFFFFu; // chunk_part[] of a chunk nobody owns
-
-struct ChunkSrc {                 // how level 2 reads a chunked level-1 output
-    const void *pay;              // pool (PT payloads)
-    const uint32_t *plist;        // chunk ids ordered by partition
-    const uint8_t *fill8;         // payloads in the chunk minus one
-};
-
-// A level-2 workgroup first copies its slice of the chunk list (ids and fill levels) into LDS, so
-// that fetching element e is ONE global load again (plist -> fill8 -> payload would be a chain of
-// three dependent loads per element).
-template <bool CHUNKED>
-__device__ __forceinline__ void p2_stage_chunks(const ChunkSrc &cs, const Part2Block &pb, uint32_t *s_chk, uint16_t *s_cfill,
-                                                int tid, int nthreads) {
-    if (!CHUNKED) return;
-    const uint32_t nc = (uint32_t)(pb.hi - pb.lo);
-    for (uint32_t i = tid; i < nc; i += nthreads) {
-        const uint32_t chunk = cs.plist[pb.lo + i];
-        s_chk[i] = chunk;
-        s_cfill[i] = (uint16_t)((uint32_t)cs.fill8[chunk] + 1u);
-    }
-}
-
-// element e of a level-2 workgroup's input; returns false past the data
-template <bool CHUNKED, typename PT>
-__device__ __forceinline__ bool p2_load(const PT *__restrict__ dense, const ChunkSrc &cs, const Part2Block &pb,
-                                        const uint32_t *s_chk, const uint16_t *s_cfill, uint32_t e, uint32_t n, PT &out) {
-    if (!CHUNKED) {
-        out = dense[pb.lo + (e < n ? e : n - 1)];
-        return e < n;
-    }
-    const uint32_t ec = e < n ? e : n - 1;
-    const uint32_t chunk = s_chk[ec >> 8];
-    const uint32_t off = ec & (CHUNK_PAY - 1);
-    const uint32_t have = s_cfill[ec >> 8];
-    out = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (off < have ? off : 0)];
-    return e < n && off < have;
-}
-template <bool CHUNKED>
-__device__ __forceinline__ uint32_t p2_count_of(const Part2Block &pb) {
-    return CHUNKED ? (uint32_t)(pb.hi - pb.lo) * CHUNK_PAY : (uint32_t)(pb.hi - pb.lo);
-}
-
-// Exclusive scan of s_cnt[0..N) into s_lofs[0..N) (N = 512 or 1024) by a workgroup of >= N / 4 lanes.
-// s_wsum: 4 words of scratch.  Ends with a barrier.
-template <int N, typename LT>
-__device__ __forceinline__ void block_exclusive_scan_n(const uint32_t *s_cnt, LT *s_lofs, uint32_t *s_wsum, int tid) {
-    constexpr int LANES = N / 4;
-    uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0, incl = 0;
-    if (tid < LANES) {
-        v0 = s_cnt[4 * tid];
-        v1 = s_cnt[4 * tid + 1];
-        v2 = s_cnt[4 * tid + 2];
-        v3 = s_cnt[4 * tid + 3];
-        incl = v0 + v1 + v2 + v3;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t n = __shfl_up(incl, off, 64);
-            if ((tid & 63) >= off) incl += n;
-        }
-        if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
-    }
-    __syncthreads();
-    if (tid < LANES) {
-        uint32_t base = 0;
-        for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
-        const uint32_t excl = base + incl - (v0 + v1 + v2 + v3);
-        s_lofs[4 * tid] = (LT)excl;
-        s_lofs[4 * tid + 1] = (LT)(excl + v0);
-        s_lofs[4 * tid + 2] = (LT)(excl + v0 + v1);
-        s_lofs[4 * tid + 3] = (LT)(excl + v0 + v1 + v2);
-    }
-    __syncthreads();
-}
-template <typename LT>
-__device__ __forceinline__ void block_exclusive_scan_1024(const uint32_t *s_cnt, LT *s_lofs, uint32_t *s_wsum, int tid) {
-    block_exclusive_scan_n<1024, LT>(s_cnt, s_lofs, s_wsum, tid);
-}
-
-// ---------------------------------------------------------------------------------------------
-// level 1, single pass: extraction + scatter into pool chunks, no counting pass
-// ---------------------------------------------------------------------------------------------
-struct ChunkDst {  // per partition, per batch: where staged element i (local index e = i - lofs) goes
-    u64 a;         // e <  split: pool index = a + i   (the partition's current chunk)
-    u64 b;         // e >= split: pool index = b + i   (freshly taken, consecutive chunks)
-};
-// a and b are biased by -lofs (and b by -split), so they wrap below zero for the first chunks of the pool:
-// b lies in [-(RTILE + CHUNK_PAY), pool size) modulo 2^64, any value in there is a real destination
-// (-1 included: it comes up once in a few hundred batches).  The "drop" marker sits far outside.
-constexpr u64 CHUNK_DST_DROP = 1ull << 63;
-
-// PT = uint32_t: one sorting round of 16 windows per lane per tile.  PT = u64 (k >= 22): TWO rounds of 8
-// windows per lane, so that the staged payloads take the same 64 KiB of LDS and the per-partition runs
-// the same 64 bytes; the extraction state (Roller) simply carries on between the rounds.
-// KT: 0 = k is a run-time value; 21 / 31 = the kernel is compiled for that k (the BASELINE configurations):
-// window masks, the revcomp insert position and the Feistel shifts become immediates, the 64-bit shift that
-// splits the key into its halves becomes one v_alignbit, and for 21 the level-1 geometry (1024 partitions,
-// payload = the low 32 hash bits) is fixed too.  Same values as the generic form (the tests run both).
-template <bool QUAL, int MODE, bool FAST, typename PT, int KT>
-__global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
-    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k, uint32_t thr, PartGeom g, PT *__restrict__ pool,
-    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
-    Counters *ctr) {
-    constexpr int ROUNDS = sizeof(PT) == 8 ? 2 : 1;
-    constexpr int WPR = CHUNK / ROUNDS;         // windows per lane per round
-    constexpr int RTILE = PART_NT * WPR;        // staged payloads per round
-    __shared__ uint32_t s_code[2][PART_NT + 2];
-    __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ PT s_stage[RTILE + 2];           // 64 KiB (+ a trash slot for windows without a key)
-    __shared__ uint16_t s_pid[RTILE + 2];       // 32 / 16 KiB
-    __shared__ uint32_t s_cnt[MAX_P1];
-    __shared__ uint32_t s_meta[MAX_P1];         // lofs | split << 16
-    __shared__ ChunkDst s_dst[MAX_P1];          // 16 KiB
-    __shared__ uint32_t s_wsum[4];
-    __shared__ uint16_t s_lofs[MAX_P1];
-    __shared__ u64 s_priv_next, s_priv_end;     // the workgroup's private range of chunk ids
-    const int tid = threadIdx.x;
-    if (KT) k = KT;
-    const uint32_t p1b = (KT == 21 && FAST) ? 10u : g.p1_bits;
-    s_cnt[tid] = 0;
-    if (tid == 0) {
-        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-        s_priv_end = s_priv_next + POOL_GRAB;
-    }
-    // lane tid owns partition tid: its current chunk and how full it is
-    u64 cur = 0;
-    uint32_t fill = CHUNK_PAY;  // "full": the first payload takes a chunk
-    bool have_chunk = false;
-    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
-    u64 te = tb + tiles_per_block;
-    if (te > tile0 + ntiles) te = tile0 + ntiles;
-    int buf = 0;
-    uint32_t lost = 0;
-    __syncthreads();
-    // The next tile's bases are requested right after this tile's first barrier and encoded into the other code buffer
-    // BEFORE this tile's first write-out: a wait for them placed after stores is a wait for the stores' acknowledgement
-    // (vmcnt counts both; see part1_bins_kernel).
-    {
-        const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
-        stage_encode<QUAL, PART_NT>(s_code, s_val, 0, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
-    }
-    for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        __syncthreads();
-        const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        const WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
-        Roller roll;
-        roll.init(w, k, wlo);
-#pragma unroll
-        for (int h = 0; h < ROUNDS; ++h) {
-            PT pay[WPR];
-            uint32_t tag[WPR];  // (p1 << 16) | rank-in-partition, 0xFFFFFFFF = no key
-#pragma unroll
-            for (int j = 0; j < WPR; ++j) {
-                u64 key;
-#if KH_ABL & 8  /* timing experiment: no window extraction */
-                key = (u64)roll.code * (2 * j + 1) + tid;
-                const bool ok = true;
-#else
-                const bool ok = roll.next(h * WPR + j, key);
-#endif
-                uint32_t p1 = 0;
-                // Without quality masking nearly every window is valid (N is rare): hashing unconditionally
-                // is cheaper than an exec-mask region per window.  With -Q ~40 % of the windows are masked,
-                // there the branch pays.
-                if (!QUAL || ok) {
-                    if (sizeof(PT) == 8) {
-                        pay[j] = (PT)key;
-                        const u64 H = kh_table_hash<MODE>(key, k) << g.shard_shift;
-                        p1 = p1_of_hash(H, g);
-                    } else if (FAST) {
-                        uint32_t pw;
-#if KH_ABL & 1  /* timing experiment: no hash */
-                        p1 = (uint32_t)key & 1023u;
-                        pw = (uint32_t)(key >> 10);
-#else
-                        hash_p1_pay32<MODE>(k, p1b, key, p1, pw);
-#endif
-                        pay[j] = (PT)pw;
-                    } else {
-                        const u64 H = part_hash<MODE>(g, key);
-                        pay[j] = (PT)Pay<uint32_t>::make(key, H, g);
-                        p1 = p1_of_hash(H, g);
-                    }
-                }
-                tag[j] = ok ? (p1 << 16) : 0xFFFFFFFFu;
-            }
-            // ranks in a second sweep: all LDS atomics in flight instead of one wait per window
-#pragma unroll
-            for (int j = 0; j < WPR; ++j)
-#if KH_ABL & 16  /* timing experiment: no rank atomics (everything then collapses to an empty sort) */
-                tag[j] &= 0xFFFF0000u;
-#else
-                if (tag[j] != 0xFFFFFFFFu) tag[j] |= atomicAdd(&s_cnt[tag[j] >> 16], 1u);
-#endif
-            __syncthreads();
-            block_exclusive_scan_1024(s_cnt, s_lofs, s_wsum, tid);
-            // Branch-free staging: every lane reads its run starts back to back (one wait instead of an
-            // exposed LDS round trip behind a branch per window); windows without a key go to a trash slot.
-            uint32_t rs[WPR];
-#pragma unroll
-            for (int j = 0; j < WPR; ++j) rs[j] = s_lofs[(tag[j] >> 16) & (MAX_P1 - 1)];
-#pragma unroll
-            for (int j = 0; j < WPR; ++j) {
-                const uint32_t slot = tag[j] != 0xFFFFFFFFu ? rs[j] + (tag[j] & 0xFFFFu) : (uint32_t)RTILE;
-                s_stage[slot] = pay[j];
-                s_pid[slot] = (uint16_t)(tag[j] >> 16);
-            }
-            {  // lane tid places partition tid's run: the rest of its current chunk, then fresh chunks
-                const uint32_t c = s_cnt[tid], lo = s_lofs[tid];
-                const uint32_t space = CHUNK_PAY - fill;
-                ChunkDst d;
-                d.a = cur * CHUNK_PAY + fill - lo;
-                d.b = 0;
-                if (c > space) {
-                    const uint32_t r = c - space;
-                    const uint32_t nnew = (r + CHUNK_PAY - 1) / CHUNK_PAY;
-                    u64 first = atomicAdd(&s_priv_next, (u64)nnew);  // LDS
-                    if (first + nnew > s_priv_end) first = atomicAdd(pool_next, (u64)nnew);  // private range ran out (rare)
-                    if (first + nnew > pool_chunks) {  // cannot happen with the host's pool sizing; never write past it
-                        lost += r;
-                        first = 0;
-                        d.b = CHUNK_DST_DROP;  // marks "drop" for the write-out
-                    } else {
-                        for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
-                        d.b = first * CHUNK_PAY - space - lo;
-                        cur = first + nnew - 1;
-                        fill = r - (nnew - 1) * CHUNK_PAY;
-                        have_chunk = true;
-                    }
-                } else {
-                    fill += c;
-                }
-                s_dst[tid] = d;
-                s_meta[tid] = lo | (space << 16);
-            }
-            const uint32_t total = (uint32_t)s_lofs[MAX_P1 - 1] + s_cnt[MAX_P1 - 1];
-            __syncthreads();
-            s_cnt[tid] = 0;  // ordered before the next atomics by the barrier below / the next tile's stage_tile() barrier
-            if (tid == 0 && s_priv_next + POOL_LOW > s_priv_end) {  // refill the private range for the next round
-                s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-                s_priv_end = s_priv_next + POOL_GRAB;
-            }
-            if (h == 0)  // tile t + 1's codes -> the other buffer, before any store of this tile
-                stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
-#if !(KH_ABL & 4)  /* timing experiment: no write-out */
-#pragma unroll 2
-            for (uint32_t i = tid; i < total; i += PART_NT) {
-                const uint32_t p = s_pid[i];
-                const uint32_t meta = s_meta[p];
-                const ChunkDst d = s_dst[p];
-                const uint32_t e = i - (meta & 0xFFFFu);
-#if KH_ABL & 2  /* timing experiment: LDS side of the write-out only, no global stores */
-                if (s_stage[i] == 0x12345678u && e == 77 && d.a == 5) pool[0] = 1;
-#else
-                if (e < (meta >> 16)) pool[d.a + i] = s_stage[i];
-                else if (d.b != CHUNK_DST_DROP) pool[d.b + i] = s_stage[i];
-#endif
-            }
-#endif
-            // s_stage / s_dst / s_meta are rewritten only after the next round's / tile's barriers; the
-            // counters, though, are hit by the next round's atomics right away
-            if (h + 1 < ROUNDS) __syncthreads();
-        }
-    }
-    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
-    const u64 l = wave_sum((u64)lost);
-    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
-}
-
-constexpr uint32_t P1B_CAP = 32;                 // payloads per partition bin
-constexpr uint32_t P1B_WORDS = MAX_P1 * P1B_CAP;   // 128 KiB
-
-// ---------------------------------------------------------------------------------------------
-// level 1 for 32-bit payloads: per-partition BINS in LDS, flushed in whole aligned 64-byte segments
-// ---------------------------------------------------------------------------------------------
-// What this kernel is shaped by was measured, not assumed (profiles/README.md r02c; tools/ubench/):
-//  (1) THE STORE PATTERN.  scatter_runs.hip: 256 K lanes each appending to its own stream of 1-KiB pool chunks reach
-//      1.3 TB/s in runs of 48 bytes and 2.8 TB/s in runs of one ALIGNED 64-BYTE SEGMENT (3.6 in 128-byte lines).  The
-//      earlier level-1 kernels flushed every whole 16-byte unit of a partition every tile -- runs of ~56 bytes, 52 GB
-//      of them per S100M batch: that was their whole 37 ms, whatever the instruction stream did.  Here a partition's
-//      payloads collect in a 32-payload bin (128 KiB for 1024 partitions, which is what LDS there is), a flush writes
-//      whole segments (16 payloads) and keeps up to 15 back, and to leave room for those the bins are flushed TWICE
-//      per tile, after 8 windows per lane each (6.9 arrivals per partition on average: a bin overflows once in ~10^4
-//      partition-flushes on well-mixed input).
-//  (2) vmcnt COUNTS LOADS AND STORES ALIKE.  A wait for prefetched bases that sits after the flush -- where the
-//      compiler puts it when the tile is staged at the top of the loop, or when the loaded registers are carried
-//      around the loop (it copies them at the back edge) -- is a wait for the acknowledgement of every store just
-//      issued.  So the next tile's bases are requested right after B0 and encoded into the other code buffer right
-//      after the first B1 of the same iteration, before any store of it.
-//  (3) No sorting pass: a payload's place is bin(p) + rank, known when the rank atomic returns -- no scan of the
-//      1024 counts, no region table, two barriers per flush:
-//          B0/B2  (codes staged / previous flush over)
-//          8 windows: hash; rank = atomicAdd(&s_cnt[p], 1); s_bin[p][rank] = payload
-//          B1
-//          lane p (owner of partition p): whole segments of its bin -> the partition's chunk; the <= 15 payloads left
-//          over move to the front of the bin; s_cnt[p] = that count
-//      A window without a key bumps one of 64 waste counters (one per lane of a wave) that start every flush at
-//      0x8000: the rank they return fails the "< 32" test that guards the store by itself, and "some real rank did
-//      not fit" is (OR of all ranks) & 0x7FE0.
-//  (4) Overflow is exact, not a fallback to another kernel -- and it is the normal case on skewed input (a
-//      homopolymer run sends a tile's 16384 payloads to ONE partition): a real rank >= 32 raises s_flag; after B1 the
-//      owner, which sees the partition's full count c, reserves room for all c / 16 segments in the partition's chunk
-//      sequence as usual, flushes the bin's two, and leaves in the (now free) bin where the others go; one more
-//      barrier (taken only then), and the payloads that did not fit store themselves, 4 bytes each.  They do not keep
-//      payload and rank in registers across the flush: a lane remembers WHICH of its windows they were, rolls over its
-//      windows again and takes a second rank from the same counter, which the owner has restarted at -(whole
-//      segments' worth of them): a negative rank is a position in the run, 0..14 a carried payload's bin slot, and
-//      the counter ends at c % 16 as it must.  Chunk fill levels stay multiples of 16 until the end of the kernel:
-//      same pool format, same reader.
-//  (5) THE INSTRUCTION STREAM, for k = 21 at the headline geometry (1024 partitions).  valu_rates.hip: per wave, at
-//      4 waves per SIMD, v_xor/and/or/add/sub/lshrrev/mov/not and v_bitop3 cost ~2.9 cycles; v_lshlrev, v_min/max,
-//      v_bfe, v_alignbit, every fused three-operand form and every multiply (24- and 32-bit alike) ~4.9; v_cmp ~5.5;
-//      a v_cndmask on a mask in an SGPR pair ~3.4; a v_cndmask reading a VCC that the instruction before it did not
-//      just write ~20 (the usual "v_cmp_lt_u64 vcc; v_cndmask; v_cndmask" of a 64-bit min: 27).  The compiler's code
-//      for a window adds up to ~215 such cycles, ~60 instructions (both strands rolled through registers, a second VCC
-//      read in the canonical choice, left shifts and compares for tags and addresses).  Written out it is ~27
-//      instructions, ~105 cycles, one asm statement per window (the compiler schedules the sixteen as units and
-//      allocates everything but five scratch registers):
-//        * no rolling state: the lane's 48 bases are three words (w2:w1:w0, first base in the top bits) and their
-//          reverse complements three more (c2:c1:c0 = 2-bit groups reversed and inverted, made once per tile); BOTH
-//          strands of window J are 42-bit fields of those at fixed offsets (forward: bit 2 (15 - J); reverse
-//          complement: bit 2 (J + 12)): v_alignbit + v_bfe each;
-//        * canonical choice: v_cmp_lt_u64 into an SGPR pair, two v_cndmask on it;
-//        * Feistel rounds of v_mul_u32_u24, v_lshrrev, v_xor: no masks (21-bit halves stay 21-bit), no copies (the
-//          halves swap by name);
-//        * outputs are what the LDS instructions need, derived from the left half L by shift-right + and: the
-//          counter's byte address (L >> 9) & 0xFFC, the bin's (L >> 4) & 0x1FF80, payload (L << 21) | R; a window
-//          without a key gets the lane's waste counter by a sign-extended v_bfe of its validity bit + v_bitop3.
-//      Other k / other geometries take the same kernel with the window in C++ (Roller + hash_p1_pay32).
-#define KH_W21_HASH_AND_OUT \
-    "v_cmp_lt_u64_e64 s[98:99], v[120:121], v[122:123]\n" \
-    "v_cndmask_b32_e64 v120, v122, v120, s[98:99]\n" \
-    "v_cndmask_b32_e64 v121, v123, v121, s[98:99]\n" \
-    "v_alignbit_b32 v122, v121, v120, 21\n"        /* L */ \
-    "v_and_b32 v123, 0x1fffff, v120\n"             /* R */ \
-    "v_mul_u32_u24 v124, 0x3779b1, v123\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v122, v124, v122\n" \
-    "v_mul_u32_u24 v124, 0xebca77, v122\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v123, v124, v123\n" \
-    "v_mul_u32_u24 v124, 0xb2ae3d, v123\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v122, v124, v122\n" \
-    "v_mul_u32_u24 v124, 0xd4eb2f, v122\n v_lshrrev_b32 v124, 11, v124\n v_xor_b32 v123, v124, v123\n" \
-    "v_lshl_or_b32 %[pay], v122, 21, v123\n"       /* L = v122, R = v123 */ \
-    "v_lshrrev_b32 v124, 9, v122\n v_and_b32 v124, 0xffc, v124\n" \
-    "v_bfe_i32 v120, %[good], %[gb], 1\n" \
-    "v_bitop3_b32 %[cnta], v120, v124, %[waste] bitop3:0xca\n" \
-    "v_lshrrev_b32 v124, 4, v122\n v_and_b32 %[binb], 0x1ff80, v124\n"
-#define KH_W21_OPERANDS \
-    : [pay] "=&v"(pay), [cnta] "=&v"(cnta), [binb] "=&v"(binb) \
-    : [w0] "v"(w0), [w1] "v"(w1), [w2] "v"(w2), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [good] "v"(good), [waste] "v"(waste), \
-      [sf] "n"(SF), [sr] "n"(SR & 31), [gb] "n"(15 - J) \
-    : "v120", "v121", "v122", "v123", "v124", "s98", "s99"
-template <int J>
-__device__ __forceinline__ void p1_window21(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t c0, uint32_t c1, uint32_t c2,
-                                            uint32_t good, uint32_t waste, uint32_t &pay, uint32_t &cnta, uint32_t &binb) {
-    constexpr int SF = 2 * (15 - J), SR = 2 * (J + 12);
-    if constexpr (J <= 3) {  // both fields straddle two words at their top end
-        asm("v_alignbit_b32 v120, %[w1], %[w0], %[sf]\n v_alignbit_b32 v121, %[w2], %[w1], %[sf]\n v_and_b32 v121, 0x3ff, v121\n"
-            "v_alignbit_b32 v122, %[c1], %[c0], %[sr]\n v_alignbit_b32 v123, %[c2], %[c1], %[sr]\n v_and_b32 v123, 0x3ff, v123\n"
-            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
-    } else if constexpr (J == 4) {  // the reverse-complement field starts on a word boundary
-        asm("v_alignbit_b32 v120, %[w1], %[w0], %[sf]\n v_bfe_u32 v121, %[w1], %[sf], 10\n"
-            "v_mov_b32 v122, %[c1]\n v_and_b32 v123, 0x3ff, %[c2]\n"
-            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
-    } else if constexpr (J <= 14) {
-        asm("v_alignbit_b32 v120, %[w1], %[w0], %[sf]\n v_bfe_u32 v121, %[w1], %[sf], 10\n"
-            "v_alignbit_b32 v122, %[c2], %[c1], %[sr]\n v_bfe_u32 v123, %[c2], %[sr], 10\n"
-            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
-    } else {  // the forward field starts on a word boundary
-        asm("v_mov_b32 v120, %[w0]\n v_and_b32 v121, 0x3ff, %[w1]\n"
-            "v_alignbit_b32 v122, %[c2], %[c1], %[sr]\n v_bfe_u32 v123, %[c2], %[sr], 10\n"
-            KH_W21_HASH_AND_OUT KH_W21_OPERANDS);
-    }
-}
-// 2-bit groups of x reversed and complemented: base m of a code word (bits 31-2m..30-2m) lands, complemented, at bits 2m..2m+1
-__device__ __forceinline__ uint32_t rev2_complement(uint32_t x) {
-    const uint32_t y = __builtin_bitreverse32(~x);
-    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-}
-
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-constexpr uint32_t K21_CNT_OFF = 0;                                // 1024 counters + 64 waste counters
-constexpr uint32_t K21_BIN_OFF = (MAX_P1 + 64) * 4;                // the bins, 128 KiB
-constexpr uint32_t K21_TRASH_OFF = K21_BIN_OFF + P1B_WORDS * 4;    // one unit nobody reads
-constexpr uint32_t K21_WASTE0 = 0x8000u;
-
-// ASM21: the written-out window (k = 21, 1024 partitions, no shard shift); otherwise MODE / FAST as in
-// part1_scatter_chunked_kernel, k and the geometry are run-time values.
-template <bool QUAL, int MODE, bool FAST, bool ASM21>
-__global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
-    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend, u64 wlo,
-    u64 tile0, u64 ntiles, uint32_t tiles_per_block, uint32_t k_rt, uint32_t thr, PartGeom g, uint32_t *__restrict__ pool,
-    uint16_t *__restrict__ chunk_part, uint8_t *__restrict__ fill8, u64 *__restrict__ pool_next, u64 pool_chunks,
-    Counters *ctr) {
-    const uint32_t k = ASM21 ? 21u : k_rt, p1b = ASM21 ? 10u : g.p1_bits;
-    constexpr int HALF = CHUNK / 2;          // windows per lane per flush
-    constexpr uint32_t SEG = 16;             // payloads per 64-byte segment: what a flush writes is whole segments
-    __shared__ __attribute__((aligned(16))) uint32_t s_mem[(K21_TRASH_OFF + 16) / 4];
-    __shared__ uint32_t s_code[2][PART_NT + 2];
-    __shared__ uint16_t s_val[2][PART_NT + 2];
-    __shared__ uint32_t s_flag;              // some rank of this half-tile did not fit its bin
-    __shared__ u64 s_priv_next, s_priv_end;  // the workgroup's private range of chunk ids
-    uint32_t *const s_cnt = s_mem + K21_CNT_OFF / 4;
-    uint32_t *const s_bin = s_mem + K21_BIN_OFF / 4;
-    __attribute__((address_space(3))) char *const lds = (__attribute__((address_space(3))) char *)s_mem;
-    const int tid = threadIdx.x;
-    s_cnt[tid] = 0;
-    if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
-    if (tid == 0) {
-        s_flag = 0;
-        s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
-        s_priv_end = s_priv_next + POOL_GRAB;
-    }
-    // lane tid owns partition tid: its current chunk and how full it is (a multiple of 16 until the very end)
-    u64 cur = 0;
-    uint32_t fill = CHUNK_PAY;  // "full": the first segment takes a chunk
-    uint32_t res = 0;           // payloads carried in the bin (== s_cnt[tid] between flushes)
-    bool have_chunk = false;
-    const u64 tb = tile0 + (u64)blockIdx.x * tiles_per_block;
-    u64 te = tb + tiles_per_block;
-    if (te > tile0 + ntiles) te = tile0 + ntiles;
-    int buf = 0;
-    uint32_t lost = 0;
-    const uint32_t waste = K21_CNT_OFF + 4u * (MAX_P1 + ((uint32_t)tid & 63u));
-    uint32_t *const bin = s_bin + (uint32_t)tid * P1B_CAP;
-    __syncthreads();
-    auto take_chunk = [&](u64 &first) -> bool {
-        first = atomicAdd(&s_priv_next, 1ull);  // LDS
-        if (first + 1 > s_priv_end) first = atomicAdd(pool_next, 1ull);  // private range ran out (rare)
-        if (first + 1 > pool_chunks) return false;  // cannot happen with the host's pool sizing; never write past it
-        chunk_part[first] = (uint16_t)tid;
-        return true;
-    };
-    // Lane tid flushes partition tid, in WHOLE ALIGNED 64-BYTE SEGMENTS: tools/ubench/scatter_runs.hip measures
-    // what the memory system takes from 256 K lanes each appending to its own stream of 1-KiB chunks: 1.3 TB/s in
-    // runs of 48 bytes, 2.8 TB/s in runs of one aligned 64-byte segment (3.6 in 128-byte lines) -- and the
-    // 56-byte runs of a flush of every whole 16-byte unit, 52 GB of them per S100M batch, were the whole 37 ms of
-    // this kernel, whatever the instruction stream did.  So a partition keeps up to 15 payloads back; to have room
-    // for them in a 32-payload bin the bins are flushed twice per tile, after 8 windows per lane each (6.9
-    // arrivals per partition on average; a bin overflows once in ~10^4 partition-flushes on well-mixed input).
-    // c = what the bin's counter says (carried + new, possibly more than fit).  Returns the carried count.
-    auto flush = [&](uint32_t c) -> uint32_t {
-        const uint32_t nseg = c / SEG;                        // whole segments of the partition's run ...
-        const uint32_t bseg = min(nseg, P1B_CAP / SEG);       // ... of which in the bin (the others: slow path)
-        const uint32_t r = c % SEG;
-        uint32_t nout = nseg;                                 // segments that find room in the pool
-        u64 dst[P1B_CAP / SEG];                               // pool index of the bin's segments
-        const uint32_t space = (CHUNK_PAY - fill) / SEG;      // segments left in the current chunk
-        u64 ib = 0;                                           // first fresh chunk taken, if any (they are consecutive only
-        uint32_t ntaken = 0;                                  //   when taken by one call: here one chunk at a time)
-        // the run's segments fill the current chunk, then fresh chunks one after the other
-        u64 run_a = cur * CHUNK_PAY + fill, run_b = 0;        // run position e < 16 space goes to run_a + e, else run_b + e
-        if (nseg > space) {
-            const uint32_t need = nseg - space;               // segments beyond the current chunk
-            const uint32_t nnew = (need * SEG + CHUNK_PAY - 1) / CHUNK_PAY;
-            u64 first = 0;
-            bool ok = true;
-            if (nnew == 1) ok = take_chunk(first);
-            else {  // only a skewed batch does this: several consecutive chunks at once
-                first = atomicAdd(pool_next, (u64)nnew);
-                ok = first + nnew <= pool_chunks;
-                if (ok) for (uint32_t q = 0; q < nnew; ++q) chunk_part[first + q] = (uint16_t)tid;
-            }
-            if (!ok) {
-                lost += need * SEG;
-                nout = space;
-            } else {
-                ib = first;
-                ntaken = nnew;
-                run_b = first * CHUNK_PAY - (u64)space * SEG;
-                cur = first + nnew - 1;
-                fill = need * SEG - (nnew - 1) * CHUNK_PAY;
-                have_chunk = true;
-            }
-        } else {
-            fill += nseg * SEG;
-        }
-        (void)ib; (void)ntaken;
-#pragma unroll
-        for (uint32_t sg = 0; sg < P1B_CAP / SEG; ++sg) dst[sg] = (sg < space ? run_a : run_b) + (u64)sg * SEG;
-        const uint32_t nb = min(bseg, nout);
-#pragma unroll
-        for (uint32_t sg = 0; sg < P1B_CAP / SEG; ++sg)
-            if (sg < nb) {
-                uint4 *d = reinterpret_cast<uint4 *>(pool + dst[sg]);
-                const uint4 *src = reinterpret_cast<const uint4 *>(bin + sg * SEG);
-                const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
-                d[0] = x0; d[1] = x1; d[2] = x2; d[3] = x3;
-            }
-        if (c <= P1B_CAP) {
-            if (bseg) {  // what does not fill a segment moves to the front of the bin, 16 bytes at a time
-                const uint4 *src = reinterpret_cast<const uint4 *>(bin + bseg * SEG);
-                uint4 *d = reinterpret_cast<uint4 *>(bin);
-                const uint32_t nu = (r + 3u) / 4u;
-                for (uint32_t i = 0; i < nu; ++i) d[i] = src[i];
-            }
-            s_cnt[tid] = r;
-        } else {  // where the payloads that did not fit go: left in the second half of the emptied bin
-            bin[16] = (uint32_t)run_a;
-            bin[17] = (uint32_t)(run_a >> 32);
-            bin[18] = (uint32_t)run_b;
-            bin[19] = (uint32_t)(run_b >> 32);
-            bin[20] = space * SEG;  // run positions before this one go to run_a + e, the others to run_b + e
-            bin[21] = nout * SEG;   // ... if below this (less than the next only when the pool ran out)
-            bin[22] = nseg * SEG;   // end of the run's whole segments
-            // Those payloads take a second rank in the slow path, counted from -(their share of whole segments):
-            // negative = run position 16 nseg + rank, 0..14 = carried in bin slot rank; the counter ends at c % 16.
-            s_cnt[tid] = r - (c - P1B_CAP);
-        }
-        if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
-        return r;
-    };
-    // The bases are fetched and encoded ONE tile ahead, between B0 and the first flush: vmcnt counts loads and
-    // stores alike, so a wait for the prefetched bases placed after a flush (where the compiler puts it if the tile
-    // is staged at the top of the loop, or if the loaded registers are carried around the loop: it copies them at
-    // the back edge) is a wait for the acknowledgement of every store the flush has just issued.
-    {
-        const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
-        stage_encode<QUAL, PART_NT>(s_code, s_val, 0, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
-    }
-    for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        __syncthreads();  // B0: tile t's codes are in s_code[buf], the previous flush is over
-        const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        const WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
-        const uint32_t good = window_good(w, k, wlo);
-        const uint32_t w0 = (uint32_t)w.lo64, w1 = (uint32_t)(w.lo64 >> 32), w2 = w.hi;
-        const uint32_t c0 = ASM21 ? rev2_complement(w2) : 0u, c1 = ASM21 ? rev2_complement(w1) : 0u, c2 = ASM21 ? rev2_complement(w0) : 0u;
-        Roller roll;  // (the C++ window rolls through the lane's 16 windows in order, across both halves)
-        if (!ASM21) roll.init(w, k, wlo);
-        // the C++ window: same outputs as p1_window21 (payload, byte address of the counter, byte offset of the bin)
-        auto window = [&](int j, uint32_t &pay, uint32_t &cnta, uint32_t &binb) {
-            u64 key;
-            const bool ok = roll.next(j, key);
-            uint32_t p1 = 0;
-            pay = 0;
-            if (!QUAL || ok) {  // (see part1_scatter_chunked_kernel)
-                if (FAST) {
-                    hash_p1_pay32<MODE>(k, p1b, key, p1, pay);
-                } else {
-                    const u64 H = part_hash<MODE>(g, key);
-                    pay = Pay<uint32_t>::make(key, H, g);
-                    p1 = p1_of_hash(H, g);
-                }
-            }
-            cnta = ok ? K21_CNT_OFF + 4u * p1 : waste;
-            binb = p1 * (P1B_CAP * 4u);
-        };
-#define KH_W21(J)                                                                                            \
-    {                                                                                                        \
-        uint32_t cnta;                                                                                       \
-        if constexpr (ASM21) p1_window21<J>(w0, w1, w2, c0, c1, c2, good, waste, pay[(J) % HALF], cnta, binb[(J) % HALF]); \
-        else window(J, pay[(J) % HALF], cnta, binb[(J) % HALF]);                                             \
-        rk[(J) % HALF] = __hip_atomic_fetch_add((lds_u32 *)(lds + cnta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-    }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint32_t omask = 0;  // bit j: window h * 8 + j has a key and its rank did not fit the bin
-            {
-                uint32_t pay[HALF], binb[HALF], rk[HALF];
-                if (h == 0) { KH_W21(0) KH_W21(1) KH_W21(2) KH_W21(3) KH_W21(4) KH_W21(5) KH_W21(6) KH_W21(7) }
-                else { KH_W21(8) KH_W21(9) KH_W21(10) KH_W21(11) KH_W21(12) KH_W21(13) KH_W21(14) KH_W21(15) }
-                uint32_t racc = 0;
-#pragma unroll
-                for (int j = 0; j < HALF; ++j) {
-                    const uint32_t r = rk[j];
-                    *(lds_u32 *)(lds + K21_BIN_OFF + (r < P1B_CAP ? binb[j] + 4u * r : K21_TRASH_OFF - K21_BIN_OFF)) = pay[j];
-                    racc |= r;
-                }
-                if (racc & (K21_WASTE0 - P1B_CAP)) {  // a real rank (< 0x8000) of 32 or more
-                    s_flag = 1u;
-#pragma unroll
-                    for (int j = 0; j < HALF; ++j)
-                        if (rk[j] >= P1B_CAP && rk[j] < K21_WASTE0) omask |= 1u << j;
-                }
-            }
-            if (h == 1 && tid == 0 && s_priv_next + 2 * POOL_LOW > s_priv_end) {  // refill the private range (nobody takes
-                s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);               // chunks between a B0/B2 and the next B1;
-                s_priv_end = s_priv_next + POOL_GRAB;                             // a vmcnt wait here finds only old stores)
-            }
-            __syncthreads();  // B1
-            const bool slow = s_flag != 0u;  // uniform
-            if (h == 0)  // tile t + 1's codes -> the other buffer (its bases were requested at B0)
-                stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
-            res = flush(s_cnt[tid]);
-            if (slow) {
-                __syncthreads();  // B2'
-                if (omask) {  // the registers of the fast path are gone: roll over the lane's windows again
-                    Roller again;
-                    again.init(w, k, wlo);
-#pragma unroll
-                    for (int j = 0; j < CHUNK; ++j) {
-                        u64 key;
-                        again.next(j, key);
-                        if (j / HALF == h && ((omask >> (j % HALF)) & 1u)) {
-                            uint32_t p, pv;
-                            if (FAST) {
-                                hash_p1_pay32<MODE>(k, p1b, key, p, pv);
-                            } else {
-                                const u64 H = part_hash<MODE>(g, key);
-                                pv = Pay<uint32_t>::make(key, H, g);
-                                p = p1_of_hash(H, g);
-                            }
-                            uint32_t *const pbin = s_bin + p * P1B_CAP;
-                            const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 1u);
-                            if (r2 >= 0) {
-                                pbin[r2] = pv;
-                            } else {
-                                const u64 ra = ((u64)pbin[17] << 32) | pbin[16];
-                                const u64 rb = ((u64)pbin[19] << 32) | pbin[18];
-                                const uint32_t split = pbin[20], lim = pbin[21];
-                                const uint32_t e = pbin[22] + (uint32_t)r2;
-                                if (e < lim) pool[(e < split ? ra : rb) + e] = pv;
-                            }
-                        }
-                    }
-                }
-                if (tid == 0) s_flag = 0u;  // (everybody read it before B2'; it is set again after the next barrier)
-            }
-            if (h == 0) __syncthreads();  // B2: the first flush is over (after the second one: the next tile's B0)
-        }
-#undef KH_W21
-    }
-    __syncthreads();  // (the last slow path may have left carried payloads in other lanes' bins)
-    res = s_cnt[tid];
-    // the payloads still carried: one by one into the partition's chunk
-    if (res) {
-        bool room = true;
-        if (fill + res > CHUNK_PAY) {  // (fill is a multiple of 16, so this means fill == 256: a fresh chunk)
-            u64 first;
-            room = take_chunk(first);
-            if (room) {
-                cur = first;
-                fill = 0;
-                have_chunk = true;
-            } else {
-                lost += res;
-            }
-        }
-        if (room) {
-            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = bin[i];
-            fill += res;
-        }
-    }
-    if (have_chunk) fill8[cur] = (uint8_t)(fill - 1);
-    const u64 l = wave_sum((u64)lost);
-    if (lane_id() == 0 && l) atomicAdd(&ctr->failed, l);
-}
 
 // ---- chunk list: chunk ids ordered by partition ---------------------------------------------------
 // pcount[p] += chunks owned by partition p among ids [0, nchunks)

@@ -49,8 +49,7 @@ def test_headline_numbers_of_the_documents_are_the_committed_bench_line():
 
 
 def test_kernels_named_in_design_exist_in_the_source():
-    src = _read("krust_amd", "csrc", "partition.hip.h") + _read("krust_amd", "csrc", "kernels.hip.h") + \
-        _read("krust_amd", "csrc", "rawparse.hip.h") + _read("krust_amd", "csrc", "shard.hip.h")
+    src = "".join(_read("krust_amd", "csrc", f) for f in ("partition.hip.h", "level1.hip.h", "kernels.hip.h", "rawparse.hip.h", "shard.hip.h"))
     design = _read("DESIGN.md")
     sec = design[design.index("### 4.2"):design.index("### 4.3")]
     table = [l for l in sec.splitlines() if l.startswith("| `")]
@@ -65,3 +64,31 @@ def test_kernels_named_in_design_exist_in_the_source():
     stats = _read("profiles", f"{tag}_kernel_stats.csv")
     for n in ("part1_bins_kernel", "part2_arena_kernel", "region_count_kernel32"):
         assert n in stats
+
+
+def test_kernels_named_by_the_bench_line_exist_and_were_profiled():
+    """bench.py names the kernels of a step from what ran (kh_stats.stage_ms -> kernels_of): every name it can emit must
+    be a __global__ kernel of krust_amd/csrc, and the ones of the headline configuration must be in the committed
+    rocprofv3 kernel trace of that command (the r02 line named kernels that no longer existed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    src = "".join(_read("krust_amd", "csrc", f) for f in ("partition.hip.h", "level1.hip.h", "kernels.hip.h"))
+    emitted = set()
+    for k in (15, 21, 31):
+        for stages in ({"direct": 1.0}, {"level1": 1.0, "level2": 1.0, "region": 1.0}, {"level1": 1.0, "level2_count": 1.0, "level2": 1.0, "region": 1.0}):
+            emitted.update(bench.kernels_of(stages, k).values())
+    assert {"part1_bins_kernel", "part1_bins64_kernel", "part2_arena_kernel", "part2_count_kernel", "region_count_kernel64"} <= emitted
+    for n in emitted:
+        assert re.search(r"\bvoid " + n + r"\(", src), n
+    tag = json.loads(_read("profiles", "hbm_traffic.json"))["tag"]
+    stats = _read("profiles", f"{tag}_kernel_stats.csv")
+    headline = bench.kernels_of({"level1": 1.0, "level2": 1.0, "region": 1.0, "misc": 0.1}, 21)
+    assert headline and all(n in stats for n in headline.values()), headline
+    # the stage names of the binding are the ones the bench line looks up
+    from krust_amd import native
+    assert set(headline) <= set(native.STAGES)
+    b = _bench(tag)
+    if "kernels" in b["roofline"]:     # (lines written since round 3 carry the names themselves)
+        assert all(n in stats for n in b["roofline"]["kernels"].values())

@@ -1027,16 +1027,22 @@ def test_level2_unit_writer_and_its_stand_down(K, monkeypatch, mode, k, hint):
 
 @pytest.mark.parametrize("minq", [None, 20], ids=["noqual", "q20"])
 @pytest.mark.parametrize("k,hint,generic", [(21, 6_000_000, False), (21, 6_000_000, True), (21, 40_000_000, False),
-                                            (20, 6_000_000, False), (17, 3_000_000, False)],
-                         ids=["k21-written-out", "k21-c++window", "k21-64buckets", "k20", "k17"])
+                                            (20, 6_000_000, False), (17, 3_000_000, False),
+                                            (22, 6_000_000, False), (25, 6_000_000, False), (31, 6_000_000, False), (31, 6_000_000, True),
+                                            (32, 6_000_000, False), (31, 40_000_000, False), (19, 6_000_000, "pay64")],
+                         ids=["k21-written-out", "k21-c++window", "k21-64buckets", "k20", "k17",
+                              "k22-bins64", "k25-bins64", "k31-bins64", "k31-bins64-generic", "k32-bins64", "k31-bins64-32buckets", "k19-forced-64bit-payloads"])
 def test_level1_bins_kernel_overflow_and_masks(K, monkeypatch, k, hint, generic, minq):
-    """Level 1 with 32-bit payloads: per-partition bins in LDS, flushed in whole 64-byte segments twice per tile
-    (part1_bins_kernel: the hand-written k = 21 window and the C++ one).  The input is made to hit everything the
+    """Level 1: per-partition bins in LDS, flushed in whole 64-byte segments -- with 32-bit payloads twice per tile
+    (part1_bins_kernel: the hand-written k = 21 window and the C++ one), with 64-bit payloads (k >= 22,
+    part1_bins64_kernel: 16-payload bins) every two windows, with -Q every four.  The input is made to hit everything the
     kernel treats specially: 12 % of the reads are homopolymers / dinucleotide repeats (thousands of payloads of one
     tile for ONE bin: the overflow path, second ranks, descriptors in the emptied bin), N runs and lower case
     (windows without a key: the waste counters), reads of every length mod 16 (tile seams), and quality masking.
     Several batches of very different sizes into one table; against the oracle."""
-    if generic:
+    if generic == "pay64":
+        monkeypatch.setenv("KMERHIP_PAYLOAD", "64")   # (read at kh_create: the 24-bit-multiplier instance of the 64-bit kernel)
+    elif generic:
         monkeypatch.setenv("KMERHIP_GENERIC_K", "1")
     rng = np.random.default_rng(4242 + k)
     n_reads = 60_000
@@ -1139,5 +1145,51 @@ def test_level2_arena_path_and_its_fallbacks(K, monkeypatch, mode, k, skewed):
             assert counted or mode == "list-full" and not skewed
         elif not skewed or mode == "no-skew-limit":
             assert not counted, "the arena path stepped aside where it should not have"
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
+
+
+@pytest.mark.parametrize("minq", [None, 20], ids=["noqual", "q20"])
+@pytest.mark.parametrize("k", list(range(10, 33)))
+def test_written_out_window_every_k(K, k, minq):
+    """The level-1 window is generated for every k = 11..32 (krust_amd/csrc/window.hip.h: one kernel per k; 4-byte
+    payloads up to k = 21, the 8-byte key above; k = 10 takes the C++ window and rides along).  Reads with N, lower
+    case and low qualities, lengths of every residue mod 16, three batches of different sizes through the partitioned
+    path into a table of 2^12 regions (1024 level-1 partitions: the geometry the written-out window is for); the whole
+    map against the oracle.  (The reference serves k = 1..32 uniformly, src/kmer.rs:100-110.)"""
+    rng = np.random.default_rng(7700 + k)
+    n_reads = 24_000
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1 << 17)
+    recs, quals = [], []
+    for i in range(n_reads):
+        n = int(rng.integers(20, 240))
+        o = int(rng.integers(0, genome.size - n))
+        s = genome[o:o + n].copy()
+        u = rng.random()
+        if u > 0.9:
+            a = int(rng.integers(0, n))
+            s[a:a + int(rng.integers(1, 4))] = ord("N")
+        if u < 0.05:
+            s = np.frombuffer(s.tobytes().lower(), dtype=np.uint8).copy()
+        if i % 2:
+            s = np.frombuffer(s.tobytes().translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1], dtype=np.uint8).copy()  # both strands
+        recs.append(s.tobytes())
+        quals.append(rng.choice(np.frombuffer(b"#5IIIIII", dtype=np.uint8), size=n).astype(np.uint8).tobytes())
+    bases = np.frombuffer(b"\n".join(recs) + b"\n", dtype=np.uint8)
+    qual = np.frombuffer(b"\n".join(quals) + b"\n", dtype=np.uint8)
+    m = O.OracleMap()
+    m.scan_flat(bases, k, qual=qual if minq is not None else None, min_quality=minq, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    import torch
+    tb = torch.from_numpy(bases.copy()).cuda()
+    tq = torch.from_numpy(qual.copy()).cuda() if minq is not None else None
+    torch.cuda.synchronize()
+    ends = np.flatnonzero(bases == 10) + 1
+    cut = [0, int(ends[499]), int(ends[9_000]), bases.size]
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=6_000_000, path="partition") as dc:
+        for a, b in zip(cut, cut[1:]):
+            dc.push_device(tb.data_ptr() + a, tq.data_ptr() + a if tq is not None else None, b - a)
+        st = dc.finish()
+        assert st["kmers"] == m.total() and st["part_batches"] == 3 and st["table_slots"] == 1 << 24
         keys, cnts = dc.result()
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
