@@ -371,15 +371,102 @@ def end_to_end(dc, tb, torch, k):
     t_pairs = time.perf_counter() - t0
     ok = bool(int(cnts.sum(dtype=np.uint64)) == st["kmers"] == sum(c * f for c, f in hist) and keys.size == st["distinct"])
     kmers = int(st["kmers"])
+    n_pairs = int(keys.size)
+    del keys, cnts
+    # the same with memory the device reaches by DMA (kh_host_alloc: what a host that reads its file into such a buffer
+    # sees): no staging memcpy on the way in, no bounce and no first-touch faults on the way out
+    pinned = None
+    try:
+        import krust_amd
+        with krust_amd.PinnedArray(host.size) as pin, krust_amd.PinnedArray(n_pairs, np.uint64) as pk, krust_amd.PinnedArray(n_pairs, np.uint64) as pc:
+            pin.array[:] = host   # (setting the stage, not timed)
+            dc.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dc.push(pin.array)
+            st2 = dc.finish()
+            t_push2 = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            k2, c2 = dc.result(sort=False, out=(pk.array, pc.array))
+            t_pairs2 = time.perf_counter() - t0
+            ok2 = bool(int(c2.sum(dtype=np.uint64)) == st2["kmers"] == kmers and k2.size == n_pairs)
+            pinned = {"what": "the same from / into kh_host_alloc'ed (pinned) memory: DMA straight from the caller's buffer and into the caller's arrays",
+                      "push_finish_s": t_push2, "push_GBps": host.size / t_push2 / 1e9, "h2d_ms": st2["h2d_ms"],
+                      "count_kernel_ms": st2["count_kernel_ms"], "part_batches": int(st2["part_batches"]),
+                      "result_copy_s": t_pairs2, "result_copy_GBps": 16.0 * n_pairs / t_pairs2 / 1e9,
+                      "kmers_per_s_push_only": kmers / t_push2, "kmers_per_s_pairs_out": kmers / (t_push2 + t_pairs2), "consistent": ok2}
+            del k2, c2
+    except Exception as e:  # (never lose the line over an extra)
+        pinned = {"error": repr(e)}
     return {"what": "pageable host bases -> kh_push -> kh_finish -> results on the host; reads resident in HBM is `value`, not this",
+            "pinned": pinned,
             "bytes_in": int(host.size), "push_finish_s": t_push, "push_GBps": host.size / t_push / 1e9,
             "h2d_ms": st["h2d_ms"], "count_kernel_ms": st["count_kernel_ms"], "part_batches": int(st["part_batches"]),
-            "pairs_out": int(keys.size), "result_copy_s": t_pairs, "result_copy_GBps": 16.0 * keys.size / t_pairs / 1e9,
+            "pairs_out": n_pairs, "result_copy_s": t_pairs, "result_copy_GBps": 16.0 * n_pairs / t_pairs / 1e9,
             "histogram_s": t_hist, "histogram_lines": len(hist),
             "kmers_per_s_push_only": kmers / t_push,
             "kmers_per_s_histogram_out": kmers / (t_push + t_hist),
             "kmers_per_s_pairs_out": kmers / (t_push + t_pairs),
             "consistent": ok, "staging_copy_s_untimed": t_stage}
+
+
+def cli_leg(krust_amd, torch, dev, local_rank, reads=10_000_000, k=21):
+    """north_star's drop-in IS the command line (`kmerust <k> <path>`, src/main.rs:54-231 -> src/run.rs:185-200): S10M as a
+    FASTQ FILE in /dev/shm -> `kmerust 21 f.fq --format histogram -q`, wall time of the whole process with the phase walls
+    the binary reports (KMERUST_TIMING=1: create / read / push / finish / result / write), and the printed histogram
+    compared line by line with kh_histogram of the same reads pushed through the C ABI."""
+    import subprocess
+    import numpy as np
+    exe = os.path.join(ROOT, "krust_amd", "host", "kmerust")
+    if not os.path.exists(exe):
+        return {"error": f"{exe} is missing (make -C krust_amd/host)"}
+    stride, W = READ_LEN + 1, 166 + READ_LEN  # "@r%09d\n" seq "\n+\n" qual "\n"
+    tb = torch.empty(reads * stride, dtype=torch.uint8, device=dev)
+    tq = torch.empty(reads * stride, dtype=torch.uint8, device=dev)
+    krust_amd.synth_reads_device(tb.data_ptr(), tq.data_ptr(), SEED, GENOME_LEN, READ_LEN, 0, reads, device=local_rank,
+                                 stream=torch.cuda.current_stream().cuda_stream)
+    rec = torch.empty((reads, W), dtype=torch.uint8, device=dev)
+    rec[:, 0], rec[:, 1], rec[:, 11] = ord("@"), ord("r"), 10
+    r = torch.arange(reads, device=dev)
+    for j in range(9):
+        rec[:, 10 - j] = ((r // 10 ** j) % 10 + 48).to(torch.uint8)
+    rec[:, 12:12 + READ_LEN] = tb.view(reads, stride)[:, :READ_LEN]
+    rec[:, 12 + READ_LEN], rec[:, 13 + READ_LEN], rec[:, 14 + READ_LEN] = 10, ord("+"), 10
+    rec[:, 15 + READ_LEN:15 + 2 * READ_LEN] = tq.view(reads, stride)[:, :READ_LEN]
+    rec[:, 15 + 2 * READ_LEN] = 10
+    torch.cuda.synchronize()
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    path = os.path.join(d, f"kmerust_bench_{os.getpid()}.fq")
+    try:
+        rec.cpu().numpy().tofile(path)
+        nbytes = os.path.getsize(path)
+        del rec
+        with krust_amd.DeviceCounter(k, device=local_rank) as dc:   # the reference result through the C ABI
+            dc.push_device(tb.data_ptr(), None, reads * stride)
+            st = dc.finish()
+            want = dc.histogram()
+        del tb, tq
+        torch.cuda.empty_cache()
+        env = dict(os.environ, KMERUST_TIMING="1")
+        runs = []
+        for rep in range(2):   # (the first run pages the binary and the ROCm libraries in)
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, str(k), path, "--format", "histogram", "-q"], capture_output=True, env=env, timeout=600)
+            wall = time.perf_counter() - t0
+            tj = None
+            for line in p.stderr.decode(errors="replace").splitlines():
+                if line.startswith('{"kmerust_timing"'):
+                    tj = json.loads(line)["kmerust_timing"]
+            got = [tuple(map(int, l.split(b"\t"))) for l in p.stdout.splitlines()]
+            runs.append({"wall_s": wall, "rc": p.returncode, "phases": tj, "matches_c_abi_histogram": bool(got == [tuple(x) for x in want])})
+        best = min(runs, key=lambda x: x["wall_s"])
+        return {"what": f"kmerust {k} <S10M FASTQ file> --format histogram -q: process wall time, file in {d}",
+                "reads": reads, "text_bytes": nbytes, "kmers": int(st["kmers"]), "runs": runs,
+                "wall_s": best["wall_s"], "text_GBps": nbytes / best["wall_s"] / 1e9, "kmers_per_s": st["kmers"] / best["wall_s"],
+                "ok": bool(all(x["rc"] == 0 and x["matches_c_abi_histogram"] for x in runs))}
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
 
 
 def main():
@@ -622,6 +709,10 @@ def main():
                 except Exception as e:
                     subs.append({"workload": "configs[4] hg-shaped FASTA", "error": repr(e)})
             out["configs"] = subs
+            try:
+                out["cli"] = cli_leg(krust_amd, torch, dev, local_rank, reads=min(10_000_000, reads))
+            except Exception as e:
+                out["cli"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
 
     dc.close()

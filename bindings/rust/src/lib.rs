@@ -93,6 +93,11 @@ pub mod sys {
         pub fn kh_histogram(ctx: *mut KhCtx, min_count: u64, count: *mut u64, freq: *mut u64,
                             cap: u64, n: *mut u64) -> c_int;
         pub fn kh_lookup(ctx: *mut KhCtx, keys: *const u64, n: u64, counts: *mut u64) -> c_int;
+        // host memory the device reaches by DMA (no staging copy in kh_push / kh_push_text / kh_result_copy)
+        pub fn kh_host_alloc(out: *mut *mut c_void, bytes: u64) -> c_int;
+        pub fn kh_host_free(p: *mut c_void) -> c_int;
+        pub fn kh_host_register(p: *mut c_void, bytes: u64) -> c_int;
+        pub fn kh_host_unregister(p: *mut c_void) -> c_int;
         pub fn kh_pack(bases: *const u8, k: u32, packed: *mut u64, err_pos: *mut u32) -> c_int;
         pub fn kh_unpack(packed: u64, k: u32, out: *mut u8) -> c_int;
         pub fn kh_canonical(packed: u64, k: u32, canonical: *mut u64, is_rc: *mut c_int) -> c_int;
@@ -133,6 +138,54 @@ fn check(ctx: *const sys::KhCtx, rc: c_int) -> Result<(), HipError> {
         }
     }
     Err(HipError::Device(msg))
+}
+
+/// Pinned host memory (`kh_host_alloc`): `kh_push` / `kh_push_text` from it and `kh_result_copy` into it move by DMA,
+/// without the staging `memcpy` pageable memory needs.  Where `src/reader.rs:58-79` collects records into
+/// `Vec<Bytes>`, a host that wants PCIe speed appends them to one of these instead.
+pub struct PinnedBuf {
+    ptr: *mut u8,
+    cap: usize,
+    len: usize,
+}
+
+unsafe impl Send for PinnedBuf {}
+
+impl PinnedBuf {
+    pub fn with_capacity(cap: usize) -> Result<Self, HipError> {
+        let mut p: *mut c_void = std::ptr::null_mut();
+        check(std::ptr::null(), unsafe { sys::kh_host_alloc(&mut p, cap.max(1) as u64) })?;
+        Ok(Self { ptr: p as *mut u8, cap, len: 0 })
+    }
+    pub fn len(&self) -> usize {
+        self.len
+    }
+    pub fn is_empty(&self) -> bool {
+        self.len == 0
+    }
+    pub fn clear(&mut self) {
+        self.len = 0;
+    }
+    pub fn room(&self) -> usize {
+        self.cap - self.len
+    }
+    /// Appends `s` (the caller checks `room()` first).
+    pub fn extend_from_slice(&mut self, s: &[u8]) {
+        assert!(s.len() <= self.room());
+        // SAFETY: [ptr + len, ptr + len + s.len()) lies inside the allocation and does not overlap `s`
+        unsafe { std::ptr::copy_nonoverlapping(s.as_ptr(), self.ptr.add(self.len), s.len()) };
+        self.len += s.len();
+    }
+    pub fn as_slice(&self) -> &[u8] {
+        // SAFETY: the first `len` bytes are initialised
+        unsafe { std::slice::from_raw_parts(self.ptr, self.len) }
+    }
+}
+
+impl Drop for PinnedBuf {
+    fn drop(&mut self) {
+        unsafe { sys::kh_host_free(self.ptr as *mut c_void) };
+    }
 }
 
 /// Drop-in for `KmerMap` (`src/run.rs:491-583`): `build` / `build_with_quality` / `into_hashmap`.
@@ -178,16 +231,22 @@ impl HipKmerMap {
     /// `KmerMap::build` (`src/run.rs:500-503`).  Records are concatenated into flat buffers with a
     /// `\n` between them: any byte outside `ACGTacgt` separates records, no k-mer spans it.
     pub fn build<I: Iterator<Item = Bytes>>(self, sequences: I) -> Result<Self, HipError> {
-        let mut flat = Vec::with_capacity(BATCH + (1 << 20));
+        // the batch buffer is pinned: kh_push DMAs from it, no staging copy inside the library
+        let mut flat = PinnedBuf::with_capacity(BATCH + (1 << 20))?;
         for seq in sequences {
-            flat.extend_from_slice(&seq);
-            flat.push(b'\n');
-            if flat.len() >= BATCH {
-                self.push(&flat, None)?;
+            if seq.len() + 1 > flat.room() {
+                self.push(flat.as_slice(), None)?;
                 flat.clear();
             }
+            if seq.len() + 1 > flat.room() {
+                // a record larger than the batch buffer (a chromosome): straight from its own (pageable) memory, then the separator
+                self.push(&seq, None)?;
+                continue;
+            }
+            flat.extend_from_slice(&seq);
+            flat.extend_from_slice(b"\n");
         }
-        self.push(&flat, None)?;
+        self.push(flat.as_slice(), None)?;
         Ok(self)
     }
 

@@ -144,6 +144,18 @@ int kh_push_text_device(kh_ctx *ctx, const uint8_t *d_text, uint64_t n, int form
 /* Wait for all pushed work; fill stats (may be NULL). */
 int kh_finish(kh_ctx *ctx, kh_stats *stats);
 
+/* ---- host memory the device reaches directly ---------------------------- */
+/* kh_push / kh_push_text stage PAGEABLE caller memory through pinned chunks (a multi-threaded memcpy: ~20-30 GB/s, below
+ * PCIe's ~57) and kh_result_copy bounces the other way (plus the first-touch page faults of a fresh array).  Buffers
+ * from kh_host_alloc (pinned, any device of the process), or the caller's own memory after kh_host_register, skip both:
+ * the copy engine reads / writes them itself.  Detected per call (hipPointerGetAttributes): nothing else changes, and
+ * kh_push still returns only when the buffers may be reused.  The reference reads a whole file into Vec<Bytes> before
+ * counting (src/reader.rs:58-79); a Rust host would read() into such a buffer instead. */
+int kh_host_alloc(void **out, uint64_t bytes);
+int kh_host_free(void *p);
+int kh_host_register(void *p, uint64_t bytes);
+int kh_host_unregister(void *p);
+
 /* ---- output: replaces KmerMap::into_hashmap ----------------------------- */
 /* Number of distinct canonical k-mers with count >= min_count
  * (min_count filter of output_counts, run.rs:447-450). */

@@ -5,8 +5,8 @@ Layout:
   native.py  ctypes binding of that C ABI (plumbing; no CPU fallback)
 """
 from . import native  # noqa: F401
-from .native import (DeviceCounter, DeviceGroup, KmerHipError, KmerLengthError, canonical, comm_unique_id, lib, owner,  # noqa: F401
-                     pack, synth_reads_device, unpack)
+from .native import (DeviceCounter, DeviceGroup, KmerHipError, KmerLengthError, PinnedArray, canonical, comm_unique_id,  # noqa: F401
+                     host_register, host_unregister, lib, owner, pack, synth_reads_device, unpack)
 
-__all__ = ["DeviceCounter", "DeviceGroup", "KmerHipError", "KmerLengthError", "canonical", "comm_unique_id", "lib", "owner",
-           "pack", "synth_reads_device", "unpack"]
+__all__ = ["DeviceCounter", "DeviceGroup", "KmerHipError", "KmerLengthError", "PinnedArray", "canonical", "comm_unique_id",
+           "host_register", "host_unregister", "lib", "owner", "pack", "synth_reads_device", "unpack"]

@@ -37,7 +37,10 @@ constexpr u64 DEFAULT_CAP = 1ull << 20;
 constexpr u64 SUB_TILES = 1ull << 16;      // tiles per count launch (2^28 positions)
 constexpr u64 SUB_TILES_MIN = 1ull << 10;  // smallest launch when squeezing under LOAD_HARD
 constexpr u64 STAGE_BYTES = 64ull << 20;   // host staging chunk for kh_push
-constexpr u64 ACC_MAX = 2ull << 30;        // device accumulation buffer of kh_push (x2, x2 with qualities)
+constexpr u64 ACC_MAX = 8ull << 30;        // device accumulation buffer of kh_push (x2, x2 with qualities): an upper limit --
+                                           // acc_limit() also keeps the buffers within a quarter of the free memory.  (Round 2: 2 GiB,
+                                           // i.e. 8 partitioned batches per S100M, each non-fresh region pass re-reading and re-writing
+                                           // the whole 34 GB table: 177 ms of kernels against 74 resident.  8 GiB: two batches.)
 constexpr u64 ACC_MIN = 1ull << 20;
 constexpr u64 HALO = 32;                   // >= k-1 bytes re-sent in front of every staged chunk
 constexpr int GRID_CAP = 256 * 8;          // 256 CUs x 8 resident workgroups of 256 threads
@@ -206,6 +209,7 @@ int grid_for(u64 items) {
 
 int flush_acc(kh_ctx *c, bool carry);
 int clear_if_dirty(kh_ctx *c);
+bool is_pinned_host(const void *p);
 void comm_release(kh_ctx *c);
 
 // Every entry point starts here.  Host pushes are accumulated on the device and counted lazily;
@@ -592,7 +596,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
     const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 5 && g.p2_bits <= 9;
     const u64 arena_pay = arena ? (n_ub + nregions) + ((n_ub + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
-    const u64 ovf_need = arena ? n_ub / 16 + (2ull << 20) : 0;
+    // the overflow list: a sixteenth of the batch, plus what the workgroups RESERVE without using -- every workgroup that
+    // overflows at all takes private 8192-entry segments (part2_arena_kernel, OVF_SEG), so a batch in which most of the
+    // P1 partitions hold one moderately heavy bucket needs P1 segments before the first entry beyond them is "list full"
+    const u64 ovf_need = arena ? n_ub / 16 + 2 * P1 * 8192ull + (1ull << 20) : 0;
     const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
     const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
     // A: the level-1 pool.  B: the level-2 output -- exact path: every payload + sentinel padding; arenas: a quarter more
@@ -1021,6 +1028,12 @@ int ensure_stage(kh_ctx *c) {
 int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes) {
     int rc = ensure_stage(c);
     if (rc != KH_OK) return rc;
+    if (is_pinned_host(dst)) {  // a registered destination takes the DMA itself: no bounce, no first-touch faults
+        HIP_TRY(c, hipStreamSynchronize(c->stream));  // d_src was produced on the compute stream
+        HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->cstream));
+        HIP_TRY(c, hipStreamSynchronize(c->cstream));
+        return KH_OK;
+    }
     // A fresh destination array is all first-touch page faults (they, not the copy, were most of the time of
     // kh_result_copy): ask for transparent huge pages on its page-aligned interior -- a hint, errors are ignored.
     if (bytes >= (64ull << 20)) {
@@ -1050,6 +1063,37 @@ int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes) {
 }
 
 u64 acc_stride(u64 cap) { return HALO + cap + 64; }  // one of the two halves (bases / qual) of a buffer
+
+// Largest accumulation buffer this device affords: a power of two, the two buffers with their quality halves within a
+// quarter of what is free now (plus what the current buffers hold), never above ACC_MAX.
+u64 acc_limit(const kh_ctx *c) {
+    size_t fr = 0, tot = 0;
+    u64 lim = ACC_MAX;
+    if (const char *e = getenv("KMERHIP_ACC_MAX_MB")) {  // (tests: small buffers exercise the seams)
+        const u64 v = strtoull(e, nullptr, 10);
+        if (v) lim = std::max<u64>(ACC_MIN, v << 20);
+    }
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        const u64 avail = (u64)fr + (c->acc_cap ? 4 * acc_stride(c->acc_cap) : 0);
+        while (lim > ACC_MIN && 4 * lim > avail / 4) lim /= 2;
+    } else {
+        (void)hipGetLastError();
+    }
+    return lim;
+}
+
+// Host memory the device can DMA from / into directly: hipHostMalloc'ed (kh_host_alloc) or hipHostRegister'ed
+// (kh_host_register, or the caller's own).  Pageable memory goes through the pinned staging chunks instead.
+bool is_pinned_host(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // (older runtimes: "invalid value" for memory they do not know)
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
 
 // (Re)allocates the two accumulation buffers for `cap` bytes of bases each.  Only when empty.
 int alloc_acc(kh_ctx *c, u64 cap) {
@@ -1253,9 +1297,10 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
         rc = flush_acc(c, false);
         if (rc != KH_OK) return rc;
     }
-    // size the accumulation buffers for this push (grow-only, 1 MiB .. 2 GiB)
+    // size the accumulation buffers for this push (grow-only, 1 MiB .. acc_limit)
     u64 want = ACC_MIN;
-    while (want < n + 1 && want < ACC_MAX) want *= 2;
+    const u64 lim = acc_limit(c);
+    while (want < n + 1 && want < lim) want *= 2;
     if (want > c->acc_cap) {
         rc = flush_acc(c, false);
         if (rc == KH_OK) rc = alloc_acc(c, want);
@@ -1263,6 +1308,35 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
     }
     c->acc_qual = with_qual;
     const u64 stride = acc_stride(c->acc_cap);
+    // Pinned / registered source (kh_host_alloc, kh_host_register): the copy engine reads the caller's memory itself --
+    // no staging memcpy (which, not PCIe, bounded kh_push from pageable memory: ~20-30 against 57 GB/s).
+    const bool direct = is_pinned_host(bases) && (!with_qual || is_pinned_host(qual));
+    if (direct) {
+        hipEvent_t t0, t1;
+        HIP_TRY(c, hipEventCreate(&t0));
+        HIP_TRY(c, hipEventCreate(&t1));
+        HIP_TRY(c, hipEventRecord(t0, c->cstream));
+        for (u64 off = 0; off < n;) {
+            if (c->acc_len + 1 >= c->acc_cap) {
+                rc = flush_acc(c, off != 0);
+                if (rc != KH_OK) return rc;
+            }
+            const u64 len = std::min(n - off, c->acc_cap - c->acc_len - 1);
+            uint8_t *dst = c->acc[c->acc_cur] + HALO + c->acc_len;
+            HIP_TRY(c, hipMemcpyAsync(dst, bases + off, len, hipMemcpyHostToDevice, c->cstream));
+            if (with_qual) HIP_TRY(c, hipMemcpyAsync(dst + stride, qual + off, len, hipMemcpyHostToDevice, c->cstream));
+            c->acc_len += len;
+            off += len;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->acc[c->acc_cur] + HALO + c->acc_len, '\n', 1, c->cstream));
+        if (with_qual) HIP_TRY(c, hipMemsetAsync(c->acc[c->acc_cur] + stride + HALO + c->acc_len, '\n', 1, c->cstream));
+        c->acc_len += 1;
+        HIP_TRY(c, hipEventRecord(t1, c->cstream));
+        c->h2d_events.emplace_back(t0, t1);
+        HIP_TRY(c, hipStreamSynchronize(c->cstream));  // the caller may reuse its buffers when this returns
+        c->bases_pushed += n;
+        return KH_OK;
+    }
     for (u64 off = 0; off < n; off += STAGE_BYTES) {
         const u64 len = std::min(STAGE_BYTES, n - off);
         if (c->acc_len + len + 1 > c->acc_cap) {  // +1: the separator appended after the push
@@ -1421,6 +1495,15 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
         HIP_TRY(c, hipStreamWaitEvent(c->cstream, c->txt_raw_free, 0));
         c->txt_raw_busy = false;
     }
+    if (is_pinned_host(text)) {  // pinned / registered text: one DMA, no staging memcpy
+        hipEvent_t t0, t1;
+        HIP_TRY(c, hipEventCreate(&t0));
+        HIP_TRY(c, hipEventCreate(&t1));
+        HIP_TRY(c, hipEventRecord(t0, c->cstream));
+        HIP_TRY(c, hipMemcpyAsync(c->txt_raw, text, n, hipMemcpyHostToDevice, c->cstream));
+        HIP_TRY(c, hipEventRecord(t1, c->cstream));
+        c->h2d_events.emplace_back(t0, t1);
+    } else
     for (u64 off = 0; off < n; off += 2 * STAGE_BYTES) {
         const u64 len = std::min(2 * STAGE_BYTES, n - off);
         const int p = c->stage_next;
@@ -2131,6 +2214,58 @@ extern "C" int kh_merge_regions_packed_device(kh_ctx *c, uint32_t nsenders, uint
 extern "C" int kh_merge_regions_heads_device(kh_ctx *c, uint32_t nsenders, uint64_t sender_regions,
                                              const uint32_t *const *d_heads, const uint32_t *const *d_region_counts) {
     return merge_regions(c, XF_HEADS32, nsenders, sender_regions, (const void *const *)d_heads, nullptr, d_region_counts);
+}
+
+// =============================================================================================
+// host memory the device can reach directly
+// =============================================================================================
+extern "C" int kh_host_alloc(void **out, uint64_t bytes) {
+    if (!out) return KH_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return KH_ERR_NO_DEVICE;
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return KH_ERR_OOM;
+    }
+    *out = p;
+    return KH_OK;
+}
+
+extern "C" int kh_host_free(void *p) {
+    if (!p) return KH_OK;
+    if (hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return KH_ERR_BAD_ARG;
+    }
+    return KH_OK;
+}
+
+extern "C" int kh_host_register(void *p, uint64_t bytes) {
+    if (!p || !bytes) return KH_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return KH_ERR_NO_DEVICE;
+    }
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return KH_ERR_OOM;
+    }
+    return KH_OK;
+}
+
+extern "C" int kh_host_unregister(void *p) {
+    if (!p) return KH_ERR_BAD_ARG;
+    if (hipHostUnregister(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return KH_ERR_BAD_ARG;
+    }
+    return KH_OK;
 }
 
 // =============================================================================================

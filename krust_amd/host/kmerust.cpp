@@ -13,6 +13,8 @@
 
 #include "kmerust_host.h"
 
+#include <chrono>
+
 namespace kmerust {
 
 static const char *USAGE =
@@ -225,6 +227,20 @@ int cli_main(int argc, char **argv) {
     if (min_quality >= 0 && from_stdin)  // src/main.rs:145-152
         fprintf(stderr, "warning: --min-quality is not yet supported for stdin input\n");
 
+    const auto t_begin = std::chrono::steady_clock::now();
+    struct TimingPrinter {  // KMERUST_TIMING=1: one JSON line on stderr when the command is done (bench.py's `cli` leg reads it)
+        std::chrono::steady_clock::time_point t0;
+        ~TimingPrinter() {
+            const char *e = getenv("KMERUST_TIMING");
+            if (!e || !e[0] || e[0] == '0') return;
+            const Timing &t = timing();
+            const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "{\"kmerust_timing\": {\"total_s\": %.6f, \"create_s\": %.6f, \"read_s\": %.6f, \"push_s\": %.6f, \"finish_s\": %.6f, "
+                            "\"result_s\": %.6f, \"write_s\": %.6f, \"bytes_read\": %llu, \"chunks\": %llu, \"device_record_scan\": %s}}\n",
+                    total, t.create_s, t.read_s, t.push_s, t.finish_s, t.result_s, t.write_s, (unsigned long long)t.bytes_read,
+                    (unsigned long long)t.chunks, t.text_path ? "true" : "false");
+        }
+    } timing_printer{t_begin};
     try {
         KmerCounter kc;
         kc.k(k).min_count(min_count).format(fmt).input_format(in_fmt).min_quality(min_quality).devices(devices);

@@ -3,12 +3,14 @@
 #include "kmerust_host.h"
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cctype>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <memory>
@@ -200,6 +202,23 @@ uint64_t read_sequences(const std::string &path, SequenceFormat fmt, bool want_q
 // =============================================================================================
 // counting session over the C ABI
 // =============================================================================================
+Timing &timing() {
+    static Timing t;
+    return t;
+}
+
+namespace {
+double wall_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct Lap {  // adds the scope's wall time to one field of timing()
+    double &dst;
+    const double t0;
+    explicit Lap(double &d) : dst(d), t0(wall_s()) {}
+    ~Lap() { dst += wall_s() - t0; }
+};
+}  // namespace
+
 struct Session {
     // One context per device.  More than one device (KmerCounter::devices, `kmerust --gpus N`): a kh_group --
     // chunks of whole records go to the devices in turn, every device counts its share into its own table, and
@@ -212,6 +231,7 @@ struct Session {
     size_t next_ctx = 0;
     Session(const KmerCounter &kc, bool use_qual) : k((uint32_t)kc.k_) {
         if (!kc.k_set_) throw Error("k-mer length not set");
+        Lap lap(timing().create_s);
         kh_config cfg;
         memset(&cfg, 0, sizeof(cfg));
         cfg.struct_size = sizeof(cfg);
@@ -348,9 +368,85 @@ struct Session {
         Joiner joiner{stopper};
 
         const size_t chunk = text_chunk_bytes();
-        std::vector<uint8_t> buf(chunk);
+        // The chunk buffer is PINNED memory (kh_host_alloc): kh_push_text then DMAs from it -- no staging memcpy inside the
+        // library -- and a plain file is read into it by several pread() calls side by side (one read() moves ~6 GB/s
+        // out of the page cache, less than the device scans and counts).  If pinned memory cannot be had the buffer is
+        // ordinary memory and everything still works, through the library's staging.
+        struct ChunkBuf {
+            uint8_t *p = nullptr;
+            size_t cap = 0;
+            bool pinned = false;
+            ~ChunkBuf() { release(); }
+            void release() {
+                if (p) {
+                    if (pinned) (void)kh_host_free(p);
+                    else free(p);
+                }
+                p = nullptr;
+                cap = 0;
+            }
+            void reserve(size_t n, size_t keep) {  // grows to n bytes, keeping the first `keep`
+                if (n <= cap) return;
+                void *q = nullptr;
+                bool pin = kh_host_alloc(&q, n) == KH_OK;
+                if (!pin) q = malloc(n);
+                if (!q) throw Error("out of memory for the text chunk buffer");
+                if (keep) memcpy(q, p, keep);
+                release();
+                p = (uint8_t *)q;
+                cap = n;
+                pinned = pin;
+            }
+            uint8_t *data() { return p; }
+            size_t size() const { return cap; }
+        } buf;
+        buf.reserve(chunk, 0);
         size_t have = 0;
         bool eof = false, pushed = false;
+        // plain files: where the next byte comes from, and how many there are (pread needs no shared cursor)
+        off_t file_pos = 0, file_size = 0;
+        bool can_pread = false;
+        if (!gz) {
+            struct stat sb;
+            if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+                file_size = sb.st_size;
+                can_pread = true;
+            }
+        }
+        auto read_parallel = [&](uint8_t *dst, size_t want) -> size_t {  // 0 = end of file
+            const size_t left = (size_t)(file_size - file_pos);
+            want = std::min(want, left);
+            if (want == 0) return 0;
+            const size_t min_part = (size_t)8 << 20;
+            const unsigned parts = (unsigned)std::max<size_t>(1, std::min<size_t>(read_threads(), want / min_part));
+            const size_t per = (want + parts - 1) / parts;
+            std::vector<std::thread> th;
+            std::vector<int> errs(parts, 0);
+            auto part = [&](unsigned i) {
+                size_t off = (size_t)i * per, end = std::min(want, off + per);
+                while (off < end) {
+                    const ssize_t n = pread(fd, dst + off, end - off, file_pos + (off_t)off);
+                    if (n > 0) off += (size_t)n;
+                    else if (n == 0 || errno != EINTR) {
+                        errs[i] = n == 0 ? EIO : errno;  // (the file shrank under us, or a real error)
+                        return;
+                    }
+                }
+            };
+            try {
+                for (unsigned i = 1; i < parts; ++i) th.emplace_back(part, i);
+            } catch (...) {  // (no thread: the caller's thread reads those parts too)
+                for (auto &t : th) t.join();
+                for (unsigned i = (unsigned)th.size() + 1; i < parts; ++i) part(i);
+                th.clear();
+            }
+            part(0);
+            for (auto &t : th) t.join();
+            for (int e : errs)
+                if (e) throw Error("failed to read sequence file '" + path + "': " + std::strerror(e));
+            file_pos += (off_t)want;
+            return want;
+        };
         auto refuse = [&]() {
             (void)stop_workers();
             if (pushed) reset_all();
@@ -358,7 +454,12 @@ struct Session {
         };
         while (!eof) {
             while (have < buf.size()) {
-                const size_t n = read_some(buf.data() + have, buf.size() - have);
+                    size_t n;
+                {
+                    Lap lap(timing().read_s);
+                    n = can_pread ? read_parallel(buf.data() + have, buf.size() - have) : read_some(buf.data() + have, buf.size() - have);
+                    timing().bytes_read += n;
+                }
                 if (n == 0) {
                     eof = true;
                     break;
@@ -370,11 +471,13 @@ struct Session {
                 cut = fastq ? fastq_cut(buf.data(), have) : fasta_cut(buf.data(), have);
                 if (cut == 0) {  // no record boundary in a whole chunk: grow and read on
                     if (buf.size() >= (size_t)8 << 30) return refuse();
-                    buf.resize(buf.size() * 2);
+                    buf.reserve(buf.size() * 2, have);
                     continue;
                 }
             }
+            if (cut) timing().chunks++;
             if (cut && ndev == 1) {
+                Lap lap(timing().push_s);
                 const int rc = kh_push_text(ctx, buf.data(), cut, text_fmt);
                 if (rc == KH_ERR_FORMAT) return refuse();
                 check(rc, "kh_push_text");
@@ -394,7 +497,7 @@ struct Session {
                     (void)stop_workers();
                     check_on(wc, rc, "kh_push_text");
                 }
-                w->job.assign(buf.begin(), buf.begin() + (ptrdiff_t)cut);
+                w->job.assign(buf.data(), buf.data() + cut);
                 w->has_job = true;
                 w->cv.notify_all();
                 pushed = true;
@@ -409,6 +512,12 @@ struct Session {
         }
         check_on(failed_ctx ? failed_ctx : ctx, rc, "kh_push_text");
         return true;
+    }
+    static unsigned read_threads() {
+        const char *e = getenv("KMERUST_READ_THREADS");
+        if (e && atoi(e) > 0) return (unsigned)atoi(e);
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::max(1u, std::min(4u, hw ? hw : 1u));
     }
     static size_t text_chunk_bytes() {
         const char *e = getenv("KMERUST_TEXT_CHUNK_KB");  // tests use small chunks to exercise the cuts
@@ -447,7 +556,9 @@ struct Session {
     void count_file(const std::string &path, SequenceFormat fmt, bool want_qual) {
         const char *hp = getenv("KMERUST_HOST_PARSE");
         const bool host_only = is_stdin_path(path) || (hp && hp[0] && hp[0] != '0');
+        timing().text_path = !host_only;
         if (host_only || !count_file_text(path, resolve_format(fmt, &path))) {
+            timing().text_path = false;
             const size_t batch = ctxs.size() > 1 ? (size_t)64 << 20 : (size_t)512 << 20;
             read_sequences(path, fmt, want_qual, batch, [&](const Batch &b) {
                 kh_ctx *c = ctxs[next_ctx++ % ctxs.size()];
@@ -455,6 +566,7 @@ struct Session {
                          "kh_push");
             });
         }
+        Lap lap(timing().finish_s);
         for (kh_ctx *c : ctxs) check_on(c, kh_finish(c, nullptr), "kh_finish");
         if (group) {
             const int rc = kh_group_merge(group, nullptr);
@@ -467,6 +579,7 @@ struct Session {
         }
     }
     PackedCounts result(uint64_t min_count) {
+        Lap lap(timing().result_s);
         PackedCounts pc;
         pc.k = k;
         std::vector<uint64_t> ns(ctxs.size(), 0);
@@ -489,6 +602,7 @@ struct Session {
         return pc;
     }
     std::vector<std::pair<uint64_t, uint64_t>> histogram(uint64_t min_count) {
+        Lap lap(timing().result_s);
         std::map<uint64_t, uint64_t> sum;  // a histogram of disjoint shards is element-wise additive
         for (kh_ctx *c : ctxs) {
             uint64_t cap = 1u << 16;
@@ -570,6 +684,7 @@ std::string unpack_to_string(uint64_t bits, uint32_t k) {
 }
 
 void write_histogram(FILE *out, const std::vector<std::pair<uint64_t, uint64_t>> &hist) {
+    Lap lap(timing().write_s);
     for (const auto &cf : hist) fprintf(out, "%llu\t%llu\n", (unsigned long long)cf.first, (unsigned long long)cf.second);
     fflush(out);
 }

@@ -105,6 +105,21 @@ private:
     std::vector<int> devices_;
 };
 
+// ---- phase walls of the last count (KMERUST_TIMING=1 makes the CLI print them as one JSON line on stderr) ---------
+// Stands where the reference has its tracing spans "read_sequences" / "process_sequences" / "unpack_kmers"
+// (src/run.rs:253-279, feature `tracing`).
+struct Timing {
+    double create_s = 0;   // device context(s): runtime start-up, table allocation
+    double read_s = 0;     // file -> host buffer (pread / gzread / line parser)
+    double push_s = 0;     // kh_push_text / kh_push: H2D, record scan, counting of the chunk
+    double finish_s = 0;   // kh_finish (+ the multi-GPU merge)
+    double result_s = 0;   // kh_histogram / kh_result_copy
+    double write_s = 0;    // formatting and writing the output
+    uint64_t bytes_read = 0, chunks = 0;
+    bool text_path = false;  // records were found on the device (kh_push_text)
+};
+Timing &timing();
+
 // ---- output (src/run.rs:441-486) -------------------------------------------------------------
 std::string unpack_to_string(uint64_t bits, uint32_t k);  // src/kmer.rs:451-456
 void write_counts(FILE *out, const PackedCounts &pc, OutputFormat fmt, uint64_t min_count);

@@ -97,6 +97,10 @@ SYMBOLS = {
     "kh_group_size": (C.c_uint32, [_P]),
     "kh_group_merge": (C.c_int, [_P, C.POINTER(KhMergeInfo)]),
     "kh_group_destroy": (None, [_P]),
+    "kh_host_alloc": (C.c_int, [C.POINTER(_P), _U64]),
+    "kh_host_free": (C.c_int, [_P]),
+    "kh_host_register": (C.c_int, [_P, _U64]),
+    "kh_host_unregister": (C.c_int, [_P]),
     "kh_pack": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(_U64), C.POINTER(C.c_uint32)]),
     "kh_unpack": (C.c_int, [_U64, C.c_uint32, C.c_char_p]),
     "kh_canonical": (C.c_int, [_U64, C.c_uint32, C.POINTER(_U64), C.POINTER(C.c_int)]),
@@ -255,11 +259,16 @@ class DeviceCounter:
         self._check(lib().kh_result_size(self._h, int(min_count), C.byref(n)))
         return int(n.value)
 
-    def result(self, min_count=1, sort=True):
-        """(keys, counts) as uint64 arrays; packed canonical keys."""
+    def result(self, min_count=1, sort=True, out=None):
+        """(keys, counts) as uint64 arrays; packed canonical keys.  out = (keys, counts) arrays to fill (e.g. views of
+        PinnedArray memory: the copy is then one DMA each)."""
         n = self.result_size(min_count)
-        keys = np.empty(n, dtype=np.uint64)
-        cnts = np.empty(n, dtype=np.uint64)
+        if out is not None:
+            keys, cnts = out[0][:n], out[1][:n]
+            assert keys.size == n and cnts.size == n, "out arrays too small"
+        else:
+            keys = np.empty(n, dtype=np.uint64)
+            cnts = np.empty(n, dtype=np.uint64)
         got = _U64(0)
         self._check(lib().kh_result_copy(self._h, keys.ctypes.data, cnts.ctypes.data, n, int(min_count), C.byref(got)))
         assert got.value == n
@@ -474,6 +483,50 @@ class DeviceGroup:
 
     def __exit__(self, *exc):
         self.close()
+
+
+# ---- host memory the device reaches directly --------------------------------
+class PinnedArray:
+    """A numpy view of kh_host_alloc'ed (pinned) memory: push() / push_text() from it and result(out=...) into it move
+    by DMA, without the staging copies pageable memory needs.  Free with close() (or the context manager)."""
+
+    def __init__(self, n, dtype=np.uint8):
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(n) * self.dtype.itemsize
+        p = _P()
+        rc = lib().kh_host_alloc(C.byref(p), max(self.nbytes, 1))
+        if rc != KH_OK:
+            raise KmerHipError(rc)
+        self._p = p
+        buf = (C.c_uint8 * max(self.nbytes, 1)).from_address(p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(n))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            lib().kh_host_free(self._p)
+            self._p = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def host_register(arr):
+    """hipHostRegister the memory of a contiguous numpy array (kh_host_register); pair with host_unregister."""
+    rc = lib().kh_host_register(arr.ctypes.data, arr.nbytes)
+    if rc != KH_OK:
+        raise KmerHipError(rc)
+
+
+def host_unregister(arr):
+    rc = lib().kh_host_unregister(arr.ctypes.data)
+    if rc != KH_OK:
+        raise KmerHipError(rc)
 
 
 # ---- pure helpers (host) ----------------------------------------------------

@@ -87,6 +87,18 @@ int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int format) {
     return KH_OK;
 }
 int kh_push_text_device(kh_ctx *, const uint8_t *, uint64_t, int) { return KH_ERR_NO_DEVICE; }
+// "pinned" memory of the stub is plain heap memory: what matters under ASan is that the host keeps inside it and frees it once
+int kh_host_alloc(void **out, uint64_t bytes) {
+    if (!out) return KH_ERR_BAD_ARG;
+    *out = getenv("KH_STUB_NO_PINNED") ? nullptr : malloc(bytes ? bytes : 1);
+    return *out ? KH_OK : KH_ERR_OOM;
+}
+int kh_host_free(void *p) {
+    free(p);
+    return KH_OK;
+}
+int kh_host_register(void *, uint64_t) { return KH_OK; }
+int kh_host_unregister(void *) { return KH_OK; }
 int kh_finish(kh_ctx *c, kh_stats *st) {
     if (st) memset(st, 0, sizeof(*st));
     return c ? KH_OK : KH_ERR_BAD_ARG;

@@ -1143,7 +1143,8 @@ def test_level2_arena_path_and_its_fallbacks(K, monkeypatch, mode, k, skewed):
         counted = st["stage_ms"]["level2_count"] > 0          # some batch went through count -> scan -> scatter
         if mode in ("exact", "unaligned-exact", "list-full"):
             assert counted or mode == "list-full" and not skewed
-        elif not skewed or mode == "no-skew-limit":
+        elif not skewed or mode == "no-skew-limit" or skewed == "many":
+            # (many-heavy: nearly every workgroup reserves a segment of the overflow list -- the list is sized for that)
             assert not counted, "the arena path stepped aside where it should not have"
         keys, cnts = dc.result()
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
