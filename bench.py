@@ -693,9 +693,9 @@ def main():
                     ("configs[2] S100M: 100 M x 150 bp, k=31, -Q 20", dict(reads=100_000_000, k=31, min_quality=20)),
                     ("k=19 twin of the headline (S100M, k=19): the level-1 window is generated for every k", dict(reads=100_000_000, k=19, min_quality=None)),
                     ("configs[3] rank 3's share of S1B: 125 M x 150 bp, k=21, table hinted to 2^31 slots",
-                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, verify=True)),
-                    ("configs[3] the same share, no capacity hint (the CLI's case)",
-                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, hint=0))]
+                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX)),
+                    ("configs[3] the same share, no capacity hint (the CLI's case: 2^32 slots, 1024 buckets per level-1 partition)",
+                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, hint=0, verify=True))]
             for name, kw in plan:
                 if not full and kw["reads"] > reads:
                     continue  # (a reduced --reads run: keep the extras proportionate)

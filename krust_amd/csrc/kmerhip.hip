@@ -96,6 +96,7 @@ struct kh_ctx {
     u64 acc_len = 0;                           // bytes accumulated in acc[acc_cur] (after the HALO head)
     u64 acc_carry = 0;                         // HALO bytes at the head are the tail of the previous buffer
     bool acc_qual = false;
+    bool acc_has_qual = false;                 // the buffers were allocated with their quality halves
     hipEvent_t acc_free[2] = {nullptr, nullptr};
     bool acc_busy[2] = {false, false};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> h2d_events;
@@ -594,7 +595,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
     // each), 32..512 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
     const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
-    const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 5 && g.p2_bits <= 9;
+    const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 5 && g.p2_bits <= 10;
     const u64 arena_pay = arena ? (n_ub + nregions) + ((n_ub + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
     // the overflow list: a sixteenth of the batch, plus what the workgroups RESERVE without using -- every workgroup that
     // overflows at all takes private 8192-entry segments (part2_arena_kernel, OVF_SEG), so a batch in which most of the
@@ -709,8 +710,12 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const uint32_t skew_x = [] { const char *e = getenv("KMERHIP_L2_SKEW_X"); return e ? (uint32_t)atoi(e) : 2u; }();
             hipLaunchKernelGGL(kh::arena_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
                                c->ovf, skew_x);
-            hipLaunchKernelGGL((kh::part2_arena_kernel<PT, sizeof(PT) == 4 ? KH_ARENA_UNITB : 64>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
-                               (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
+            if (g.p2_bits == 10)  // 2^20 regions: 1024 buckets per partition, 128-byte bins, 64-byte units
+                hipLaunchKernelGGL((kh::part2_arena_kernel<PT, 64, 1024>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
+                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
+            else
+                hipLaunchKernelGGL((kh::part2_arena_kernel<PT, sizeof(PT) == 4 ? KH_ARENA_UNITB : 64, 512>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
+                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
         }
         u64 hov[2] = {0, 0};
         HIP_TRY(c, hipMemcpyAsync(hov, c->ovf, sizeof(hov), hipMemcpyDeviceToHost, c->stream));
@@ -1074,8 +1079,12 @@ u64 acc_limit(const kh_ctx *c) {
         if (v) lim = std::max<u64>(ACC_MIN, v << 20);
     }
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-        const u64 avail = (u64)fr + (c->acc_cap ? 4 * acc_stride(c->acc_cap) : 0);
-        while (lim > ACC_MIN && 4 * lim > avail / 4) lim /= 2;
+        // what a batch of `lim` bases takes besides the table: two accumulation buffers with their quality halves (4 x)
+        // and the partition buffers and overflow list of its ~lim windows (11 B per window with 4-byte payloads, 20 with
+        // 8-byte ones).  What this context already holds of those counts as available: it is what they would be made of.
+        const u64 held = (c->acc_cap ? (c->acc_has_qual ? 4 : 2) * acc_stride(c->acc_cap) : 0) + c->key_cap + c->keyb_cap;
+        const u64 avail = (u64)fr + held;
+        while (lim > ACC_MIN && 24 * lim > avail - avail / 8) lim /= 2;
     } else {
         (void)hipGetLastError();
     }
@@ -1095,15 +1104,17 @@ bool is_pinned_host(const void *p) {
     return a.type == hipMemoryTypeHost;
 }
 
-// (Re)allocates the two accumulation buffers for `cap` bytes of bases each.  Only when empty.
-int alloc_acc(kh_ctx *c, u64 cap) {
+// (Re)allocates the two accumulation buffers for `cap` bytes of bases each (and as many quality bytes if with_qual).
+// Only when empty.
+int alloc_acc(kh_ctx *c, u64 cap, bool with_qual) {
     HIP_TRY(c, hipStreamSynchronize(c->cstream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->acc_has_qual = with_qual;
     for (int i = 0; i < 2; ++i) {
         if (c->acc[i]) (void)hipFree(c->acc[i]);
         c->acc[i] = nullptr;
         c->acc_busy[i] = false;
-        hipError_t e = hipMalloc((void **)&c->acc[i], 2 * acc_stride(cap));
+        hipError_t e = hipMalloc((void **)&c->acc[i], (with_qual ? 2 : 1) * acc_stride(cap));
         if (e != hipSuccess) {
             (void)hipGetLastError();
             c->acc_cap = 0;
@@ -1301,9 +1312,9 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
     u64 want = ACC_MIN;
     const u64 lim = acc_limit(c);
     while (want < n + 1 && want < lim) want *= 2;
-    if (want > c->acc_cap) {
+    if (want > c->acc_cap || (with_qual && !c->acc_has_qual)) {
         rc = flush_acc(c, false);
-        if (rc == KH_OK) rc = alloc_acc(c, want);
+        if (rc == KH_OK) rc = alloc_acc(c, std::max(want, c->acc_cap), with_qual || c->acc_has_qual);
         if (rc != KH_OK) return rc;
     }
     c->acc_qual = with_qual;
@@ -1627,8 +1638,15 @@ extern "C" int kh_result_copy(kh_ctx *c, uint64_t *keys, uint64_t *counts, uint6
     }
     *n = 0;
     if (need == 0) return KH_OK;
+    // The compacted pairs need two device arrays on their way out.  The partition buffers are idle here (every batch is
+    // counted: enter() flushed) and, after any sizeable count, far larger than the result: use them instead of two fresh
+    // multi-gigabyte allocations (mapping and unmapping 17 GB cost more than the compaction itself).
     uint64_t *dk = nullptr, *dc = nullptr;
-    if (hipMalloc((void **)&dk, need * sizeof(u64)) != hipSuccess || hipMalloc((void **)&dc, need * sizeof(u64)) != hipSuccess) {
+    const bool scratch = c->keysA && c->keysB && c->key_cap >= need * sizeof(u64) && c->keyb_cap >= need * sizeof(u64);
+    if (scratch) {
+        dk = reinterpret_cast<uint64_t *>(c->keysA);
+        dc = reinterpret_cast<uint64_t *>(c->keysB);
+    } else if (hipMalloc((void **)&dk, need * sizeof(u64)) != hipSuccess || hipMalloc((void **)&dc, need * sizeof(u64)) != hipSuccess) {
         (void)hipGetLastError();
         if (dk) (void)hipFree(dk);
         return fail(c, KH_ERR_OOM, "hipMalloc(result)");
@@ -1638,8 +1656,10 @@ extern "C" int kh_result_copy(kh_ctx *c, uint64_t *keys, uint64_t *counts, uint6
     if (rc == KH_OK) rc = d2h_staged(c, keys, dk, got * sizeof(u64));
     if (rc == KH_OK) rc = d2h_staged(c, counts, dc, got * sizeof(u64));
     if (rc == KH_OK) *n = got;
-    (void)hipFree(dk);
-    (void)hipFree(dc);
+    if (!scratch) {
+        (void)hipFree(dk);
+        (void)hipFree(dc);
+    }
     return rc;
 }
 

@@ -227,9 +227,9 @@ constexpr uint32_t P1B_WORDS = MAX_P1 * P1B_CAP;   // 128 KiB
 //          B1
 //          lane p (owner of partition p): whole segments of its bin -> the partition's chunk; the <= 15 payloads left
 //          over move to the front of the bin; s_cnt[p] = that count
-//      A window without a key bumps one of 64 waste counters (one per lane of a wave) that start every flush at
-//      0x8000: the rank they return fails the "< 32" test that guards the store by itself, and "some real rank did
-//      not fit" is (OR of all ranks) & 0x7FE0.
+//      A window without a key bumps the lane's own waste counter, which starts every flush at 0x10000 (K21_WASTE0): the
+//      rank it returns fails the "< 32" test that guards the store by itself, and "some real rank did not fit" is
+//      (OR of all ranks) & 0xFF80 (ranks are kept as byte offsets, 4 x rank: see (6)).
 //  (4) Overflow is exact, not a fallback to another kernel -- and it is the normal case on skewed input (a
 //      homopolymer run sends a tile's 16384 payloads to ONE partition): a real rank >= 32 raises s_flag; after B1 the
 //      owner, which sees the partition's full count c, reserves room for all c / 16 segments in the partition's chunk
@@ -267,10 +267,32 @@ __device__ __forceinline__ uint32_t rev2_complement(uint32_t x) {
 }
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-constexpr uint32_t K21_CNT_OFF = 0;                                // 1024 counters + 64 waste counters
-constexpr uint32_t K21_BIN_OFF = (MAX_P1 + 64) * 4;                // the bins, 128 KiB
+// (6) LDS BANKS (round 3; profiles/README.md r03).  Round 2's SQ counters: 62.5 % of this kernel's LDS cycles were bank
+//      conflicts.  Two sources, both structural: a bin is 128 bytes, so lane p's bin starts at bank 32 p mod 64 -- the owner
+//      lanes' ds_read_b128 of "unit j of my bin" in a flush all land on the same two 4-bank groups (8-way conflicts on
+//      every read of every flushed segment), and a payload store goes to bank (rank mod 32) whatever its partition.
+//      Hence the 16-byte units of bin p are kept in the order u ^ (p & 7): a permutation INSIDE the bin (the payloads of a
+//      partition are a multiset: order is free), which spreads equal unit indices of neighbouring bins over all banks.
+//      It costs the window two instructions (the rotation is derived from the bin offset itself) because the counters
+//      count BYTES (a rank comes back as 4 x rank, 8 x in the 64-bit kernel): the store address is bin ^ rank, one
+//      instruction as before (it was bin + 4 rank).  KH_L1_SWIZZLE=0 builds the unswizzled layout (A/B).
+//      Also: one waste counter per LANE of the workgroup (there were 64, shared by the 16 waves): with -Q more than half
+//      of the windows have no key, the shared counters ran past the bits the "some real rank did not fit" test looks at,
+//      and nearly every flush took the slow path's extra barrier for nothing.
+#ifndef KH_L1_SWIZZLE
+#define KH_L1_SWIZZLE 1
+#endif
+constexpr uint32_t L1_ROT_MASK = KH_L1_SWIZZLE ? 0x70u : 0u;       // byte-offset bits the unit permutation touches
+constexpr uint32_t K21_CNT_OFF = 0;                                // 1024 counters + one waste counter per lane
+constexpr uint32_t K21_BIN_OFF = (MAX_P1 + PART_NT) * 4;           // the bins, 128 KiB
 constexpr uint32_t K21_TRASH_OFF = K21_BIN_OFF + P1B_WORDS * 4;    // one unit nobody reads
-constexpr uint32_t K21_WASTE0 = 0x8000u;
+constexpr uint32_t K21_WASTE0 = 0x10000u;  // counters count bytes: a partition's real count stays below (8192 + 15) * 4 (8 in the 64-bit kernel: (4096 + 7) * 8)
+// byte offset of the bin of partition p, with the partition's unit rotation in bits 4..6
+__device__ __forceinline__ uint32_t l1_bin_offset(uint32_t p) { return (p << 7) | ((p << 4) & L1_ROT_MASK); }
+// word index w of a 4-byte-payload bin (u64 index of an 8-byte-payload bin) of partition p -> where it is kept
+__device__ __forceinline__ uint32_t l1_word(uint32_t p, uint32_t w) { return w ^ (((p << 4) & L1_ROT_MASK) >> 2); }
+__device__ __forceinline__ uint32_t l1_word64(uint32_t p, uint32_t w) { return w ^ (((p << 4) & L1_ROT_MASK) >> 3); }
+__device__ __forceinline__ uint32_t l1_unit(uint32_t p, uint32_t u) { return u ^ (((p << 4) & L1_ROT_MASK) >> 4); }
 
 // KW = 11..21: the written-out window for that k (window.hip.h; 1024 partitions, no shard shift: the host checks);
 // KW = 0: the C++ window, MODE / FAST as in part1_scatter_chunked_kernel, k and the geometry are run-time values.
@@ -293,8 +315,8 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
     uint32_t *const s_bin = s_mem + K21_BIN_OFF / 4;
     __attribute__((address_space(3))) char *const lds = (__attribute__((address_space(3))) char *)s_mem;
     const int tid = threadIdx.x;
-    s_cnt[tid] = 0;
-    if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
+    s_cnt[tid] = 0;                    // (the counters count BYTES: 4 x payloads)
+    s_cnt[MAX_P1 + tid] = K21_WASTE0;  // the lane's own waste counter
     if (tid == 0) {
         s_flag = 0;
         s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
@@ -310,7 +332,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
     if (te > tile0 + ntiles) te = tile0 + ntiles;
     int buf = 0;
     uint32_t lost = 0;
-    const uint32_t waste = K21_CNT_OFF + 4u * (MAX_P1 + ((uint32_t)tid & 63u));
+    const uint32_t waste = K21_CNT_OFF + 4u * (MAX_P1 + (uint32_t)tid);
     uint32_t *const bin = s_bin + (uint32_t)tid * P1B_CAP;
     __syncthreads();
     auto take_chunk = [&](u64 &first) -> bool {
@@ -368,35 +390,34 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
 #pragma unroll
         for (uint32_t sg = 0; sg < P1B_CAP / SEG; ++sg) dst[sg] = (sg < space ? run_a : run_b) + (u64)sg * SEG;
         const uint32_t nb = min(bseg, nout);
+        uint4 *const bin4 = reinterpret_cast<uint4 *>(bin);  // the bin's eight 16-byte units, kept in the order u ^ (tid & 7)
 #pragma unroll
         for (uint32_t sg = 0; sg < P1B_CAP / SEG; ++sg)
             if (sg < nb) {
                 uint4 *d = reinterpret_cast<uint4 *>(pool + dst[sg]);
-                const uint4 *src = reinterpret_cast<const uint4 *>(bin + sg * SEG);
-                const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+                const uint4 x0 = bin4[l1_unit(tid, 4 * sg)], x1 = bin4[l1_unit(tid, 4 * sg + 1)], x2 = bin4[l1_unit(tid, 4 * sg + 2)],
+                            x3 = bin4[l1_unit(tid, 4 * sg + 3)];
                 d[0] = x0; d[1] = x1; d[2] = x2; d[3] = x3;
             }
         if (c <= P1B_CAP) {
             if (bseg) {  // what does not fill a segment moves to the front of the bin, 16 bytes at a time
-                const uint4 *src = reinterpret_cast<const uint4 *>(bin + bseg * SEG);
-                uint4 *d = reinterpret_cast<uint4 *>(bin);
                 const uint32_t nu = (r + 3u) / 4u;
-                for (uint32_t i = 0; i < nu; ++i) d[i] = src[i];
+                for (uint32_t i = 0; i < nu; ++i) bin4[l1_unit(tid, i)] = bin4[l1_unit(tid, 4 * bseg + i)];
             }
-            s_cnt[tid] = r;
+            s_cnt[tid] = r * 4u;
         } else {  // where the payloads that did not fit go: left in the second half of the emptied bin
-            bin[16] = (uint32_t)run_a;
-            bin[17] = (uint32_t)(run_a >> 32);
-            bin[18] = (uint32_t)run_b;
-            bin[19] = (uint32_t)(run_b >> 32);
-            bin[20] = space * SEG;  // run positions before this one go to run_a + e, the others to run_b + e
-            bin[21] = nout * SEG;   // ... if below this (less than the next only when the pool ran out)
-            bin[22] = nseg * SEG;   // end of the run's whole segments
+            bin[l1_word(tid, 16)] = (uint32_t)run_a;
+            bin[l1_word(tid, 17)] = (uint32_t)(run_a >> 32);
+            bin[l1_word(tid, 18)] = (uint32_t)run_b;
+            bin[l1_word(tid, 19)] = (uint32_t)(run_b >> 32);
+            bin[l1_word(tid, 20)] = space * SEG;  // run positions before this one go to run_a + e, the others to run_b + e
+            bin[l1_word(tid, 21)] = nout * SEG;   // ... if below this (less than the next only when the pool ran out)
+            bin[l1_word(tid, 22)] = nseg * SEG;   // end of the run's whole segments
             // Those payloads take a second rank in the slow path, counted from -(their share of whole segments):
             // negative = run position 16 nseg + rank, 0..14 = carried in bin slot rank; the counter ends at c % 16.
-            s_cnt[tid] = r - (c - P1B_CAP);
+            s_cnt[tid] = (r - (c - P1B_CAP)) * 4u;
         }
-        if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
+        s_cnt[MAX_P1 + tid] = K21_WASTE0;
         return r;
     };
     // The bases are fetched and encoded ONE tile ahead, between B0 and the first flush: vmcnt counts loads and
@@ -432,7 +453,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
                 }
             }
             cnta = ok ? K21_CNT_OFF + 4u * p1 : waste;
-            binb = p1 * (P1B_CAP * 4u);
+            binb = l1_bin_offset(p1);
         };
 #define KH_W21(J)                                                                                            \
     {                                                                                                        \
@@ -440,9 +461,9 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
         if constexpr (ASM) {                                                                                 \
             uint32_t flo, fhi, rlo, rhi;                                                                     \
             win_fields<KW ? KW : 21, J>(w0, w1, w2, c0, c1, c2, flo, fhi, rlo, rhi);                         \
-            win_hash32<KW ? KW : 21, J>(flo, fhi, rlo, rhi, good, waste, pay[(J) % HALF], cnta, binb[(J) % HALF]); \
+            win_hash32<KW ? KW : 21, J>(flo, fhi, rlo, rhi, good, waste, L1_ROT_MASK, pay[(J) % HALF], cnta, binb[(J) % HALF]); \
         } else window(J, pay[(J) % HALF], cnta, binb[(J) % HALF]);                                           \
-        rk[(J) % HALF] = __hip_atomic_fetch_add((lds_u32 *)(lds + cnta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        rk[(J) % HALF] = __hip_atomic_fetch_add((lds_u32 *)(lds + cnta), 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
     }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -454,15 +475,15 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
                 uint32_t racc = 0;
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
-                    const uint32_t r = rk[j];
-                    *(lds_u32 *)(lds + K21_BIN_OFF + (r < P1B_CAP ? binb[j] + 4u * r : K21_TRASH_OFF - K21_BIN_OFF)) = pay[j];
-                    racc |= r;
+                    const uint32_t r4 = rk[j];  // 4 x rank: the byte offset in the bin, before the unit permutation
+                    *(lds_u32 *)(lds + K21_BIN_OFF + (r4 < 4u * P1B_CAP ? (binb[j] ^ r4) : K21_TRASH_OFF - K21_BIN_OFF)) = pay[j];
+                    racc |= r4;
                 }
-                if (racc & (K21_WASTE0 - P1B_CAP)) {  // a real rank (< 0x8000) of 32 or more
+                if (racc & (K21_WASTE0 - 4u * P1B_CAP)) {  // a real rank (below the waste counters' range) of 32 or more
                     s_flag = 1u;
 #pragma unroll
                     for (int j = 0; j < HALF; ++j)
-                        if (rk[j] >= P1B_CAP && rk[j] < K21_WASTE0) omask |= 1u << j;
+                        if (rk[j] >= 4u * P1B_CAP && rk[j] < K21_WASTE0) omask |= 1u << j;
                 }
             }
             if (h == 1 && tid == 0 && s_priv_next + 2 * POOL_LOW > s_priv_end) {  // refill the private range (nobody takes
@@ -473,7 +494,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
             const bool slow = s_flag != 0u;  // uniform
             if (h == 0)  // tile t + 1's codes -> the other buffer (its bases were requested at B0)
                 stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
-            res = flush(s_cnt[tid]);
+            res = flush(s_cnt[tid] >> 2);
             if (slow) {
                 __syncthreads();  // B2'
                 if (omask) {  // the registers of the fast path are gone: roll over the lane's windows again
@@ -493,14 +514,14 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
                                 p = p1_of_hash(H, g);
                             }
                             uint32_t *const pbin = s_bin + p * P1B_CAP;
-                            const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 1u);
+                            const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 4u) >> 2;
                             if (r2 >= 0) {
-                                pbin[r2] = pv;
+                                pbin[l1_word(p, (uint32_t)r2)] = pv;
                             } else {
-                                const u64 ra = ((u64)pbin[17] << 32) | pbin[16];
-                                const u64 rb = ((u64)pbin[19] << 32) | pbin[18];
-                                const uint32_t split = pbin[20], lim = pbin[21];
-                                const uint32_t e = pbin[22] + (uint32_t)r2;
+                                const u64 ra = ((u64)pbin[l1_word(p, 17)] << 32) | pbin[l1_word(p, 16)];
+                                const u64 rb = ((u64)pbin[l1_word(p, 19)] << 32) | pbin[l1_word(p, 18)];
+                                const uint32_t split = pbin[l1_word(p, 20)], lim = pbin[l1_word(p, 21)];
+                                const uint32_t e = pbin[l1_word(p, 22)] + (uint32_t)r2;
                                 if (e < lim) pool[(e < split ? ra : rb) + e] = pv;
                             }
                         }
@@ -513,7 +534,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
 #undef KH_W21
     }
     __syncthreads();  // (the last slow path may have left carried payloads in other lanes' bins)
-    res = s_cnt[tid];
+    res = s_cnt[tid] >> 2;
     // the payloads still carried: one by one into the partition's chunk
     if (res) {
         bool room = true;
@@ -529,7 +550,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
             }
         }
         if (room) {
-            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = bin[i];
+            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = bin[l1_word(tid, i)];
             fill += res;
         }
     }
@@ -557,7 +578,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
 // revcomp insert position become immediates).
 constexpr uint32_t P1B64_CAP = 16;                     // payloads per partition bin (128 bytes)
 constexpr uint32_t P1B64_SEG = 8;                      // payloads per 64-byte segment
-constexpr uint32_t K64_BIN_OFF = (MAX_P1 + 64) * 4;    // 1024 counters + 64 waste counters in front of the bins
+constexpr uint32_t K64_BIN_OFF = (MAX_P1 + PART_NT) * 4;   // 1024 counters + one waste counter per lane in front of the bins
 constexpr uint32_t K64_TRASH_OFF = K64_BIN_OFF + MAX_P1 * P1B64_CAP * 8;
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
@@ -592,8 +613,8 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
     __attribute__((address_space(3))) char *const lds = (__attribute__((address_space(3))) char *)s_mem;
     typedef __attribute__((address_space(3))) u64 lds_u64;
     const int tid = threadIdx.x;
-    s_cnt[tid] = 0;
-    if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
+    s_cnt[tid] = 0;                    // (the counters count BYTES: 8 x payloads)
+    s_cnt[MAX_P1 + tid] = K21_WASTE0;  // the lane's own waste counter
     if (tid == 0) {
         s_flag = 0;
         s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
@@ -608,7 +629,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
     if (te > tile0 + ntiles) te = tile0 + ntiles;
     int buf = 0;
     uint32_t lost = 0;
-    const uint32_t waste = 4u * (MAX_P1 + ((uint32_t)tid & 63u));  // byte address of the lane's waste counter
+    const uint32_t waste = 4u * (MAX_P1 + (uint32_t)tid);  // byte address of the lane's waste counter
     u64 *const bin = s_bin + (uint32_t)tid * CAP;
     __syncthreads();
     auto take_chunk = [&](u64 &first) -> bool {
@@ -651,32 +672,31 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
             fill += nseg * SEG;
         }
         const uint32_t nb = min(bseg, nout);
+        uint4 *const bin4 = reinterpret_cast<uint4 *>(bin);  // the bin's eight 16-byte units, kept in the order u ^ (tid & 7)
 #pragma unroll
         for (uint32_t sg = 0; sg < CAP / SEG; ++sg)
             if (sg < nb) {
                 uint4 *d = reinterpret_cast<uint4 *>(pool + (sg < space ? run_a : run_b) + (u64)sg * SEG);
-                const uint4 *src = reinterpret_cast<const uint4 *>(bin + sg * SEG);
-                const uint4 x0 = src[0], x1 = src[1], x2 = src[2], x3 = src[3];
+                const uint4 x0 = bin4[l1_unit(tid, 4 * sg)], x1 = bin4[l1_unit(tid, 4 * sg + 1)], x2 = bin4[l1_unit(tid, 4 * sg + 2)],
+                            x3 = bin4[l1_unit(tid, 4 * sg + 3)];
                 d[0] = x0; d[1] = x1; d[2] = x2; d[3] = x3;
             }
         if (c <= CAP) {
             if (bseg) {  // what does not fill a segment moves to the front of the bin, 16 bytes at a time
-                const uint4 *src = reinterpret_cast<const uint4 *>(bin + bseg * SEG);
-                uint4 *d = reinterpret_cast<uint4 *>(bin);
                 const uint32_t nu = (r + 1u) / 2u;
-                for (uint32_t i = 0; i < nu; ++i) d[i] = src[i];
+                for (uint32_t i = 0; i < nu; ++i) bin4[l1_unit(tid, i)] = bin4[l1_unit(tid, 4 * bseg + i)];
             }
-            s_cnt[tid] = r;
+            s_cnt[tid] = r * 8u;
         } else {  // where the payloads that did not fit go: left in the second half of the emptied bin
-            bin[8] = run_a;
-            bin[9] = run_b;
-            bin[10] = (u64)(space * SEG) | ((u64)(nout * SEG) << 32);  // run positions below the first go to run_a + e, the others
-            bin[11] = (u64)(nseg * SEG);                               // to run_b + e if below the second; end of the whole segments
+            bin[l1_word64(tid, 8)] = run_a;
+            bin[l1_word64(tid, 9)] = run_b;
+            bin[l1_word64(tid, 10)] = (u64)(space * SEG) | ((u64)(nout * SEG) << 32);  // run positions below the first go to run_a + e, the others
+            bin[l1_word64(tid, 11)] = (u64)(nseg * SEG);                               // to run_b + e if below the second; end of the whole segments
             // those payloads take a second rank in the slow path, counted from -(their share of whole segments):
             // negative = run position 8 nseg + rank, 0..6 = carried in bin slot rank; the counter ends at c % 8
-            s_cnt[tid] = r - (c - CAP);
+            s_cnt[tid] = (r - (c - CAP)) * 8u;
         }
-        if (tid < 64) s_cnt[MAX_P1 + tid] = K21_WASTE0;
+        s_cnt[MAX_P1 + tid] = K21_WASTE0;
     };
     auto p1_of = [&](u64 key) -> uint32_t { return p1_of_hash(kh_table_hash<MODE>(key, k) << g.shard_shift, g); };
     {
@@ -704,7 +724,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
                     if constexpr (ASM) {
                         uint32_t flo, fhi, rlo, rhi;
                         win_fields<KW ? KW : 31, J>(w0, w1, w2, c0, c1, c2, flo, fhi, rlo, rhi);
-                        win_hash64<KW ? KW : 31, J>(flo, fhi, rlo, rhi, good, waste, klo[j], khi[j], cnta, binb[j]);
+                        win_hash64<KW ? KW : 31, J>(flo, fhi, rlo, rhi, good, waste, L1_ROT_MASK, klo[j], khi[j], cnta, binb[j]);
                     } else {
                         u64 key;
                         const bool ok = roll.next(J, key);
@@ -713,22 +733,22 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
                         klo[j] = (uint32_t)key;
                         khi[j] = (uint32_t)(key >> 32);
                         cnta = ok ? 4u * p : waste;
-                        binb[j] = p * (CAP * 8u);
+                        binb[j] = l1_bin_offset(p);
                     }
-                    rk[j] = __hip_atomic_fetch_add((lds_u32 *)(lds + cnta), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    rk[j] = __hip_atomic_fetch_add((lds_u32 *)(lds + cnta), 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 });
                 uint32_t racc = 0;
 #pragma unroll
                 for (int j = 0; j < FW; ++j) {
-                    const uint32_t r = rk[j];  // (a waste counter's rank is >= 0x8000: the trash slot)
-                    *(lds_u64 *)(lds + (r < CAP ? K64_BIN_OFF + binb[j] + 8u * r : K64_TRASH_OFF)) = ((u64)khi[j] << 32) | klo[j];
-                    racc |= r;
+                    const uint32_t r8 = rk[j];  // 8 x rank: the byte offset in the bin, before the unit permutation (a waste counter's: the trash slot)
+                    *(lds_u64 *)(lds + (r8 < 8u * CAP ? K64_BIN_OFF + (binb[j] ^ r8) : K64_TRASH_OFF)) = ((u64)khi[j] << 32) | klo[j];
+                    racc |= r8;
                 }
-                if (racc & (K21_WASTE0 - CAP)) {  // a real rank (< 0x8000) of 16 or more
+                if (racc & (K21_WASTE0 - 8u * CAP)) {  // a real rank (below the waste counters' range) of 16 or more
                     s_flag = 1u;
 #pragma unroll
                     for (int j = 0; j < FW; ++j)
-                        if (rk[j] >= CAP && rk[j] < K21_WASTE0) omask |= 1u << j;
+                        if (rk[j] >= 8u * CAP && rk[j] < K21_WASTE0) omask |= 1u << j;
                 }
             }
             if (h == NFLUSH - 1 && tid == 0 && s_priv_next + 2 * POOL_LOW > s_priv_end) {  // refill the private range (nobody takes
@@ -739,7 +759,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
             const bool slow = s_flag != 0u;  // uniform
             if (h == 0)  // tile t + 1's codes -> the other buffer (its bases were requested at B0)
                 stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
-            flush(s_cnt[tid]);
+            flush(s_cnt[tid] >> 3);
             if (slow) {
                 __syncthreads();  // B2'
                 if (omask) {  // the registers of the fast path are gone: roll over the lane's windows again
@@ -752,13 +772,14 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
                         if (j / FW == h && ((omask >> (j % FW)) & 1u)) {
                             const uint32_t p = p1_of(key);
                             u64 *const pbin = s_bin + p * CAP;
-                            const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 1u);
+                            const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 8u) >> 3;
                             if (r2 >= 0) {
-                                pbin[r2] = key;
+                                pbin[l1_word64(p, (uint32_t)r2)] = key;
                             } else {
-                                const u64 ra = pbin[8], rb = pbin[9];
-                                const uint32_t split = (uint32_t)pbin[10], lim = (uint32_t)(pbin[10] >> 32);
-                                const uint32_t e = (uint32_t)pbin[11] + (uint32_t)r2;
+                                const u64 ra = pbin[l1_word64(p, 8)], rb = pbin[l1_word64(p, 9)];
+                                const u64 d10 = pbin[l1_word64(p, 10)];
+                                const uint32_t split = (uint32_t)d10, lim = (uint32_t)(d10 >> 32);
+                                const uint32_t e = (uint32_t)pbin[l1_word64(p, 11)] + (uint32_t)r2;
                                 if (e < lim) pool[(e < split ? ra : rb) + e] = key;
                             }
                         }
@@ -770,7 +791,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
         });
     }
     __syncthreads();  // (the last slow path may have left carried payloads in other lanes' bins)
-    const uint32_t res = s_cnt[tid];
+    const uint32_t res = s_cnt[tid] >> 3;
     // the payloads still carried: one by one into the partition's chunk
     if (res) {
         bool room = true;
@@ -786,7 +807,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
             }
         }
         if (room) {
-            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = bin[i];
+            for (uint32_t i = 0; i < res; ++i) pool[cur * CHUNK_PAY + fill + i] = bin[l1_word64(tid, i)];
             fill += res;
         }
     }

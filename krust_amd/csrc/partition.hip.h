@@ -643,16 +643,22 @@ struct OvfEntry {
 // UNITB: bytes a flush writes at a time -- 128 (whole lines: 3.6 instead of 2.8 TB/s for such appends,
 // tools/ubench/scatter_runs.hip) for 4-byte payloads, 64 for 8-byte ones (a bin is 256 bytes either way, and what a
 // flush keeps back has to leave room for a half batch's arrivals).
-template <typename PT, int UNITB>
+// NBK: 512 (2^5 .. 2^9 buckets per partition) or 1024 (2^10: tables of 2^20 regions -- 2^32 slots, what an hg38-sized or an
+// unhinted 2-billion-key input gets; round 2 sent those to the exact path with the unaligned scatter).  The 128 KiB of
+// bins are shared out among the partition's buckets either way: 32 4-byte (16 8-byte) payloads per bin at 1024, units of
+// 64 bytes there, and the ranks that do not fit such a small bin (Poisson tail of ~8 arrivals per flush) take the overflow list.
+template <typename PT, int UNITB, int NBK>
 __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
                                                              const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
                                                              PT *__restrict__ out, u64 *__restrict__ bend,
                                                              OvfEntry *__restrict__ ovf_list, u64 *__restrict__ ovf, u64 ovf_cap) {
-    constexpr int NBK = P2L_NBK, UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
+    constexpr int UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
     constexpr int HALF = PER / 2;
-    constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin (256 bytes)
+    constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin at 512 buckets (256 bytes)
+    constexpr uint32_t TOTAL = P2L_NBK * CAP;                 // payloads all bins hold together (128 KiB)
     constexpr uint32_t UW = UNITB / 16;                       // 16-byte words per unit
-    __shared__ __attribute__((aligned(16))) PT s_bin[NBK * CAP + UNIT];  // 128 KiB (+ a trash unit)
+    static_assert(NBK == 512 || (NBK == 1024 && UNITB == 64), "1024 buckets: 128-byte bins, 64-byte units");
+    __shared__ __attribute__((aligned(16))) PT s_bin[TOTAL + UNIT];  // 128 KiB (+ a trash unit)
     __shared__ uint32_t s_cnt[NBK];
     __shared__ uint32_t s_chk[CPB];
     __shared__ uint16_t s_cfill[CPB];
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     __syncthreads();
     if (s_skip) return;
     const uint32_t P2 = 1u << g.p2_bits;
-    const uint32_t capr = CAP << (9u - g.p2_bits);  // payloads per bin: the 128 KiB are shared out among the P2 <= 512 buckets
+    const uint32_t capr = TOTAL >> g.p2_bits;  // payloads per bin: the 128 KiB are shared out among the partition's P2 buckets
     if (tid == 0) {
         s_ovf_next = 0;
         s_ovf_end = 0;
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
                     const uint32_t r = rk[j];
-                    s_bin[r < capr ? dg[j] * capr + r : (uint32_t)(NBK * CAP)] = pay[h * HALF + j];
+                    s_bin[r < capr ? dg[j] * capr + r : TOTAL] = pay[h * HALF + j];
                     omask |= (r != 0xFFFFFFFFu && r >= capr) ? (1u << j) : 0u;
                 }
                 if (__any(omask != 0)) {  // ranks that did not fit their bins (a heavy bucket): straight to the overflow list

@@ -127,7 +127,8 @@ KH_HD void win_outputs_ref(uint64_t key, uint32_t &p1, uint32_t &pay32) {
     cshift_insn " v124, %[cs], v122\n v_and_b32 v124, 0xffc, v124\n"              \
     "v_bfe_i32 v120, %[good], %[gb], 1\n"                                         \
     "v_bitop3_b32 %[cnta], v120, v124, %[waste] bitop3:0xca\n"                    \
-    bshift_insn " v124, %[bs], v122\n v_and_b32 %[binb], 0x1ff80, v124\n"
+    bshift_insn " v124, %[bs], v122\n v_and_b32 %[binb], 0x1ff80, v124\n"     \
+    "v_lshrrev_b32 v124, 3, %[binb]\n v_and_or_b32 %[binb], v124, %[rot], %[binb]\n"  /* | (p1 & 7) << 4: the bin's unit permutation (level1.hip.h (6)) */
 
 // 32-bit payloads, K = 11..21.  In: forward / reverse complement (hi words are zero for K <= 16), the lane's validity
 // word and waste counter address.  Out: payload, byte address of the partition's counter (or the waste counter), byte
@@ -135,7 +136,7 @@ KH_HD void win_outputs_ref(uint64_t key, uint32_t &p1, uint32_t &pay32) {
 // halves (for the selects): the same registers, the compiler builds the pair around the halves.
 template <int K, int J>
 __device__ __forceinline__ void win_hash32(uint32_t flo, uint32_t fhi, uint32_t rlo, uint32_t rhi, uint32_t good, uint32_t waste,
-                                           uint32_t &pay, uint32_t &cnta, uint32_t &binb) {
+                                           uint32_t rot, uint32_t &pay, uint32_t &cnta, uint32_t &binb) {
     static_assert(K >= 11 && K <= 21, "32-bit payloads: 2k - 10 <= 32");
     constexpr uint32_t KM = (1u << K) - 1u;
     constexpr int RS = 32 - K;                    // the round keeps the top k bits of the product's low word
@@ -146,7 +147,7 @@ __device__ __forceinline__ void win_hash32(uint32_t flo, uint32_t fhi, uint32_t 
 #define KH_W32_OPERANDS                                                                                                   \
     : [pay] "=&v"(pay), [cnta] "=&v"(cnta), [binb] "=&v"(binb)                                                            \
     : [flo] "v"(flo), [fhi] "v"(fhi), [rlo] "v"(rlo), [rhi] "v"(rhi), [f] "v"(f64), [r] "v"(r64), [good] "v"(good),      \
-      [waste] "v"(waste), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3),                                        \
+      [waste] "v"(waste), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3), [rot] "s"(rot),                        \
       [k] "n"(K), [km] "n"(KM), [rs] "n"(RS), [pl] "n"(PL), [pr] "n"(PR), [cs] "n"(CS), [bs] "n"(BS), [gb] "n"(15 - J)   \
     : "v120", "v121", "v122", "v123", "v124", "s98", "s99"
 #define KH_W32_PAY "v_lshlrev_b32 v124, %[pr], v123\n v_lshl_or_b32 %[pay], v122, %[pl], v124\n"
@@ -174,7 +175,7 @@ __device__ __forceinline__ void win_hash32(uint32_t flo, uint32_t fhi, uint32_t 
         asm(KH_W32_CANON32 KH_WIN_ROUNDS32 KH_W32_PAY KH_WIN_ADDR("v_lshlrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
     }
 #else
-    (void)f64; (void)r64; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)PL; (void)PR; (void)CS; (void)BS;
+    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)PL; (void)PR; (void)CS; (void)BS;
     pay = cnta = binb = 0;
 #endif
 #undef KH_W32_CANON32
@@ -188,7 +189,7 @@ __device__ __forceinline__ void win_hash32(uint32_t flo, uint32_t fhi, uint32_t 
 // counter's), the bin's byte offset (16 payloads of 8 bytes = 128 bytes per bin: the same (L >> (K - 17)) & 0x1ff80).
 template <int K, int J>
 __device__ __forceinline__ void win_hash64(uint32_t flo, uint32_t fhi, uint32_t rlo, uint32_t rhi, uint32_t good, uint32_t waste,
-                                           uint32_t &klo, uint32_t &khi, uint32_t &cnta, uint32_t &binb) {
+                                           uint32_t rot, uint32_t &klo, uint32_t &khi, uint32_t &cnta, uint32_t &binb) {
     static_assert(K >= 22 && K <= 32, "64-bit payloads");
     constexpr uint32_t KM = K < 32 ? (1u << (K & 31)) - 1u : 0xFFFFFFFFu;
     constexpr int RS = 32 - K;
@@ -198,7 +199,7 @@ __device__ __forceinline__ void win_hash64(uint32_t flo, uint32_t fhi, uint32_t 
 #define KH_W64_OPERANDS                                                                                                   \
     : [klo] "=&v"(klo), [khi] "=&v"(khi), [cnta] "=&v"(cnta), [binb] "=&v"(binb)                                          \
     : [flo] "v"(flo), [fhi] "v"(fhi), [rlo] "v"(rlo), [rhi] "v"(rhi), [f] "v"(f64), [r] "v"(r64), [good] "v"(good),      \
-      [waste] "v"(waste), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3),                                        \
+      [waste] "v"(waste), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3), [rot] "s"(rot),                        \
       [k] "n"(K & 31), [km] "n"(KM), [rs] "n"(RS), [cs] "n"(CS), [bs] "n"(BS), [gb] "n"(15 - J)                          \
     : "v120", "v122", "v123", "v124", "s98", "s99"
 #define KH_W64_CANON                                                \
@@ -216,7 +217,7 @@ __device__ __forceinline__ void win_hash64(uint32_t flo, uint32_t fhi, uint32_t 
         asm(KH_W64_CANON KH_W64_SPLIT_K32 KH_WIN_ROUNDS32_K32 KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
     }
 #else
-    (void)f64; (void)r64; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)CS; (void)BS;
+    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)CS; (void)BS;
     klo = khi = cnta = binb = 0;
 #endif
 #undef KH_W64_SPLIT_K32

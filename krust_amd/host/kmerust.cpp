@@ -236,8 +236,8 @@ int cli_main(int argc, char **argv) {
             const Timing &t = timing();
             const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             fprintf(stderr, "{\"kmerust_timing\": {\"total_s\": %.6f, \"create_s\": %.6f, \"read_s\": %.6f, \"push_s\": %.6f, \"finish_s\": %.6f, "
-                            "\"result_s\": %.6f, \"write_s\": %.6f, \"bytes_read\": %llu, \"chunks\": %llu, \"device_record_scan\": %s}}\n",
-                    total, t.create_s, t.read_s, t.push_s, t.finish_s, t.result_s, t.write_s, (unsigned long long)t.bytes_read,
+                            "\"result_s\": %.6f, \"write_s\": %.6f, \"buffers_s\": %.6f, \"destroy_s\": %.6f, \"bytes_read\": %llu, \"chunks\": %llu, \"device_record_scan\": %s}}\n",
+                    total, t.create_s, t.read_s, t.push_s, t.finish_s, t.result_s, t.write_s, t.buffers_s, t.destroy_s, (unsigned long long)t.bytes_read,
                     (unsigned long long)t.chunks, t.text_path ? "true" : "false");
         }
     } timing_printer{t_begin};

@@ -253,6 +253,7 @@ struct Session {
         ctx = ctxs[0];
     }
     ~Session() {
+        Lap lap(timing().destroy_s);
         if (group) kh_group_destroy(group);
         else if (ctx) kh_destroy(ctx);
     }
@@ -367,7 +368,17 @@ struct Session {
         std::function<int()> stopper = stop_workers;
         Joiner joiner{stopper};
 
-        const size_t chunk = text_chunk_bytes();
+        size_t chunk = text_chunk_bytes();
+        if (!gz && !getenv("KMERUST_TEXT_CHUNK_KB")) {
+            // large plain files: larger chunks (every chunk is one partitioned pass, and every pass rewrites the table):
+            // a quarter of the file, between 256 MiB and 1 GiB
+            struct stat sb;
+            if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
+                size_t want = chunk;
+                while (want < (size_t)sb.st_size / 4 && want < ((size_t)1 << 30)) want *= 2;
+                chunk = want;
+            }
+        }
         // The chunk buffer is PINNED memory (kh_host_alloc): kh_push_text then DMAs from it -- no staging memcpy inside the
         // library -- and a plain file is read into it by several pread() calls side by side (one read() moves ~6 GB/s
         // out of the page cache, less than the device scans and counts).  If pinned memory cannot be had the buffer is
@@ -388,6 +399,7 @@ struct Session {
             void reserve(size_t n, size_t keep) {  // grows to n bytes, keeping the first `keep`
                 if (n <= cap) return;
                 void *q = nullptr;
+                Lap lap(timing().buffers_s);
                 bool pin = kh_host_alloc(&q, n) == KH_OK;
                 if (!pin) q = malloc(n);
                 if (!q) throw Error("out of memory for the text chunk buffer");
@@ -399,7 +411,7 @@ struct Session {
             }
             uint8_t *data() { return p; }
             size_t size() const { return cap; }
-        } buf;
+        } buf, buf2;  // (buf2: the chunk being filled while `buf` is pushed -- plain files on one device)
         buf.reserve(chunk, 0);
         size_t have = 0;
         bool eof = false, pushed = false;
@@ -476,6 +488,53 @@ struct Session {
                 }
             }
             if (cut) timing().chunks++;
+            if (cut && ndev == 1 && can_pread && !eof) {
+                // The next chunk is read (tail of this one first) while the device takes this one: kh_push_text blocks for
+                // the transfer, the record scan and the counting of the chunk.
+                buf2.reserve(buf.size(), 0);
+                const size_t tail = have - cut;
+                size_t got = 0;
+                std::exception_ptr rd_err;
+                double rd_s = 0;
+                std::thread reader([&] {
+                    const double t0 = wall_s();
+                    try {
+                        memcpy(buf2.data(), buf.data() + cut, tail);
+                        got = read_parallel(buf2.data() + tail, buf2.size() - tail);
+                    } catch (...) {
+                        rd_err = std::current_exception();
+                    }
+                    rd_s = wall_s() - t0;
+                });
+                int rc;
+                {
+                    Lap lap(timing().push_s);
+                    rc = kh_push_text(ctx, buf.data(), cut, text_fmt);
+                }
+                reader.join();
+                timing().read_s += rd_s;  // (overlapped with push_s: the two no longer add up to the wall time)
+                timing().bytes_read += got;
+                if (rd_err) std::rethrow_exception(rd_err);
+                if (rc == KH_ERR_FORMAT) return refuse();
+                check(rc, "kh_push_text");
+                pushed = true;
+                std::swap(buf.p, buf2.p);
+                std::swap(buf.cap, buf2.cap);
+                std::swap(buf.pinned, buf2.pinned);
+                have = tail + got;
+                if (got == 0) eof = true;  // (what is left in the buffer is pushed by the next round, as the last chunk)
+                if (eof && have == 0) break;
+                if (eof) {  // the last chunk: whole records up to the end of the file
+                    timing().chunks++;
+                    Lap lap(timing().push_s);
+                    const int rc2 = kh_push_text(ctx, buf.data(), have, text_fmt);
+                    if (rc2 == KH_ERR_FORMAT) return refuse();
+                    check(rc2, "kh_push_text");
+                    have = 0;
+                    break;
+                }
+                continue;
+            }
             if (cut && ndev == 1) {
                 Lap lap(timing().push_s);
                 const int rc = kh_push_text(ctx, buf.data(), cut, text_fmt);

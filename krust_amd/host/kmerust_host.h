@@ -115,6 +115,8 @@ struct Timing {
     double finish_s = 0;   // kh_finish (+ the multi-GPU merge)
     double result_s = 0;   // kh_histogram / kh_result_copy
     double write_s = 0;    // formatting and writing the output
+    double buffers_s = 0;  // pinned chunk buffers (kh_host_alloc)
+    double destroy_s = 0;  // releasing the device context(s)
     uint64_t bytes_read = 0, chunks = 0;
     bool text_path = false;  // records were found on the device (kh_push_text)
 };
