@@ -142,7 +142,8 @@ struct kh_ctx {
     u64 *bend = nullptr;             // arena path: end of every region's data (the exact path uses bstart + 1)
     u64 *ptotal = nullptr;           // [MAX_P1] payloads per level-1 partition
     uint32_t *pcap = nullptr;        // [MAX_P1] arena capacity of that partition's buckets
-    u64 *ovf = nullptr;              // [2] overflow list: entries handed out, "list full" flag
+    uint8_t *heavy = nullptr;        // [MAX_P1] the partition is too heavy for one workgroup: the exact kernels take it
+    u64 *ovf = nullptr;              // [4] overflow list: entries handed out, "list full" flag; heavy partitions, payloads in them
     kh::OvfEntry *ovf_list = nullptr;
     u64 ovf_cap = 0;
     u64 ovf_pending = 0;             // entries of the overflow list still to be inserted (this batch)
@@ -603,8 +604,14 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     const u64 ovf_need = arena ? n_ub / 16 + 2 * P1 * 8192ull + (1ull << 20) : 0;
     const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
     const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
+    // Heavy level-1 partitions (a homopolymer's, a satellite's: arena_plan_kernel) go through the exact kernels while the
+    // others take the arenas; their buckets follow the arenas in the same buffer: room for an eighth of the batch there
+    // (more than that in heavy partitions: the batch takes the exact path as a whole).
+    const u64 heavy_room = arena ? n_ub / 8 : 0;
+    const u64 heavy_base = (arena_pay + 31) & ~31ull;   // payload index behind the arenas (an upper bound of their total)
+    const u64 heavy_pad = (arena && lines) ? ((heavy_room / (kh::CPB * kh::CHUNK_PAY) + 2 * P1) << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;
     // A: the level-1 pool.  B: the level-2 output -- exact path: every payload + sentinel padding; arenas: a quarter more
-    const u64 b_bytes = std::max((n_ub + pad_ub) * (u64)sizeof(PT), arena_pay * (u64)sizeof(PT));
+    const u64 b_bytes = std::max((n_ub + pad_ub) * (u64)sizeof(PT), arena ? (heavy_base + heavy_room + heavy_pad + 64) * (u64)sizeof(PT) : 0);
     if (c->key_cap < a_bytes) {  // (capacities in BYTES)
         u64 z = c->keysA ? c->key_cap : 0;
         if ((rc = ensure_buf(c, &c->keysA, &z, a_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
@@ -623,7 +630,9 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             z = 0;
             if ((rc = ensure_buf(c, &c->pcap, &z, (u64)kh::MAX_P1, "hipMalloc(pcap)")) != KH_OK) return rc;
             z = 0;
-            if ((rc = ensure_buf(c, &c->ovf, &z, 2, "hipMalloc(ovf)")) != KH_OK) return rc;
+            if ((rc = ensure_buf(c, &c->ovf, &z, 4, "hipMalloc(ovf)")) != KH_OK) return rc;
+            z = 0;
+            if ((rc = ensure_buf(c, &c->heavy, &z, (u64)kh::MAX_P1, "hipMalloc(heavy)")) != KH_OK) return rc;
         }
         if (c->ovf_cap < ovf_need) {
             u64 z = c->ovf_list ? c->ovf_cap : 0;
@@ -692,47 +701,60 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
                                (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, arena ? c->ptotal : (u64 *)nullptr);
             if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
             hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
-                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide);
+                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)nullptr);
             hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
                                (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
             HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
         }
     }
     const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
-    bool arena_done = false;
+    bool arena_done = false, heavy_exact = false;
     const u64 ovf_test_cap = [] { const char *e = getenv("KMERHIP_L2_OVF_CAP"); return e ? (u64)strtoull(e, nullptr, 10) : ~0ull; }();
     const u64 ovf_lim = std::min(c->ovf_cap, ovf_test_cap);
     if (arena) {
         {
             StageTimer t(c, ST_P2_SCATTER);
-            // (test knobs: KMERHIP_L2_SKEW_X = how many times the mean a partition may hold, 0 = no limit; KMERHIP_L2_OVF_CAP =
-            //  entries the overflow list may take)
+            // (test knobs: KMERHIP_L2_SKEW_X = how many times the mean a partition may hold before it counts as heavy, 0 = no
+            //  limit; KMERHIP_L2_OVF_CAP = entries the overflow list may take; KMERHIP_L2_HEAVY_ROOM = payloads of room for heavy partitions)
             const uint32_t skew_x = [] { const char *e = getenv("KMERHIP_L2_SKEW_X"); return e ? (uint32_t)atoi(e) : 2u; }();
+            const u64 room = [&] { const char *e = getenv("KMERHIP_L2_HEAVY_ROOM"); return e ? std::min<u64>(heavy_room, strtoull(e, nullptr, 10)) : heavy_room; }();
             hipLaunchKernelGGL(kh::arena_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
-                               c->ovf, skew_x);
+                               c->ovf, skew_x, c->heavy, room);
             if (g.p2_bits == 10)  // 2^20 regions: 1024 buckets per partition, 128-byte bins, 64-byte units
                 hipLaunchKernelGGL((kh::part2_arena_kernel<PT, 64, 1024>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
-                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
+                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy);
             else
                 hipLaunchKernelGGL((kh::part2_arena_kernel<PT, sizeof(PT) == 4 ? KH_ARENA_UNITB : 64, 512>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
-                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim);
+                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy);
         }
-        u64 hov[2] = {0, 0};
+        u64 hov[4] = {0, 0, 0, 0};
         HIP_TRY(c, hipMemcpyAsync(hov, c->ovf, sizeof(hov), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         if (hov[1] == 0) {
             arena_done = true;
+            heavy_exact = hov[2] != 0;
             bend = c->bend;
             c->ovf_pending = std::min<u64>(hov[0], ovf_lim);  // (the cursor moves in whole segments: it may end beyond the list)
             HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
+            if (heavy_exact && c->trace)
+                fprintf(stderr, "[kmerhip] %llu heavy level-1 partition(s) (%llu payloads) take the exact level-2 kernels, the others the arenas\n", hov[2], hov[3]);
         } else if (c->trace) {
-            fprintf(stderr, hov[1] == 2 ? "[kmerhip] level-1 partitions too uneven for one workgroup each: this batch takes the exact level-2 path\n"
-                                        : "[kmerhip] level-2 overflow list full (%llu entries): this batch takes the exact path\n", (u64)hov[0]);
+            fprintf(stderr, hov[1] == 2 ? "[kmerhip] heavy level-1 partitions hold %llu payloads, more than the room behind the arenas: this batch takes the exact level-2 path\n"
+                                        : "[kmerhip] level-2 overflow list full (%llu entries): this batch takes the exact path\n", (u64)(hov[1] == 2 ? hov[3] : hov[0]));
         }
     }
-    if (!arena_done) {
+    if (!arena_done || heavy_exact) {
+    // the exact kernels: over every partition (the plan above), or over the heavy ones of an arena batch alone -- their
+    // buckets then go behind the arenas, and their (small) counting pass is booked under "misc": stage_ms[P2_COUNT] == 0
+    // still says "this batch's level 2 was the arena kernel"
+    PT *const outB = heavy_exact ? bufB + heavy_base : bufB;
+    if (heavy_exact) {
+        StageTimer t(c, ST_MISC);
+        hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
+                           c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)c->heavy);
+    }
     {
-        StageTimer t(c, ST_P2_COUNT);
+        StageTimer t(c, heavy_exact ? ST_MISC : ST_P2_COUNT);
         hipLaunchKernelGGL((kh::part2_count_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA, cs,
                            (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2, lines ? (uint32_t)kh::P2L<PT>::UNIT : 1u);
     }
@@ -745,13 +767,13 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         const uint32_t fallback = lines ? 1u : 0u;  // behind the unit kernel the unaligned one runs only where that stood down
         if (lines)  // whole aligned 64-byte units only (32-bit payloads, 2..512 buckets per partition)
             hipLaunchKernelGGL((kh::part2_scatter_lines_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::P2L_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB);
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB);
         if (g.p2_bits <= 9)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
             hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 512>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB, fallback);
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
         else
             hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 1024>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, bufB, fallback);
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
     }
 #if KH_ABL2 || KH_ABL3
     if (getenv("KMERHIP_STOP_AFTER_P2")) {  // ablation builds only: time level 2 alone (its output is garbage)
@@ -761,12 +783,18 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 #endif
     {
         StageTimer t(c, ST_MISC);
-        hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((nregions + 256) / 256)), dim3(256), 0, c->stream,
-                           (const u64 *)c->O2, (u64)n2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, c->bstart);
-        HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
+        if (heavy_exact) {
+            hipLaunchKernelGGL(kh::bucket_bounds_heavy_kernel, dim3((unsigned)((nregions + 255) / 256)), dim3(256), 0, c->stream,
+                               (const u64 *)c->O2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, (const uint8_t *)c->heavy, heavy_base,
+                               c->bstart, c->bend);
+        } else {
+            hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((nregions + 256) / 256)), dim3(256), 0, c->stream,
+                               (const u64 *)c->O2, (u64)n2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, c->bstart);
+            HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
+        }
     }
-    c->ovf_pending = 0;
-    }  // !arena_done
+    if (!heavy_exact) c->ovf_pending = 0;
+    }  // exact kernels
     const bool was_empty = c->table_empty;
     {
         StageTimer t(c, ST_REGION);
@@ -1241,7 +1269,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->bend, c->ptotal, c->pcap, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->bstart, c->bend, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)

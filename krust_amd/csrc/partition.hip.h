@@ -91,20 +91,23 @@ __global__ __launch_bounds__(1024) void chunk_list_kernel(const uint16_t *__rest
 
 // Level-2 plan over chunk lists.  pstart = exclusive scan of pcount (P1 + 1 entries).  Same outputs as
 // part2_plan_kernel; info[2] is left to the level-2 scan (the grand total is not known yet).
+// only (optional): plan blocks for the partitions with only[p] != 0 alone -- the heavy partitions of a batch whose other
+// partitions went through the arena kernel; the others then have no blocks (nch = 0).  cursors is left alone then.
 __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__restrict__ pstart, PartGeom g,
                                                                   Part2Block *__restrict__ blocks, u64 max_blocks,
                                                                   u64 *__restrict__ moff, uint32_t *__restrict__ nch,
                                                                   u64 *__restrict__ info, uint32_t *__restrict__ cursors,
-                                                                  uint32_t force_wide) {
+                                                                  uint32_t force_wide, const uint8_t *__restrict__ only) {
     __shared__ u64 s_bbase[MAX_P1 + 1];
     const int tid = threadIdx.x;
     const int P1 = 1 << g.p1_bits;
-    if (tid < P1) cursors[tid] = (uint32_t)pstart[tid];
+    if (tid < P1 && !only) cursors[tid] = (uint32_t)pstart[tid];
+    auto nchunks_of = [&](int p) -> u64 { return (only && !only[p]) ? 0ull : pstart[p + 1] - pstart[p]; };
     if (tid == 0) {
         u64 b = 0;
         for (int p = 0; p < P1; ++p) {
             s_bbase[p] = b;
-            b += (pstart[p + 1] - pstart[p] + CPB - 1) / CPB;
+            b += (nchunks_of(p) + CPB - 1) / CPB;
         }
         s_bbase[P1] = b;
         info[0] = b;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__r
         // down for the whole batch and the unaligned one runs (both are launched, each checks this word).
         u64 wide = force_wide;  // (KMERHIP_P2_FORCE_WIDE=1: tests exercise the stand-down without 4 G k-mers)
         for (int p = 0; p < P1; ++p) {
-            const u64 nchunks = pstart[p + 1] - pstart[p];
+            const u64 nchunks = nchunks_of(p);
             const u64 nblocks = (nchunks + CPB - 1) / CPB;
             if (nchunks * CHUNK_PAY + nblocks * 1024ull * 64ull >= (1ull << 32)) wide = 1;
         }
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__r
     }
     __syncthreads();
     if (tid < P1) {
-        const u64 lo = pstart[tid], hi = pstart[tid + 1];
+        const u64 lo = pstart[tid], hi = lo + nchunks_of(tid);
         const u64 b0 = s_bbase[tid];
         const uint32_t n = (uint32_t)(s_bbase[tid + 1] - b0);
         moff[tid] = b0 << g.p2_bits;
@@ -603,30 +606,50 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
 // bstart[r] for r = (p, b): arenas of cap_p = align32(ceil(n_p / P2) * 5 / 4 + 1024) payloads, partition after partition
 // ovf[1] = 2 if some partition holds more than skew_x times the mean (one workgroup handles a whole partition: a
 // partition that heavy -- a homopolymer's, say -- would be the whole pass; the exact path splits partitions into blocks)
+// Round 3: a HEAVY partition (more than skew_x times the mean: a homopolymer's, a satellite's) no longer sends the whole
+// batch to the exact path.  It gets no arenas and no workgroup here (heavy[p] = 1, capacity 0); the host then runs the exact
+// count -> scan -> scatter kernels over the heavy partitions' chunk lists alone (they split a partition into blocks of 1024
+// chunks, any number of workgroups) and their buckets follow the arenas in the same buffer.  ovf[2] = heavy partitions,
+// ovf[3] = payloads in them; ovf[1] = 2 only if those exceed heavy_room payloads (the room the host has reserved behind
+// the arenas): then the batch does take the exact path as a whole.
 __global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict__ ptotal, PartGeom g, u64 *__restrict__ bstart,
-                                                          uint32_t *__restrict__ pcap, u64 *__restrict__ ovf, uint32_t skew_x) {
+                                                          uint32_t *__restrict__ pcap, u64 *__restrict__ ovf, uint32_t skew_x,
+                                                          uint8_t *__restrict__ heavy, u64 heavy_room) {
     __shared__ u64 s_base[MAX_P1 + 1];
     __shared__ uint32_t s_cap[MAX_P1];
+    __shared__ u64 s_limit;
     const int tid = threadIdx.x;
     const int P1 = 1 << g.p1_bits;
     const uint32_t P2 = 1u << g.p2_bits;
+    if (tid == 0) {
+        u64 tot = 0;
+        for (int p = 0; p < P1; ++p) tot += ptotal[p];
+        s_limit = skew_x ? (u64)skew_x * (tot / P1) + (1u << 20) : ~0ull;
+    }
+    __syncthreads();
     if (tid < P1) {
+        const bool hv = ptotal[tid] > s_limit;
+        heavy[tid] = hv ? 1 : 0;
         const u64 m = (ptotal[tid] + P2 - 1) / P2;
-        s_cap[tid] = (uint32_t)((m + (m >> 2) + 1024 + 31) & ~31ull);
+        s_cap[tid] = hv ? 0u : (uint32_t)((m + (m >> 2) + 1024 + 31) & ~31ull);
         pcap[tid] = s_cap[tid];
     }
     __syncthreads();
     if (tid == 0) {
-        u64 b = 0, tot = 0, mx = 0;
+        u64 b = 0, nh = 0, ht = 0;
         for (int p = 0; p < P1; ++p) {
             s_base[p] = b;
             b += (u64)s_cap[p] * P2;
-            tot += ptotal[p];
-            mx = max(mx, ptotal[p]);
+            if (heavy[p]) {
+                ++nh;
+                ht += ptotal[p];
+            }
         }
         s_base[P1] = b;
         ovf[0] = 0;
-        ovf[1] = (skew_x && mx > (u64)skew_x * (tot / P1) + (1u << 20)) ? 2 : 0;
+        ovf[1] = ht > heavy_room ? 2 : 0;
+        ovf[2] = nh;
+        ovf[3] = ht;
     }
     __syncthreads();
     for (int p = 0; p < P1; ++p)
@@ -651,7 +674,8 @@ template <typename PT, int UNITB, int NBK>
 __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
                                                              const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
                                                              PT *__restrict__ out, u64 *__restrict__ bend,
-                                                             OvfEntry *__restrict__ ovf_list, u64 *__restrict__ ovf, u64 ovf_cap) {
+                                                             OvfEntry *__restrict__ ovf_list, u64 *__restrict__ ovf, u64 ovf_cap,
+                                                             const uint8_t *__restrict__ heavy) {
     constexpr int UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
     constexpr int HALF = PER / 2;
     constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin at 512 buckets (256 bytes)
@@ -671,7 +695,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     // found the overflow list full): nothing to do, the host takes the exact path.  Decided by ONE lane for the whole
     // workgroup -- the flag can change while the lanes are reading it, and a workgroup must not split at a barrier.
     __shared__ uint32_t s_skip;
-    if (tid == 0) s_skip = ovf[1] != 0;
+    if (tid == 0) s_skip = ovf[1] != 0 || heavy[p] != 0;  // (a heavy partition: the exact kernels take it, see arena_plan_kernel)
     __syncthreads();
     if (s_skip) return;
     const uint32_t P2 = 1u << g.p2_bits;
@@ -689,15 +713,34 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     constexpr uint32_t LP = KH_ARENA_LANES < UW ? KH_ARENA_LANES : UW;
     constexpr uint32_t NB = (NBK * LP + NT - 1) / NT;  // buckets per lane group
     const uint32_t og = (uint32_t)tid / LP, oi = (uint32_t)tid % LP;
-    u64 abase[NB];
-    uint32_t apos[NB];
-#pragma unroll
-    for (uint32_t it = 0; it < NB; ++it) {
-        const uint32_t ob = og + it * (NT / LP);
-        abase[it] = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
-        apos[it] = 0;
-    }
+    // A lane group's buckets' write positions: in registers (512 buckets: two per group).  With 1024 buckets a group owns
+    // four; four more base / position pairs beside the two payload sets pushed the kernel over the 128 registers a
+    // 1024-lane workgroup has -- 1.1 KB of scratch per lane and 525 ms for a 125 M-read batch (measured, round 3) -- so
+    // there the positions live in LDS (s_apos) and the bases are computed: a partition's arenas are equally large and
+    // consecutive (arena_plan_kernel), bucket b's starts at the partition's first + b x capacity.
+#ifndef KH_ARENA_POS_LDS
+#define KH_ARENA_POS_LDS 0  // 1: positions in LDS for 512 buckets too (A/B builds)
+#endif
+    constexpr bool POS_LDS = NBK == 1024 || KH_ARENA_POS_LDS;
+    __shared__ uint32_t s_apos[POS_LDS ? NBK : 1];
     const uint32_t acap = pcap[p];
+    const u64 pbase = bstart[(u64)p * P2];
+    u64 abase_r[POS_LDS ? 1 : NB];
+    uint32_t apos_r[POS_LDS ? 1 : NB];
+    if constexpr (POS_LDS) {
+        if (tid < NBK) s_apos[tid] = 0;
+    } else {
+#pragma unroll
+        for (uint32_t it = 0; it < NB; ++it) {
+            const uint32_t ob = og + it * (NT / LP);
+            abase_r[it] = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
+            apos_r[it] = 0;
+        }
+    }
+    auto abase_of = [&](uint32_t it, uint32_t ob) -> u64 {
+        if constexpr (POS_LDS) return pbase + (u64)ob * acap;
+        else return abase_r[it];
+    };
     if (tid < NBK) s_cnt[tid] = 0;
     const uint32_t woff = (uint32_t)tid & (CHUNK_PAY - 1);  // offset inside the chunk
     // Appends k entries of this lane to the overflow list; false if the list is full (the host then redoes the batch).
@@ -758,22 +801,26 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         };
         // the lane group writes the whole units of its buckets' bins to their arenas (or, an arena full, its first lane to the overflow list)
         auto flush = [&]() {
-#pragma unroll
+#pragma unroll POS_LDS ? 1 : NB
             for (uint32_t it = 0; it < NB; ++it) {
                 const uint32_t ob = og + it * (NT / LP);
                 if (ob >= P2) continue;
+                const u64 abase = abase_of(it, ob);
+                uint32_t apos;
+                if constexpr (POS_LDS) apos = s_apos[ob];
+                else apos = apos_r[it];
                 uint4 *const bin4 = reinterpret_cast<uint4 *>(s_bin + ob * capr);
                 const uint32_t c = min(s_cnt[ob], capr);  // (ranks beyond the bin went to the overflow list)
                 const uint32_t nun = c / UNIT, r = c % UNIT;
                 for (uint32_t u = 0; u < nun; ++u) {
-                    if (apos[it] + UNIT <= acap) {
+                    if (apos + UNIT <= acap) {
                         uint4 x[UW / LP];
 #pragma unroll
                         for (uint32_t q = 0; q < UW / LP; ++q) x[q] = bin4[UW * u + oi + LP * q];
-                        uint4 *d = reinterpret_cast<uint4 *>(out + abase[it] + apos[it]);
+                        uint4 *d = reinterpret_cast<uint4 *>(out + abase + apos);
 #pragma unroll
                         for (uint32_t q = 0; q < UW / LP; ++q) d[oi + LP * q] = x[q];
-                        apos[it] += UNIT;
+                        apos += UNIT;
                     } else if (oi == 0) {
                         u64 at;
                         if (ovf_take(UNIT, at)) {
@@ -799,6 +846,11 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                         if (oi + LP * q < nw) bin4[oi + LP * q] = m[q];
                 }
                 if (oi == 0) s_cnt[ob] = r;
+                if constexpr (POS_LDS) {
+                    if (oi == 0) s_apos[ob] = apos;  // (the group's lanes read it together at the top: same wave, next flush is behind barriers)
+                } else {
+                    apos_r[it] = apos;
+                }
             }
         };
         auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
@@ -857,16 +909,20 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     }
     // what is left in the bins (< UNIT payloads per bucket), one by one; then the bucket's end
     __syncthreads();  // (a partition without chunks comes here straight from the initialisation of the counters)
-#pragma unroll
+#pragma unroll POS_LDS ? 1 : NB
     for (uint32_t it = 0; it < NB; ++it) {
         const uint32_t ob = og + it * (NT / LP);
         if (oi != 0 || ob >= P2) continue;
         const uint32_t r = s_cnt[ob];
         const PT *bin = s_bin + ob * capr;
+        const u64 abase = abase_of(it, ob);
+        uint32_t apos;
+        if constexpr (POS_LDS) apos = s_apos[ob];
+        else apos = apos_r[it];
         if (r) {
-            if (apos[it] + r <= acap) {
-                for (uint32_t i = 0; i < r; ++i) out[abase[it] + apos[it] + i] = bin[i];
-                apos[it] += r;
+            if (apos + r <= acap) {
+                for (uint32_t i = 0; i < r; ++i) out[abase + apos + i] = bin[i];
+                apos += r;
             } else {
                 u64 at;
                 if (ovf_take(r, at))
@@ -879,7 +935,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                     }
             }
         }
-        bend[(u64)p * P2 + ob] = abase[it] + apos[it];
+        bend[(u64)p * P2 + ob] = abase + apos;
     }
     __syncthreads();
     for (u64 i = s_ovf_next + tid; i < s_ovf_end && i < ovf_cap; i += NT) ovf_list[i].region = 0xFFFFFFFFu;
@@ -943,6 +999,24 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restric
     // an empty level-1 partition has no chunks: its buckets all start where the partition starts,
     // which is the O2 value at the next partition's first entry (or the grand total)
     bstart[r] = nch[p1] ? O2[moff[p1] + (u64)p2 * nch[p1]] : O2[moff[p1]];
+}
+
+// The same for the HEAVY partitions of an arena batch: their buckets were written by the exact kernels into the buffer
+// behind the arenas (at payload offset `base`); start and end of every bucket of a heavy partition, nothing for the others.
+__global__ __launch_bounds__(256) void bucket_bounds_heavy_kernel(const u64 *__restrict__ O2, const u64 *__restrict__ moff,
+                                                                  const uint32_t *__restrict__ nch, PartGeom g,
+                                                                  const uint8_t *__restrict__ heavy, u64 base,
+                                                                  u64 *__restrict__ bstart, u64 *__restrict__ bend) {
+    const u64 nregions = 1ull << g.rbits;
+    const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nregions) return;
+    const uint32_t p1 = (uint32_t)(r >> g.p2_bits), p2 = (uint32_t)r & ((1u << g.p2_bits) - 1u);
+    if (!heavy[p1]) return;
+    const u64 n = nch[p1];  // (> 0: a heavy partition has chunks)
+    // the partition's [bucket][block] matrix is contiguous in the scan: bucket p2 + 1 starts where bucket p2 ends, and
+    // the entry behind the last bucket is the next heavy partition's first (or the scan's total)
+    bstart[r] = base + O2[moff[p1] + (u64)p2 * n];
+    bend[r] = base + O2[moff[p1] + (u64)(p2 + 1) * n];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -241,6 +241,9 @@ int cli_main(int argc, char **argv) {
                     (unsigned long long)t.chunks, t.text_path ? "true" : "false");
         }
     } timing_printer{t_begin};
+#if !defined(__SANITIZE_ADDRESS__)
+    leak_at_exit() = !getenv("KMERUST_CLEAN_EXIT");
+#endif
     try {
         KmerCounter kc;
         kc.k(k).min_count(min_count).format(fmt).input_format(in_fmt).min_quality(min_quality).devices(devices);

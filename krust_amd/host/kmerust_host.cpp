@@ -207,6 +207,13 @@ Timing &timing() {
     return t;
 }
 
+// The command line is one count per process: releasing tens of gigabytes of device memory allocation by allocation
+// before exiting (0.03 - 0.27 s measured) buys nothing.  Library users (KmerCounter in a long-lived process) never set this.
+bool &leak_at_exit() {
+    static bool v = false;
+    return v;
+}
+
 namespace {
 double wall_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -254,6 +261,7 @@ struct Session {
     }
     ~Session() {
         Lap lap(timing().destroy_s);
+        if (leak_at_exit() && !group) return;  // (the process is about to end: the driver reclaims everything at once)
         if (group) kh_group_destroy(group);
         else if (ctx) kh_destroy(ctx);
     }
@@ -368,17 +376,10 @@ struct Session {
         std::function<int()> stopper = stop_workers;
         Joiner joiner{stopper};
 
-        size_t chunk = text_chunk_bytes();
-        if (!gz && !getenv("KMERUST_TEXT_CHUNK_KB")) {
-            // large plain files: larger chunks (every chunk is one partitioned pass, and every pass rewrites the table):
-            // a quarter of the file, between 256 MiB and 1 GiB
-            struct stat sb;
-            if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode)) {
-                size_t want = chunk;
-                while (want < (size_t)sb.st_size / 4 && want < ((size_t)1 << 30)) want *= 2;
-                chunk = want;
-            }
-        }
+        // (256 MiB chunks.  Larger ones mean fewer partitioned passes -- every pass rewrites the table -- but the chunk buffers
+        //  are pinned, and pinning runs at ~5 GB/s: two 1 GiB buffers cost 0.38 s, more than the passes they saved; measured
+        //  on a 3.2 GB FASTQ, profiles/README.md r03.)
+        const size_t chunk = text_chunk_bytes();
         // The chunk buffer is PINNED memory (kh_host_alloc): kh_push_text then DMAs from it -- no staging memcpy inside the
         // library -- and a plain file is read into it by several pread() calls side by side (one read() moves ~6 GB/s
         // out of the page cache, less than the device scans and counts).  If pinned memory cannot be had the buffer is

@@ -121,6 +121,7 @@ struct Timing {
     bool text_path = false;  // records were found on the device (kh_push_text)
 };
 Timing &timing();
+bool &leak_at_exit();  // the CLI sets it: device contexts are not torn down before the process ends
 
 // ---- output (src/run.rs:441-486) -------------------------------------------------------------
 std::string unpack_to_string(uint64_t bits, uint32_t k);  // src/kmer.rs:451-456
