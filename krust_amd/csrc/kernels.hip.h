@@ -33,7 +33,7 @@ struct Counters {
     u64 big;       // scratch cursor for the histogram's big-count list
     u64 part_failed;  // regions that overflowed in region_count_kernel (re-inserted after growth)
     u64 heads_wide;   // a count too large for 32-bit exchange heads was seen (region_count_kernel32)
-    u64 pad[1];
+    u64 narrow_ovf;   // overflow-list entries whose count would not fit the 8-byte table image (left in the list: ovf_insert_kernel)
 };
 
 constexpr int BLOCK = 256;           // 4 waves of 64

@@ -73,6 +73,16 @@ struct kh_ctx {
 
     Slot *table = nullptr;
     u64 cap = 0;
+    // The 8-byte image of the table (partition.hip.h, region_count_kernel32<.., NARROW>): count << 32 | 32-bit payload per
+    // slot.  While `narrow` is set IT holds the counts and the 16-byte table is stale; ensure_wide() converts.  A fresh
+    // partitioned pass with 32-bit payloads writes it, later such passes update it, kh_finish / kh_result_* / kh_histogram /
+    // kh_lookup read it as it is; everything else (the direct path, growth, exports, merges) goes through enter(), which
+    // widens first.
+    u64 *ntab = nullptr;
+    u64 ntab_cap = 0;
+    bool narrow = false;
+    bool narrow_banned = false;   // a count left 32 bits once: this table stays 16-byte until kh_reset
+    kh::PartGeom narrow_g;        // the geometry the image's payloads are relative to
     Counters *d_ctr = nullptr;
     Counters *h_ctr = nullptr;  // pinned
 
@@ -220,7 +230,9 @@ void comm_release(kh_ctx *c);
 // partitioned batch into an empty table overwrites every region anyway).
 int close_fresh_window(kh_ctx *c);
 
-int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool keep_window = false) {
+int ensure_wide(kh_ctx *c);
+
+int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool keep_window = false, bool narrow_ok = false) {
     if (!c) return KH_ERR_BAD_ARG;
     if (c->poisoned) return fail(c, KH_ERR_STATE, "context is poisoned by an earlier error");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -232,7 +244,11 @@ int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool kee
         int rc = flush_acc(c, false);
         if (rc != KH_OK) return rc;
     }
-    return need_table ? clear_if_dirty(c) : KH_OK;
+    if (c->narrow && !narrow_ok) {
+        int rc = ensure_wide(c);
+        if (rc != KH_OK) return rc;
+    }
+    return (need_table && !c->narrow) ? clear_if_dirty(c) : KH_OK;
 }
 
 int alloc_table(kh_ctx *c, u64 cap, Slot **out) {
@@ -272,6 +288,18 @@ int close_fresh_window(kh_ctx *c) {
     return KH_OK;
 }
 
+// The 8-byte image -> the 16-byte table (every slot of it is rewritten: a lazily reset wide table needs no clearing first).
+int ensure_wide(kh_ctx *c) {
+    if (!c->narrow) return KH_OK;
+    hipLaunchKernelGGL(kh::ntable_widen_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, (const u64 *)c->ntab, c->cap,
+                       c->narrow_g, c->table);
+    HIP_TRY(c, hipGetLastError());
+    c->narrow = false;
+    c->table_dirty = false;
+    if (c->trace) fprintf(stderr, "[kmerhip] 8-byte table image widened to %llu 16-byte slots\n", c->cap);
+    return KH_OK;
+}
+
 // Blocks until the stream is idle and refreshes the exact counters.
 int sync_counters(kh_ctx *c) {
     HIP_TRY(c, hipMemcpyAsync(c->h_ctr, c->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
@@ -308,7 +336,9 @@ kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap) {
 
 int grow_to(kh_ctx *c, u64 newcap) {
     Slot *nt = nullptr;
-    int rc = alloc_table(c, newcap, &nt);
+    int rc = ensure_wide(c);  // (the rehash reads the 16-byte table)
+    if (rc != KH_OK) return rc;
+    rc = alloc_table(c, newcap, &nt);
     if (rc != KH_OK) return rc;
     if (c->table_dirty) {  // logically empty: nothing to carry over, and the new table is clean
         c->table_dirty = false;
@@ -501,9 +531,9 @@ int head_count_bits(const kh_ctx *c, u64 regions) {
 
 // region rebuild launch, by payload type
 template <typename PT>
-void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend);
+void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow);
 template <>
-void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend) {
+void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
@@ -513,18 +543,19 @@ void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot,
                            (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
 }
 template <>
-void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend) {
+void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
     c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
-    if (c->table_empty)
-        hipLaunchKernelGGL(kh::region_count_kernel32<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty,
-                           c->rheads_cb, c->rheads, c->d_ctr, c->rreal);
-    else
-        hipLaunchKernelGGL(kh::region_count_kernel32<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g,
-                           (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, 0u, 0u,
-                           (uint32_t *)nullptr, c->d_ctr, c->rreal);
+    // (a narrow FRESH pass must write every region of the image whatever the table held: dirty = 1)
+#define KH_REGION32(FRESH, NARROW, DIRTY, CB, RH) \
+    hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW>), dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g, \
+                       (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab)
+    if (c->table_empty && narrow) KH_REGION32(true, true, 1u, c->rheads_cb, c->rheads);
+    else if (c->table_empty) KH_REGION32(true, false, (uint32_t)c->table_dirty, c->rheads_cb, c->rheads);
+    else if (narrow) KH_REGION32(false, true, 0u, 0u, (uint32_t *)nullptr);
+    else KH_REGION32(false, false, 0u, 0u, (uint32_t *)nullptr);
+#undef KH_REGION32
 }
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
@@ -796,18 +827,47 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     if (!heavy_exact) c->ovf_pending = 0;
     }  // exact kernels
     const bool was_empty = c->table_empty;
+    // The 8-byte table image (see kh_ctx::ntab): a fresh pass with 32-bit payloads writes it, a pass over a table that is
+    // in that form updates it.  KMERHIP_NARROW=0: always the 16-byte table (A/B).
+    const bool narrow_on = [] { const char *e = getenv("KMERHIP_NARROW"); return !(e && e[0] == '0'); }();
+    // (not for a rank of a multi-GPU run: the exports of kh_merge_across read the 16-byte table, the widening would cost
+    //  more there than the image saves)
+    bool nar = sizeof(PT) == 4 && narrow_on && !c->narrow_banned && !c->shard_shift && !c->comm && (c->table_empty || c->narrow);
+    if (nar && c->ntab_cap != c->cap) {
+        if (c->ntab) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->ntab);
+            c->ntab = nullptr;
+            c->ntab_cap = 0;
+        }
+        if (hipMalloc((void **)&c->ntab, c->cap * sizeof(u64)) != hipSuccess) {  // (no room for the image: the 16-byte table it is)
+            (void)hipGetLastError();
+            c->ntab = nullptr;
+            nar = false;
+        } else {
+            c->ntab_cap = c->cap;
+        }
+    }
+    if (!nar && c->narrow && (rc = ensure_wide(c)) != KH_OK) return rc;
+    if (nar) c->narrow_g = g;
     {
         StageTimer t(c, ST_REGION);
         // buckets more than 4x the mean (upper bound) take the skew-guarded probing loop
-        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend);
+        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend, nar);
     }
+    if (nar) c->narrow = true;
     {
         StageTimer t(c, ST_MISC);
         hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
                            (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const u64 *)c->rreal, (u64)nregions, c->d_ctr);
-        if (c->ovf_pending)  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
-            hipLaunchKernelGGL(kh::ovf_insert_kernel<PT>, dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream,
-                               table_geom(c, c->table, c->cap), g, (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr);
+        if (c->ovf_pending) {  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
+            if (nar)
+                hipLaunchKernelGGL((kh::ovf_insert_kernel<PT, true>), dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream,
+                                   table_geom(c, c->table, c->cap), g, c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, c->ntab);
+            else
+                hipLaunchKernelGGL((kh::ovf_insert_kernel<PT, false>), dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream,
+                                   table_geom(c, c->table, c->cap), g, c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, (u64 *)nullptr);
+        }
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
@@ -822,6 +882,17 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     // anything else touches it
     c->rheads_valid = was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->h_ctr->part_failed == 0 && c->ovf_pending == 0;
     c->rheads_wide = c->h_ctr->heads_wide != 0;
+    if (nar && c->h_ctr->narrow_ovf) {
+        // overflow-list entries whose count would not fit the 8-byte image were left in the list: widen, insert them the
+        // 16-byte way (the entries already applied are marked consumed), and keep this table wide from now on
+        if ((rc = ensure_wide(c)) != KH_OK) return rc;
+        c->narrow_banned = true;
+        HIP_TRY(c, hipMemsetAsync(&c->d_ctr->narrow_ovf, 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL((kh::ovf_insert_kernel<PT, false>), dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream,
+                           table_geom(c, c->table, c->cap), g, c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, (u64 *)nullptr);
+        HIP_TRY(c, hipGetLastError());
+        if ((rc = sync_counters(c)) != KH_OK) return rc;
+    }
     if (c->h_ctr->part_failed) {
         // some regions overflowed: they were left untouched; grow, then insert their buckets directly.
         // Worst case every key of a failed bucket is new: size the grown table for that.
@@ -831,20 +902,35 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         HIP_TRY(c, hipMemcpy(hb.data(), c->bstart, nregions * sizeof(u64), hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(he.data(), bend, nregions * sizeof(u64), hipMemcpyDeviceToHost));
         u64 failed_keys = 0;
+        bool any_full = false, any_count = false;
         for (u64 r = 0; r < nregions; ++r)
-            if (hf[r]) failed_keys += he[r] - hb[r];
-        u64 newcap = c->cap * 2;
-        while ((double)(c->distinct_known + failed_keys) > LOAD_HARD * (double)newcap ||
-               (double)c->distinct_known > LOAD_TARGET * (double)newcap)
+            if (hf[r]) {
+                failed_keys += he[r] - hb[r];
+                any_full |= hf[r] == 1;
+                any_count |= hf[r] == 2;  // (8-byte image: a count left 32 bits -- the region itself has room)
+            }
+        if (any_count) c->narrow_banned = true;
+        if ((rc = ensure_wide(c)) != KH_OK) return rc;  // (the re-insert below goes through the 16-byte table)
+        u64 newcap = c->cap;
+        if (any_full) {
             newcap *= 2;
+            while ((double)(c->distinct_known + failed_keys) > LOAD_HARD * (double)newcap ||
+                   (double)c->distinct_known > LOAD_TARGET * (double)newcap)
+                newcap *= 2;
+            c->hinted = false;  // the capacity hint (if any) was too small: size later batches for the worst case
+        } else {
+            while ((double)(c->distinct_known + failed_keys) > LOAD_HARD * (double)newcap) newcap *= 2;
+        }
         if (c->trace)
-            fprintf(stderr, "[kmerhip] %llu regions overflowed (%llu keys): growing and re-inserting them directly\n",
+            fprintf(stderr, any_full ? "[kmerhip] %llu regions overflowed (%llu keys): growing and re-inserting them directly\n"
+                                     : "[kmerhip] a count left 32 bits in %llu regions (%llu keys): 16-byte table from here on, re-inserting them directly\n",
                     (u64)c->h_ctr->part_failed, failed_keys);
-        c->hinted = false;  // the capacity hint (if any) was too small: size later batches for the worst case
         {
             StageTimer t(c, ST_GROW);
-            rc = grow_to(c, newcap);
-            if (rc != KH_OK) return rc;
+            if (newcap != c->cap) {
+                rc = grow_to(c, newcap);
+                if (rc != KH_OK) return rc;
+            }
             hipLaunchKernelGGL(kh::failed_buckets_insert_kernel<PT>, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
                                table_geom(c, c->table, c->cap), g, (const PT *)bufB, (const u64 *)c->bstart, bend,
                                (const uint8_t *)c->rfail, c->d_ctr);
@@ -866,7 +952,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 
 int direct_range(kh_ctx *c, const RangeArgs &ra, u64 first_tile, u64 end_tile) {
     {
-        int rc = clear_if_dirty(c);
+        int rc = ensure_wide(c);  // (device atomics work on the 16-byte slots)
+        if (rc == KH_OK) rc = clear_if_dirty(c);
         if (rc != KH_OK) return rc;
     }
     u64 t = first_tile;
@@ -1275,6 +1362,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     for (void *q : scratch)
         if (q) (void)hipFree(q);
     if (c->table) (void)hipFree(c->table);
+    if (c->ntab) (void)hipFree(c->ntab);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_txt) (void)hipHostFree(c->h_txt);
@@ -1288,7 +1376,7 @@ extern "C" int kh_reset(kh_ctx *c) {
         c->win_open = false;
         if (c->win_dirty) c->table_dirty = true;
     }
-    int rc = enter(c, false);
+    int rc = enter(c, false, true, false, true);
     if (rc != KH_OK) return rc;
     if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
     c->acc_len = c->acc_carry = 0;  // pushes not yet counted are forgotten with everything else
@@ -1297,6 +1385,8 @@ extern "C" int kh_reset(kh_ctx *c) {
     // Lazy: no table_init here (5.5 ms for a 34 GB table).  A partitioned batch into an empty table
     // rewrites every region; any other use clears first (clear_if_dirty).
     if (!c->table_empty) c->table_dirty = true;
+    c->narrow = false;         // (both images are stale now; the next fresh pass chooses again)
+    c->narrow_banned = false;
     c->rheads_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->distinct_known = c->pending_bound = 0;
@@ -1314,7 +1404,7 @@ extern "C" int kh_reset(kh_ctx *c) {
 // input
 // =============================================================================================
 extern "C" int kh_push_device(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual, uint64_t n) {
-    int rc = enter(c, true, false);
+    int rc = enter(c, true, false, false, true);
     if (rc != KH_OK) return rc;
     if (n && !d_bases) return fail(c, KH_ERR_BAD_ARG, "d_bases is NULL");
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
@@ -1324,7 +1414,7 @@ extern "C" int kh_push_device(kh_ctx *c, const uint8_t *d_bases, const uint8_t *
 }
 
 extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uint64_t n) {
-    int rc = enter(c, false, false);
+    int rc = enter(c, false, false, false, true);
     if (rc != KH_OK) return rc;
     if (n && !bases) return fail(c, KH_ERR_BAD_ARG, "bases is NULL");
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
@@ -1507,7 +1597,7 @@ int text_args(kh_ctx *c, const uint8_t *text, u64 n, int format) {
 }  // namespace
 
 extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n, int format) {
-    int rc = enter(c, true, false);
+    int rc = enter(c, true, false, false, true);
     if (rc != KH_OK) return rc;
     if ((rc = text_args(c, d_text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
@@ -1518,7 +1608,7 @@ extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n,
 }
 
 extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int format) {
-    int rc = enter(c, true, false);
+    int rc = enter(c, true, false, false, true);
     if (rc != KH_OK) return rc;
     if ((rc = text_args(c, text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
@@ -1570,7 +1660,7 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
 }
 
 extern "C" int kh_finish(kh_ctx *c, kh_stats *st) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, true);
     if (rc != KH_OK) return rc;
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
@@ -1619,11 +1709,15 @@ int read_cursor(kh_ctx *c, u64 *cursor, u64 *big) {
 }  // namespace
 
 extern "C" int kh_result_size(kh_ctx *c, uint64_t min_count, uint64_t *n) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, true);
     if (rc != KH_OK) return rc;
     if (!n) return fail(c, KH_ERR_BAD_ARG, "n is NULL");
     rc = zero_cursors(c);
     if (rc != KH_OK) return rc;
+    if (c->narrow)
+        hipLaunchKernelGGL(kh::ntable_count_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, (const u64 *)c->ntab,
+                           c->cap, (u64)min_count, c->d_ctr);
+    else
     hipLaunchKernelGGL(kh::table_count_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
                        c->cap, (u64)min_count, c->d_ctr);
     HIP_TRY(c, hipGetLastError());
@@ -1636,11 +1730,15 @@ extern "C" int kh_result_size(kh_ctx *c, uint64_t min_count, uint64_t *n) {
 
 extern "C" int kh_result_copy_device(kh_ctx *c, uint64_t *d_keys, uint64_t *d_counts, uint64_t cap,
                                      uint64_t min_count, uint64_t *n) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, true);
     if (rc != KH_OK) return rc;
     if (!n || (cap && (!d_keys || !d_counts))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
     rc = zero_cursors(c);
     if (rc != KH_OK) return rc;
+    if (c->narrow)  // (keys come back through the inverse hash, slot by slot)
+        hipLaunchKernelGGL(kh::ntable_compact_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, (const u64 *)c->ntab,
+                           c->cap, c->narrow_g, (u64)min_count, (u64 *)d_keys, (u64 *)d_counts, (u64)cap, c->d_ctr);
+    else
     hipLaunchKernelGGL(kh::table_compact_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
                        c->cap, (u64)min_count, (u64 *)d_keys, (u64 *)d_counts, (u64)cap, c->d_ctr);
     HIP_TRY(c, hipGetLastError());
@@ -1654,7 +1752,7 @@ extern "C" int kh_result_copy_device(kh_ctx *c, uint64_t *d_keys, uint64_t *d_co
 
 extern "C" int kh_result_copy(kh_ctx *c, uint64_t *keys, uint64_t *counts, uint64_t cap, uint64_t min_count,
                               uint64_t *n) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, true);
     if (rc != KH_OK) return rc;
     if (!n || (cap && (!keys || !counts))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
     uint64_t need = 0;
@@ -1693,7 +1791,7 @@ extern "C" int kh_result_copy(kh_ctx *c, uint64_t *keys, uint64_t *counts, uint6
 
 extern "C" int kh_histogram(kh_ctx *c, uint64_t min_count, uint64_t *count, uint64_t *freq, uint64_t cap,
                             uint64_t *n) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, true);
     if (rc != KH_OK) return rc;
     if (!n || (cap && (!count || !freq))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
     u64 *d_dense = nullptr, *d_big = nullptr;
@@ -1711,6 +1809,10 @@ extern "C" int kh_histogram(kh_ctx *c, uint64_t min_count, uint64_t *count, uint
             rc = fail(c, KH_ERR_HIP, "hipMemsetAsync(histogram)");
         u64 nbig = 0;
         if (rc == KH_OK) {
+            if (c->narrow)
+                hipLaunchKernelGGL(kh::ntable_hist_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, (const u64 *)c->ntab,
+                                   c->cap, (u64)min_count, d_dense, d_big, big_cap, c->d_ctr);
+            else
             hipLaunchKernelGGL(kh::table_hist_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table,
                                c->cap, (u64)min_count, d_dense, d_big, big_cap, c->d_ctr);
             if (hipGetLastError() != hipSuccess) rc = fail(c, KH_ERR_HIP, "table_hist_kernel");
@@ -1748,7 +1850,7 @@ extern "C" int kh_histogram(kh_ctx *c, uint64_t min_count, uint64_t *count, uint
 }
 
 extern "C" int kh_lookup(kh_ctx *c, const uint64_t *keys, uint64_t n, uint64_t *counts) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, true);
     if (rc != KH_OK) return rc;
     if (n == 0) return KH_OK;
     if (!keys || !counts) return fail(c, KH_ERR_BAD_ARG, "NULL argument");
@@ -1760,6 +1862,10 @@ extern "C" int kh_lookup(kh_ctx *c, const uint64_t *keys, uint64_t n, uint64_t *
     }
     hipError_t e = hipMemcpyAsync(dk, keys, n * sizeof(u64), hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
+        if (c->narrow)
+            hipLaunchKernelGGL(kh::ntable_lookup_kernel, dim3(grid_for(n)), dim3(kh::BLOCK), 0, c->stream, (const u64 *)c->ntab,
+                               c->narrow_g, dk, (u64)n, dc);
+        else
         hipLaunchKernelGGL(kh::table_lookup_kernel, dim3(grid_for(n)), dim3(kh::BLOCK), 0, c->stream,
                            table_geom(c, c->table, c->cap), dk, (u64)n, dc);
         e = hipGetLastError();

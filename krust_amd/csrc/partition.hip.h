@@ -941,46 +941,195 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     for (u64 i = s_ovf_next + tid; i < s_ovf_end && i < ovf_cap; i += NT) ovf_list[i].region = 0xFFFFFFFFu;
 }
 
-// the overflow list through the direct path (after the region pass: the table then holds the batch's other k-mers)
-template <typename PT>
-__global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeom g, const OvfEntry *__restrict__ list,
-                                                           const u64 *__restrict__ ovf, u64 ovf_cap, Counters *ctr) {
+// ---- the 8-byte table image (round 3): slot = count << 32 | 32-bit payload, 0 = free --------------------------------
+// Written by region_count_kernel32<.., NARROW = true>; region r = slots [4096 r, 4096 (r + 1)), in-region start as in the
+// 16-byte table (the same hash bits), linear probing inside the region.  The key of slot i:
+__device__ __forceinline__ u64 narrow_key(const PartGeom &g, u64 slot_index, uint32_t pay) {
+    const uint32_t r = (uint32_t)(slot_index >> REGION_BITS);
+    return Pay<uint32_t>::key(pay, r >> g.p2_bits, g);
+}
+__device__ __forceinline__ uint32_t narrow_start(const PartGeom &g, uint32_t pay) {
+    return (pay >> (32 - g.p2_bits - REGION_BITS)) & REGION_MASK;
+}
+// count[pay] += addend in the narrow image of one region; false = the count would leave 32 bits (nothing changed)
+__device__ __forceinline__ bool narrow_upsert(u64 *nreg, const PartGeom &g, uint32_t pay, u64 addend, uint32_t &ndistinct, uint32_t &nfailed) {
+    uint32_t off = narrow_start(g, pay);
+    for (uint32_t probes = 0; probes < REGION_SLOTS; ++probes, off = (off + 1) & REGION_MASK) {
+        u64 cur = __hip_atomic_load(&nreg[off], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur >> 32) == 0) {
+            const u64 old = atomicCAS(&nreg[off], 0ull, (addend << 32) | pay);
+            if (old == 0) {
+                ++ndistinct;
+                return true;
+            }
+            cur = old;  // someone else claimed it first; may be our payload
+        }
+        if ((uint32_t)cur == pay) {
+            for (;;) {
+                const u64 c2 = (cur >> 32) + addend;
+                if (c2 > 0xFFFFFFFFull) return false;
+                const u64 old = atomicCAS(&nreg[off], cur, (c2 << 32) | pay);
+                if (old == cur) return true;
+                cur = old;
+            }
+        }
+    }
+    ++nfailed;  // region full: the host keeps the load factor far below this
+    return true;
+}
+
+// ntab -> the 16-byte table (every slot of it is written)
+__global__ __launch_bounds__(BLOCK) void ntable_widen_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, Slot *__restrict__ table) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
+        const u64 sl = ntab[i];
+        const u64 cnt = sl >> 32;
+        const u64 key = cnt ? narrow_key(g, i, (uint32_t)sl) : (u64)KH_EMPTY_KEY;
+        *reinterpret_cast<uint4 *>(&table[i]) = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)cnt, 0u);
+    }
+}
+// the narrow twins of table_count_kernel / table_compact_kernel / table_hist_kernel / table_lookup_kernel (kernels.hip.h)
+__global__ __launch_bounds__(BLOCK) void ntable_count_kernel(const u64 *__restrict__ ntab, u64 cap, u64 min_count, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    u64 n = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
+        const u64 cnt = ntab[i] >> 32;
+        n += (cnt != 0 && cnt >= min_count) ? 1 : 0;
+    }
+    n = wave_sum(n);
+    if (lane_id() == 0 && n) atomicAdd(&ctr->cursor, n);
+}
+__global__ __launch_bounds__(BLOCK) void ntable_compact_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, u64 min_count, u64 *keys,
+                                                               u64 *counts, u64 out_cap, Counters *ctr) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    const u64 first = (u64)blockIdx.x * BLOCK + threadIdx.x;
+    const u64 rounds = (cap + stride - 1) / stride;  // uniform trip count: ballots need whole waves
+    for (u64 r = 0; r < rounds; ++r) {
+        const u64 i = first + r * stride;
+        const u64 sl = i < cap ? ntab[i] : 0ull;
+        const u64 cnt = sl >> 32;
+        const bool live = cnt != 0 && cnt >= min_count;
+        const u64 m = __ballot(live);
+        if (m == 0) continue;
+        u64 base = 0;
+        if (lane_id() == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&ctr->cursor, (u64)__builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (live) {
+            const u64 o = base + mbcnt(m);
+            if (o < out_cap) {
+                keys[o] = narrow_key(g, i, (uint32_t)sl);
+                counts[o] = cnt;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void ntable_hist_kernel(const u64 *__restrict__ ntab, u64 cap, u64 min_count, u64 *dense, u64 *big,
+                                                            u64 big_cap, Counters *ctr) {
+    __shared__ uint32_t s_bins[HIST_LDS];
+    for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) s_bins[i] = 0;
+    __syncthreads();
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
+        const u64 cnt = ntab[i] >> 32;
+        if (cnt == 0 || cnt < min_count) continue;
+        if (cnt < HIST_LDS) {
+            atomicAdd(&s_bins[(uint32_t)cnt], 1u);
+        } else if (cnt < HIST_DENSE) {
+            atomicAdd(&dense[cnt], 1ull);
+        } else {
+            const u64 o = atomicAdd(&ctr->big, 1ull);
+            if (o < big_cap) big[o] = cnt;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) {
+        const uint32_t v = s_bins[i];
+        if (v) atomicAdd(&dense[i], (u64)v);
+    }
+}
+__global__ __launch_bounds__(BLOCK) void ntable_lookup_kernel(const u64 *__restrict__ ntab, PartGeom g, const u64 *keys, u64 n, u64 *out) {
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const u64 key = keys[i];
+        const u64 H = part_hash(g, key);
+        const u64 region = g.rbits ? (H >> (64 - g.rbits)) : 0ull;
+        const uint32_t pay = Pay<uint32_t>::make(key, H, g);
+        const u64 *reg = ntab + region * REGION_SLOTS;
+        uint32_t off = narrow_start(g, pay);
+        u64 res = 0;
+        for (uint32_t probes = 0; probes < REGION_SLOTS; ++probes) {
+            const u64 sl = reg[off];
+            if ((sl >> 32) == 0) break;
+            if ((uint32_t)sl == pay) { res = sl >> 32; break; }
+            off = (off + 1) & REGION_MASK;
+        }
+        out[i] = res;
+    }
+}
+
+// the overflow list through the direct path (after the region pass: the table then holds the batch's other k-mers).
+// NARROW: into the 8-byte image; an entry whose count would not fit stays in the list (ctr->narrow_ovf counts them), every
+// other entry is marked consumed (region = ~0), so that the host can widen the table and run the wide form over what is left.
+template <typename PT, bool NARROW>
+__global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeom g, OvfEntry *__restrict__ list,
+                                                           const u64 *__restrict__ ovf, u64 ovf_cap, Counters *ctr, u64 *__restrict__ ntab) {
     // ovf[0] is a CURSOR, advanced by whole segments (part2_arena_kernel, ovf_refill): a workgroup's last segment may
     // straddle or lie beyond the list's end without the "list full" flag ever being raised (nothing was appended there).
     // Entries are only ever written, and unused ones only ever marked invalid, below ovf_cap: never read past it.
     const u64 n = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;
     uint32_t nd = 0, nf = 0;
-    u64 km = 0;
+    u64 km = 0, kept = 0;
     const u64 nround = (n + BLOCK - 1) / BLOCK * BLOCK;  // (whole waves take part in the ballots)
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < nround; i += (u64)gridDim.x * BLOCK) {
         OvfEntry e;
         e.region = 0xFFFFFFFFu;
         e.pay = 0;
         if (i < n) e = list[i];
-        bool mine = e.region != 0xFFFFFFFFu;
-        km += mine;
-        const u64 key = mine ? Pay<PT>::key((PT)e.pay, e.region >> g.p2_bits, g) : 0ull;
+        const bool valid = e.region != 0xFFFFFFFFu;
+        bool mine = valid;
+        const u64 key = NARROW ? (((u64)e.region << 32) | (uint32_t)e.pay)  // (identity inside the image: region + payload)
+                               : (mine ? Pay<PT>::key((PT)e.pay, e.region >> g.p2_bits, g) : 0ull);
         // skew guard as in count_direct_kernel: an overflow list is mostly copies of a few heavy keys
         u64 weight = 1;
+        int first = -1;
+        bool absorbed = false;
         const u64 vmask = __ballot(mine);
         if (vmask) {
-            const int first = __builtin_ctzll(vmask);
+            first = __builtin_ctzll(vmask);
             const u64 lead = __shfl(key, first, 64);
             const bool same = mine && key == lead;
             const u64 smask = __ballot(same);
             if (__builtin_popcountll(smask) > 1) {
                 if ((int)lane_id() == first) weight = (u64)__builtin_popcountll(smask);
-                else if (same) mine = false;
+                else if (same) {
+                    mine = false;
+                    absorbed = true;
+                }
             }
         }
-        if (mine) upsert(tg, key, weight, nd, nf);
+        bool ok = true;
+        if (mine) {
+            if (NARROW) ok = narrow_upsert(ntab + (u64)e.region * REGION_SLOTS, g, (uint32_t)e.pay, weight, nd, nf);
+            else upsert(tg, key, weight, nd, nf);
+        }
+        if (NARROW) {
+            const bool lead_ok = first >= 0 ? (bool)__shfl((int)ok, first, 64) : true;
+            if (absorbed) ok = lead_ok;
+            if (valid && ok) list[i].region = 0xFFFFFFFFu;  // consumed
+            if (valid && !ok) ++kept;
+            km += (valid && ok) ? 1 : 0;
+        } else {
+            km += valid;
+        }
     }
     const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
     km = wave_sum(km);
+    kept = wave_sum(kept);
     if (lane_id() == 0) {
         if (d) atomicAdd(&ctr->distinct, d);
         if (f) atomicAdd(&ctr->failed, f);
         if (km) atomicAdd(&ctr->kmers, km);
+        if (kept) atomicAdd(&ctr->narrow_ovf, kept);
     }
 }
 
@@ -1289,12 +1438,19 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
 //     inserted by a single lane at write-back.
 // A failed region is left untouched in HBM; its bucket then goes through the direct path.
 
-template <bool FRESH>
+// NARROW (round 3): the table image this pass reads and writes is the 8-byte form -- one u64 per slot, count << 32 | the
+// slot's 32-bit payload (the very word the partition buffers carry), 0 = free: `ntab`, laid out like the table (region r
+// = slots [4096 r, 4096 (r + 1))).  Half the bytes of the 16-byte {key, count} slots on the way out (and, on a pass over
+// a filled table, on the way in), no inverse hash at the write-back, half the registers for the old slots.  The key of a
+// narrow slot is Pay<uint32_t>::key(payload, region >> p2_bits, g): ntable_widen_kernel turns the image into the 16-byte
+// table when something needs that (kmerhip.hip ensure_wide); counting, histogram, compaction and lookups read it as it is.
+// A count that does not fit 32 bits fails the region (rfail = 2): the host widens the table and re-inserts the bucket.
+template <bool FRESH, bool NARROW>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr,
-                                                                   u64 *__restrict__ rreal) {
+                                                                   u64 *__restrict__ rreal, u64 *__restrict__ ntab) {
     // rreal[r] = payloads of the bucket that are k-mers (the bucket may hold SENTINELS, payloads with another
     // level-2 digit that pad its segments to whole lines: part2_scatter_lines_kernel; they are skipped here)
     // head_cb != 0 (FRESH only): also leave in rheads[r] the number of 32-bit exchange heads the region
@@ -1309,8 +1465,16 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bend[r];
+    auto write_empty = [&]() {
+        if (NARROW) {
+            uint4 *o4 = reinterpret_cast<uint4 *>(ntab + r * REGION_SLOTS);
+            for (uint32_t i = tid; i < REGION_SLOTS / 2; i += REGION_NT) o4[i] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            write_empty_region(tg.table + r * REGION_SLOTS, tid);
+        }
+    };
     if (lo == hi) {
-        if (FRESH && dirty) write_empty_region(tg.table + r * REGION_SLOTS, tid);
+        if (FRESH && dirty) write_empty();
         if (tid == 0) {
             rnew[r] = 0;
             rreal[r] = 0;
@@ -1319,7 +1483,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         return;
     }
     if (hi - lo >= 0xFFFFFFFFull) {  // a 32-bit delta could wrap
-        if (FRESH && dirty) write_empty_region(tg.table + r * REGION_SLOTS, tid);
+        if (FRESH && dirty) write_empty();
         if (tid == 0) {
             rfail[r] = 1;
             rnew[r] = 0;
@@ -1347,14 +1511,25 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         const uint32_t i = (uint32_t)j * REGION_NT + tid;
         kbuf[j] = src[i < n ? i : n - 1];
     }
-    Slot old[R32_SLOTS_PER_LANE];
+    Slot old[NARROW ? 1 : R32_SLOTS_PER_LANE];
+    u64 oldn[NARROW ? R32_SLOTS_PER_LANE : 1];  // the narrow form of the lane's old slots
+    const u64 *const nreg = NARROW ? ntab + r * REGION_SLOTS : nullptr;
     bool unrepresentable = false;
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
 #pragma unroll
     for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
         const uint32_t i = (uint32_t)q * REGION_NT + tid;
         uint32_t w = R32_FREE;
-        if (FRESH) {
+        if (NARROW) {
+            oldn[q] = FRESH ? 0ull : nreg[i];
+            if (oldn[q] >> 32) {  // live: the payload is stored as it is probed for
+                w = (uint32_t)oldn[q];
+                if (w == R32_FREE) {  // (see below: the slot must not look free)
+                    if (g.p2_bits) w = 0u;
+                    else unrepresentable = true;
+                }
+            }
+        } else if (FRESH) {
             old[q].key = KH_EMPTY_KEY;
             old[q].count = 0;
         } else {
@@ -1477,9 +1652,20 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         uint32_t probes = 0;
         bool is_new = false;
         for (; probes < REGION_SLOTS; ++probes, off = (off + 1) & REGION_MASK) {
-            const u64 o = FRESH ? (u64)KH_EMPTY_KEY : reg[off].key;
-            if (o == key) break;
-            if (o == KH_EMPTY_KEY && s_pay[off] == R32_FREE) {
+            bool old_is_key = false, old_is_free = true;  // what the table held in this slot before the batch
+            if (!FRESH) {
+                if (NARROW) {
+                    const u64 ns = nreg[off];
+                    old_is_free = (ns >> 32) == 0;
+                    old_is_key = !old_is_free && (uint32_t)ns == R32_FREE;  // (in a narrow image the payload IS the key's identity)
+                } else {
+                    const u64 o = reg[off].key;
+                    old_is_free = o == KH_EMPTY_KEY;
+                    old_is_key = o == key;
+                }
+            }
+            if (old_is_key) break;
+            if (old_is_free && s_pay[off] == R32_FREE) {
                 is_new = true;
                 break;
             }
@@ -1493,18 +1679,48 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         }
     }
     __syncthreads();
+    const uint32_t sp_off = s_special ? s_sp_off : 0xFFFFFFFFu;
+    if (NARROW && !s_fail) {  // would a count leave 32 bits?  Then nothing of the region is written (uniform decision: two barriers)
+        bool wide_cnt = false;
+#pragma unroll
+        for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
+            const uint32_t i = (uint32_t)q * REGION_NT + tid;
+            const u64 cc = (oldn[q] >> 32) + s_add[i] + (i == sp_off ? s_special : 0u);
+            wide_cnt |= cc > 0xFFFFFFFFull;
+        }
+        if (wide_cnt) s_fail = 2;
+        __syncthreads();
+    }
     if (s_fail) {
-        if (FRESH && dirty) write_empty_region(reg, tid);
+        if (FRESH && dirty) write_empty();
         if (tid == 0) {
-            rfail[r] = 1;
+            rfail[r] = (uint8_t)s_fail;
             rnew[r] = 0;
         }
         return;
     }
-    const uint32_t sp_off = s_special ? s_sp_off : 0xFFFFFFFFu;
     uint4 *o4 = reinterpret_cast<uint4 *>(reg);
     uint32_t nheads = 0;
     bool too_wide = false;
+    if (NARROW) {
+        u64 *const nout = ntab + r * REGION_SLOTS;
+#pragma unroll
+        for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
+            const uint32_t i = (uint32_t)q * REGION_NT + tid;
+            const uint32_t delta = s_add[i];
+            u64 cc = (oldn[q] >> 32) + delta;
+            uint32_t pp = (oldn[q] >> 32) ? (uint32_t)oldn[q] : s_pay[i];  // an old slot keeps its payload; a new one's is in the image
+            if (i == sp_off) {
+                if (s_sp_new) pp = R32_FREE;
+                cc += s_special;
+            }
+            nout[i] = cc ? ((cc << 32) | pp) : 0ull;
+            if (FRESH && head_cb && cc) {
+                nheads += (uint32_t)((cc + (1ull << head_cb) - 1) >> head_cb);
+                too_wide |= cc > (64ull << head_cb);
+            }
+        }
+    } else
 #pragma unroll
     for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
         const uint32_t i = (uint32_t)q * REGION_NT + tid;

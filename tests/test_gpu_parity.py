@@ -1197,3 +1197,91 @@ def test_written_out_window_every_k(K, k, minq):
         assert st["kmers"] == m.total() and st["part_batches"] == 3 and st["table_slots"] == 1 << 24
         keys, cnts = dc.result()
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
+
+
+@pytest.mark.parametrize("narrow", ["1", "0"], ids=["narrow-image", "wide-only"])
+@pytest.mark.parametrize("k", [21, 17, 13])
+def test_narrow_table_image_and_its_transitions(K, monkeypatch, k, narrow):
+    """Round 3: a partitioned pass with 32-bit payloads keeps the table as an 8-byte image (count << 32 | payload) and only
+    widens it to 16-byte {key, count} slots when something needs those.  One table through every transition: fresh narrow
+    pass -> pass over the narrow image -> results / histogram / lookups / min-count straight from the image -> a small push
+    (direct path: widens) -> another partitioned pass (stays wide) -> reset -> narrow again.  Against the oracle at every
+    step, and with KMERHIP_NARROW=0 (never narrow) for the same answers."""
+    monkeypatch.setenv("KMERHIP_NARROW", narrow)
+    n_reads = 90_000
+    bases, _ = O.synth_reads(SEED + 3 * k, 1 << 19, 150, 0, n_reads, with_qual=False)
+    import torch
+    tb = torch.from_numpy(bases.copy()).cuda()
+    torch.cuda.synchronize()
+
+    def oracle(upto):
+        m = O.OracleMap()
+        m.scan_flat(bases[: upto * 151], k, nthreads=NCPU)
+        return m
+
+    def check(dc, m):
+        wk, wc = m.arrays()
+        st = dc.finish()
+        assert st["kmers"] == m.total() and st["distinct"] == len(m)
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, wk) and np.array_equal(cnts, wc)
+        sel = wc >= 3
+        k3, c3 = dc.result(min_count=3)
+        assert np.array_equal(k3, wk[sel]) and np.array_equal(c3, wc[sel]) and dc.result_size(3) == int(sel.sum())
+        hist = dc.histogram()
+        u, f = np.unique(wc, return_counts=True)
+        assert hist == list(zip(u.tolist(), f.tolist()))
+        probe = np.concatenate([wk[:: max(1, wk.size // 5000)], np.array([0, 1, (1 << (2 * k)) - 1], dtype=np.uint64)])
+        want = np.array([m.as_dict().get(int(x), 0) for x in probe[-3:]], dtype=np.uint64)
+        got = dc.lookup(probe)
+        assert np.array_equal(got[:-3], wc[:: max(1, wk.size // 5000)]) and np.array_equal(got[-3:], want)
+
+    with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:
+        dc.push_device(tb.data_ptr(), None, 40_000 * 151)                      # fresh
+        check(dc, oracle(40_000))
+        dc.push_device(tb.data_ptr() + 40_000 * 151, None, 30_000 * 151)       # over the image
+        check(dc, oracle(70_000))
+    with K.DeviceCounter(k, capacity_hint=6_000_000) as dc:                    # path chosen per push
+        dc.push_device(tb.data_ptr(), None, 60_000 * 151)                      # partitioned (fresh)
+        dc.push_device(tb.data_ptr() + 60_000 * 151, None, 2_000 * 151)        # small: the direct path -- the image is widened
+        check(dc, oracle(62_000))
+        dc.push_device(tb.data_ptr() + 62_000 * 151, None, 28_000 * 151)       # partitioned over the 16-byte table
+        check(dc, oracle(90_000))
+        dc.reset()
+        dc.push_device(tb.data_ptr(), None, 40_000 * 151)                      # fresh again after the reset
+        check(dc, oracle(40_000))
+
+
+def test_count_beyond_32_bits(K):
+    """a count of 2^32 and more (poly-A pushed batch after batch).  The 8-byte table image keeps 32-bit
+    counts: the region pass that would take a count past them fails that region (code 2), the host widens the table to
+    16-byte slots, re-inserts the bucket and stays wide.  u64 counts are the reference's range (src/run.rs:569)."""
+    k = 21
+    rng = np.random.default_rng(5)
+    n_a = 1_600_000
+    poly = np.full((n_a, 151), ord("A"), dtype=np.uint8)
+    poly[:, 150] = 10
+    other, _ = O.synth_reads(SEED, 1 << 18, 150, 0, 50_000, with_qual=False)
+    m = O.OracleMap()
+    m.scan_flat(other, k, nthreads=NCPU)
+    wk, wc = m.arrays()
+    import torch
+    ta = torch.from_numpy(poly.reshape(-1)).cuda()
+    to = torch.from_numpy(other.copy()).cuda()
+    torch.cuda.synchronize()
+    per_push = n_a * 130
+    pushes = (1 << 32) // per_push + 2
+    with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:
+        dc.push_device(to.data_ptr(), None, to.numel())
+        for _ in range(pushes):
+            dc.push_device(ta.data_ptr(), None, ta.numel())
+        st = dc.finish()
+        want0 = pushes * per_push + int(m.as_dict().get(0, 0))
+        assert want0 > 1 << 32
+        assert st["kmers"] == m.total() + pushes * per_push
+        assert int(dc.lookup(np.array([0], dtype=np.uint64))[0]) == want0
+        keys, cnts = dc.result()
+        exp = dict(m.as_dict())
+        exp[0] = want0
+        assert dict(zip(keys.tolist(), cnts.tolist())) == exp
+        assert dc.histogram()[-1] == (want0, 1)
