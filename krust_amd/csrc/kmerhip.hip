@@ -830,9 +830,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     // The 8-byte table image (see kh_ctx::ntab): a fresh pass with 32-bit payloads writes it, a pass over a table that is
     // in that form updates it.  KMERHIP_NARROW=0: always the 16-byte table (A/B).
     const bool narrow_on = [] { const char *e = getenv("KMERHIP_NARROW"); return !(e && e[0] == '0'); }();
-    // (not for a rank of a multi-GPU run: the exports of kh_merge_across read the 16-byte table, the widening would cost
-    //  more there than the image saves)
-    bool nar = sizeof(PT) == 4 && narrow_on && !c->narrow_banned && !c->shard_shift && !c->comm && (c->table_empty || c->narrow);
+    bool nar = sizeof(PT) == 4 && narrow_on && !c->narrow_banned && !c->shard_shift && (c->table_empty || c->narrow);
     if (nar && c->ntab_cap != c->cap) {
         if (c->ntab) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2033,9 +2031,18 @@ enum { XF_WIDE = 0, XF_PACKED64 = 1, XF_HEADS32 = 2 };  // exchange unit formats
 
 
 // fmt XF_PACKED64: one u64 per pair into d_keys (d_counts unused); XF_HEADS32: u32 heads into d_keys
+// what the export kernels read: the 16-byte table, or its 8-byte image while that holds the counts
+kh::SlotSrc slot_src(const kh_ctx *c) {
+    kh::SlotSrc s;
+    s.table = c->table;
+    s.ntab = c->narrow ? c->ntab : nullptr;
+    s.p2_bits = c->narrow ? c->narrow_g.p2_bits : 0;
+    return s;
+}
+
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap,
                    uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, fmt != XF_WIDE);  // (packed and heads come straight out of the 8-byte image)
     if (rc != KH_OK) return rc;
     const bool packed = fmt != XF_WIDE;
     const u64 nregions = c->cap / kh::REGION_SLOTS;
@@ -2063,10 +2070,10 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
         rc = zero_cursors(c);
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           (const Slot *)c->table, (uint32_t)cb, d_region_counts, &c->d_ctr->big);
+                           slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big);
     } else {
         hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           (const Slot *)c->table, d_region_counts);
+                           slot_src(c), d_region_counts);
     }
     HIP_TRY(c, hipGetLastError());
     if (c->win_n > 1) {
@@ -2100,20 +2107,20 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
     if (total && (!d_keys || (!packed && !d_counts))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
     if (total && fmt == XF_HEADS32) {
         hipLaunchKernelGGL(kh::region_compact_heads_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           (const Slot *)c->table, (const u64 *)c->merge_off, region_bits(c->cap), c->k, (uint32_t)cb,
+                           slot_src(c), (const u64 *)c->merge_off, region_bits(c->cap), c->k, (uint32_t)cb,
                            (uint32_t *)d_keys);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     } else if (total && !packed) {
         hipLaunchKernelGGL(kh::region_compact_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           (const Slot *)c->table, (const u64 *)c->merge_off, (u64 *)d_keys, (u64 *)d_counts);
+                           (const Slot *)c->table, (const u64 *)c->merge_off, (u64 *)d_keys, (u64 *)d_counts);  // (XF_WIDE: enter() widened)
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     } else if (total) {
         rc = zero_cursors(c);
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL(kh::region_compact_packed_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           (const Slot *)c->table, (const u64 *)c->merge_off, region_bits(c->cap), c->k, (u64 *)d_keys,
+                           slot_src(c), (const u64 *)c->merge_off, region_bits(c->cap), c->k, (u64 *)d_keys,
                            &c->d_ctr->big);
         HIP_TRY(c, hipGetLastError());
         u64 wide = 0;
@@ -2129,7 +2136,7 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
 // the window) -- what a pipelined exchange needs to announce the sizes of ALL its pieces up front.
 extern "C" int kh_region_unit_counts_device(kh_ctx *c, uint32_t unit_bytes, uint32_t *d_region_counts, uint64_t region_cap,
                                             uint64_t *table_regions) {
-    int rc = enter(c);
+    int rc = enter(c, true, true, false, true);
     if (rc != KH_OK) return rc;
     if (unit_bytes != 4 && unit_bytes != 8 && unit_bytes != 16) return fail(c, KH_ERR_BAD_ARG, "unit_bytes is 4 (heads), 8 (packed) or 16 (pairs)");
     const u64 nregions = c->cap / kh::REGION_SLOTS;
@@ -2149,7 +2156,7 @@ extern "C" int kh_region_unit_counts_device(kh_ctx *c, uint32_t unit_bytes, uint
             rc = zero_cursors(c);
             if (rc != KH_OK) return rc;
             hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                               (const Slot *)c->table, (uint32_t)cb, d_region_counts, &c->d_ctr->big);
+                               slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big);
             HIP_TRY(c, hipGetLastError());
             u64 wide = 0;
             rc = read_cursor(c, nullptr, &wide);
@@ -2158,7 +2165,7 @@ extern "C" int kh_region_unit_counts_device(kh_ctx *c, uint32_t unit_bytes, uint
         }
     } else {
         hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           (const Slot *)c->table, d_region_counts);
+                           slot_src(c), d_region_counts);
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -11,15 +11,48 @@
 
 namespace kh {
 
+// What an export reads: the 16-byte table, or (ntab != nullptr) its 8-byte image -- count << 32 | the 32-bit payload
+// of the partition passes, whose bits below the level-2 digit ARE the hash bits below the region index that the packed
+// and the heads formats carry (round 3: a rank's table can stay in the narrow form through the exchange).
+struct SlotSrc {
+    const Slot *table;
+    const u64 *ntab;
+    uint32_t p2_bits;  // narrow: the level-2 digit on top of every payload (the image's geometry)
+};
+struct SlotVal {
+    bool live;
+    u64 count;
+    u64 key_or_pay;  // wide: the key; narrow: the payload
+};
+__device__ __forceinline__ SlotVal slot_read(const SlotSrc &src, u64 i) {
+    SlotVal v;
+    if (src.ntab) {
+        const u64 sl = src.ntab[i];
+        v.count = sl >> 32;
+        v.live = v.count != 0;
+        v.key_or_pay = (uint32_t)sl;
+    } else {
+        const Slot s = src.table[i];
+        v.live = s.key != KH_EMPTY_KEY;
+        v.count = s.count;
+        v.key_or_pay = s.key;
+    }
+    return v;
+}
+// bits [rbits, rbits + 32) of the slot's table hash
+__device__ __forceinline__ uint32_t slot_hash_below_region(const SlotSrc &src, const SlotVal &v, uint32_t rbits, uint32_t k) {
+    if (src.ntab) return (uint32_t)v.key_or_pay << src.p2_bits;
+    return (uint32_t)((kh_table_hash(v.key_or_pay, k) << rbits) >> 32);
+}
+
 // rcount[r] = live slots of region r.  One workgroup per region.
-__global__ __launch_bounds__(BLOCK) void region_live_count_kernel(const Slot *__restrict__ table, uint32_t *__restrict__ rcount) {
+__global__ __launch_bounds__(BLOCK) void region_live_count_kernel(SlotSrc src, uint32_t *__restrict__ rcount) {
     __shared__ uint32_t s_n;
     const u64 r = blockIdx.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const Slot *reg = table + r * REGION_SLOTS;
     uint32_t n = 0;
-    for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) n += reg[i].key != KH_EMPTY_KEY;
+    for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) n += slot_read(src, r * REGION_SLOTS + i).live;
     n = (uint32_t)wave_sum((u64)n);
     if (lane_id() == 0 && n) atomicAdd(&s_n, n);
     __syncthreads();
@@ -56,7 +89,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__res
 // table hash.  The receiver knows the region index of every segment, so these 32 bits identify the
 // key whenever 2k - rbits <= 32 (the hash is a bijection); halves the bytes on the xGMI links.
 // *wide is raised if a count does not fit 32 bits (the caller then uses the unpacked export).
-__global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(const Slot *__restrict__ table, const u64 *__restrict__ roff,
+__global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc src, const u64 *__restrict__ roff,
                                                                       uint32_t rbits, uint32_t k, u64 *__restrict__ pairs,
                                                                       u64 *__restrict__ wide) {
     __shared__ uint32_t s_cur;
@@ -65,20 +98,18 @@ __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(const Slot
     if (roff[r + 1] == base) return;
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
-    const Slot *reg = table + r * REGION_SLOTS;
     bool too_wide = false;
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {
-        const Slot s = reg[i];
-        const bool live = s.key != KH_EMPTY_KEY;
+        const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
+        const bool live = s.live;
         const u64 m = __ballot(live);
         if (m == 0) continue;
         uint32_t wbase = 0;
         if ((int)lane_id() == __builtin_ctzll(m)) wbase = atomicAdd(&s_cur, (uint32_t)__builtin_popcountll(m));
         wbase = (uint32_t)__shfl((int)wbase, __builtin_ctzll(m), 64);
         if (live) {
-            const u64 H = kh_table_hash(s.key, k);
             too_wide |= (s.count >> 32) != 0;
-            pairs[base + wbase + mbcnt(m)] = (s.count << 32) | (uint32_t)((H << rbits) >> 32);
+            pairs[base + wbase + mbcnt(m)] = (s.count << 32) | slot_hash_below_region(src, s, rbits, k);
         }
     }
     if (__any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
@@ -92,18 +123,17 @@ __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(const Slot
 // 23 hash bits + 9 count bits, 4 bytes per pair instead of 16.
 __device__ __forceinline__ uint32_t heads_of(u64 count, uint32_t cb) { return (uint32_t)((count + (1ull << cb) - 1) >> cb); }
 
-__global__ __launch_bounds__(BLOCK) void region_head_count_kernel(const Slot *__restrict__ table, uint32_t cb,
+__global__ __launch_bounds__(BLOCK) void region_head_count_kernel(SlotSrc src, uint32_t cb,
                                                                   uint32_t *__restrict__ rcount, u64 *__restrict__ wide) {
     __shared__ uint32_t s_n;
     const u64 r = blockIdx.x;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const Slot *reg = table + r * REGION_SLOTS;
     uint32_t n = 0;
     bool too_wide = false;
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {
-        const Slot s = reg[i];
-        if (s.key == KH_EMPTY_KEY) continue;
+        const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
+        if (!s.live) continue;
         too_wide |= s.count > (64ull << cb);
         n += too_wide ? 1u : heads_of(s.count, cb);
     }
@@ -115,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void region_head_count_kernel(const Slot *__
 }
 
 // Heads of region r go to [roff[r], roff[r+1]) (any order inside the region).
-__global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(const Slot *__restrict__ table, const u64 *__restrict__ roff,
+__global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src, const u64 *__restrict__ roff,
                                                                      uint32_t rbits, uint32_t k, uint32_t cb,
                                                                      uint32_t *__restrict__ heads) {
     __shared__ uint32_t s_cur;
@@ -124,11 +154,10 @@ __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(const Slot 
     if (roff[r + 1] == base) return;
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
-    const Slot *reg = table + r * REGION_SLOTS;
     const uint32_t cmask = (1u << cb) - 1u;
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {  // uniform trip count
-        const Slot s = reg[i];
-        const bool live = s.key != KH_EMPTY_KEY;
+        const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
+        const bool live = s.live;
         const uint32_t nh = live ? heads_of(s.count, cb) : 0u;
         // wave-inclusive prefix of nh
         uint32_t incl = nh;
@@ -143,8 +172,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(const Slot 
         if (lane_id() == 63) wbase = atomicAdd(&s_cur, wtotal);
         wbase = (uint32_t)__shfl((int)wbase, 63, 64);
         if (live) {
-            const u64 H = kh_table_hash(s.key, k);
-            const uint32_t hw = (uint32_t)((H << rbits) >> 32) & ~cmask;  // the hb hash bits, top-aligned
+            const uint32_t hw = slot_hash_below_region(src, s, rbits, k) & ~cmask;  // the hb hash bits, top-aligned
             u64 o = base + wbase + (incl - nh);
             u64 left = s.count;
             for (uint32_t h = 0; h < nh; ++h) {
