@@ -1051,6 +1051,10 @@ __global__ __launch_bounds__(BLOCK) void ntable_lookup_kernel(const u64 *__restr
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
+        if (key & ~kh_kmask(g.k)) {  // not a k-mer of this k (the hash only looks at 2k bits: it must not alias one)
+            out[i] = 0;
+            continue;
+        }
         const u64 H = part_hash(g, key);
         const u64 region = g.rbits ? (H >> (64 - g.rbits)) : 0ull;
         const uint32_t pay = Pay<uint32_t>::make(key, H, g);

@@ -1235,6 +1235,8 @@ def test_narrow_table_image_and_its_transitions(K, monkeypatch, k, narrow):
         want = np.array([m.as_dict().get(int(x), 0) for x in probe[-3:]], dtype=np.uint64)
         got = dc.lookup(probe)
         assert np.array_equal(got[:-3], wc[:: max(1, wk.size // 5000)]) and np.array_equal(got[-3:], want)
+        # a key with bits beyond 2k is no k-mer of this k: absent, not an alias of the k-mer in its low bits
+        assert not dc.lookup(wk[:100] | np.uint64(1 << 63)).any() and not dc.lookup(wk[:100] | np.uint64(1 << (2 * k))).any()
 
     with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:
         dc.push_device(tb.data_ptr(), None, 40_000 * 151)                      # fresh

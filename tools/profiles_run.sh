@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-}"   # BENCH_ARGS: e.g. "--k 31 --min-quality 20"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-extras --no-verify ${BENCH_ARGS:-}"   # BENCH_ARGS: e.g. "--k 31 --min-quality 20"
 # 1) per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 # 2) counters, each in its own pass (TCC has 4 slots: FETCH_SIZE=3, WRITE_SIZE=2)

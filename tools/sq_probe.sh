@@ -5,7 +5,7 @@ TAG=${1:-sq}
 OUT=$PWD/gpurun_out/sq_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-verify ${BENCH_ARGS:-}"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p1 -- python3 bench.py $ARGS > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/p2 -- python3 bench.py $ARGS > $OUT/p2.log 2>&1
 python3 - <<PY
