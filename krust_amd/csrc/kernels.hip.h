@@ -34,6 +34,7 @@ struct Counters {
     u64 part_failed;  // regions that overflowed in region_count_kernel (re-inserted after growth)
     u64 heads_wide;   // a count too large for 32-bit exchange heads was seen (region_count_kernel32)
     u64 narrow_ovf;   // overflow-list entries whose count would not fit the 8-byte table image (left in the list: ovf_insert_kernel)
+    u64 hot;          // buckets the region pass left to hot_buckets_kernel (hot_list_kernel counts them; partition.hip.h)
 };
 
 constexpr int BLOCK = 256;           // 4 waves of 64
@@ -71,6 +72,17 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
 constexpr uint32_t REGION_BITS = KH_REGION_BITS;
 constexpr uint32_t REGION_SLOTS = 1u << REGION_BITS;
 constexpr uint32_t REGION_MASK = REGION_SLOTS - 1;
+// A key's probe sequence inside its region starts at an EVEN slot (and goes on slot by slot from there): the region pass
+// then sees the two slots a key most likely sits in with ONE 8-byte LDS read (region_count_kernel32: at load 0.5 a key is in
+// its home slot two times in three, in its home pair more than four times in five).  Everything that probes uses start_of /
+// narrow_start (or this mask), so the layout is one decision.  Measured (S100M, k = 21; 125 M reads at load 0.61), region
+// pass: groups of 1 / 2 / 4 slots 24.5 / 21.7 / 22.5 ms and 43.0 / 36.9 / 36.6 ms -- a 16-byte read costs the LDS twice the
+// cycles of an 8-byte one, and eight of them in flight do not fit the registers of two workgroups per CU.
+#ifndef KH_REGION_GROUP
+#define KH_REGION_GROUP 2  // 1, 2 or 4 (A/B builds: make VARIANT=_g4 EXTRA=-DKH_REGION_GROUP=4)
+#endif
+constexpr uint32_t REGION_GROUP = KH_REGION_GROUP;
+constexpr uint32_t REGION_START_MASK = REGION_MASK & ~(REGION_GROUP - 1);
 
 struct TableGeom {
     Slot *table;
@@ -84,7 +96,7 @@ struct TableGeom {
 __device__ __forceinline__ u64 table_hash(const TableGeom &tg, u64 key) { return kh_table_hash(key, tg.k) << tg.shard_shift; }
 __device__ __forceinline__ u64 region_of(const TableGeom &tg, u64 H) { return H >> (64 - tg.rbits); }
 __device__ __forceinline__ uint32_t start_of(const TableGeom &tg, u64 H) {
-    return (uint32_t)(H >> (64 - tg.rbits - REGION_BITS)) & REGION_MASK;
+    return (uint32_t)(H >> (64 - tg.rbits - REGION_BITS)) & REGION_START_MASK;
 }
 
 __device__ __forceinline__ void count_add(Slot *s, u64 addend) {
@@ -479,6 +491,29 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
         if (d) atomicAdd(&ctr->distinct, d);
         if (f) atomicAdd(&ctr->failed, f);
     }
+}
+
+// How many windows of a range survive masking (N, soft-masked, quality below the threshold)?  Counted over every
+// `stride`-th 4096-position tile: the host sizes the partition buffers of a quality-masked range from this instead of
+// from "every window" (kmerhip.hip, count_device_range; a wrong estimate costs a retry, never a result).
+template <bool QUAL>
+__global__ __launch_bounds__(BLOCK) void survival_sample_kernel(
+    const uint8_t *__restrict__ abase, const uint8_t *__restrict__ qbase, int qaligned, u64 vbeg, u64 vend,
+    u64 wlo, u64 tile0, u64 ntiles, u64 stride, uint32_t k, uint32_t thr, u64 *__restrict__ out) {
+    __shared__ uint32_t s_code[2][BLOCK + 2];
+    __shared__ uint16_t s_val[2][BLOCK + 2];
+    // (a workgroup per sampled tile would be 4 same-address atomics each: 230 k of them at ~10 ns took 2.8 ms on S100M; a
+    //  fixed grid, every workgroup over its share of the sampled tiles, one atomic per wave at the end: 0.1 ms)
+    uint32_t n = 0;
+    int buf = 0;
+    for (u64 t = tile0 + (u64)blockIdx.x * stride; t < tile0 + ntiles; t += (u64)gridDim.x * stride, buf ^= 1) {
+        const WinCtx w = stage_tile<QUAL, BLOCK>(s_code, s_val, buf, true, (int)threadIdx.x, abase, qbase, qaligned, t, vbeg, vend, thr);
+        n += (uint32_t)__builtin_popcount(window_good(w, k, wlo));
+        __syncthreads();  // (stage_tile carries this tile's last words into the other buffer's look-back slots, which the next
+                          //  -- not consecutive -- tile fills from memory: keep the two writes apart)
+    }
+    const u64 s = wave_sum((u64)n);
+    if (lane_id() == 0 && s) atomicAdd(out, s);
 }
 
 #ifndef KH_HELPERS_ONLY  // (the level-1 translation units take the helpers above, not the kernels below: one definition each)

@@ -124,6 +124,7 @@ struct kh_ctx {
     bool table_dirty = false;  // kh_reset is lazy: the slots hold stale data that the next operation either
                                // overwrites wholesale (a FRESH region pass) or clears first (everything else)
     bool hinted = false;       // caller gave a capacity hint
+    double new_rate = -1.0;    // new keys per window of the last partitioned range (-1: none yet): sizes an unhinted table
     int path_mode = 0;         // 0 auto, 1 force direct, 2 force partitioned
     int pay_mode = 0;          // 0 auto, 64 = always 64-bit payloads (env KMERHIP_PAYLOAD=64, for A/B)
     uint32_t shard_shift = 0;  // table holds shard `shard_index` of 2^shard_shift (kh_set_shard)
@@ -150,6 +151,7 @@ struct kh_ctx {
     bool rheads_wide = false;
     uint32_t rheads_cb = 0;
     u64 *bend = nullptr;             // arena path: end of every region's data (the exact path uses bstart + 1)
+    uint32_t *hot_list = nullptr;    // [regions] buckets left to hot_buckets_kernel (partition.hip.h)
     u64 *ptotal = nullptr;           // [MAX_P1] payloads per level-1 partition
     uint32_t *pcap = nullptr;        // [MAX_P1] arena capacity of that partition's buckets
     uint8_t *heavy = nullptr;        // [MAX_P1] the partition is too heavy for one workgroup: the exact kernels take it
@@ -514,7 +516,22 @@ struct RangeArgs {
     int qaligned;
     bool use_qual;
     u64 vbeg, vend, wlo;
+    // share of the range's windows expected to survive masking (1 = size the partition buffers for every window);
+    // below 1 only for quality-masked ranges, from survival_sample_kernel -- see sized_for()
+    double survive = 1.0;
 };
+
+// Internal result of partition_batch: the level-1 pool, sized from RangeArgs::survive, ran out -- nothing but the pool
+// was written; the caller runs the same tiles again sized for every window.
+constexpr int KH_RETRY_FULL_SIZE = 1000;
+
+// payloads to make room for when at most n windows exist and a share `survive` of them is expected to be countable:
+// an eighth over the estimate plus a 64th of the windows (the sample is a 64th of the tiles)
+u64 sized_for(u64 n, double survive) {
+    if (survive >= 1.0) return n;
+    const double e = (double)n * (survive * 1.125 + 1.0 / 64) + 65536.0;
+    return e >= (double)n ? n : (u64)e;
+}
 
 uint32_t qual_thr(const kh_ctx *c) {
     int t = c->minq + 33;  // saturating_add(33) on u8, run.rs:538
@@ -531,26 +548,26 @@ int head_count_bits(const kh_ctx *c, u64 regions) {
 
 // region rebuild launch, by payload type
 template <typename PT>
-void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow);
+void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip);
 template <>
-void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool) {
+void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool, u64 skip) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     if (c->table_empty)
         hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
+                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal, skip);
     else
         hipLaunchKernelGGL(kh::region_count_kernel64<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal);
+                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal, skip);
 }
 template <>
-void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow) {
+void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
     c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
     // (a narrow FRESH pass must write every region of the image whatever the table held: dirty = 1)
 #define KH_REGION32(FRESH, NARROW, DIRTY, CB, RH) \
     hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW>), dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g, \
-                       (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab)
+                       (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab, skip)
     if (c->table_empty && narrow) KH_REGION32(true, true, 1u, c->rheads_cb, c->rheads);
     else if (c->table_empty) KH_REGION32(true, false, (uint32_t)c->table_dirty, c->rheads_cb, c->rheads);
     else if (narrow) KH_REGION32(false, true, 0u, 0u, (uint32_t *)nullptr);
@@ -565,7 +582,9 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     constexpr bool CHUNKED = true;  // level 1 always goes into the chunk pool (partition.hip.h)
     const u64 nregions = 1ull << g.rbits;
     const u64 P1 = 1ull << g.p1_bits;
-    const u64 n_ub = ntiles * kh::PART_TILE;  // upper bound on keys
+    const u64 n_all = ntiles * kh::PART_TILE;  // every window of these tiles
+    const bool estimated = ra.survive < 1.0;
+    const u64 n_ub = sized_for(n_all, ra.survive);  // upper bound on keys (an estimate when `estimated`: checked after level 1)
     // chunk pool: every payload + one partial chunk per (workgroup, partition) + the unused tail of
     // every workgroup's private ranges
     const u64 pool_chunks = (n_ub / kh::CHUNK_PAY) + (n_ub / kh::CHUNK_PAY) / 24 + (u64)PART_G1 * (P1 + kh::POOL_GRAB) + 1024;
@@ -608,6 +627,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->rreal, &z, nregions, "hipMalloc(rreal)")) != KH_OK) return rc;
         z = c->bend ? c->region_cap : 0;
         if ((rc = ensure_buf(c, &c->bend, &z, nregions, "hipMalloc(bend)")) != KH_OK) return rc;
+        z = c->hot_list ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->hot_list, &z, nregions, "hipMalloc(hot_list)")) != KH_OK) return rc;
         c->region_cap = nregions;
     }
     if (c->pool_cap < pool_chunks) {
@@ -654,7 +675,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         c->keyb_cap = b_bytes;
     }
     PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);
-    if (arena) {
+    if (arena || estimated) {
         if (!c->ptotal) {
             u64 z = 0;
             if ((rc = ensure_buf(c, &c->ptotal, &z, (u64)kh::MAX_P1, "hipMalloc(ptotal)")) != KH_OK) return rc;
@@ -665,7 +686,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             z = 0;
             if ((rc = ensure_buf(c, &c->heavy, &z, (u64)kh::MAX_P1, "hipMalloc(heavy)")) != KH_OK) return rc;
         }
-        if (c->ovf_cap < ovf_need) {
+        if (arena && c->ovf_cap < ovf_need) {
             u64 z = c->ovf_list ? c->ovf_cap : 0;
             if ((rc = ensure_buf(c, &c->ovf_list, &z, ovf_need, "hipMalloc(ovf_list)")) != KH_OK) return rc;
             c->ovf_cap = ovf_need;
@@ -727,15 +748,34 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 #endif
         {
             StageTimer t(c, ST_MISC);
-            if (arena) HIP_TRY(c, hipMemsetAsync(c->ptotal, 0, kh::MAX_P1 * sizeof(u64), c->stream));
+            if (arena || estimated) HIP_TRY(c, hipMemsetAsync(c->ptotal, 0, kh::MAX_P1 * sizeof(u64), c->stream));
             hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
-                               (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, arena ? c->ptotal : (u64 *)nullptr);
+                               (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, (arena || estimated) ? c->ptotal : (u64 *)nullptr);
             if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
             hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
                                c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)nullptr);
             hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
                                (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
             HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
+        }
+        if (estimated) {
+            // Everything behind the pool is sized for n_ub payloads, an estimate: are there more?  (The pool itself has
+            // slack -- a partial chunk per workgroup and partition -- so level 1 may well have found room for them: what
+            // counts is the total, from chunk_hist_kernel; and payloads level 1 found no room for are in ctr->failed,
+            // which is 0 on entry.)  Nothing but the pool and its chunk lists has been written yet.
+            std::vector<u64> pt(kh::MAX_P1);
+            u64 lost = 0, total = 0;
+            HIP_TRY(c, hipMemcpyAsync(pt.data(), c->ptotal, kh::MAX_P1 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&lost, &c->d_ctr->failed, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (u64 p = 0; p < P1; ++p) total += pt[p];
+            if (lost || total > n_ub) {
+                HIP_TRY(c, hipMemsetAsync(&c->d_ctr->failed, 0, sizeof(u64), c->stream));
+                if (c->trace)
+                    fprintf(stderr, "[kmerhip] sized for %.3f of the windows (%llu payloads), found %llu%s: again at full size\n", ra.survive, n_ub,
+                            total, lost ? " and more that did not fit the pool" : "");
+                return KH_RETRY_FULL_SIZE;
+            }
         }
     }
     const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
@@ -848,10 +888,23 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     }
     if (!nar && c->narrow && (rc = ensure_wide(c)) != KH_OK) return rc;
     if (nar) c->narrow_g = g;
+    // A bucket holding more than a thousandth of the batch (and a million payloads) would keep ONE workgroup of the region
+    // pass busy for as long as the whole pass takes: the pass skips it, hot_buckets_kernel counts it afterwards (below).
+    // KMERHIP_HOT_CUT=n: another threshold (tests); 0 = no bucket is hot.
+    const u64 hot_cut = [&] {
+        const char *e = getenv("KMERHIP_HOT_CUT");
+        if (e) return e[0] == '0' && !e[1] ? ~0ull : (u64)strtoull(e, nullptr, 10);
+        return std::max<u64>(n_all >> 10, 1ull << 20);
+    }();
+    if (hot_cut != ~0ull) {
+        StageTimer t(c, ST_MISC);
+        hipLaunchKernelGGL(kh::hot_list_kernel, dim3((unsigned)((nregions + kh::BLOCK - 1) / kh::BLOCK)), dim3(kh::BLOCK), 0, c->stream,
+                           (const u64 *)c->bstart, bend, (u64)nregions, hot_cut, c->hot_list, c->d_ctr);
+    }
     {
         StageTimer t(c, ST_REGION);
         // buckets more than 4x the mean (upper bound) take the skew-guarded probing loop
-        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend, nar);
+        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend, nar, hot_cut);
     }
     if (nar) c->narrow = true;
     {
@@ -938,6 +991,22 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         rc = sync_counters(c);
         if (rc != KH_OK) return rc;
     }
+    if (c->h_ctr->hot) {
+        // the buckets the region pass skipped (see hot_cut above), spread over the whole grid, through device atomics on the
+        // 16-byte table -- which the table stays from here on: input like this is not what the 8-byte image is for
+        const u64 nhot = c->h_ctr->hot;
+        if (c->trace) fprintf(stderr, "[kmerhip] %llu hot bucket(s) (more than %llu payloads) counted apart from the region pass\n", nhot, hot_cut);
+        if ((rc = ensure_wide(c)) != KH_OK) return rc;
+        {
+            StageTimer t(c, ST_MISC);
+            hipLaunchKernelGGL(kh::hot_buckets_kernel<PT>, dim3(kh::HOT_GRID), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
+                               (const PT *)bufB, (const u64 *)c->bstart, bend, (const uint32_t *)c->hot_list, nhot, c->d_ctr);
+            HIP_TRY(c, hipMemsetAsync(&c->d_ctr->hot, 0, sizeof(u64), c->stream));
+        }
+        HIP_TRY(c, hipGetLastError());
+        c->rheads_valid = false;
+        if ((rc = sync_counters(c)) != KH_OK) return rc;
+    }
     if ((double)c->distinct_known > LOAD_PART * (double)c->cap) {
         u64 newcap = c->cap * 2;
         while ((double)c->distinct_known > LOAD_TARGET * (double)newcap) newcap *= 2;
@@ -1005,6 +1074,29 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     bool part = false;
     if (c->path_mode == 2) part = true;
     else if (c->path_mode == 0) part = windows >= PART_MIN_WINDOWS && (double)c->cap <= 7.0 * (double)windows;
+    if (part && ra.use_qual) {
+        // A quality-masked range: most windows may be gone (-Q 20 on typical reads keeps 0.4 of them at k = 31).  Count the
+        // survivors of every 64th 4096-position tile and size pool, arenas and batches from that instead of from "every
+        // window" -- configs[2] then runs as one batch instead of two.  KMERHIP_SURVIVAL=x: use x instead of the sample
+        // (tests: a far too small x exercises the retry); =1: size for every window.
+        const char *e = getenv("KMERHIP_SURVIVAL");
+        if (e && atof(e) > 0) {
+            ra.survive = std::min(1.0, atof(e));
+        } else {
+            const u64 t0 = ra.wlo / kh::TILE, t1 = (ra.vend + kh::TILE - 1) / kh::TILE, stride = 64;
+            const u64 nsamp = (t1 - t0 + stride - 1) / stride;
+            u64 *d_out = &c->d_ctr->cursor;
+            u64 good = 0;
+            StageTimer tm(c, ST_MISC);
+            HIP_TRY(c, hipMemsetAsync(d_out, 0, sizeof(u64), c->stream));
+            hipLaunchKernelGGL(kh::survival_sample_kernel<true>, dim3((unsigned)std::min<u64>(nsamp, 2048)), dim3(kh::BLOCK), 0, c->stream, ra.abase, ra.qbase,
+                               ra.qaligned, ra.vbeg, ra.vend, ra.wlo, t0, t1 - t0, stride, c->k, qual_thr(c), d_out);
+            HIP_TRY(c, hipMemcpyAsync(&good, d_out, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            ra.survive = std::min(1.0, (double)good / (double)(nsamp * kh::TILE));
+        }
+        if (c->trace) fprintf(stderr, "[kmerhip] quality-masked range: %.3f of the windows expected to survive\n", ra.survive);
+    }
     if (part && !c->hinted) {
         // No capacity hint: this batch may bring up to `windows` NEW keys.  A region pass that overflows
         // falls back to re-inserting the overflowing buckets through device atomics -- correct, but
@@ -1023,7 +1115,12 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
             while (lim * 2 * sizeof(Slot) <= bytes) lim *= 2;
             limit = std::max(limit, lim);
         }
-        const u64 want = std::min(round_cap((double)(c->distinct_known + windows) / LOAD_PART), limit);
+        // ... the worst case for the first range; after that, half again of what the last range brought per window (reads of
+        // one file arrive in file order: the rate changes slowly and mostly falls), at least a 16th of the windows.  A range
+        // that brings more overflows some regions and takes the fallback for those.
+        u64 expect = sized_for(windows, ra.survive);
+        if (c->new_rate >= 0.0) expect = std::min<u64>(expect, (u64)((double)windows * std::max(c->new_rate * 1.5, 1.0 / 16)) + (1u << 20));
+        const u64 want = std::min(round_cap((double)(c->distinct_known + expect) / LOAD_PART), limit);
         if (want > c->cap) {
             if (c->table_empty) {
                 Slot *nt = nullptr;
@@ -1062,20 +1159,28 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     }
     const u64 first_tile = ra.wlo / kh::PART_TILE;
     const u64 end_tile = (ra.vend + kh::PART_TILE - 1) / kh::PART_TILE;
+    const u64 distinct_before = c->distinct_known;
     for (u64 t = first_tile; t < end_tile;) {
         const GeomChoice gc = make_geom(c, c->cap);  // re-evaluated per batch: the table may have grown
         if (!gc.ok) return direct_range(c, ra, t * (kh::PART_TILE / kh::TILE), (ra.vend + kh::TILE - 1) / kh::TILE);
         // bytes per key over the two buffers and the overflow list: pool (1.04 x payload) + arenas (1.25 x + 1) + 1
         const u64 per_key = gc.use32 ? 11 : 20;
-        u64 batch_tiles = std::max<u64>(1, c->part_budget / per_key / kh::PART_TILE);
         const u64 left = end_tile - t;
+        // (a range sized from its survival rate: so many windows per batch that the expected payloads fit the budget)
+        const double share = (double)sized_for(left * kh::PART_TILE, ra.survive) / (double)(left * kh::PART_TILE);
+        u64 batch_tiles = std::max<u64>(1, (u64)((double)(c->part_budget / per_key / kh::PART_TILE) / share));
         const u64 nb = (left + batch_tiles - 1) / batch_tiles;  // equal-sized batches
         batch_tiles = (left + nb - 1) / nb;
         const u64 nt = std::min(batch_tiles, left);
         int rc = gc.use32 ? partition_batch<uint32_t>(c, ra, gc.g, t, nt) : partition_batch<u64>(c, ra, gc.g, t, nt);
+        if (rc == KH_RETRY_FULL_SIZE) {  // the sample misjudged these tiles: the rest of the range is sized for every window
+            ra.survive = 1.0;
+            continue;
+        }
         if (rc != KH_OK) return rc;
         t += nt;
     }
+    c->new_rate = (double)(c->distinct_known - distinct_before) / (double)windows;
     return KH_OK;
 }
 
@@ -1354,7 +1459,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->bend, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)
@@ -1385,6 +1490,7 @@ extern "C" int kh_reset(kh_ctx *c) {
     if (!c->table_empty) c->table_dirty = true;
     c->narrow = false;         // (both images are stale now; the next fresh pass chooses again)
     c->narrow_banned = false;
+    c->new_rate = -1.0;
     c->rheads_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     c->distinct_known = c->pending_bound = 0;

@@ -949,7 +949,7 @@ __device__ __forceinline__ u64 narrow_key(const PartGeom &g, u64 slot_index, uin
     return Pay<uint32_t>::key(pay, r >> g.p2_bits, g);
 }
 __device__ __forceinline__ uint32_t narrow_start(const PartGeom &g, uint32_t pay) {
-    return (pay >> (32 - g.p2_bits - REGION_BITS)) & REGION_MASK;
+    return (pay >> (32 - g.p2_bits - REGION_BITS)) & REGION_START_MASK;
 }
 // count[pay] += addend in the narrow image of one region; false = the count might leave 32 bits (nothing changed).
 // `guard` = an upper bound of everything the running kernel may still add to one key (the length of its list): a count
@@ -1195,7 +1195,7 @@ template <bool FRESH>
 __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
-                                                                   u64 *__restrict__ rreal) {
+                                                                   u64 *__restrict__ rreal, u64 skip_threshold) {
     __shared__ u64 s_key[REGION_SLOTS];
     __shared__ u64 s_cnt[REGION_SLOTS];
     __shared__ uint32_t s_fail;
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bend[r];
     Slot *reg = tg.table + r * REGION_SLOTS;
-    if (lo == hi) {  // nothing new for this region
+    if (lo == hi || hi - lo > skip_threshold) {  // nothing new for this region, or a bucket left to hot_buckets_kernel
         if (FRESH && dirty) write_empty_region(reg, tid);
         if (tid == 0) {
             rnew[r] = 0;
@@ -1327,15 +1327,22 @@ constexpr uint32_t R32_FREE = 0xFFFFFFFFu;  // free marker of the 32-bit LDS ima
 // dominated by one key (poly-A, satellites) would send every lane's increment to one LDS word, so
 // lanes whose current payload equals the first active lane's hand their weight to that lane and
 // move on.  It costs a shuffle and two ballots per iteration, hence only for hot buckets.
+// The lanes' payload queues in LDS: one block of (REGION_RK + 1) rows x 64 lanes per WAVE, row-major -- lane l's private
+// queue is column l of its wave's block (conflict-free), and the n-th item a wave queues together (first probe of
+// region_count_kernel32) is word n of the block.  Row REGION_RK is a dummy row for predicated stores.
+constexpr uint32_t R32_QBLOCK = (REGION_RK + 1) * 64;
+__device__ __forceinline__ uint32_t r32_qbase(int tid) { return ((uint32_t)tid >> 6) * R32_QBLOCK + ((uint32_t)tid & 63u); }
+
 template <bool GUARD>
-__device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t (*s_q)[REGION_NT], uint32_t *s_pay,
+__device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t *s_q, uint32_t *s_pay,
                                                      uint32_t *s_add, uint32_t *s_special, uint32_t *s_fail, int tid,
                                                      uint32_t sshift, uint32_t &nd) {
     uint32_t idx = 0, pay = 0, off = 0, probes = 0, weight = 1;
+    const uint32_t qb = r32_qbase(tid);
     bool active = nk > 0;
     if (active) {
-        pay = s_q[0][tid];
-        off = (pay >> sshift) & REGION_MASK;
+        pay = s_q[qb];
+        off = (pay >> sshift) & REGION_START_MASK;
     }
     for (;;) {
         const u64 amask = __ballot(active);
@@ -1384,8 +1391,8 @@ __device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t
             active = idx < nk;
             weight = 1;
             if (active) {
-                pay = s_q[idx][tid];
-                off = (pay >> sshift) & REGION_MASK;
+                pay = s_q[qb + idx * 64];
+                off = (pay >> sshift) & REGION_START_MASK;
                 probes = 0;
             }
         }
@@ -1395,39 +1402,88 @@ __device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t
 // The same round for regions in which no payload can equal the free marker (the top p2_bits of every
 // payload are the region's own level-2 digit: unless that digit is all ones, 0xFFFFFFFF cannot occur)
 // and that are not hot -- i.e. nearly all of them: predicated straight-line code instead of nested
-// branches (the general round spends more scalar than vector instructions on exec-mask bookkeeping).
-__device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t (*s_q)[REGION_NT], uint32_t *s_pay,
+// branches (the general round spends more scalar than vector instructions on exec-mask bookkeeping),
+// and a GROUP of REGION_GROUP = 2 slots per step: a probe sequence starts at an even slot (REGION_START_MASK), so one
+// 8-byte LDS read shows the two slots a key most likely sits in, or its first free one.
+// the REGION_GROUP slots from s_pay[grp] on (grp a multiple of REGION_GROUP): one LDS read
+struct R32Group {
+    uint32_t v[REGION_GROUP];
+};
+__device__ __forceinline__ R32Group r32_group_load(const uint32_t *s_pay, uint32_t grp) {
+    R32Group c;
+    if constexpr (REGION_GROUP == 4) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(&s_pay[grp]);
+        c.v[0] = x.x; c.v[1] = x.y; c.v[2] = x.z; c.v[3] = x.w;
+    } else if constexpr (REGION_GROUP == 2) {
+        const uint2 x = *reinterpret_cast<const uint2 *>(&s_pay[grp]);
+        c.v[0] = x.x; c.v[1] = x.y;
+    } else {
+        c.v[0] = s_pay[grp];
+    }
+    return c;
+}
+// is `pay` in the group, and where (o: its slot's offset inside the group; a payload sits in at most one slot)
+__device__ __forceinline__ bool r32_group_find(const R32Group &c, uint32_t pay, uint32_t &o) {
+    bool any = c.v[0] == pay;
+    o = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < REGION_GROUP; ++i) {
+        const bool m = c.v[i] == pay;
+        any = any || m;
+        o = m ? i : o;
+    }
+    return any;
+}
+// the first free slot of the group (false: none)
+__device__ __forceinline__ bool r32_group_free(const R32Group &c, uint32_t &fo) {
+    bool any = false;
+    fo = 0;
+#pragma unroll
+    for (int i = (int)REGION_GROUP - 1; i >= 0; --i) {
+        const bool f = c.v[i] == R32_FREE;
+        any = any || f;
+        fo = f ? (uint32_t)i : fo;
+    }
+    return any;
+}
+
+__device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t *s_q, uint32_t *s_pay,
                                                     uint32_t *s_add, uint32_t *s_fail, int tid, uint32_t sshift, uint32_t &nd) {
     uint32_t idx = 0, probes = 0;
+    const uint32_t qb = r32_qbase(tid);
     bool active = nk > 0;
-    uint32_t pay = s_q[0][tid];  // (every queue slot holds a loaded payload, real or clamped)
-    uint32_t off = (pay >> sshift) & REGION_MASK;
+    uint32_t pay = s_q[qb];  // (every queue slot holds a loaded payload, real or clamped)
+    uint32_t grp = (pay >> sshift) & REGION_START_MASK;
     while (__ballot(active) != 0) {
-        uint32_t cur = s_pay[off];
-        const bool claim = active && cur == R32_FREE;
+        const R32Group c = r32_group_load(s_pay, grp);
+        uint32_t o, fo;
+        bool hit = r32_group_find(c, pay, o) && active;
+        const bool claim = r32_group_free(c, fo) && active && !hit;
+        bool again = false;
         if (__ballot(claim) != 0) {  // uniform; rare once the region's keys are in
             if (claim) {
-                const uint32_t old = atomicCAS(&s_pay[off], R32_FREE, pay);
+                const uint32_t old = atomicCAS(&s_pay[grp + fo], R32_FREE, pay);
                 if (old == R32_FREE) ++nd;
-                cur = old == R32_FREE ? pay : old;
+                hit = old == R32_FREE || old == pay;
+                o = fo;
+                again = !hit;  // another key took that slot meanwhile: look at the group again
             }
         }
-        const bool hit = active && cur == pay;
-        if (hit) atomicAdd(&s_add[off], 1u);  // no-return ds_add_u32
-        const bool miss = active && !hit;
-        probes += miss ? 1u : 0u;
+        if (hit) atomicAdd(&s_add[grp + o], 1u);  // no-return ds_add_u32
+        const bool miss = active && !hit && !again;  // four slots, four other keys
+        probes += miss ? REGION_GROUP : 0u;
         bool done = hit;
         if (miss && probes >= REGION_SLOTS) {  // region full
             *s_fail = 1;
             done = true;
         }
-        off = miss ? ((off + 1) & REGION_MASK) : off;
+        grp = miss ? ((grp + REGION_GROUP) & REGION_MASK) : grp;
         if (done) {
             ++idx;
             active = idx < nk;
             probes = 0;
-            pay = s_q[active ? idx : 0][tid];
-            off = (pay >> sshift) & REGION_MASK;
+            pay = s_q[qb + (active ? idx : 0u) * 64];
+            grp = (pay >> sshift) & REGION_START_MASK;
         }
     }
 }
@@ -1454,7 +1510,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr,
-                                                                   u64 *__restrict__ rreal, u64 *__restrict__ ntab) {
+                                                                   u64 *__restrict__ rreal, u64 *__restrict__ ntab, u64 skip_threshold) {
     // rreal[r] = payloads of the bucket that are k-mers (the bucket may hold SENTINELS, payloads with another
     // level-2 digit that pad its segments to whole lines: part2_scatter_lines_kernel; they are skipped here)
     // head_cb != 0 (FRESH only): also leave in rheads[r] the number of 32-bit exchange heads the region
@@ -1465,7 +1521,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
     __shared__ uint32_t s_special, s_sp_off, s_sp_new, s_heads, s_real;
-    __shared__ uint32_t s_q[REGION_RK + 1][REGION_NT];  // per-lane payload queues (32 KiB; + a dummy row for predicated stores)
+    __shared__ uint32_t s_q[(REGION_RK + 1) * REGION_NT];  // the lanes' payload queues, one block per wave (r32_qbase)
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bend[r];
@@ -1477,7 +1533,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             write_empty_region(tg.table + r * REGION_SLOTS, tid);
         }
     };
-    if (lo == hi) {
+    if (lo == hi || hi - lo > skip_threshold) {  // (a bucket above skip_threshold is left to hot_buckets_kernel)
         if (FRESH && dirty) write_empty();
         if (tid == 0) {
             rnew[r] = 0;
@@ -1593,7 +1649,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             uint32_t rq = 0;  // real payloads, compacted into the lane's queue (sentinels dropped)
 #pragma unroll
             for (int j = 0; j < REGION_RK; ++j)
-                if ((uint32_t)j < nk && (((pj[j] >> dshift) ^ digit) & dmask) == 0) s_q[rq++][tid] = pj[j];
+                if ((uint32_t)j < nk && (((pj[j] >> dshift) ^ digit) & dmask) == 0) s_q[r32_qbase(tid) + 64 * rq++] = pj[j];
             nreal += rq;
             if (hot) region32_probe_round<true>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
             else if (may_special) region32_probe_round<false>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
@@ -1610,30 +1666,38 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
             // kernel's 24.9 ms), and with private queues that lane has twice the average work.  The wave's items are
             // numbered by ballot + mbcnt and item n goes to row n / 64, column n % 64 of the wave's 8 x 64 corner of s_q:
             // every lane then takes rows 0 .. of its own column, one item more or less than its neighbours.
-            constexpr int FP = REGION_RK;
+#ifndef KH_REGION_FP
+#define KH_REGION_FP 4
+#endif
+            // group reads in flight: FP x REGION_GROUP registers (8 x 4 would not fit two workgroups per CU: 52 bytes of scratch
+            // per lane, 29 ms); measured with pairs: 4 in flight 21.2 ms, 8 in flight 21.9 ms
+            constexpr int FP = KH_REGION_FP;
             uint32_t wrun = 0;  // items queued by the wave so far (wave-uniform)
-            const uint32_t lane = (uint32_t)tid & 63u, wbase = (uint32_t)tid & ~63u;
+            const uint32_t lane = (uint32_t)tid & 63u, wq = ((uint32_t)tid >> 6) * R32_QBLOCK;
 #pragma unroll
             for (int h = 0; h < REGION_RK; h += FP) {
-                uint32_t oj[FP], cj[FP];
+                uint32_t oj[FP];
+                R32Group cj[FP];
 #pragma unroll
-                for (int j = 0; j < FP; ++j) oj[j] = (pj[h + j] >> sshift) & REGION_MASK;
+                for (int j = 0; j < FP; ++j) oj[j] = (pj[h + j] >> sshift) & REGION_START_MASK;
 #pragma unroll
-                for (int j = 0; j < FP; ++j) cj[j] = s_pay[oj[j]];
+                for (int j = 0; j < FP; ++j) cj[j] = r32_group_load(s_pay, oj[j]);
 #pragma unroll
                 for (int j = 0; j < FP; ++j) {
                     // (predicated, not branched: the exec-mask bookkeeping of sixteen small branches per round cost
                     //  as many scalar instructions as the kernel has vector ones)
-                    const bool valid = (uint32_t)(h + j) < nk && (((pj[h + j] >> dshift) ^ digit) & dmask) == 0;
+                    const uint32_t pay = pj[h + j];
+                    const bool valid = (uint32_t)(h + j) < nk && (((pay >> dshift) ^ digit) & dmask) == 0;
                     nreal += valid;
-                    const bool hit = valid && cj[j] == pj[h + j];
+                    uint32_t o;
+                    const bool hit = r32_group_find(cj[j], pay, o) && valid;
 #if !(KH_ABLR & 2)  /* timing experiment otherwise: no count updates in the first probe */
-                    atomicAdd(&s_add[hit ? oj[j] : REGION_SLOTS + (uint32_t)tid], 1u);  // no-return ds_add_u32; misses add to a private dummy word
+                    atomicAdd(&s_add[hit ? oj[j] + o : REGION_SLOTS + (uint32_t)tid], 1u);  // no-return ds_add_u32; misses add to a private dummy word
 #endif
                     const bool queue = valid && !hit;
                     const u64 qm = __ballot(queue);
                     const uint32_t pos = wrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
-                    s_q[queue ? (pos >> 6) : (uint32_t)REGION_RK][wbase + (queue ? (pos & 63u) : lane)] = pj[h + j];  // (row REGION_RK is a dummy row)
+                    s_q[wq + (queue ? pos : (uint32_t)REGION_RK * 64u + lane)] = pay;  // (row REGION_RK is a dummy row)
                     wrun += (uint32_t)__builtin_popcountll(qm);
                 }
             }
@@ -1652,7 +1716,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         // The payload equal to the free marker was only counted.  One lane places it now by plain
         // linear probing over the combined image (old keys from HBM, new claims from s_pay).
         const u64 key = Pay<uint32_t>::key(R32_FREE, p1, g);
-        uint32_t off = (R32_FREE >> sshift) & REGION_MASK;
+        uint32_t off = (R32_FREE >> sshift) & REGION_START_MASK;
         uint32_t probes = 0;
         bool is_new = false;
         for (; probes < REGION_SLOTS; ++probes, off = (off + 1) & REGION_MASK) {
@@ -1813,5 +1877,118 @@ __global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(TableGeom 
         if (km) atomicAdd(&ctr->kmers, km);
     }
 }
+
+// ---- hot buckets ------------------------------------------------------------------------------------------------------
+// The region pass gives every bucket to ONE workgroup, which takes ~1.4 G payloads/s: a bucket holding a thousandth of the
+// batch costs as much as the whole pass (10 % poly-A reads, round 3: 65 M copies of one payload, 47.6 ms in one workgroup
+// behind a 24 ms pass).  Such a bucket is dominated by one or a few keys -- the hash spreads distinct keys evenly -- so the
+// region pass skips buckets above `cut` payloads (the same rule, in the same launch, as hot_list_kernel), and after it
+// hot_buckets_kernel spreads each of them over the whole grid in slices: every workgroup adds up its slices in a small LDS
+// table (payload -> count) and applies the sums to the table with device atomics, a few per workgroup instead of one per
+// payload.  A hot bucket that is NOT dominated by few keys still comes out right: the LDS table is applied and cleared
+// whenever it is half full.  (16-byte table only: kmerhip.hip widens an 8-byte image first.)
+constexpr int HOT_SLICE = 16384;  // payloads per slice
+constexpr int HOT_TAB = 4096;     // entries of the LDS table (applied when more than half are taken)
+constexpr int HOT_GRID = 1024;
+
+__global__ __launch_bounds__(BLOCK) void hot_list_kernel(const u64 *__restrict__ bstart, const u64 *__restrict__ bend, u64 nregions, u64 cut,
+                                                         uint32_t *__restrict__ list, Counters *ctr) {
+    const u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x;
+    if (r < nregions && bend[r] - bstart[r] > cut) list[atomicAdd(&ctr->hot, 1ull)] = (uint32_t)r;
+}
+
+template <typename PT>
+__global__ __launch_bounds__(BLOCK) void hot_buckets_kernel(TableGeom tg, PartGeom g, const PT *__restrict__ pays, const u64 *__restrict__ bstart,
+                                                            const u64 *__restrict__ bend, const uint32_t *__restrict__ list, u64 nhot,
+                                                            Counters *ctr) {
+    constexpr PT FREE = (PT)~(PT)0;  // (32-bit payloads: a legal value, counted apart; 64-bit: KH_EMPTY_KEY, the padding)
+    __shared__ PT s_key[HOT_TAB];
+    __shared__ uint32_t s_cnt[HOT_TAB];
+    __shared__ uint32_t s_fill, s_free_cnt;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HOT_TAB; i += BLOCK) {
+        s_key[i] = FREE;
+        s_cnt[i] = 0;
+    }
+    if (tid == 0) {
+        s_fill = 0;
+        s_free_cnt = 0;
+    }
+    __syncthreads();
+    uint32_t nd = 0, nf = 0;
+    u64 real = 0;
+    for (u64 b = 0; b < nhot; ++b) {
+        const u64 r = list[b];
+        const u64 lo = bstart[r], n = bend[r] - lo;
+        const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
+        const uint32_t digit = g.p2_bits ? ((uint32_t)r & ((1u << g.p2_bits) - 1u)) : 0u;
+        auto apply = [&]() {  // the LDS table -> the table in HBM; leaves it empty (all threads)
+            __syncthreads();
+            for (int i = tid; i < HOT_TAB; i += BLOCK) {
+                const uint32_t cnt = s_cnt[i];
+                if (cnt) {
+                    upsert(tg, Pay<PT>::key(s_key[i], p1, g), (u64)cnt, nd, nf);
+                    s_key[i] = FREE;
+                    s_cnt[i] = 0;
+                }
+            }
+            if (tid == 0) {
+                if (sizeof(PT) == 4 && s_free_cnt) upsert(tg, Pay<PT>::key(FREE, p1, g), (u64)s_free_cnt, nd, nf);
+                s_free_cnt = 0;
+                s_fill = 0;
+            }
+            __syncthreads();
+        };
+        bool touched = false;
+        for (u64 s = blockIdx.x; s * HOT_SLICE < n; s += gridDim.x) {
+            touched = true;
+            const u64 s0 = s * HOT_SLICE, s1 = s0 + HOT_SLICE < n ? s0 + HOT_SLICE : n;
+            for (u64 c0 = s0; c0 < s1; c0 += 4 * BLOCK) {  // 1024 payloads between two looks at the fill
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const u64 i = c0 + (u64)j * BLOCK + tid;
+                    if (i >= s1) continue;
+                    const PT v = pays[lo + i];
+                    // a payload with another level-2 digit (32-bit) / the empty key (64-bit) pads the segments: not a k-mer
+                    if (sizeof(PT) == 4 && g.p2_bits && (uint32_t)((u64)v >> (32 - g.p2_bits)) != digit) continue;
+                    if (sizeof(PT) == 8 && (u64)v == KH_EMPTY_KEY) continue;
+                    ++real;
+                    if (v == FREE) {
+                        atomicAdd(&s_free_cnt, 1u);
+                        continue;
+                    }
+                    uint32_t h = ((uint32_t)((u64)v ^ ((u64)v >> 29)) * 2654435761u) >> 20;  // 12 bits
+                    for (;;) {
+                        PT cur = s_key[h];
+                        if (cur == FREE) {
+                            cur = atomicCAS(&s_key[h], FREE, v);
+                            if (cur == FREE) {
+                                atomicAdd(&s_fill, 1u);
+                                cur = v;
+                            }
+                        }
+                        if (cur == v) {
+                            atomicAdd(&s_cnt[h], 1u);
+                            break;
+                        }
+                        h = (h + 1) & (HOT_TAB - 1);
+                    }
+                }
+                __syncthreads();
+                const bool full = s_fill > HOT_TAB / 2;  // (uniform: read between two barriers; at most 4 * BLOCK more before the next look)
+                __syncthreads();
+                if (full) apply();
+            }
+        }
+        if (touched) apply();  // the next bucket has another region
+    }
+    const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf), km = wave_sum(real);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (f) atomicAdd(&ctr->failed, f);
+        if (km) atomicAdd(&ctr->kmers, km);
+    }
+}
+
 
 }  // namespace kh

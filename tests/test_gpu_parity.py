@@ -1199,6 +1199,97 @@ def test_written_out_window_every_k(K, k, minq):
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
 
 
+@pytest.mark.parametrize("cut", ["100000", "2500", "0"], ids=["heavy-keys-only", "ordinary-buckets-too", "off"])
+@pytest.mark.parametrize("k", [21, 31])
+def test_hot_buckets_are_counted_apart_from_the_region_pass(K, monkeypatch, k, cut):
+    """A bucket dominated by one key (poly-A: 10 % of the S100M-shaped reads put 65 M copies into one bucket) would keep one
+    workgroup of the region pass busy for twice as long as the whole pass: buckets above a threshold are skipped by the
+    pass and counted by hot_buckets_kernel instead (slices over the whole grid, LDS sums, a few device atomics each).
+    Here with the threshold lowered (KMERHIP_HOT_CUT) so that the repeats' buckets are hot -- and, with 2500, a good part
+    of the ordinary buckets as well (mean 2900 payloads: the LDS table is applied and refilled many times) -- on a fresh
+    table and on a filled one (the skipped region must stay as it is), 4- and 8-byte payloads, the map against the
+    oracle after every batch, lookups and histogram from the widened table."""
+    monkeypatch.setenv("KMERHIP_HOT_CUT", cut)
+    rng = np.random.default_rng(5100 + k)
+    n_reads = 80_000
+    bases, _ = O.synth_reads(SEED + 3 * k, 1 << 19, 150, 0, n_reads, with_qual=False)
+    bases = bases.copy()
+    v = bases.reshape(n_reads, 151)
+    reps = [np.resize(np.frombuffer(r, dtype=np.uint8), 150) for r in (b"A", b"AC", b"ACGTTGCA", b"GATTACA")]
+    for i in rng.choice(n_reads, size=n_reads // 8, replace=False):
+        v[i, :150] = reps[i % 4]
+    import torch
+    tb = torch.from_numpy(bases).cuda()
+    torch.cuda.synchronize()
+    half = (n_reads // 2) * 151
+    m = O.OracleMap()
+    with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:     # 2^12 regions
+        for a, b in ((0, half), (half, bases.size)):
+            m.scan_flat(bases[a:b], k, nthreads=NCPU)
+            dc.push_device(tb.data_ptr() + a, None, b - a)
+            st = dc.finish()
+            assert st["kmers"] == m.total() and st["distinct"] == len(m), (a, st)
+            want_k, want_c = m.arrays()
+            keys, cnts = dc.result()
+            assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c), a
+        poly_a = 0                                                               # AAAA...A, the heaviest key
+        assert int(dc.lookup(np.array([poly_a], dtype=np.uint64))[0]) == int(want_c[np.searchsorted(want_k, poly_a)])
+        assert dc.histogram() == m.histogram()
+
+
+@pytest.mark.parametrize("k", [31, 21])
+def test_quality_masked_range_is_sized_from_its_survival_rate(K, monkeypatch, k):
+    """A range pushed with qualities and --min-quality: the partition buffers are sized from a sample of the windows that
+    survive masking (survival_sample_kernel), not from "every window", so BASELINE configs[2] (k = 31, -Q 20, ~0.4 of the
+    windows left) is one batch instead of two.  Here: a budget that holds 0.7 of the worst case -- one batch with the
+    sample, two with KMERHIP_SURVIVAL=1; an estimate that is far too small (0.02) makes level 1 run out of pool, which is
+    noticed before anything but the pool was written, and the tiles run again at full size.  Same map every time."""
+    rng = np.random.default_rng(4242 + k)
+    n_reads, rl = 60_000, 150
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1 << 20)
+    offs = rng.integers(0, genome.size - rl, size=n_reads)
+    bases = np.empty(n_reads * (rl + 1), dtype=np.uint8)
+    bases.reshape(n_reads, rl + 1)[:, :rl] = genome[offs[:, None] + np.arange(rl)[None, :]]
+    bases.reshape(n_reads, rl + 1)[:, rl] = 10
+    # every read is good ('I') up to a cut point and bad ('#') behind it: a little under half of the windows survive -Q 20
+    cutp = rng.integers(0, 200, size=n_reads)
+    q = np.where(np.arange(rl + 1)[None, :] < cutp[:, None], ord("I"), ord("#")).astype(np.uint8)
+    q[:, rl] = 10
+    qual = q.reshape(-1)
+    m = O.OracleMap()
+    m.scan_flat(bases, k, qual=qual, min_quality=20, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    windows = bases.size
+    share = m.total() / windows
+    assert 0.1 < share < 0.6, share
+    import torch
+    tb, tq = torch.from_numpy(bases).cuda(), torch.from_numpy(qual.copy()).cuda()
+    torch.cuda.synchronize()
+    per_key = 20 if k > 21 else 11
+    monkeypatch.setenv("KMERHIP_PART_BUDGET_GB", repr(0.7 * per_key * windows / 2**30))
+    for survival, batches in ((None, 1), ("1", 2), ("0.02", None), ("0.9", 2)):
+        if survival is None:
+            monkeypatch.delenv("KMERHIP_SURVIVAL", raising=False)
+        else:
+            monkeypatch.setenv("KMERHIP_SURVIVAL", survival)
+        with K.DeviceCounter(k, min_quality=20, capacity_hint=6_000_000, path="partition") as dc:   # 2^12 regions: 4-byte payloads at k = 21
+            dc.push_device(tb.data_ptr(), tq.data_ptr(), bases.size)
+            st = dc.finish()
+            assert st["kmers"] == m.total()
+            if batches is not None:
+                assert st["part_batches"] == batches, (survival, st["part_batches"])
+            keys, cnts = dc.result()
+            assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c), survival
+        # without qualities (or without a threshold) nothing is sampled and nothing changes
+    monkeypatch.delenv("KMERHIP_SURVIVAL", raising=False)
+    m2 = O.OracleMap()
+    m2.scan_flat(bases, k, nthreads=NCPU)
+    with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:
+        dc.push_device(tb.data_ptr(), tq.data_ptr(), bases.size)
+        st = dc.finish()
+        assert st["kmers"] == m2.total() and st["part_batches"] == 2
+
+
 @pytest.mark.parametrize("narrow", ["1", "0"], ids=["narrow-image", "wide-only"])
 @pytest.mark.parametrize("k", [21, 17, 13])
 def test_narrow_table_image_and_its_transitions(K, monkeypatch, k, narrow):
