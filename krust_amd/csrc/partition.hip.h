@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    u64 *__restrict__ rreal, u64 skip_threshold) {
-    __shared__ u64 s_key[REGION_SLOTS];
+    __shared__ __attribute__((aligned(16))) u64 s_key[REGION_SLOTS];
     __shared__ u64 s_cnt[REGION_SLOTS];
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
@@ -1272,24 +1272,40 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
                 }
             }
             if (key == KH_EMPTY_KEY) continue;
+            // a probe sequence starts at a multiple of REGION_GROUP slots (start_of): the group's keys come with one LDS read;
+            // a value that is not EMPTY is final, a stale EMPTY is corrected by what the compare-and-swap returns
             uint32_t off = start_of(tg, table_hash(tg, key));
             uint32_t probes = 0;
-            for (; probes < REGION_SLOTS; ++probes) {
-                u64 cur = s_key[off];
-                if (cur == KH_EMPTY_KEY) {
-                    cur = atomicCAS(&s_key[off], (u64)KH_EMPTY_KEY, key);  // ds_cmpst_rtn_b64
+            bool placed = false;
+            for (; probes < REGION_SLOTS && !placed; probes += REGION_GROUP) {
+                u64 grp[REGION_GROUP];
+                if constexpr (REGION_GROUP == 2) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(&s_key[off]);  // ds_read_b128
+                    grp[0] = ((u64)x.y << 32) | x.x;
+                    grp[1] = ((u64)x.w << 32) | x.z;
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < REGION_GROUP; ++i) grp[i] = s_key[off + i];
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < REGION_GROUP; ++i) {
+                    if (placed) continue;
+                    u64 cur = grp[i];
                     if (cur == KH_EMPTY_KEY) {
-                        ++nd;
-                        cur = key;
+                        cur = atomicCAS(&s_key[off + i], (u64)KH_EMPTY_KEY, key);  // ds_cmpst_rtn_b64
+                        if (cur == KH_EMPTY_KEY) {
+                            ++nd;
+                            cur = key;
+                        }
+                    }
+                    if (cur == key) {
+                        atomicAdd(&s_cnt[off + i], weight);  // ds_add_u64
+                        placed = true;
                     }
                 }
-                if (cur == key) {
-                    atomicAdd(&s_cnt[off], weight);  // ds_add_u64
-                    break;
-                }
-                off = (off + 1) & REGION_MASK;
+                off = (off + REGION_GROUP) & REGION_MASK;
             }
-            if (probes == REGION_SLOTS) s_fail = 1;
+            if (!placed) s_fail = 1;
         }
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) kbuf[j] = nbuf[j];
@@ -1671,6 +1687,9 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
 #endif
             // group reads in flight: FP x REGION_GROUP registers (8 x 4 would not fit two workgroups per CU: 52 bytes of scratch
             // per lane, 29 ms); measured with pairs: 4 in flight 21.2 ms, 8 in flight 21.9 ms
+#if KH_ABLR & 8  /* timing experiment: loads, LDS image and write-back only -- no probing at all */
+            if (n) continue;
+#endif
             constexpr int FP = KH_REGION_FP;
             uint32_t wrun = 0;  // items queued by the wave so far (wave-uniform)
             const uint32_t lane = (uint32_t)tid & 63u, wq = ((uint32_t)tid >> 6) * R32_QBLOCK;
