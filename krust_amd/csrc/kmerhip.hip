@@ -188,6 +188,10 @@ struct kh_ctx {
     struct TxtHost { u64 total; u64 end_mark; uint32_t err; uint8_t first, last; } *h_txt = nullptr;  // pinned
     hipEvent_t txt_raw_free = nullptr;
     bool txt_raw_busy = false;
+    // kh_push_text leaves the COUNTING of its text (scanned into txt_out / txt_qual) to the next call that enters the
+    // context: the next kh_push_text then copies its text to the device while this one is counted (flush_text)
+    u64 txt_pending = 0;          // bases in txt_out still to be counted (0 = nothing pending)
+    bool txt_pending_qual = false;
     double text_ms = 0.0;
 
     bool poisoned = false;
@@ -234,6 +238,7 @@ int close_fresh_window(kh_ctx *c);
 
 int ensure_wide(kh_ctx *c);
 
+int flush_text(kh_ctx *c);
 int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool keep_window = false, bool narrow_ok = false) {
     if (!c) return KH_ERR_BAD_ARG;
     if (c->poisoned) return fail(c, KH_ERR_STATE, "context is poisoned by an earlier error");
@@ -244,6 +249,10 @@ int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool kee
     }
     if (flush_pending && c->acc_len) {
         int rc = flush_acc(c, false);
+        if (rc != KH_OK) return rc;
+    }
+    if (flush_pending && c->txt_pending) {
+        int rc = flush_text(c);
         if (rc != KH_OK) return rc;
     }
     if (c->narrow && !narrow_ok) {
@@ -1483,6 +1492,7 @@ extern "C" int kh_reset(kh_ctx *c) {
     if (rc != KH_OK) return rc;
     if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
     c->acc_len = c->acc_carry = 0;  // pushes not yet counted are forgotten with everything else
+    c->txt_pending = 0;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
     // Lazy: no table_init here (5.5 ms for a 34 GB table).  A partitioned batch into an empty table
@@ -1609,7 +1619,7 @@ int text_fail(kh_ctx *c, const char *why) { return fail(c, KH_ERR_FORMAT, why); 
 
 // d_text: 16-byte aligned device text holding whole records.  raw_event: record c->txt_raw_free once
 // the scanning kernels (the only readers of d_text) are enqueued.
-int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, bool raw_event) {
+int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, bool raw_event, bool defer_count = false) {
     const bool fastq = format == KH_TEXT_FASTQ;
     const bool with_qual = fastq && c->minq >= 0;
     const u64 ntiles = (n + kh::RAW_TILE - 1) / kh::RAW_TILE;
@@ -1688,7 +1698,22 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, bool raw_even
         c->txt_raw_busy = true;
     }
     if (out_len == 0) return KH_OK;
+    if (defer_count) {  // (kh_push_text: counted when the context is entered next -- under the next text's copy, if that is what comes)
+        c->txt_pending = out_len;
+        c->txt_pending_qual = with_qual;
+        return KH_OK;
+    }
     return count_device_range(c, c->txt_out, with_qual ? c->txt_qual : nullptr, out_len, 0);
+}
+
+}  // namespace
+namespace {
+// counts the text kh_push_text has scanned and left in txt_out
+int flush_text(kh_ctx *c) {
+    const u64 n = c->txt_pending;
+    c->txt_pending = 0;
+    if (!n) return KH_OK;
+    return count_device_range(c, c->txt_out, c->txt_pending_qual ? c->txt_qual : nullptr, n, 0);
 }
 
 int text_args(kh_ctx *c, const uint8_t *text, u64 n, int format) {
@@ -1712,7 +1737,8 @@ extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n,
 }
 
 extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int format) {
-    int rc = enter(c, true, false, false, true);
+    // (what earlier calls left pending is counted below, once this text's copy is under way -- not by enter())
+    int rc = enter(c, false, false, false, true);
     if (rc != KH_OK) return rc;
     if ((rc = text_args(c, text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
@@ -1756,9 +1782,19 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
     hipEvent_t ready;
     HIP_TRY(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(ready, c->cstream));
+    // While the copy runs: count what the previous kh_push_text scanned (and what kh_push has accumulated).  The scan of
+    // THIS text -- the part that can refuse it -- stays inside this call; its counting is left to the next one.
+    rc = KH_OK;
+    if (c->acc_len) rc = flush_acc(c, false);
+    if (rc == KH_OK) rc = flush_text(c);
+    if (rc != KH_OK) {
+        (void)hipEventSynchronize(ready);  // (the caller gets its buffer back when we return)
+        (void)hipEventDestroy(ready);
+        return rc;
+    }
     HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
     (void)hipEventDestroy(ready);
-    rc = scan_text(c, c->txt_raw, n, format, true);
+    rc = scan_text(c, c->txt_raw, n, format, true, true);
     if (rc == KH_OK) c->bases_pushed += n;
     return rc;
 }

@@ -576,8 +576,10 @@ struct Session {
     static unsigned read_threads() {
         const char *e = getenv("KMERUST_READ_THREADS");
         if (e && atoi(e) > 0) return (unsigned)atoi(e);
+        // (a chunk's read runs beside the previous chunk's push, ~10 ms per 256 MiB since the library counts one text under the
+        //  next one's copy: four pread()s side by side take as long, eight leave a margin -- measured, profiles/README.md r03b)
         const unsigned hw = std::thread::hardware_concurrency();
-        return std::max(1u, std::min(4u, hw ? hw : 1u));
+        return std::max(1u, std::min(8u, hw ? hw : 1u));
     }
     static size_t text_chunk_bytes() {
         const char *e = getenv("KMERUST_TEXT_CHUNK_KB");  // tests use small chunks to exercise the cuts

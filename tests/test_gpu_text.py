@@ -214,6 +214,52 @@ def test_push_text_device_needs_alignment_and_matches_host_text():
     assert dict(zip(keys.tolist(), counts.tolist())) == expect(text, "fastq", 21, 20)
 
 
+def test_text_counted_under_the_next_call_is_never_lost_or_doubled():
+    """kh_push_text returns when its text is on the device and scanned; the COUNTING is left to the next call that enters
+    the context (the next kh_push_text copies its text meanwhile).  Whatever comes next -- another text, plain bases, a
+    lookup, the results, a refused text, a reset -- the pending text is counted exactly once, or forgotten with the reset."""
+    import torch
+    rng = np.random.default_rng(31)
+    a, b, c3 = (make_fastq(rng, 700, 40, 160) for _ in range(3))
+    fa = make_fasta(rng, 30, 100, 3000, 60)
+    plain = rand_seq(rng, 40_000, b"ACGT")
+    k, minq = 21, 20
+
+    def add(d, e):
+        for kk, v in e.items():
+            d[kk] = d.get(kk, 0) + v
+        return d
+    ea, eb, ec = (expect(t, "fastq", k, minq) for t in (a, b, c3))
+    efa = expect(fa, "fasta", k, minq)
+    eplain = O.count_records([plain], k).as_dict()
+    with native.DeviceCounter(k, min_quality=minq) as dc:
+        dc.push_text(a, "fastq")                                   # pending
+        some = np.array(list(ea)[:64], dtype=np.uint64)
+        assert dc.lookup(some).tolist() == [ea[int(x)] for x in some]   # a lookup counts it first
+        dc.push_text(b, "fastq")                                   # pending
+        dc.push_text(fa, "fasta")                                  # counts b under fa's copy; fa pending (other format, no qualities)
+        t = torch.frombuffer(bytearray(plain), dtype=torch.uint8).cuda()
+        dc.push_device(t.data_ptr(), None, t.numel())              # counts fa, then the plain bases
+        dc.push_text(c3, "fastq")                                   # pending
+        with pytest.raises(native.KmerHipError) as e:              # a refused text: c3 is counted under its copy, it is not
+            dc.push_text(b"@r\nACGT\n-\nIIII\n", "fastq")
+        assert e.value.status == native.KH_ERR_FORMAT
+        keys, counts = dc.result()
+        want = {}
+        for e_ in (ea, eb, efa, eplain, ec):
+            add(want, e_)
+        assert dict(zip(keys.tolist(), counts.tolist())) == want
+        st = dc.finish()
+        assert st["kmers"] == sum(want.values())
+        dc.push_text(a, "fastq")                                   # pending ...
+        dc.reset()                                                 # ... and forgotten
+        st = dc.finish()
+        assert st["kmers"] == 0 and dc.result_size() == 0
+        dc.push_text(b, "fastq")
+        st = dc.finish()                                           # finish counts it
+        assert st["kmers"] == sum(eb.values())
+
+
 # ---------------------------------------------------------------------------
 # property tests: arbitrary small texts, device scanner vs a line-by-line restatement
 # ---------------------------------------------------------------------------
