@@ -798,7 +798,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             //  limit; KMERHIP_L2_OVF_CAP = entries the overflow list may take; KMERHIP_L2_HEAVY_ROOM = payloads of room for heavy partitions)
             const uint32_t skew_x = [] { const char *e = getenv("KMERHIP_L2_SKEW_X"); return e ? (uint32_t)atoi(e) : 2u; }();
             const u64 room = [&] { const char *e = getenv("KMERHIP_L2_HEAVY_ROOM"); return e ? std::min<u64>(heavy_room, strtoull(e, nullptr, 10)) : heavy_room; }();
-            hipLaunchKernelGGL(kh::arena_plan_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
+            hipLaunchKernelGGL(kh::arena_plan_kernel, dim3((unsigned)std::min<u64>(64, (nregions + 1023) / 1024)), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
                                c->ovf, skew_x, c->heavy, room);
             if (g.p2_bits == 10)  // 2^20 regions: 1024 buckets per partition, 128-byte bins, 64-byte units
                 hipLaunchKernelGGL((kh::part2_arena_kernel<PT, 64, 1024>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
@@ -918,7 +918,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     if (nar) c->narrow = true;
     {
         StageTimer t(c, ST_MISC);
-        hipLaunchKernelGGL(kh::region_reduce_kernel, dim3(grid_for(nregions)), dim3(kh::BLOCK), 0, c->stream,
+        // (three same-address atomics per WAVE at ~10 ns each: a block per 256 regions -- 2048 blocks -- took 0.2 ms for 7 MB)
+        hipLaunchKernelGGL(kh::region_reduce_kernel, dim3((unsigned)std::min<u64>(128, (nregions + kh::BLOCK - 1) / kh::BLOCK)), dim3(kh::BLOCK), 0, c->stream,
                            (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const u64 *)c->rreal, (u64)nregions, c->d_ctr);
         if (c->ovf_pending) {  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
             if (nar)

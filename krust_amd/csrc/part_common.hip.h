@@ -9,6 +9,9 @@
 #ifndef KH_ABL2
 #define KH_ABL2 0  // the same for part2_scatter_kernel
 #endif
+#ifndef KH_ABL_ARENA
+#define KH_ABL_ARENA 0  // timing experiments on part2_arena_kernel (bit 0: no barrier B2, bit 1: no barrier B1); 0 in any product build
+#endif
 #ifndef KH_ABLR
 #define KH_ABLR 0  // the same for region_count_kernel32
 #endif

@@ -93,36 +93,50 @@ __global__ __launch_bounds__(1024) void chunk_list_kernel(const uint16_t *__rest
 // part2_plan_kernel; info[2] is left to the level-2 scan (the grand total is not known yet).
 // only (optional): plan blocks for the partitions with only[p] != 0 alone -- the heavy partitions of a batch whose other
 // partitions went through the arena kernel; the others then have no blocks (nch = 0).  cursors is left alone then.
+// exclusive prefix sum over the 1024 lanes of a workgroup (s_scan: 1024 words of LDS); returns the lane's prefix, *total = the sum
+// (the plan kernels' serial loops over 1024 partitions -- one lane, a dependent global load per step -- were 0.2 ms each)
+__device__ __forceinline__ u64 block_scan_1024(u64 v, u64 *s_scan, int tid, u64 *total) {
+    s_scan[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const u64 add = tid >= o ? s_scan[tid - o] : 0ull;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+    }
+    const u64 incl = s_scan[tid];
+    if (total) *total = s_scan[1023];
+    __syncthreads();
+    return incl - v;
+}
+
 __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__restrict__ pstart, PartGeom g,
                                                                   Part2Block *__restrict__ blocks, u64 max_blocks,
                                                                   u64 *__restrict__ moff, uint32_t *__restrict__ nch,
                                                                   u64 *__restrict__ info, uint32_t *__restrict__ cursors,
                                                                   uint32_t force_wide, const uint8_t *__restrict__ only) {
     __shared__ u64 s_bbase[MAX_P1 + 1];
+    __shared__ u64 s_scan[1024];
     const int tid = threadIdx.x;
     const int P1 = 1 << g.p1_bits;
     if (tid < P1 && !only) cursors[tid] = (uint32_t)pstart[tid];
     auto nchunks_of = [&](int p) -> u64 { return (only && !only[p]) ? 0ull : pstart[p + 1] - pstart[p]; };
+    const u64 my_chunks = tid < P1 ? nchunks_of(tid) : 0ull;
+    const u64 my_blocks = (my_chunks + CPB - 1) / CPB;
+    u64 b = 0;
+    const u64 my_base = block_scan_1024(my_blocks, s_scan, tid, &b);
+    if (tid < P1) s_bbase[tid] = my_base;
+    // info[3]: some partition's level-2 output (payloads + unit padding) does not fit 32-bit offsets -- only
+    // when > 4 G k-mers of one batch share a level-1 digit.  The unit-writing level-2 kernel then stands
+    // down for the whole batch and the unaligned one runs (both are launched, each checks this word).
+    // (KMERHIP_P2_FORCE_WIDE=1: tests exercise the stand-down without 4 G k-mers)
+    const int wide = __syncthreads_or((force_wide || my_chunks * CHUNK_PAY + my_blocks * 1024ull * 64ull >= (1ull << 32)) ? 1 : 0);
     if (tid == 0) {
-        u64 b = 0;
-        for (int p = 0; p < P1; ++p) {
-            s_bbase[p] = b;
-            b += (nchunks_of(p) + CPB - 1) / CPB;
-        }
         s_bbase[P1] = b;
         info[0] = b;
         info[1] = b << g.p2_bits;
         info[2] = 0;
-        // info[3]: some partition's level-2 output (payloads + unit padding) does not fit 32-bit offsets -- only
-        // when > 4 G k-mers of one batch share a level-1 digit.  The unit-writing level-2 kernel then stands
-        // down for the whole batch and the unaligned one runs (both are launched, each checks this word).
-        u64 wide = force_wide;  // (KMERHIP_P2_FORCE_WIDE=1: tests exercise the stand-down without 4 G k-mers)
-        for (int p = 0; p < P1; ++p) {
-            const u64 nchunks = nchunks_of(p);
-            const u64 nblocks = (nchunks + CPB - 1) / CPB;
-            if (nchunks * CHUNK_PAY + nblocks * 1024ull * 64ull >= (1ull << 32)) wide = 1;
-        }
-        info[3] = wide;
+        info[3] = wide ? 1 : 0;
     }
     __syncthreads();
     if (tid < P1) {
@@ -617,44 +631,48 @@ __global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict_
                                                           uint8_t *__restrict__ heavy, u64 heavy_room) {
     __shared__ u64 s_base[MAX_P1 + 1];
     __shared__ uint32_t s_cap[MAX_P1];
-    __shared__ u64 s_limit;
+    __shared__ u64 s_scan[1024];
     const int tid = threadIdx.x;
     const int P1 = 1 << g.p1_bits;
     const uint32_t P2 = 1u << g.p2_bits;
-    if (tid == 0) {
-        u64 tot = 0;
-        for (int p = 0; p < P1; ++p) tot += ptotal[p];
-        s_limit = skew_x ? (u64)skew_x * (tot / P1) + (1u << 20) : ~0ull;
-    }
-    __syncthreads();
+    const u64 mine = tid < P1 ? ptotal[tid] : 0ull;
+    u64 tot = 0;
+    (void)block_scan_1024(mine, s_scan, tid, &tot);
+    const u64 limit = skew_x ? (u64)skew_x * (tot / P1) + (1u << 20) : ~0ull;
+    const bool hv = tid < P1 && mine > limit;
+    uint32_t cap = 0;
+    const bool first = blockIdx.x == 0;  // (every workgroup makes the plan -- four scans -- for its share of bstart[]; one publishes it)
     if (tid < P1) {
-        const bool hv = ptotal[tid] > s_limit;
-        heavy[tid] = hv ? 1 : 0;
-        const u64 m = (ptotal[tid] + P2 - 1) / P2;
-        s_cap[tid] = hv ? 0u : (uint32_t)((m + (m >> 2) + 1024 + 31) & ~31ull);
-        pcap[tid] = s_cap[tid];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        u64 b = 0, nh = 0, ht = 0;
-        for (int p = 0; p < P1; ++p) {
-            s_base[p] = b;
-            b += (u64)s_cap[p] * P2;
-            if (heavy[p]) {
-                ++nh;
-                ht += ptotal[p];
-            }
+        const u64 m = (mine + P2 - 1) / P2;
+        cap = hv ? 0u : (uint32_t)((m + (m >> 2) + 1024 + 31) & ~31ull);
+        s_cap[tid] = cap;
+        if (first) {
+            heavy[tid] = hv ? 1 : 0;
+            pcap[tid] = cap;
         }
-        s_base[P1] = b;
-        ovf[0] = 0;
-        ovf[1] = ht > heavy_room ? 2 : 0;
-        ovf[2] = nh;
-        ovf[3] = ht;
+    }
+    u64 end = 0, nh = 0, ht = 0;
+    const u64 base = block_scan_1024((u64)cap * P2, s_scan, tid, &end);
+    (void)block_scan_1024(hv ? 1ull : 0ull, s_scan, tid, &nh);
+    (void)block_scan_1024(hv ? mine : 0ull, s_scan, tid, &ht);
+    if (tid < P1) s_base[tid] = base;
+    if (tid == 0) {
+        s_base[P1] = end;
+        if (first) {
+            ovf[0] = 0;
+            ovf[1] = ht > heavy_room ? 2 : 0;
+            ovf[2] = nh;
+            ovf[3] = ht;
+        }
     }
     __syncthreads();
-    for (int p = 0; p < P1; ++p)
-        for (uint32_t b = tid; b < P2; b += 1024) bstart[(u64)p * P2 + b] = s_base[p] + (u64)b * s_cap[p];
-    if (tid == 0) bstart[(u64)P1 * P2] = s_base[P1];
+    // bstart[] of every bucket: this workgroup's share (the launch has one workgroup per 1024 buckets, or fewer: they stride)
+    const u64 nb = (u64)P1 * P2;
+    for (u64 r = (u64)blockIdx.x * 1024 + tid; r < nb; r += (u64)gridDim.x * 1024) {
+        const uint32_t p = (uint32_t)(r >> g.p2_bits), bk = (uint32_t)r & (P2 - 1);
+        bstart[r] = s_base[p] + (u64)bk * s_cap[p];
+    }
+    if (blockIdx.x == 0 && tid == 0) bstart[nb] = s_base[P1];
 }
 
 struct OvfEntry {
@@ -887,13 +905,17 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                             }
                     }
                 }
+#if !(KH_ABL_ARENA & 2)  /* timing experiment otherwise (wrong results): no barrier between the ranks and the flush */
                 __syncthreads();  // B1
+#endif
                 if (h == 0) {  // the wait for the next batch's payloads goes HERE, before the first store (vmcnt: see part1_bins_kernel)
 #pragma unroll
                     for (int j = 0; j < PER; ++j) asm volatile("" : "+v"(nxt[j]));
                 }
                 flush();
+#if !(KH_ABL_ARENA & 1)  /* timing experiment otherwise (wrong results): no barrier between the flush and the next half batch's ranks */
                 __syncthreads();  // B2
+#endif
                 if (s_ovf_want || s_ovf_end) ovf_refill();  // (uniform; skipped entirely while nothing has overflowed)
             }
         };

@@ -110,9 +110,15 @@ KH_HD void win_outputs_ref(uint64_t key, uint32_t &p1, uint32_t &pay32) {
 #define KH_WIN_ROUND24(a, b, c24) "v_mul_u32_u24 v124, " c24 ", " b "\n v_lshrrev_b32 v124, %[rs], v124\n v_xor_b32 " a ", v124, " a "\n"
 #define KH_WIN_ROUND32(a, b, fc) "v_mul_lo_u32 v124, " b ", " fc "\n v_lshrrev_b32 v124, %[rs], v124\n v_xor_b32 " a ", v124, " a "\n"
 #define KH_WIN_ROUND32_K32(a, b, fc) "v_mul_lo_u32 v124, " b ", " fc "\n v_xor_b32 " a ", v124, " a "\n"
+#if KH_ABL_ROUNDS3  /* timing experiment only (wrong hash): three Feistel rounds */
+#define KH_WIN_ROUNDS24 \
+    KH_WIN_ROUND24("v122", "v123", "0x3779b1") KH_WIN_ROUND24("v123", "v122", "0xebca77") \
+    KH_WIN_ROUND24("v122", "v123", "0xb2ae3d")
+#else
 #define KH_WIN_ROUNDS24 \
     KH_WIN_ROUND24("v122", "v123", "0x3779b1") KH_WIN_ROUND24("v123", "v122", "0xebca77") \
     KH_WIN_ROUND24("v122", "v123", "0xb2ae3d") KH_WIN_ROUND24("v123", "v122", "0xd4eb2f")
+#endif
 #define KH_WIN_ROUNDS32 \
     KH_WIN_ROUND32("v122", "v123", "%[f0]") KH_WIN_ROUND32("v123", "v122", "%[f1]") \
     KH_WIN_ROUND32("v122", "v123", "%[f2]") KH_WIN_ROUND32("v123", "v122", "%[f3]")
