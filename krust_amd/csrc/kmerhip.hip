@@ -124,6 +124,7 @@ struct kh_ctx {
     bool table_dirty = false;  // kh_reset is lazy: the slots hold stale data that the next operation either
                                // overwrites wholesale (a FRESH region pass) or clears first (everything else)
     bool hinted = false;       // caller gave a capacity hint
+    u64 hint_keys = 0;         // ... of this many distinct k-mers
     double new_rate = -1.0;    // new keys per window of the last partitioned range (-1: none yet): sizes an unhinted table
     int path_mode = 0;         // 0 auto, 1 force direct, 2 force partitioned
     int pay_mode = 0;          // 0 auto, 64 = always 64-bit payloads (env KMERHIP_PAYLOAD=64, for A/B)
@@ -574,13 +575,21 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
     const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
     c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
     // (a narrow FRESH pass must write every region of the image whatever the table held: dirty = 1)
-#define KH_REGION32(FRESH, NARROW, DIRTY, CB, RH) \
-    hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW>), dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg, g, \
+#define KH_REGION32(FRESH, NARROW, NT, DIRTY, CB, RH) \
+    hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW, NT>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, g, \
                        (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab, skip)
-    if (c->table_empty && narrow) KH_REGION32(true, true, 1u, c->rheads_cb, c->rheads);
-    else if (c->table_empty) KH_REGION32(true, false, (uint32_t)c->table_dirty, c->rheads_cb, c->rheads);
-    else if (narrow) KH_REGION32(false, true, 0u, 0u, (uint32_t *)nullptr);
-    else KH_REGION32(false, false, 0u, 0u, (uint32_t *)nullptr);
+    // A fresh pass into a table that will end at load <= 0.6 runs in 512-lane workgroups, three per CU (at a higher load
+    // the probing loop is most of the kernel and wants the waves of two 1024-lane workgroups; a pass over a filled table
+    // keeps the old slots in registers: eight per lane would not fit).  Without a hint the table was sized for "every
+    // window is new" and ends far below that.  KMERHIP_REGION_NT=512|1024 forces one (A/B, tests).
+    const int forced = [] { const char *e = getenv("KMERHIP_REGION_NT"); return e ? atoi(e) : 0; }();
+    const bool small = forced ? forced == 512 : (!c->hinted || (double)c->hint_keys <= 0.6 * (double)c->cap);
+    if (c->table_empty && narrow && small) KH_REGION32(true, true, 512, 1u, c->rheads_cb, c->rheads);
+    else if (c->table_empty && narrow) KH_REGION32(true, true, kh::REGION_NT, 1u, c->rheads_cb, c->rheads);
+    else if (c->table_empty && small) KH_REGION32(true, false, 512, (uint32_t)c->table_dirty, c->rheads_cb, c->rheads);
+    else if (c->table_empty) KH_REGION32(true, false, kh::REGION_NT, (uint32_t)c->table_dirty, c->rheads_cb, c->rheads);
+    else if (narrow) KH_REGION32(false, true, kh::REGION_NT, 0u, 0u, (uint32_t *)nullptr);
+    else KH_REGION32(false, false, kh::REGION_NT, 0u, 0u, (uint32_t *)nullptr);
 #undef KH_REGION32
 }
 
@@ -1421,6 +1430,7 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
     const char *tr = getenv("KMERHIP_TRACE");
     c->trace = (cfg->flags & KH_FLAG_TRACE) || (tr && tr[0] && tr[0] != '0');
     c->hinted = cfg->capacity_hint != 0;
+    c->hint_keys = cfg->capacity_hint;
     c->path_mode = (cfg->flags & KH_FLAG_FORCE_DIRECT) ? 1 : (cfg->flags & KH_FLAG_FORCE_PARTITION) ? 2 : 0;
     if (const char *pm = getenv("KMERHIP_PATH")) {
         if (!strcmp(pm, "direct")) c->path_mode = 1;

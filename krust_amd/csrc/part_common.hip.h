@@ -27,7 +27,10 @@ constexpr uint32_t MAX_P1 = 1024;
 constexpr uint32_t MAX_P1_BITS = 10;
 constexpr uint32_t MAX_P2_BITS = 10;             // <= 1024 regions per level-1 partition
 constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // payloads per level-2 workgroup (262144)
-constexpr int REGION_NT = 1024;                  // lanes per workgroup in region_count_kernel
+#ifndef KH_REGION_NT
+#define KH_REGION_NT 1024  // (512: three workgroups per CU instead of two -- A/B builds)
+#endif
+constexpr int REGION_NT = KH_REGION_NT;          // lanes per workgroup in region_count_kernel
 #ifndef KH_ARENA_LANES
 #define KH_ARENA_LANES 4  // lanes that flush a bucket of the arena level 2 together (1, 2, 8: A/B builds)
 #endif

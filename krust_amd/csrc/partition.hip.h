@@ -1208,9 +1208,9 @@ __global__ __launch_bounds__(256) void bucket_bounds_heavy_kernel(const u64 *__r
 // `dirty`: kh_reset no longer clears the table (5.5 ms for 34 GB); the first FRESH pass after it
 // overwrites every region instead, so the regions it would otherwise skip (empty bucket, overflow)
 // must be written as empty images.
-__device__ __forceinline__ void write_empty_region(Slot *reg, int tid) {
+__device__ __forceinline__ void write_empty_region(Slot *reg, int tid, int nt = REGION_NT) {
     uint4 *o4 = reinterpret_cast<uint4 *>(reg);
-    for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) o4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
+    for (uint32_t i = tid; i < REGION_SLOTS; i += nt) o4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
 }
 
 template <bool FRESH>
@@ -1543,8 +1543,12 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
 // narrow slot is Pay<uint32_t>::key(payload, region >> p2_bits, g): ntable_widen_kernel turns the image into the 16-byte
 // table when something needs that (kmerhip.hip ensure_wide); counting, histogram, compaction and lookups read it as it is.
 // A count that does not fit 32 bits fails the region (rfail = 2): the host widens the table and re-inserts the bucket.
-template <bool FRESH, bool NARROW>
-__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays, const u64 *__restrict__ bend,
+// NT = lanes of the workgroup: 1024 (two workgroups per CU: 72 KiB of LDS each) or 512 (52 KiB: THREE per CU, a third fewer
+// waves).  Measured (profiles/README.md r03b): at load 0.5 -- 24 K payloads per bucket, the probing loop a third of the kernel --
+// three workgroups in different phases beat two: 21.1 -> 19.2 ms (S50M at load 0.58: 12.2 -> 11.2; S10M at 0.44: 4.1 -> 3.3);
+// at load 0.61 (30 K payloads, longer probe sequences) the loop wants the waves: 36.4 -> 40.9 ms.  kmerhip.hip (launch_region) chooses.
+template <bool FRESH, bool NARROW, int NT = REGION_NT>
+__global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr,
@@ -1555,20 +1559,21 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     // will need (shard.hip.h heads_of), so that a multi-GPU export right after this pass can skip its
     // counting pass over the table.
     __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
-    __shared__ uint32_t s_add[REGION_SLOTS + REGION_NT];  // (+ one dummy word per lane for predicated adds)
+    __shared__ uint32_t s_add[REGION_SLOTS + NT];  // (+ one dummy word per lane for predicated adds)
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
     __shared__ uint32_t s_special, s_sp_off, s_sp_new, s_heads, s_real;
-    __shared__ uint32_t s_q[(REGION_RK + 1) * REGION_NT];  // the lanes' payload queues, one block per wave (r32_qbase)
+    __shared__ uint32_t s_q[(REGION_RK + 1) * NT];  // the lanes' payload queues, one block per wave (r32_qbase)
+    constexpr int SPL = REGION_SLOTS / NT;  // slots per lane
     const int tid = threadIdx.x;
     const u64 r = blockIdx.x;
     const u64 lo = bstart[r], hi = bend[r];
     auto write_empty = [&]() {
         if (NARROW) {
             uint4 *o4 = reinterpret_cast<uint4 *>(ntab + r * REGION_SLOTS);
-            for (uint32_t i = tid; i < REGION_SLOTS / 2; i += REGION_NT) o4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t i = tid; i < REGION_SLOTS / 2; i += NT) o4[i] = make_uint4(0u, 0u, 0u, 0u);
         } else {
-            write_empty_region(tg.table + r * REGION_SLOTS, tid);
+            write_empty_region(tg.table + r * REGION_SLOTS, tid, NT);
         }
     };
     if (lo == hi || hi - lo > skip_threshold) {  // (a bucket above skip_threshold is left to hot_buckets_kernel)
@@ -1606,17 +1611,17 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     uint32_t kbuf[REGION_RK];
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {  // branch-free: clamped index
-        const uint32_t i = (uint32_t)j * REGION_NT + tid;
+        const uint32_t i = (uint32_t)j * NT + tid;
         kbuf[j] = src[i < n ? i : n - 1];
     }
-    Slot old[NARROW ? 1 : R32_SLOTS_PER_LANE];
-    u64 oldn[NARROW ? R32_SLOTS_PER_LANE : 1];  // the narrow form of the lane's old slots
+    Slot old[NARROW ? 1 : SPL];
+    u64 oldn[NARROW ? SPL : 1];  // the narrow form of the lane's old slots
     const u64 *const nreg = NARROW ? ntab + r * REGION_SLOTS : nullptr;
     bool unrepresentable = false;
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
 #pragma unroll
-    for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
-        const uint32_t i = (uint32_t)q * REGION_NT + tid;
+    for (int q = 0; q < SPL; ++q) {
+        const uint32_t i = (uint32_t)q * NT + tid;
         uint32_t w = R32_FREE;
         if (NARROW) {
             oldn[q] = FRESH ? 0ull : nreg[i];
@@ -1667,18 +1672,18 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     // cursor into a private queue of REGION_RK payloads (LDS, [slot][lane]: conflict-free) and takes
     // its next payload as soon as its current one is placed, so a round costs the largest SUM of
     // probe lengths of one lane (~1.5 per key) instead of the sum of the per-key maxima.
-    for (u64 base = 0; base < n; base += (u64)REGION_RK * REGION_NT) {
+    for (u64 base = 0; base < n; base += (u64)REGION_RK * NT) {
         // payloads of this round -> the lane's queue; how many of them are real
         const u64 rem = n - base;  // > 0
         uint32_t nk = 0;
-        if ((u64)tid < rem) nk = (uint32_t)((rem - tid + REGION_NT - 1) / REGION_NT);
+        if ((u64)tid < rem) nk = (uint32_t)((rem - tid + NT - 1) / NT);
         if (nk > REGION_RK) nk = REGION_RK;
         uint32_t pj[REGION_RK];
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) pj[j] = kbuf[j];
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) {  // next round's payloads in flight during the probing
-            const u64 i64 = base + (u64)(REGION_RK + j) * REGION_NT + tid;
+            const u64 i64 = base + (u64)(REGION_RK + j) * NT + tid;
             kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
         }
         if (hot || may_special || !FRESH) {
@@ -1792,8 +1797,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     if (NARROW && !s_fail) {  // would a count leave 32 bits?  Then nothing of the region is written (uniform decision: two barriers)
         bool wide_cnt = false;
 #pragma unroll
-        for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
-            const uint32_t i = (uint32_t)q * REGION_NT + tid;
+        for (int q = 0; q < SPL; ++q) {
+            const uint32_t i = (uint32_t)q * NT + tid;
             const u64 cc = (oldn[q] >> 32) + s_add[i] + (i == sp_off ? s_special : 0u);
             wide_cnt |= cc > 0xFFFFFFFFull;
         }
@@ -1814,8 +1819,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
     if (NARROW) {
         u64 *const nout = ntab + r * REGION_SLOTS;
 #pragma unroll
-        for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
-            const uint32_t i = (uint32_t)q * REGION_NT + tid;
+        for (int q = 0; q < SPL; ++q) {
+            const uint32_t i = (uint32_t)q * NT + tid;
             const uint32_t delta = s_add[i];
             u64 cc = (oldn[q] >> 32) + delta;
             uint32_t pp = (oldn[q] >> 32) ? (uint32_t)oldn[q] : s_pay[i];  // an old slot keeps its payload; a new one's is in the image
@@ -1831,8 +1836,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel32(TableGeom 
         }
     } else
 #pragma unroll
-    for (int q = 0; q < R32_SLOTS_PER_LANE; ++q) {
-        const uint32_t i = (uint32_t)q * REGION_NT + tid;
+    for (int q = 0; q < SPL; ++q) {
+        const uint32_t i = (uint32_t)q * NT + tid;
         u64 kk = old[q].key, cc = old[q].count;
         const uint32_t delta = s_add[i];
         if (delta) {
