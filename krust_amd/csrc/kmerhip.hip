@@ -559,15 +559,21 @@ int head_count_bits(const kh_ctx *c, u64 regions) {
 // region rebuild launch, by payload type
 template <typename PT>
 void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip);
+// (fresh passes that will end at load <= 0.6: 512-lane workgroups, three per CU -- see launch_region<uint32_t> below)
+bool region_small_groups(const kh_ctx *c) {
+    const int forced = [] { const char *e = getenv("KMERHIP_REGION_NT"); return e ? atoi(e) : 0; }();
+    return forced ? forced == 512 : (!c->hinted || (double)c->hint_keys <= 0.6 * (double)c->cap);
+}
 template <>
 void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool, u64 skip) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
-    if (c->table_empty)
-        hipLaunchKernelGGL(kh::region_count_kernel64<true>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal, skip);
-    else
-        hipLaunchKernelGGL(kh::region_count_kernel64<false>, dim3((unsigned)nregions), dim3(kh::REGION_NT), 0, c->stream, tg,
-                           (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal, skip);
+#define KH_REGION64(FRESH, NT) \
+    hipLaunchKernelGGL((kh::region_count_kernel64<FRESH, NT>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, \
+                       (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal, skip)
+    if (c->table_empty && region_small_groups(c)) KH_REGION64(true, 512);
+    else if (c->table_empty) KH_REGION64(true, kh::REGION_NT);
+    else KH_REGION64(false, kh::REGION_NT);
+#undef KH_REGION64
 }
 template <>
 void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip) {
@@ -582,8 +588,7 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
     // the probing loop is most of the kernel and wants the waves of two 1024-lane workgroups; a pass over a filled table
     // keeps the old slots in registers: eight per lane would not fit).  Without a hint the table was sized for "every
     // window is new" and ends far below that.  KMERHIP_REGION_NT=512|1024 forces one (A/B, tests).
-    const int forced = [] { const char *e = getenv("KMERHIP_REGION_NT"); return e ? atoi(e) : 0; }();
-    const bool small = forced ? forced == 512 : (!c->hinted || (double)c->hint_keys <= 0.6 * (double)c->cap);
+    const bool small = region_small_groups(c);
     if (c->table_empty && narrow && small) KH_REGION32(true, true, 512, 1u, c->rheads_cb, c->rheads);
     else if (c->table_empty && narrow) KH_REGION32(true, true, kh::REGION_NT, 1u, c->rheads_cb, c->rheads);
     else if (c->table_empty && small) KH_REGION32(true, false, 512, (uint32_t)c->table_dirty, c->rheads_cb, c->rheads);

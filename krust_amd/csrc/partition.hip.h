@@ -1213,13 +1213,16 @@ __device__ __forceinline__ void write_empty_region(Slot *reg, int tid, int nt = 
     for (uint32_t i = tid; i < REGION_SLOTS; i += nt) o4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
 }
 
-template <bool FRESH>
-__global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys, const u64 *__restrict__ bend,
+// NT: as for region_count_kernel32 -- a FRESH pass keeps 32-bit count deltas (48 KiB of LDS with the keys: three 512-lane
+// workgroups per CU); a pass over a filled table has the old 64-bit counts in LDS too (64 KiB, two workgroups per CU).
+template <bool FRESH, int NT = REGION_NT>
+__global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    u64 *__restrict__ rreal, u64 skip_threshold) {
     __shared__ __attribute__((aligned(16))) u64 s_key[REGION_SLOTS];
-    __shared__ u64 s_cnt[REGION_SLOTS];
+    __shared__ u64 s_cnt[FRESH ? 1 : REGION_SLOTS];       // counts (old + new) of a pass over a filled table
+    __shared__ uint32_t s_add[FRESH ? REGION_SLOTS : 1];  // count deltas of a fresh pass
     __shared__ uint32_t s_fail;
     __shared__ uint32_t s_new;
     __shared__ u64 s_real;
@@ -1228,10 +1231,18 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     const u64 lo = bstart[r], hi = bend[r];
     Slot *reg = tg.table + r * REGION_SLOTS;
     if (lo == hi || hi - lo > skip_threshold) {  // nothing new for this region, or a bucket left to hot_buckets_kernel
-        if (FRESH && dirty) write_empty_region(reg, tid);
+        if (FRESH && dirty) write_empty_region(reg, tid, NT);
         if (tid == 0) {
             rnew[r] = 0;
             rreal[r] = 0;
+        }
+        return;
+    }
+    if (FRESH && hi - lo >= 0xFFFFFFFFull) {  // a 32-bit delta could wrap (only with hot buckets switched off): the direct path takes it
+        if (dirty) write_empty_region(reg, tid, NT);
+        if (tid == 0) {
+            rfail[r] = 1;
+            rnew[r] = 0;
         }
         return;
     }
@@ -1244,17 +1255,17 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     u64 nreal = 0;  // keys of the bucket that are k-mers (KH_EMPTY_KEY pads its segments to whole units)
 #pragma unroll
     for (int j = 0; j < REGION_RK; ++j) {
-        const u64 i = (u64)j * REGION_NT + tid;
+        const u64 i = (u64)j * NT + tid;
         const u64 v = src[i < n ? i : n - 1];
         kbuf[j] = i < n ? v : KH_EMPTY_KEY;
         nreal += kbuf[j] != KH_EMPTY_KEY;
     }
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
 #pragma unroll
-    for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) {
+    for (uint32_t i = tid; i < REGION_SLOTS; i += NT) {
         if (FRESH) {
             s_key[i] = KH_EMPTY_KEY;
-            s_cnt[i] = 0;
+            s_add[i] = 0;
         } else {
             const uint4 v = g4[i];
             s_key[i] = ((u64)v.y << 32) | v.x;
@@ -1268,11 +1279,11 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     }
     __syncthreads();
     uint32_t nd = 0;
-    for (u64 base = 0; base < n; base += (u64)REGION_RK * REGION_NT) {
+    for (u64 base = 0; base < n; base += (u64)REGION_RK * NT) {
         u64 nbuf[REGION_RK];
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) {  // next round's keys in flight while this round is inserted
-            const u64 i = base + (u64)(REGION_RK + j) * REGION_NT + tid;
+            const u64 i = base + (u64)(REGION_RK + j) * NT + tid;
             const u64 v = src[i < n ? i : n - 1];
             nbuf[j] = i < n ? v : KH_EMPTY_KEY;
             nreal += nbuf[j] != KH_EMPTY_KEY;
@@ -1321,7 +1332,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
                         }
                     }
                     if (cur == key) {
-                        atomicAdd(&s_cnt[off + i], weight);  // ds_add_u64
+                        if (FRESH) atomicAdd(&s_add[off + i], (uint32_t)weight);  // ds_add_u32
+                        else atomicAdd(&s_cnt[off + i], weight);                   // ds_add_u64
                         placed = true;
                     }
                 }
@@ -1338,7 +1350,7 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     if ((tid & 63) == 0 && rw) atomicAdd(&s_real, rw);  // LDS, 64-bit: a hot bucket may hold >= 2^32 keys
     __syncthreads();
     if (s_fail) {
-        if (FRESH && dirty) write_empty_region(reg, tid);
+        if (FRESH && dirty) write_empty_region(reg, tid, NT);
         if (tid == 0) {
             rfail[r] = 1;
             rnew[r] = 0;
@@ -1347,8 +1359,8 @@ __global__ __launch_bounds__(REGION_NT, 8) void region_count_kernel64(TableGeom 
     }
     uint4 *o4 = reinterpret_cast<uint4 *>(reg);
 #pragma unroll
-    for (uint32_t i = tid; i < REGION_SLOTS; i += REGION_NT) {
-        const u64 kk = s_key[i], cc = s_cnt[i];
+    for (uint32_t i = tid; i < REGION_SLOTS; i += NT) {
+        const u64 kk = s_key[i], cc = FRESH ? (u64)s_add[i] : s_cnt[i];
         o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
     }
     if (tid == 0) {
