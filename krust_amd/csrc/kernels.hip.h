@@ -35,6 +35,7 @@ struct Counters {
     u64 heads_wide;   // a count too large for 32-bit exchange heads was seen (region_count_kernel32)
     u64 narrow_ovf;   // overflow-list entries whose count would not fit the 8-byte table image (left in the list: ovf_insert_kernel)
     u64 hot;          // buckets the region pass left to hot_buckets_kernel (hot_list_kernel counts them; partition.hip.h)
+    u64 hot_total;    // ... and the payloads in them
 };
 
 constexpr int BLOCK = 256;           // 4 waves of 64

@@ -913,11 +913,13 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     if (nar) c->narrow_g = g;
     // A bucket holding more than a thousandth of the batch (and a million payloads) would keep ONE workgroup of the region
     // pass busy for as long as the whole pass takes: the pass skips it, hot_buckets_kernel counts it afterwards (below).
-    // KMERHIP_HOT_CUT=n: another threshold (tests); 0 = no bucket is hot.
+    // Also 64 x the mean bucket: what makes a bucket hot is one key, not a table with too few regions for the batch (a
+    // hint that was far too small: there every bucket is large, and the region pass's overflow handling is what sizes the
+    // table) -- so at most a 64th of the buckets can be hot.  KMERHIP_HOT_CUT=n: another threshold (tests); 0 = no bucket is hot.
     const u64 hot_cut = [&] {
         const char *e = getenv("KMERHIP_HOT_CUT");
         if (e) return e[0] == '0' && !e[1] ? ~0ull : (u64)strtoull(e, nullptr, 10);
-        return std::max<u64>(n_all >> 10, 1ull << 20);
+        return std::max<u64>(std::max<u64>(n_all >> 10, 1ull << 20), 64 * (n_all / nregions));
     }();
     if (hot_cut != ~0ull) {
         StageTimer t(c, ST_MISC);
@@ -1018,14 +1020,24 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     if (c->h_ctr->hot) {
         // the buckets the region pass skipped (see hot_cut above), spread over the whole grid, through device atomics on the
         // 16-byte table -- which the table stays from here on: input like this is not what the 8-byte image is for
-        const u64 nhot = c->h_ctr->hot;
-        if (c->trace) fprintf(stderr, "[kmerhip] %llu hot bucket(s) (more than %llu payloads) counted apart from the region pass\n", nhot, hot_cut);
+        const u64 nhot = c->h_ctr->hot, hot_total = c->h_ctr->hot_total;
+        if (c->trace) fprintf(stderr, "[kmerhip] %llu hot bucket(s) (more than %llu payloads each, %llu together) counted apart from the region pass\n", nhot, hot_cut, hot_total);
         if ((rc = ensure_wide(c)) != KH_OK) return rc;
+        // The hot kernel inserts through device atomics: a region without room is an error there, not a retry.  Hot buckets
+        // are few (<= a 64th of the buckets with the default threshold) and hold few keys, and a table that is too small
+        // shows in the OTHER regions first (they fail, the table grows: above).  Where most buckets were declared hot (a
+        // forced threshold, tests) nothing has witnessed the table's size: make room for the worst case first.
+        if (nhot > nregions / 64 && (double)(c->distinct_known + hot_total) > LOAD_HARD * (double)c->cap) {
+            u64 newcap = c->cap * 2;
+            while ((double)(c->distinct_known + hot_total) > LOAD_TARGET * (double)newcap) newcap *= 2;
+            StageTimer t(c, ST_GROW);
+            if ((rc = grow_to(c, newcap)) != KH_OK) return rc;
+        }
         {
             StageTimer t(c, ST_MISC);
             hipLaunchKernelGGL(kh::hot_buckets_kernel<PT>, dim3(kh::HOT_GRID), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
                                (const PT *)bufB, (const u64 *)c->bstart, bend, (const uint32_t *)c->hot_list, nhot, c->d_ctr);
-            HIP_TRY(c, hipMemsetAsync(&c->d_ctr->hot, 0, sizeof(u64), c->stream));
+            HIP_TRY(c, hipMemsetAsync(&c->d_ctr->hot, 0, 2 * sizeof(u64), c->stream));  // hot + hot_total
         }
         HIP_TRY(c, hipGetLastError());
         c->rheads_valid = false;

@@ -1952,7 +1952,10 @@ constexpr int HOT_GRID = 1024;
 __global__ __launch_bounds__(BLOCK) void hot_list_kernel(const u64 *__restrict__ bstart, const u64 *__restrict__ bend, u64 nregions, u64 cut,
                                                          uint32_t *__restrict__ list, Counters *ctr) {
     const u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x;
-    if (r < nregions && bend[r] - bstart[r] > cut) list[atomicAdd(&ctr->hot, 1ull)] = (uint32_t)r;
+    if (r < nregions && bend[r] - bstart[r] > cut) {
+        list[atomicAdd(&ctr->hot, 1ull)] = (uint32_t)r;
+        atomicAdd(&ctr->hot_total, bend[r] - bstart[r]);
+    }
 }
 
 template <typename PT>
