@@ -114,3 +114,73 @@ def test_random_route_same_map(seed, monkeypatch):
         if len(wk):
             probe = np.concatenate([wk[:: max(1, len(wk) // 200)], np.array([0, (1 << (2 * k)) - 1 if k < 32 else 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)])
             assert dc.lookup(probe).tolist() == [wd.get(int(x), 0) for x in probe], what
+
+
+def _np_mix64(z):
+    """oracle ko_mix64 (splitmix64 finaliser), vectorised with wrap-around."""
+    z = z.astype(np.uint64)
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+MID_KNOBS = {
+    "KMERHIP_HOT_CUT": [None, None, None, "200000"],
+    "KMERHIP_SURVIVAL": [None, None, "0.1"],
+    "KMERHIP_REGION_NT": [None, None, "512", "1024"],
+    "KMERHIP_NARROW": [None, None, "0"],
+    "KMERHIP_L2_SKEW_X": [None, None, "0"],
+    "KMERHIP_L2_ARENA": [None, None, None, "0"],
+    "KMERHIP_PART_BUDGET_GB": [None, None, "0.6", "2"],
+}
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KMERHIP_STRESS_MID_SEEDS", "10"))))
+def test_random_route_same_digest_at_a_few_hundred_million_windows(seed, monkeypatch):
+    """The same idea at 1-3 M reads (150-450 M windows), where the DEFAULT thresholds bite: heavy level-1 partitions, hot
+    buckets above a thousandth of the batch, survival estimates of real batches, several batches per push.  Reads from the
+    device generator with a random share overwritten by repeats; the whole map through the order-independent digest
+    sum(mix(key ^ mix(count))) of the oracle's radix formulation, plus total and distinct."""
+    import torch
+    import krust_amd as K
+    K.lib()
+    rng = np.random.default_rng(70_000 + seed)
+    k = int(rng.choice([15, 17, 19, 21, 21, 23, 27, 31, 32]))
+    minq = [None, None, 20][int(rng.integers(0, 3))]
+    n_reads, rl = int(rng.integers(1_000_000, 3_000_001)), 150
+    glen = 1 << int(rng.integers(22, 28))
+    nbytes = n_reads * (rl + 1)
+    tb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    tq = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    K.synth_reads_device(tb.data_ptr(), tq.data_ptr(), 777 + seed, glen, rl, 0, n_reads)
+    share = float(rng.choice([0.0, 0.01, 0.1, 0.4]))
+    if share:
+        units = [b"A", b"AC", b"GATTACA", bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(11, 60))).astype(np.uint8))]
+        rows = torch.from_numpy(rng.choice(n_reads, size=int(share * n_reads), replace=False)).cuda()
+        v = tb.view(n_reads, rl + 1)
+        for j, u in enumerate(units):
+            pat = torch.from_numpy(np.resize(np.frombuffer(u, dtype=np.uint8), rl).copy()).cuda()
+            v[rows[j::len(units)], :rl] = pat
+    torch.cuda.synchronize()
+    host, hq = tb.cpu().numpy(), tq.cpu().numpy()
+    total, distinct, digest = O.count_flat_radix(host, k, qual=hq if minq is not None else None, min_quality=minq, nthreads=NCPU)
+    hint = int(rng.choice([0, distinct, max(1, distinct // 8), 4 * distinct]))
+    env = {name: vals[int(rng.integers(0, len(vals)))] for name, vals in MID_KNOBS.items()}
+    for name, val in env.items():
+        if val is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, val)
+    cuts = sorted({0, n_reads, *[int(x) for x in rng.integers(0, n_reads, size=int(rng.integers(0, 3)))]})
+    what = f"seed {seed}: k={k} minq={minq} reads={n_reads} genome=2^{glen.bit_length() - 1} repeats={share} hint={hint} cuts={cuts} env={ {a: b for a, b in env.items() if b} }"
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=hint, path="partition") as dc:
+        for a, b in zip(cuts, cuts[1:]):
+            if b > a:
+                dc.push_device(tb.data_ptr() + a * (rl + 1), tq.data_ptr() + a * (rl + 1) if minq is not None else None, (b - a) * (rl + 1))
+        st = dc.finish()
+        assert st["kmers"] == total and st["distinct"] == distinct, (what, st["kmers"], total, st["distinct"], distinct)
+        keys, cnts = dc.result(sort=False)
+    assert keys.size == distinct, what
+    with np.errstate(over="ignore"):
+        got = int(_np_mix64(keys ^ _np_mix64(cnts)).sum(dtype=np.uint64))
+    assert got == digest, what
