@@ -1018,16 +1018,21 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if (rc != KH_OK) return rc;
     }
     if (c->h_ctr->hot) {
-        // the buckets the region pass skipped (see hot_cut above), spread over the whole grid, through device atomics on the
-        // 16-byte table -- which the table stays from here on: input like this is not what the 8-byte image is for
+        // the buckets the region pass skipped (see hot_cut above), spread over the whole grid, through device atomics: on the
+        // 8-byte image where no count can leave 32 bits (the table has counted fewer than 2^32 k-mers, these included: an
+        // hg38-sized input keeps its image), else on the 16-byte table, which the table then stays
         const u64 nhot = c->h_ctr->hot, hot_total = c->h_ctr->hot_total;
-        if (c->trace) fprintf(stderr, "[kmerhip] %llu hot bucket(s) (more than %llu payloads each, %llu together) counted apart from the region pass\n", nhot, hot_cut, hot_total);
-        if ((rc = ensure_wide(c)) != KH_OK) return rc;
+        const bool crowded = nhot > nregions / 64 && (double)(c->distinct_known + hot_total) > LOAD_HARD * (double)c->cap;  // (see below)
+        const bool hot_narrow = sizeof(PT) == 4 && c->narrow && !crowded && c->h_ctr->kmers + hot_total < 0xFFFFFFFFull;
+        if (c->trace)
+            fprintf(stderr, "[kmerhip] %llu hot bucket(s) (more than %llu payloads each, %llu together) counted apart from the region pass%s\n", nhot,
+                    hot_cut, hot_total, hot_narrow ? ", into the 8-byte image" : "");
+        if (!hot_narrow && (rc = ensure_wide(c)) != KH_OK) return rc;
         // The hot kernel inserts through device atomics: a region without room is an error there, not a retry.  Hot buckets
         // are few (<= a 64th of the buckets with the default threshold) and hold few keys, and a table that is too small
         // shows in the OTHER regions first (they fail, the table grows: above).  Where most buckets were declared hot (a
         // forced threshold, tests) nothing has witnessed the table's size: make room for the worst case first.
-        if (nhot > nregions / 64 && (double)(c->distinct_known + hot_total) > LOAD_HARD * (double)c->cap) {
+        if (crowded) {
             u64 newcap = c->cap * 2;
             while ((double)(c->distinct_known + hot_total) > LOAD_TARGET * (double)newcap) newcap *= 2;
             StageTimer t(c, ST_GROW);
@@ -1035,8 +1040,12 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         }
         {
             StageTimer t(c, ST_MISC);
-            hipLaunchKernelGGL(kh::hot_buckets_kernel<PT>, dim3(kh::HOT_GRID), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
-                               (const PT *)bufB, (const u64 *)c->bstart, bend, (const uint32_t *)c->hot_list, nhot, c->d_ctr);
+            if (hot_narrow)
+                hipLaunchKernelGGL((kh::hot_buckets_kernel<PT, sizeof(PT) == 4>), dim3(kh::HOT_GRID), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
+                                   (const PT *)bufB, (const u64 *)c->bstart, bend, (const uint32_t *)c->hot_list, nhot, c->d_ctr, c->ntab);
+            else
+                hipLaunchKernelGGL((kh::hot_buckets_kernel<PT, false>), dim3(kh::HOT_GRID), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
+                                   (const PT *)bufB, (const u64 *)c->bstart, bend, (const uint32_t *)c->hot_list, nhot, c->d_ctr, (u64 *)nullptr);
             HIP_TRY(c, hipMemsetAsync(&c->d_ctr->hot, 0, 2 * sizeof(u64), c->stream));  // hot + hot_total
         }
         HIP_TRY(c, hipGetLastError());

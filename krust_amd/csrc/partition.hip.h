@@ -1958,10 +1958,12 @@ __global__ __launch_bounds__(BLOCK) void hot_list_kernel(const u64 *__restrict__
     }
 }
 
-template <typename PT>
+// NARROW: into the 8-byte image (count << 32 | payload) -- only where no count can leave 32 bits (the host checks the table's
+// k-mer total), so that input with a few hot keys keeps its image: no widening pass, and the passes after it stay narrow.
+template <typename PT, bool NARROW = false>
 __global__ __launch_bounds__(BLOCK) void hot_buckets_kernel(TableGeom tg, PartGeom g, const PT *__restrict__ pays, const u64 *__restrict__ bstart,
                                                             const u64 *__restrict__ bend, const uint32_t *__restrict__ list, u64 nhot,
-                                                            Counters *ctr) {
+                                                            Counters *ctr, u64 *__restrict__ ntab = nullptr) {
     constexpr PT FREE = (PT)~(PT)0;  // (32-bit payloads: a legal value, counted apart; 64-bit: KH_EMPTY_KEY, the padding)
     __shared__ PT s_key[HOT_TAB];
     __shared__ uint32_t s_cnt[HOT_TAB];
@@ -1988,13 +1990,17 @@ __global__ __launch_bounds__(BLOCK) void hot_buckets_kernel(TableGeom tg, PartGe
             for (int i = tid; i < HOT_TAB; i += BLOCK) {
                 const uint32_t cnt = s_cnt[i];
                 if (cnt) {
-                    upsert(tg, Pay<PT>::key(s_key[i], p1, g), (u64)cnt, nd, nf);
+                    if constexpr (NARROW) (void)narrow_upsert(ntab + r * REGION_SLOTS, g, (uint32_t)s_key[i], (u64)cnt, 0ull, nd, nf);
+                    else upsert(tg, Pay<PT>::key(s_key[i], p1, g), (u64)cnt, nd, nf);
                     s_key[i] = FREE;
                     s_cnt[i] = 0;
                 }
             }
             if (tid == 0) {
-                if (sizeof(PT) == 4 && s_free_cnt) upsert(tg, Pay<PT>::key(FREE, p1, g), (u64)s_free_cnt, nd, nf);
+                if (sizeof(PT) == 4 && s_free_cnt) {
+                    if constexpr (NARROW) (void)narrow_upsert(ntab + r * REGION_SLOTS, g, 0xFFFFFFFFu, (u64)s_free_cnt, 0ull, nd, nf);
+                    else upsert(tg, Pay<PT>::key(FREE, p1, g), (u64)s_free_cnt, nd, nf);
+                }
                 s_free_cnt = 0;
                 s_fill = 0;
             }
