@@ -1023,27 +1023,13 @@ __global__ __launch_bounds__(BLOCK) void ntable_count_kernel(const u64 *__restri
 }
 __global__ __launch_bounds__(BLOCK) void ntable_compact_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, u64 min_count, u64 *keys,
                                                                u64 *counts, u64 out_cap, Counters *ctr) {
-    const u64 stride = (u64)gridDim.x * BLOCK;
-    const u64 first = (u64)blockIdx.x * BLOCK + threadIdx.x;
-    const u64 rounds = (cap + stride - 1) / stride;  // uniform trip count: ballots need whole waves
-    for (u64 r = 0; r < rounds; ++r) {
-        const u64 i = first + r * stride;
-        const u64 sl = i < cap ? ntab[i] : 0ull;
-        const u64 cnt = sl >> 32;
-        const bool live = cnt != 0 && cnt >= min_count;
-        const u64 m = __ballot(live);
-        if (m == 0) continue;
-        u64 base = 0;
-        if (lane_id() == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&ctr->cursor, (u64)__builtin_popcountll(m));
-        base = __shfl(base, __builtin_ctzll(m), 64);
-        if (live) {
-            const u64 o = base + mbcnt(m);
-            if (o < out_cap) {
-                keys[o] = narrow_key(g, i, (uint32_t)sl);
-                counts[o] = cnt;
-            }
-        }
-    }
+    compact_tiles(cap, keys, counts, out_cap, ctr, [&](u64 i, u64 &key, u64 &count) {
+        const u64 sl = ntab[i];
+        count = sl >> 32;
+        const bool live = count != 0 && count >= min_count;
+        key = live ? narrow_key(g, i, (uint32_t)sl) : 0ull;  // (the inverse hash only for what goes out)
+        return live;
+    });
 }
 __global__ __launch_bounds__(BLOCK) void ntable_hist_kernel(const u64 *__restrict__ ntab, u64 cap, u64 min_count, u64 *dense, u64 *big,
                                                             u64 big_cap, Counters *ctr) {
