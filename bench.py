@@ -465,7 +465,10 @@ def cli_leg(krust_amd, torch, dev, local_rank, reads=10_000_000, k=21):
         torch.cuda.empty_cache()
         env = dict(os.environ, KMERUST_TIMING="1")
         runs = []
-        for rep in range(2):   # (the first run pages the binary and the ROCm libraries in)
+        # (this process has just freed a few hundred GB of HBM; a new process's runtime start-up has been seen to take 1-4 s
+        #  instead of 0.1-0.3 right after that -- `create_s` of the runs below says which it was: give the driver a moment)
+        time.sleep(3.0)
+        for rep in range(3):   # (the first run pages the binary and the ROCm libraries in)
             t0 = time.perf_counter()
             p = subprocess.run([exe, str(k), path, "--format", "histogram", "-q"], capture_output=True, env=env, timeout=600)
             wall = time.perf_counter() - t0
