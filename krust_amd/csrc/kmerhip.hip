@@ -1119,8 +1119,10 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     bool part = false;
     if (c->path_mode == 2) part = true;
     else if (c->path_mode == 0) part = windows >= PART_MIN_WINDOWS && (double)c->cap <= 7.0 * (double)windows;
-    if (part && ra.use_qual) {
-        // A quality-masked range: most windows may be gone (-Q 20 on typical reads keeps 0.4 of them at k = 31).  Count the
+    if (part && (ra.use_qual || (!c->hinted && windows >= (64ull << 20)))) {
+        // A quality-masked range: most windows may be gone (-Q 20 on typical reads keeps 0.4 of them at k = 31) -- and so may
+        // those of an unhinted one (FASTQ text as the device scanner leaves it: headers and quality lines are masked positions,
+        // 0.4 of the windows are k-mers; the table of an unhinted context is sized from the windows).  Count the
         // survivors of every 64th 4096-position tile and size pool, arenas and batches from that instead of from "every
         // window" -- configs[2] then runs as one batch instead of two.  KMERHIP_SURVIVAL=x: use x instead of the sample
         // (tests: a far too small x exercises the retry); =1: size for every window.
@@ -1134,13 +1136,17 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
             u64 good = 0;
             StageTimer tm(c, ST_MISC);
             HIP_TRY(c, hipMemsetAsync(d_out, 0, sizeof(u64), c->stream));
-            hipLaunchKernelGGL(kh::survival_sample_kernel<true>, dim3((unsigned)std::min<u64>(nsamp, 2048)), dim3(kh::BLOCK), 0, c->stream, ra.abase, ra.qbase,
-                               ra.qaligned, ra.vbeg, ra.vend, ra.wlo, t0, t1 - t0, stride, c->k, qual_thr(c), d_out);
+            if (ra.use_qual)
+                hipLaunchKernelGGL(kh::survival_sample_kernel<true>, dim3((unsigned)std::min<u64>(nsamp, 2048)), dim3(kh::BLOCK), 0, c->stream, ra.abase, ra.qbase,
+                                   ra.qaligned, ra.vbeg, ra.vend, ra.wlo, t0, t1 - t0, stride, c->k, qual_thr(c), d_out);
+            else
+                hipLaunchKernelGGL(kh::survival_sample_kernel<false>, dim3((unsigned)std::min<u64>(nsamp, 2048)), dim3(kh::BLOCK), 0, c->stream, ra.abase, (const uint8_t *)nullptr,
+                                   0, ra.vbeg, ra.vend, ra.wlo, t0, t1 - t0, stride, c->k, 0u, d_out);
             HIP_TRY(c, hipMemcpyAsync(&good, d_out, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             ra.survive = std::min(1.0, (double)good / (double)(nsamp * kh::TILE));
         }
-        if (c->trace) fprintf(stderr, "[kmerhip] quality-masked range: %.3f of the windows expected to survive\n", ra.survive);
+        if (c->trace) fprintf(stderr, "[kmerhip] %s range: %.3f of the windows expected to survive\n", ra.use_qual ? "quality-masked" : "unhinted", ra.survive);
     }
     if (part && !c->hinted) {
         // No capacity hint: this batch may bring up to `windows` NEW keys.  A region pass that overflows
