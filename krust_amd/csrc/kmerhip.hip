@@ -558,25 +558,31 @@ int head_count_bits(const kh_ctx *c, u64 regions) {
 
 // region rebuild launch, by payload type
 template <typename PT>
-void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip);
+void launch_region(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip, u64 expect);
 // (fresh passes that will end at load <= 0.6: 512-lane workgroups, three per CU -- see launch_region<uint32_t> below)
-bool region_small_groups(const kh_ctx *c) {
+bool region_small_groups(const kh_ctx *c, u64 expect, u64 nregions) {
+    // 1024 lanes only where the probing loop is most of the kernel AND has the payloads to fill them: a table that ends
+    // above load 0.6 (the hint's load, or -- without one -- as if every payload room was made for were a new key) with
+    // more than 16 K payloads per bucket.  Measured: 125 M reads into 2^31 slots (0.61, 30 K per bucket) 36.4 vs 40.9 ms
+    // with 512 lanes; an hg-shaped input in 2^32 slots (0.62, 2.9 K per bucket) 27.4 vs 20.5 ms.
     const int forced = [] { const char *e = getenv("KMERHIP_REGION_NT"); return e ? atoi(e) : 0; }();
-    return forced ? forced == 512 : (!c->hinted || (double)c->hint_keys <= 0.6 * (double)c->cap);
+    if (forced) return forced == 512;
+    const double keys = c->hinted ? (double)c->hint_keys : (double)(c->distinct_known + expect);
+    return !(keys > 0.6 * (double)c->cap && expect / nregions > 16384);
 }
 template <>
-void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool, u64 skip) {
+void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool, u64 skip, u64 expect) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
 #define KH_REGION64(FRESH, NT) \
     hipLaunchKernelGGL((kh::region_count_kernel64<FRESH, NT>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, \
                        (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal, skip)
-    if (c->table_empty && region_small_groups(c)) KH_REGION64(true, 512);
+    if (c->table_empty && region_small_groups(c, expect, nregions)) KH_REGION64(true, 512);
     else if (c->table_empty) KH_REGION64(true, kh::REGION_NT);
     else KH_REGION64(false, kh::REGION_NT);
 #undef KH_REGION64
 }
 template <>
-void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip) {
+void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip, u64 expect) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
     c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
@@ -586,9 +592,10 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
                        (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab, skip)
     // A fresh pass into a table that will end at load <= 0.6 runs in 512-lane workgroups, three per CU (at a higher load
     // the probing loop is most of the kernel and wants the waves of two 1024-lane workgroups; a pass over a filled table
-    // keeps the old slots in registers: eight per lane would not fit).  Without a hint the table was sized for "every
-    // window is new" and ends far below that.  KMERHIP_REGION_NT=512|1024 forces one (A/B, tests).
-    const bool small = region_small_groups(c);
+    // keeps the old slots in registers: eight per lane would not fit).  Without a hint: the load it would end at if every
+    // payload were a new key (a table sized for that ends far below 0.6; one capped by the memory -- an hg38-sized input
+    // in 2^32 slots -- may not).  KMERHIP_REGION_NT=512|1024 forces one (A/B, tests).
+    const bool small = region_small_groups(c, expect, nregions);
     if (c->table_empty && narrow && small) KH_REGION32(true, true, 512, 1u, c->rheads_cb, c->rheads);
     else if (c->table_empty && narrow) KH_REGION32(true, true, kh::REGION_NT, 1u, c->rheads_cb, c->rheads);
     else if (c->table_empty && small) KH_REGION32(true, false, 512, (uint32_t)c->table_dirty, c->rheads_cb, c->rheads);
@@ -929,7 +936,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     {
         StageTimer t(c, ST_REGION);
         // buckets more than 4x the mean (upper bound) take the skew-guarded probing loop
-        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend, nar, hot_cut);
+        launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend, nar, hot_cut, n_ub);
     }
     if (nar) c->narrow = true;
     {

@@ -1544,7 +1544,8 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
 // NT = lanes of the workgroup: 1024 (two workgroups per CU: 72 KiB of LDS each) or 512 (52 KiB: THREE per CU, a third fewer
 // waves).  Measured (profiles/README.md r03b): at load 0.5 -- 24 K payloads per bucket, the probing loop a third of the kernel --
 // three workgroups in different phases beat two: 21.1 -> 19.2 ms (S50M at load 0.58: 12.2 -> 11.2; S10M at 0.44: 4.1 -> 3.3);
-// at load 0.61 (30 K payloads, longer probe sequences) the loop wants the waves: 36.4 -> 40.9 ms.  kmerhip.hip (launch_region) chooses.
+// at load 0.61 with 30 K payloads per bucket the loop wants the waves: 36.4 -> 40.9 ms (but at 0.62 with 2.9 K per bucket:
+// 27.4 -> 20.5).  kmerhip.hip (region_small_groups) chooses.
 template <bool FRESH, bool NARROW, int NT = REGION_NT>
 __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
