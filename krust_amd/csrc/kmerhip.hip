@@ -837,6 +837,9 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             bend = c->bend;
             c->ovf_pending = std::min<u64>(hov[0], ovf_lim);  // (the cursor moves in whole segments: it may end beyond the list)
             HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
+            if (c->trace && c->ovf_pending)
+                fprintf(stderr, "[kmerhip] level 2: %llu entries handed out to the overflow list (%.2f %% of the batch's payload room)\n", (u64)c->ovf_pending,
+                        100.0 * (double)c->ovf_pending / (double)n_ub);
             if (heavy_exact && c->trace)
                 fprintf(stderr, "[kmerhip] %llu heavy level-1 partition(s) (%llu payloads) take the exact level-2 kernels, the others the arenas\n", hov[2], hov[3]);
         } else if (c->trace) {
