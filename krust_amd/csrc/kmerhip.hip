@@ -947,7 +947,21 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         // (three same-address atomics per WAVE at ~10 ns each: a block per 256 regions -- 2048 blocks -- took 0.2 ms for 7 MB)
         hipLaunchKernelGGL(kh::region_reduce_kernel, dim3((unsigned)std::min<u64>(128, (nregions + kh::BLOCK - 1) / kh::BLOCK)), dim3(kh::BLOCK), 0, c->stream,
                            (const u64 *)c->bstart, (const uint8_t *)c->rfail, (const uint32_t *)c->rnew, (const u64 *)c->rreal, (u64)nregions, c->d_ctr);
-        if (c->ovf_pending) {  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
+        // (a long list is mostly copies -- bursts of a tandem repeat's payloads, a repeat family's: summed in LDS first; 4-byte
+        //  payloads, and on the 8-byte image only where no count can leave 32 bits: the table's k-mers so far plus this batch's
+        //  windows stay below 2^32.  KMERHIP_OVF_AGG=0: never; =1: for lists of any length -- tests)
+        const int agg_env = [] { const char *e = getenv("KMERHIP_OVF_AGG"); return e ? atoi(e) : -1; }();
+        const bool ovf_agg = sizeof(PT) == 4 && agg_env != 0 && (agg_env == 1 || c->ovf_pending >= (1u << 16)) &&
+                             (!nar || c->h_ctr->kmers + n_all < 0xFFFFFFFFull);
+        if (c->ovf_pending && ovf_agg) {
+            const unsigned grid = (unsigned)std::min<u64>(2048, (c->ovf_pending + 8191) / 8192);
+            if (nar)
+                hipLaunchKernelGGL((kh::ovf_agg_insert_kernel<true>), dim3(grid), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
+                                   (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, c->ntab);
+            else
+                hipLaunchKernelGGL((kh::ovf_agg_insert_kernel<false>), dim3(grid), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
+                                   (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, (u64 *)nullptr);
+        } else if (c->ovf_pending) {  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
             if (nar)
                 hipLaunchKernelGGL((kh::ovf_insert_kernel<PT, true>), dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream,
                                    table_geom(c, c->table, c->cap), g, c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, c->ntab);
@@ -1556,6 +1570,7 @@ extern "C" int kh_reset(kh_ctx *c) {
     c->new_rate = -1.0;
     c->rheads_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
+    memset(c->h_ctr, 0, sizeof(Counters));  // (the host copy too: its k-mer total decides what may go into the 8-byte image)
     c->distinct_known = c->pending_bound = 0;
     c->bases_pushed = 0;
     c->launches = 0;

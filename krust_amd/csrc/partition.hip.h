@@ -1000,6 +1000,90 @@ __device__ __forceinline__ bool narrow_upsert(u64 *nreg, const PartGeom &g, uint
     return true;
 }
 
+// The overflow list of a batch with repeats is mostly copies (a tandem repeat sends the same few payloads into one bin in a
+// burst, a repeat family's copies overflow their bucket's arena; an hg-shaped 3 Gbp input hands out ~10^8 entries): every
+// workgroup sums slices of 8192 entries in an LDS table keyed by (region, payload) and applies the sums -- an atomic per key and
+// table flush instead of one per entry.  4-byte payloads only (region and payload are one 64-bit key).  NARROW: only where no
+// count can leave 32 bits in the 8-byte image (the host checks the table's k-mer total), so that nothing has to stay in the list.
+template <bool NARROW>
+__global__ __launch_bounds__(BLOCK) void ovf_agg_insert_kernel(TableGeom tg, PartGeom g, const OvfEntry *__restrict__ list,
+                                                               const u64 *__restrict__ ovf, u64 ovf_cap, Counters *ctr, u64 *__restrict__ ntab) {
+    constexpr u64 SLICE = 8192;
+    constexpr int TAB = 4096;
+    constexpr u64 FREE = ~0ull;  // (a valid entry's region is never 0xFFFFFFFF: that marks the unused entries of a segment)
+    __shared__ u64 s_key[TAB];
+    __shared__ uint32_t s_cnt[TAB];
+    __shared__ uint32_t s_fill;
+    const int tid = threadIdx.x;
+    const u64 n = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;  // (the cursor moves in whole segments: see ovf_insert_kernel)
+    for (int i = tid; i < TAB; i += BLOCK) {
+        s_key[i] = FREE;
+        s_cnt[i] = 0;
+    }
+    if (tid == 0) s_fill = 0;
+    __syncthreads();
+    uint32_t nd = 0, nf = 0;
+    u64 km = 0;
+    auto apply = [&]() {  // the LDS table -> the table in HBM; leaves it empty (all threads)
+        __syncthreads();
+        for (int i = tid; i < TAB; i += BLOCK) {
+            const uint32_t cnt = s_cnt[i];
+            if (cnt) {
+                const u64 key = s_key[i];
+                const uint32_t region = (uint32_t)(key >> 32), pay = (uint32_t)key;
+                if constexpr (NARROW) (void)narrow_upsert(ntab + (u64)region * REGION_SLOTS, g, pay, (u64)cnt, 0ull, nd, nf);
+                else upsert(tg, Pay<uint32_t>::key(pay, region >> g.p2_bits, g), (u64)cnt, nd, nf);
+                s_key[i] = FREE;
+                s_cnt[i] = 0;
+            }
+        }
+        if (tid == 0) s_fill = 0;
+        __syncthreads();
+    };
+    for (u64 s0 = (u64)blockIdx.x * SLICE; s0 < n; s0 += (u64)gridDim.x * SLICE) {  // (uniform per workgroup: barriers inside)
+        const u64 s1 = s0 + SLICE < n ? s0 + SLICE : n;
+        for (u64 c0 = s0; c0 < s1; c0 += 4 * BLOCK) {  // 1024 entries between two looks at the fill
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const u64 i = c0 + (u64)j * BLOCK + tid;
+                if (i >= s1) continue;
+                const OvfEntry e = list[i];
+                if (e.region == 0xFFFFFFFFu) continue;
+                ++km;
+                const u64 key = ((u64)e.region << 32) | (uint32_t)e.pay;
+                uint32_t h = ((uint32_t)(key ^ (key >> 29)) * 2654435761u) >> 20;  // 12 bits
+                for (;;) {
+                    u64 cur = s_key[h];
+                    if (cur == FREE) {
+                        cur = atomicCAS(&s_key[h], FREE, key);
+                        if (cur == FREE) {
+                            atomicAdd(&s_fill, 1u);
+                            cur = key;
+                        }
+                    }
+                    if (cur == key) {
+                        atomicAdd(&s_cnt[h], 1u);
+                        break;
+                    }
+                    h = (h + 1) & (TAB - 1);
+                }
+            }
+            __syncthreads();
+            const bool full = s_fill > TAB / 2;  // (uniform: read between two barriers; at most 4 * BLOCK more before the next look)
+            __syncthreads();
+            if (full) apply();
+        }
+    }
+    apply();
+    const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    km = wave_sum(km);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&ctr->distinct, d);
+        if (f) atomicAdd(&ctr->failed, f);
+        if (km) atomicAdd(&ctr->kmers, km);
+    }
+}
+
 // ntab -> the 16-byte table (every slot of it is written)
 __global__ __launch_bounds__(BLOCK) void ntable_widen_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, Slot *__restrict__ table) {
     const u64 stride = (u64)gridDim.x * BLOCK;

@@ -25,6 +25,7 @@ KNOBS = {
     "KMERHIP_PART_BUDGET_GB": [None, None, "0.07", "0.2"],
     "KMERHIP_P2_LINES": [None, None, "0"],
     "KMERHIP_GENERIC_K": [None, None, None, "1"],
+    "KMERHIP_OVF_AGG": [None, "1", "1", "0"],
 }
 
 
@@ -132,6 +133,7 @@ MID_KNOBS = {
     "KMERHIP_L2_SKEW_X": [None, None, "0"],
     "KMERHIP_L2_ARENA": [None, None, None, "0"],
     "KMERHIP_PART_BUDGET_GB": [None, None, "0.6", "2"],
+    "KMERHIP_OVF_AGG": [None, None, "1", "0"],
 }
 
 
