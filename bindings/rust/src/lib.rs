@@ -277,8 +277,9 @@ impl HipKmerMap {
 
     /// Raw FASTA / FASTQ text (whole records, uncompressed), records found on the device instead of by
     /// the `bio` readers (`src/reader.rs:58-79`).  `Ok(false)`: the device scanner declined the layout
-    /// (wrapped FASTQ, ...) and counted nothing; the caller parses the text as today and calls
-    /// `build` / `build_with_quality`.
+    /// (wrapped FASTQ, ...) and counted nothing of THIS text; the caller parses the text as today and calls
+    /// `build` / `build_with_quality`.  `text` may be reused when the call returns; the counting of an accepted text may
+    /// run under the next call's copy (it is finished by `into_packed` / `kh_finish` at the latest).
     pub fn push_text(&mut self, text: &[u8], fastq: bool) -> Result<bool, HipError> {
         let rc = unsafe { sys::kh_push_text(self.ctx, text.as_ptr(), text.len() as u64, if fastq { 2 } else { 1 }) };
         if rc == -9 {
