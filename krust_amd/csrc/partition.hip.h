@@ -1439,7 +1439,6 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(T
     }
 }
 
-constexpr int R32_SLOTS_PER_LANE = REGION_SLOTS / REGION_NT;
 constexpr uint32_t R32_FREE = 0xFFFFFFFFu;  // free marker of the 32-bit LDS image
 
 // One round of lane-decoupled probing over the lanes' private payload queues (see
