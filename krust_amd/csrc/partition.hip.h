@@ -1608,8 +1608,8 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
 }
 
 // uint32_t payloads: the LDS image is two 32-bit arrays, s_pay[] (0xFFFFFFFF = free) and s_add[] (count
-// added by this batch), 32 KiB per region, plus 32 KiB of per-lane payload queues (see the probing
-// loop); the count update is a no-return ds_add_u32.  Slots that were
+// added by this batch), 32 KiB per region, plus the lanes' payload queues -- nine words per lane: 36 KiB at 1024 lanes,
+// 18 at 512 (see the probing loop); the count update is a no-return ds_add_u32.  Slots that were
 // already occupied keep their 64-bit key and count in the registers of the lane that owns them; at
 // write-back the batch's delta is added, and new slots get their key back through the inverse hash.
 //   * a bucket of >= 2^32 payloads could wrap a 32-bit delta: such a region is failed up front;
@@ -1751,7 +1751,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
     uint32_t nd = 0;
     // Lane-decoupled probing.  A wave that walks key j of all 64 lanes together pays, for every
     // key, the LONGEST probe sequence among its lanes (~6 at load 0.5).  Here each lane keeps its own
-    // cursor into a private queue of REGION_RK payloads (LDS, [slot][lane]: conflict-free) and takes
+    // cursor into a private queue of REGION_RK payloads (LDS, a column of its wave's block: r32_qbase, conflict-free) and takes
     // its next payload as soon as its current one is placed, so a round costs the largest SUM of
     // probe lengths of one lane (~1.5 per key) instead of the sum of the per-key maxima.
     for (u64 base = 0; base < n; base += (u64)REGION_RK * NT) {
