@@ -284,7 +284,10 @@ int kh_merge_pairs(kh_ctx *ctx, const uint64_t *keys, const uint64_t *counts, ui
  * Failure is collective too.  Every small all-gather of the sequence carries each rank's status, no transfer starts
  * before such a gather has come back clean, and one more closes the merge: a rank that fails on its own (out of
  * memory for a receive buffer, a kernel error) returns its status, EVERY other rank returns KH_ERR_PEER from the same
- * call -- nobody is left waiting.  Every wait is bounded by KMERHIP_MERGE_TIMEOUT_S (default 300 s): on expiry, or on
+ * call -- nobody is left waiting.  That includes a rank whose context is unusable when it arrives (poisoned by an earlier
+ * error, or the counting its last kh_push left pending fails now): it still joins the first gather and reports there.
+ * Refused BEFORE the collective starts, on the calling rank alone: a dead communicator, and a table that is already a
+ * shard (a finished merge leaves every rank one, so that refusal is collective by itself).  Every wait is bounded by KMERHIP_MERGE_TIMEOUT_S (default 300 s): on expiry, or on
  * an asynchronous RCCL error, the communicator is aborted (ncclCommAbort) and the call returns KH_ERR_RCCL; that
  * context's communicator is dead afterwards (kh_merge_across refuses it; make a new context and communicator).
  * After any failed merge the table's content is unspecified until kh_reset. */

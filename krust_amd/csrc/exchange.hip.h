@@ -364,8 +364,12 @@ struct Fault {
 // ---- the merge sequence -----------------------------------------------------------------------------
 // Shape of every stretch below: local, fallible steps accumulate into `lrc` (a failed rank skips the rest of the
 // stretch); the stretch ends in xp_gather, which is where everybody learns about it.
-int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
+// `pre`: the status of the caller's pre-checks (a poisoned context, counting that was pending and failed, a table that
+// is already a shard).  A rank that fails them still joins the first gather -- and reports there -- so that its peers
+// leave the same kh_merge_across with KH_ERR_PEER instead of waiting in that gather for the time-out.
+int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     Comm *cm = c->comm;
+    (void)hipSetDevice(c->device);  // (enter() may have failed before it got there)
     const uint32_t W = cm->nranks, R = cm->rank;
     const double t_begin = now_ms();
     double t_export = 0, t_wait = 0, t_merge = 0;
@@ -426,7 +430,8 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info) {
         comm_abort(cm);
         return done(rccl_dead(c, "injected abort"));
     }
-    int lrc = kh_finish(c, nullptr);
+    int lrc = pre;
+    if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
     if (lrc == KH_OK) lrc = inject("start");
     const u64 n_local = lrc == KH_OK ? c->h_ctr->distinct : 0;
     const u64 nreg = c->cap / kh::REGION_SLOTS;
@@ -936,11 +941,14 @@ extern "C" int kh_comm_init(kh_ctx *c, uint32_t nranks, uint32_t rank, const kh_
 }
 
 extern "C" int kh_merge_across(kh_ctx *c, kh_merge_info *info) {
-    int rc = enter(c);
-    if (rc != KH_OK) return rc;
-    if (c->shard_shift) return fail(c, KH_ERR_STATE, "the table is already a shard (merged before); kh_reset first");
-    if (c->comm && c->comm->dead.load())
+    if (!c) return KH_ERR_BAD_ARG;
+    if (c->comm && c->comm->dead.load())  // (nobody can be waiting on a dead communicator: no gather to join)
         return fail(c, KH_ERR_RCCL, "the communicator was aborted by an earlier failed merge; create a new context and communicator");
+    // (a finished merge leaves EVERY rank a shard: this refusal is collective by itself, nobody is waiting in a gather)
+    if (c->shard_shift && !c->poisoned) return fail(c, KH_ERR_STATE, "the table is already a shard (merged before); kh_reset first");
+    int rc = enter(c);  // (counts what kh_push / kh_push_text left pending: may fail -- out of memory, table full -- on this rank alone)
+    if (c->comm && c->comm->nranks > 1) return merge_across_impl(c, info, rc);  // a failed pre-check is reported in the first gather
+    if (rc != KH_OK) return rc;
     if (!c->comm) {  // a lone context is its own world
         if (info) {
             memset(info, 0, sizeof(*info));
@@ -951,7 +959,7 @@ extern "C" int kh_merge_across(kh_ctx *c, kh_merge_info *info) {
         if (rc == KH_OK && info) info->local_distinct = info->owned_distinct = c->h_ctr->distinct;
         return rc;
     }
-    return merge_across_impl(c, info);
+    return merge_across_impl(c, info, KH_OK);
 }
 
 // ---- single-process form: one context and one host thread per device --------------------------------

@@ -350,6 +350,12 @@ int grow_to(kh_ctx *c, u64 newcap) {
     Slot *nt = nullptr;
     int rc = ensure_wide(c);  // (the rehash reads the 16-byte table)
     if (rc != KH_OK) return rc;
+    if (c->ntab) {  // the 8-byte image is for another capacity from here on: its memory is room for the new table
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->ntab);
+        c->ntab = nullptr;
+        c->ntab_cap = 0;
+    }
     rc = alloc_table(c, newcap, &nt);
     if (rc != KH_OK) return rc;
     if (c->table_dirty) {  // logically empty: nothing to carry over, and the new table is clean
@@ -1648,12 +1654,15 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
         c->bases_pushed += n;
         return KH_OK;
     }
-    for (u64 off = 0; off < n; off += STAGE_BYTES) {
-        const u64 len = std::min(STAGE_BYTES, n - off);
-        if (c->acc_len + len + 1 > c->acc_cap) {  // +1: the separator appended after the push
+    for (u64 off = 0; off < n;) {
+        // (an accumulation buffer may be SMALLER than a staging chunk -- KMERHIP_ACC_MAX_MB, or little free device memory:
+        //  acc_limit() -- so a chunk is cut to the room that is left, +1 for the separator appended after the push)
+        const u64 want = std::min(STAGE_BYTES, n - off);
+        if (c->acc_len && c->acc_len + want + 1 > c->acc_cap) {
             rc = flush_acc(c, off != 0);          // inside a push the seam needs the k-1 look-back
             if (rc != KH_OK) return rc;
         }
+        const u64 len = std::min(want, c->acc_cap - c->acc_len - 1);
         const int p = c->stage_next;
         c->stage_next ^= 1;
         if (c->stage_used[p]) HIP_TRY(c, hipEventSynchronize(c->stage_done[p]));
@@ -1671,6 +1680,7 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
         c->stage_used[p] = true;
         c->h2d_events.emplace_back(t0, t1);
         c->acc_len += len;
+        off += len;
     }
     // k-mers never span pushes: a separator byte follows the last record of every push
     HIP_TRY(c, hipMemsetAsync(c->acc[c->acc_cur] + HALO + c->acc_len, '\n', 1, c->cstream));

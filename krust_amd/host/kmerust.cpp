@@ -242,7 +242,12 @@ int cli_main(int argc, char **argv) {
                     (unsigned long long)t.chunks, t.text_path ? "true" : "false");
         }
     } timing_printer{t_begin};
-#if !defined(__SANITIZE_ADDRESS__)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define KMERUST_UNDER_ASAN 1
+#endif
+#endif
+#if !defined(__SANITIZE_ADDRESS__) && !defined(KMERUST_UNDER_ASAN) && !defined(KMERUST_ALWAYS_CLEAN_EXIT)  // (gcc / clang / make asan)
     leak_at_exit() = !getenv("KMERUST_CLEAN_EXIT");
 #endif
     try {

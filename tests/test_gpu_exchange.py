@@ -317,3 +317,28 @@ def test_rccl_world1_local_failures_and_an_aborted_communicator(K, reads, monkey
         dc.comm_init(1, 0, K.comm_unique_id())
         dc.push(reads)
         assert dc.merge_across()["owned_distinct"] == len(ok)
+
+
+def test_a_rank_whose_context_is_poisoned_joins_the_first_gather(K, monkeypatch):
+    """kh_merge_across used to return straight away when enter() failed on a rank (a poisoned
+    context; deferred counting that runs out of memory), leaving its peers in their first gather until the time-out.
+    Now that rank reports in the gather: every rank leaves within seconds, the bad one with KH_ERR_STATE, the others
+    with KH_ERR_PEER naming it."""
+    import ctypes as C
+    import time
+    monkeypatch.setenv("KMERHIP_MERGE_TIMEOUT_S", "60")
+    bases, _ = O.synth_reads(SEED, 1 << 18, 150, 0, 6000, with_qual=False)
+    L = K.lib()
+    with K.DeviceGroup(21, [0, 0, 0], capacity_hint=1_000_000) as g:
+        for dc in g.counters:
+            dc.push(bases)
+        # poison rank 1: an 8 TB device allocation (kh_lookup of 2^40 keys; fails before a single key is read)
+        one = (C.c_uint64 * 1)(0)
+        rc = L.kh_lookup(g[1]._h, one, C.c_uint64(1 << 40), one)
+        assert rc == K.native.KH_ERR_OOM
+        t0 = time.time()
+        res = _merge_each_rank_on_its_own_thread(K, g)
+        assert time.time() - t0 < 30, "the ranks left, but only after a time-out"
+        assert res[1][0] == K.native.KH_ERR_STATE and "poisoned" in res[1][1], res[1]
+        for r in (0, 2):
+            assert res[r][0] == K.native.KH_ERR_PEER and "rank 1 failed" in res[r][1], res[r]

@@ -431,6 +431,28 @@ def test_host_staging_chunk_boundary(K, path):
         assert np.array_equal(keys, okeys) and np.array_equal(cnts, ocnts)
 
 
+@pytest.mark.parametrize("with_qual", [False, True])
+def test_accumulation_buffer_smaller_than_a_staging_chunk(K, monkeypatch, path, with_qual):
+    """KMERHIP_ACC_MAX_MB=1 caps the device accumulation buffers at 1 MiB -- far below the 64 MiB staging chunk of a
+    pageable kh_push.  A chunk must then be cut to the room that is left (round 3 copied the whole chunk: a write past
+    the buffer's end); every seam needs its k-1 look-back."""
+    monkeypatch.setenv("KMERHIP_ACC_MAX_MB", "1")
+    bases, qual = O.synth_reads(SEED + 5, 1 << 18, 150, 0, 60_000)  # 9 MB: nine buffers' worth, pageable numpy memory
+    k, minq = (21, 20) if with_qual else (25, None)
+    cut = 4_000_000  # (inside a read: k-mers never span pushes, so the oracle sees the same two pushes)
+    parts = [(bases[:cut], qual[:cut] if with_qual else None), (bases[cut:], qual[cut:] if with_qual else None)]
+    m2 = O.OracleMap()
+    t2 = sum(m2.scan_flat(b, k, qual=q, min_quality=minq, nthreads=NCPU) for b, q in parts)
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=len(m2), path=path) as dc:
+        for b, q in parts:
+            dc.push(b, q)
+        st = dc.finish()
+        keys, cnts = dc.result()
+    assert st["kmers"] == t2 and st["distinct"] == len(m2)
+    okeys, ocnts = m2.arrays()
+    assert np.array_equal(keys, okeys) and np.array_equal(cnts, ocnts)
+
+
 def test_min_count_histogram_lookup(K, path):
     bases, _ = O.synth_reads(SEED, 1 << 14, 150, 0, 20_000, with_qual=False)  # high coverage: big counts
     m = O.OracleMap()
