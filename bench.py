@@ -63,6 +63,11 @@ def parse_args():
     return ap.parse_args()
 
 
+HINT_SOURCE = ("estimate_distinct(): genome length + reads x 150/256 substitutions x k (L-k+1)/L novel k-mers each x 0.92 -- an a-priori "
+               "figure from the generator's parameters.  Since round 4 a hint only sizes the first allocation: every fresh batch "
+               "sizes the table itself from the distinct keys of a few level-1 partitions (the `unhinted` twin runs without any)")
+
+
 def estimate_distinct(reads, k, world, with_qual=False):
     """Genomic canonical k-mers + error k-mers (1/256 substitutions, ~k (L-k+1)/L novel each, less what N bases and
     neighbouring errors take: x 0.92 measured on S100M / S1B shards); with -Q masking only windows free of
@@ -202,7 +207,12 @@ def roofline_of(st, nbytes_in, kernel_ms, stage_ms, k):
     sb = stage_min_bytes(st, nbytes_in, k, stages)
     dom = max((n for n in stages if n in kern), key=lambda n: stages[n], default=None)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "alg_bytes_per_step": alg, "kernel_ms_per_step": kernel_ms,
+            "traffic": None, "traffic_frac": None, "alg_bytes_per_step": alg, "kernel_ms_per_step": kernel_ms,
+            "formula": {"text": "bytes_in x (1 + has_qual) + 24 B x valid k-mers + 8 B x distinct keys (SURVEY.md 8d(i): encode + insert; "
+                                "its 16 B x distinct compaction term is NOT included: the timed step ends at kh_finish, the compaction "
+                                "kernel runs in the end_to_end / result legs)",
+                        "bytes_in": int(nbytes_in), "per_kmer": 24, "kmers": int(st["kmers"]), "per_distinct": 8, "distinct": int(st["distinct"]),
+                        "compaction_term_included": False},
             "kernel": " + ".join(kern[s] for s in ("direct", "level1", "level2_count", "level2", "region") if s in kern),
             "level2_path": None if "level2" not in kern else ("arena" if kern["level2"] == "part2_arena_kernel" else "exact"),
             "stages_ms": stages, "kernels": kern,
@@ -229,9 +239,10 @@ def verify_reads(dc, st, host, hq, k, min_quality):
             "cpu_seconds": time.perf_counter() - t0}
 
 
-def sub_config(krust_amd, torch, dev, local_rank, name, reads, k, min_quality, first=0, hint=None, verify=False):
-    """One BASELINE.json configuration as a sub-result: its own reads, its own context, one warm-up and one
-    timed step (reset + push_device + finish), with its own roofline."""
+def sub_config(krust_amd, torch, dev, local_rank, name, reads, k, min_quality, first=0, hint=None, verify=False, steps=1):
+    """One BASELINE.json configuration as a sub-result: its own reads, its own context, one warm-up and `steps`
+    timed steps (reset + push_device + finish), with its own roofline.  hint = 0: no capacity hint (KmerMap::new() takes
+    none, src/run.rs:494-498): the table is sized from a sample of level-1 partitions."""
     stride = READ_LEN + 1
     nbytes = reads * stride
     with_qual = min_quality is not None
@@ -240,22 +251,26 @@ def sub_config(krust_amd, torch, dev, local_rank, name, reads, k, min_quality, f
     krust_amd.synth_reads_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, SEED, GENOME_LEN, READ_LEN, first, reads,
                                  device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    hint_source = "none (capacity_hint = 0)" if hint == 0 else "given" if hint is not None else HINT_SOURCE
     if hint is None:
         hint = estimate_distinct(reads, k, 1, with_qual)
     dc = krust_amd.DeviceCounter(k, min_quality=min_quality, capacity_hint=hint, device=local_rank)
     try:
-        for rep in range(2):
+        dt = 0.0
+        for rep in range(1 + steps):
             dc.reset()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             dc.push_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, nbytes)
             st = dc.finish()
             torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
+            if rep:
+                dt += (time.perf_counter() - t0) / steps
         rf = roofline_of(st, nbytes * (2 if with_qual else 1), st["count_kernel_ms"], st["stage_ms"], k)
         out = {"workload": name, "k": k, "reads": reads, "first_read": first, "min_quality": min_quality, "capacity_hint": hint,
-               "value": st["kmers"] / dt, "unit": "k-mers/s",
-               "ms_per_step": dt * 1e3, "steps": 1, "kmers_per_step": int(st["kmers"]), "distinct": int(st["distinct"]),
+               "capacity_hint_source": hint_source, "value": st["kmers"] / dt, "unit": "k-mers/s",
+               "ms_per_step": dt * 1e3, "steps": steps, "kmers_per_step": int(st["kmers"]), "distinct": int(st["distinct"]),
+               "table_load": st["distinct"] / st["table_slots"],
                "table_slots": int(st["table_slots"]), "table_grows": int(st["grows"]), "part_batches": int(st["part_batches"]),
                "dtype": "u64", "roofline": rf}
         if verify:
@@ -437,31 +452,42 @@ def cli_leg(krust_amd, torch, dev, local_rank, reads=10_000_000, k=21):
     if not os.path.exists(exe):
         return {"error": f"{exe} is missing (make -C krust_amd/host)"}
     stride, W = READ_LEN + 1, 166 + READ_LEN  # "@r%09d\n" seq "\n+\n" qual "\n"
-    tb = torch.empty(reads * stride, dtype=torch.uint8, device=dev)
-    tq = torch.empty(reads * stride, dtype=torch.uint8, device=dev)
-    krust_amd.synth_reads_device(tb.data_ptr(), tq.data_ptr(), SEED, GENOME_LEN, READ_LEN, 0, reads, device=local_rank,
-                                 stream=torch.cuda.current_stream().cuda_stream)
-    rec = torch.empty((reads, W), dtype=torch.uint8, device=dev)
-    rec[:, 0], rec[:, 1], rec[:, 11] = ord("@"), ord("r"), 10
-    r = torch.arange(reads, device=dev)
-    for j in range(9):
-        rec[:, 10 - j] = ((r // 10 ** j) % 10 + 48).to(torch.uint8)
-    rec[:, 12:12 + READ_LEN] = tb.view(reads, stride)[:, :READ_LEN]
-    rec[:, 12 + READ_LEN], rec[:, 13 + READ_LEN], rec[:, 14 + READ_LEN] = 10, ord("+"), 10
-    rec[:, 15 + READ_LEN:15 + 2 * READ_LEN] = tq.view(reads, stride)[:, :READ_LEN]
-    rec[:, 15 + 2 * READ_LEN] = 10
-    torch.cuda.synchronize()
     d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
     path = os.path.join(d, f"kmerust_bench_{os.getpid()}.fq")
     try:
-        rec.cpu().numpy().tofile(path)
+        # the file is written in slices of 10 M reads (3.2 GB of text each): host memory holds the file and ONE slice, whatever the size
+        SL = 10_000_000
+        with open(path, "wb") as f:
+            for r0 in range(0, reads, SL):
+                nr = min(SL, reads - r0)
+                tb = torch.empty(nr * stride, dtype=torch.uint8, device=dev)
+                tq = torch.empty(nr * stride, dtype=torch.uint8, device=dev)
+                krust_amd.synth_reads_device(tb.data_ptr(), tq.data_ptr(), SEED, GENOME_LEN, READ_LEN, r0, nr, device=local_rank,
+                                             stream=torch.cuda.current_stream().cuda_stream)
+                rec = torch.empty((nr, W), dtype=torch.uint8, device=dev)
+                rec[:, 0], rec[:, 1], rec[:, 11] = ord("@"), ord("r"), 10
+                r = torch.arange(r0, r0 + nr, device=dev)
+                for j in range(9):
+                    rec[:, 10 - j] = ((r // 10 ** j) % 10 + 48).to(torch.uint8)
+                rec[:, 12:12 + READ_LEN] = tb.view(nr, stride)[:, :READ_LEN]
+                rec[:, 12 + READ_LEN], rec[:, 13 + READ_LEN], rec[:, 14 + READ_LEN] = 10, ord("+"), 10
+                rec[:, 15 + READ_LEN:15 + 2 * READ_LEN] = tq.view(nr, stride)[:, :READ_LEN]
+                rec[:, 15 + 2 * READ_LEN] = 10
+                torch.cuda.synchronize()
+                rec.cpu().numpy().tofile(f)
+                del rec, tb, tq, r
         nbytes = os.path.getsize(path)
-        del rec
-        with krust_amd.DeviceCounter(k, device=local_rank) as dc:   # the reference result through the C ABI
+        torch.cuda.empty_cache()
+        # the reference result through the C ABI: the same reads, resident
+        tb = torch.empty(reads * stride, dtype=torch.uint8, device=dev)
+        krust_amd.synth_reads_device(tb.data_ptr(), None, SEED, GENOME_LEN, READ_LEN, 0, reads, device=local_rank,
+                                     stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        with krust_amd.DeviceCounter(k, device=local_rank) as dc:
             dc.push_device(tb.data_ptr(), None, reads * stride)
             st = dc.finish()
             want = dc.histogram()
-        del tb, tq
+        del tb
         torch.cuda.empty_cache()
         env = dict(os.environ, KMERUST_TIMING="1")
         runs = []
@@ -662,6 +688,8 @@ def main():
             except Exception:
                 traffic = traffic_source = None
         rf.update({"traffic": traffic, "traffic_source": traffic_source,
+                   # measured HBM bytes / kernel time / peak: what the memory system really moved (frac prices the SURVEY formula)
+                   "traffic_frac": (traffic / (kernel_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and kernel_ms_step) else None,
                    "frac_of_measured_copy_peak": rf["achieved"] / 6290.0,  # MI355X_MICROARCH.md: 6.29 TB/s copy
                    "launches_per_step": int(launches / args.steps),
                    "kernel_kmers_per_s": st["kmers"] / (kernel_ms_step * 1e-3) if kernel_ms_step else None})
@@ -684,6 +712,8 @@ def main():
                                    + f", genome 2^27 bp, seed {SEED}; resident in HBM",
                        "k": k, "reads_per_gpu": reads, "kmers_per_step_per_gpu": int(st["kmers"]),
                        "distinct_per_gpu": int(st["distinct"]), "table_slots": int(st["table_slots"]),
+                       "table_load": st["distinct"] / st["table_slots"],
+                       "capacity_hint": int(hint), "capacity_hint_source": "--capacity-hint" if args.capacity_hint else HINT_SOURCE,
                        "table_grows": int(st["grows"]),
                        "parallelism": f"reads sharded x{world}" + ("; RCCL all-to-all table merge (kh_merge_across)" if world > 1 else "")},
             "roofline": rf,
@@ -708,13 +738,15 @@ def main():
             torch.cuda.empty_cache()
             subs = []
             full = reads >= READS_N1
-            plan = [("configs[1] S10M: 10 M x 150 bp, k=21", dict(reads=10_000_000, k=21, min_quality=None)),
+            plan = [("headline twin WITHOUT a capacity hint (S100M, k=21)", dict(reads=reads, k=21, min_quality=None, hint=0, steps=3, verify=True)),
+                    ("configs[1] S10M: 10 M x 150 bp, k=21", dict(reads=10_000_000, k=21, min_quality=None, steps=3)),
+                    ("configs[1] twin WITHOUT a capacity hint (S10M, k=21)", dict(reads=10_000_000, k=21, min_quality=None, hint=0, steps=3)),
                     ("configs[2] S100M: 100 M x 150 bp, k=31, -Q 20", dict(reads=100_000_000, k=31, min_quality=20)),
                     ("k=19 twin of the headline (S100M, k=19): the level-1 window is generated for every k", dict(reads=100_000_000, k=19, min_quality=None)),
-                    ("configs[3] rank 3's share of S1B: 125 M x 150 bp, k=21, table hinted to 2^31 slots",
-                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX)),
-                    ("configs[3] the same share, no capacity hint (the CLI's case: 2^32 slots, 1024 buckets per level-1 partition)",
-                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, hint=0, verify=True))]
+                    ("configs[3] rank 3's share of S1B: 125 M x 150 bp, k=21, with the a-priori capacity hint",
+                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, steps=2)),
+                    ("configs[3] the same share, no capacity hint",
+                     dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, hint=0, verify=True, steps=2))]
             for name, kw in plan:
                 if not full and kw["reads"] > reads:
                     continue  # (a reduced --reads run: keep the extras proportionate)
@@ -728,15 +760,31 @@ def main():
                 except Exception as e:
                     subs.append({"workload": "configs[4] hg-shaped FASTA", "error": repr(e)})
             out["configs"] = subs
+            # the twins without a capacity hint, beside what they are twins of (the reference API has no hint)
+            def _twin(tag):
+                return next((x for x in subs if x.get("workload", "").startswith(tag) and "value" in x), None)
+            tw = _twin("headline twin")
+            if tw:
+                out["unhinted"] = {"value": tw["value"], "ms_per_step": tw["ms_per_step"], "steps": tw["steps"], "table_slots": tw["table_slots"],
+                                   "table_load": tw["table_load"], "ratio_to_headline": tw["value"] / out["value"],
+                                   "verify_ok": (tw.get("verify") or {}).get("ok")}
+            c1, c1u = _twin("configs[1] S10M"), _twin("configs[1] twin")
+            if c1 and c1u:
+                c1u["ratio_to_hinted"] = c1u["value"] / c1["value"]
             try:
                 out["cli"] = cli_leg(krust_amd, torch, dev, local_rank, reads=min(10_000_000, reads))
                 # The same on a file four times the size (S40M, 12.6 GB): what the command line sustains once the process's
                 # fixed costs (runtime start-up, pinned buffers, exit: ~0.45 s) are spread thinner.  Only where the host has
                 # the memory for the file twice (tensor -> numpy -> /dev/shm).
-                if full and host_room_for(2 * 40_000_000 * 316 + (8 << 30)):
-                    big = cli_leg(krust_amd, torch, dev, local_rank, reads=40_000_000)
-                    out["cli"]["large"] = {k: big.get(k) for k in ("what", "reads", "text_bytes", "wall_s", "text_GBps", "kmers_per_s", "ok", "error")}
-                    out["cli"]["large"]["phases"] = [r.get("phases") for r in big.get("runs", [])]
+                # ... and on the file the METRIC is quoted on: S100M, 31.6 GB of FASTQ text (where /dev/shm and the host's memory hold
+                # it; else the largest multiple of 10 M reads that fits, stated in `reads`)
+                if full:
+                    big_reads = next((r for r in (100_000_000, 70_000_000, 40_000_000) if host_room_for(r * 316 + (12 << 30))), 0)
+                    if big_reads:
+                        big = cli_leg(krust_amd, torch, dev, local_rank, reads=big_reads)
+                        key = "s100m" if big_reads == 100_000_000 else "large"
+                        out["cli"][key] = {k: big.get(k) for k in ("what", "reads", "text_bytes", "wall_s", "text_GBps", "kmers_per_s", "ok", "error")}
+                        out["cli"][key]["phases"] = [r.get("phases") for r in big.get("runs", [])]
             except Exception as e:
                 out["cli"] = dict(out.get("cli") or {}, error=repr(e))
         print(json.dumps(out), flush=True)

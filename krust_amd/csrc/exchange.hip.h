@@ -467,9 +467,14 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     }
 
     const bool pow2 = (W & (W - 1)) == 0;
-    const bool regions_ok = pow2 && W <= (uint32_t)kh::MAX_SENDERS && nreg >= W;
+    // (a table of 1024 x b2 regions, b2 not a power of two, splits into hash-range shards that nest only if W divides b2:
+    //  kmerhip.hip merge_regions; round_cap() keeps b2 a multiple of 8 -- of 64 from 512 -- so this fails only for worlds
+    //  of 16+ ranks with small tables, which then take the generic route)
+    const kh::RegionGeom my_geo = geom_of_cap(c->cap);
+    const bool geo_ok = (my_geo.b2 & (my_geo.b2 - 1)) == 0 || my_geo.b2 % W == 0;
+    const bool regions_ok = pow2 && W <= (uint32_t)kh::MAX_SENDERS && nreg >= W && nreg % W == 0 && geo_ok;
     uint32_t npieces = merge_pieces_default();
-    bool piped = regions_ok && npieces > 1 && (npieces & (npieces - 1)) == 0 && npieces <= 64 && (nreg / W) >= 64ull * npieces;
+    bool piped = regions_ok && npieces > 1 && (npieces & (npieces - 1)) == 0 && npieces <= 64 && (nreg / W) >= 64ull * npieces && (nreg / W) % npieces == 0;
     if (!piped) npieces = 1;
 
     // send buffer: heads (2 per key), packed (1 u64 per key) and one array of wide pairs all fit 8 B x n_local

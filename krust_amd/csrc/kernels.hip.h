@@ -59,13 +59,12 @@ __device__ __forceinline__ u64 wave_sum(u64 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// open-addressing table, laid out in 2^rbits REGIONS of REGION_SLOTS slots (64 KiB each):
+// open-addressing table, laid out in REGIONS of REGION_SLOTS slots (64 KiB each):
 //   H      = kh_table_hash(key, k)             (bijective 2k-bit hash, left-aligned in 64 bits)
-//   region = H >> (64 - rbits)                  (top bits)
-//   start  = next REGION_BITS bits of H
+//   region, start = see TableGeom below        (the top bits of H; a fast-range over any multiple of 1024 regions)
 // Linear probing wraps INSIDE the region, so a region is self-contained: the direct path updates
 // it in HBM with device-scope atomics, the partitioned path rebuilds it in LDS with no global
-// atomics at all.  capacity = REGION_SLOTS << rbits.
+// atomics at all.  capacity = REGION_SLOTS * regions.
 // ---------------------------------------------------------------------------------------------
 #ifndef KH_REGION_BITS
 #define KH_REGION_BITS 12
@@ -85,20 +84,95 @@ constexpr uint32_t REGION_MASK = REGION_SLOTS - 1;
 constexpr uint32_t REGION_GROUP = KH_REGION_GROUP;
 constexpr uint32_t REGION_START_MASK = REGION_MASK & ~(REGION_GROUP - 1);
 
+// Table geometry (round 4: any multiple of 1024 regions, not only powers of two).  A table has NR = b2 << p1_bits regions:
+//   p1     = the top p1_bits bits of H                 (the level-1 partition digit of the partitioned path: <= 10 bits)
+//   x      = the next 32 bits of H
+//   region = p1 * b2 + ((x * b2) >> 32)                (a FAST-RANGE of x over the b2 buckets of partition p1)
+//   start  = the top REGION_BITS bits of the product's low word, lowest one cleared (REGION_START_MASK)
+// For b2 = 2^j this is exactly "region = the top p1_bits + j bits of H, start = the next REGION_BITS": rounds 1-3's layout,
+// and any split (p1_bits, j) of the same sum describes the same table.  A table of <= 1024 regions is always a power of
+// two with b2 = 1; a larger one has p1_bits = 10 and ANY b2 (kh_geom_of_regions: the geometry is a function of the region
+// count), so that a table can be sized to the load the region pass likes (~0.5) whatever the number of keys -- with powers
+// of two the load jumped between 0.3 and 0.6 (125 M reads at 0.61 took 36 ms where 100 M at 0.51 took 19).
+// (x, b) <-> (b, frac) is a bijection (x * b2 = b << 32 | frac, an exact division back), so everything that carries "the
+// hash bits below the region index" still identifies the key: see kh_below_region / kh_x_of_below.
 struct TableGeom {
     Slot *table;
-    uint32_t rbits;        // log2(number of regions)
+    uint32_t p1_bits;      // regions = b2 << p1_bits
+    uint32_t b2;           // buckets (= regions) per level-1 partition
     uint32_t k;
     uint32_t shard_shift;  // 0 = the table covers the whole hash space; n = it is shard `shard_index` of 2^n:
     uint32_t shard_index;  //     every key it holds has shard_index in the top n hash bits, placement uses H << n
 };
 
+// ---- geometry arithmetic shared by tables (TableGeom) and partition passes (PartGeom) ------------------------------------
+struct RegionGeom {  // (p1_bits, b2) of either
+    uint32_t p1_bits, b2;
+};
+__host__ __device__ inline u64 kh_regions_of(RegionGeom g) { return (u64)g.b2 << g.p1_bits; }
+// the geometry of a table with `nregions` regions: a power of two up to 1024 (p1_bits = log2, b2 = 1), a multiple of 1024 beyond
+__host__ __device__ inline RegionGeom kh_geom_of_regions(u64 nregions) {
+    RegionGeom g;
+    if (nregions <= 1024) {
+        g.p1_bits = 0;
+        while ((2ull << g.p1_bits) <= nregions) ++g.p1_bits;
+        g.b2 = 1;
+    } else {
+        g.p1_bits = 10;
+        g.b2 = (uint32_t)(nregions >> 10);
+    }
+    return g;
+}
+__host__ __device__ inline bool kh_regions_valid(u64 nregions) {
+    return nregions >= 1 && (nregions <= 1024 ? (nregions & (nregions - 1)) == 0 : (nregions & 1023) == 0 && (nregions >> 10) <= (1u << 20));
+}
+__host__ __device__ inline uint32_t kh_floor_log2(uint32_t v) {
+    uint32_t b = 0;
+    while ((2u << b) <= v && b < 31) ++b;
+    return b;
+}
+// x (the 32 hash bits behind the level-1 digit) of the placement hash
+__host__ __device__ __forceinline__ uint32_t kh_x_of(u64 H, uint32_t p1_bits) { return (uint32_t)((H << p1_bits) >> 32); }
+__host__ __device__ __forceinline__ uint32_t kh_p1_of(u64 H, uint32_t p1_bits) { return p1_bits ? (uint32_t)(H >> (64 - p1_bits)) : 0u; }
+// bucket of x among b2, and its in-region start
+__host__ __device__ __forceinline__ uint32_t kh_bucket_of_x(uint32_t x, uint32_t b2) { return (uint32_t)(((u64)x * b2) >> 32); }
+__host__ __device__ __forceinline__ uint32_t kh_start_of_x(uint32_t x, uint32_t b2) {
+    return ((uint32_t)(x * b2) >> (32 - REGION_BITS)) & REGION_START_MASK;
+}
+// smallest x of bucket b (b <= b2: b = b2 gives 2^32): ceil(b * 2^32 / b2)
+__host__ __device__ __forceinline__ u64 kh_xlo(uint32_t b, uint32_t b2) { return (((u64)b << 32) + b2 - 1) / b2; }
+// "The hash bits below the region index" as a 32-bit window -- what the exchange units (shard.hip.h) carry: the top
+// w = 32 - floor(log2 b2) bits hold x - xlo(bucket) (< 2^w), the bits below them are the hash bits that follow x.
+// For b2 = 2^j: bits [p1_bits + j, p1_bits + j + 32) of H, as in rounds 1-3.
+__host__ __device__ __forceinline__ uint32_t kh_below_w(uint32_t b2) { return 32u - kh_floor_log2(b2); }
+__host__ __device__ __forceinline__ uint32_t kh_below_region(u64 H, RegionGeom g) {
+    const uint32_t x = kh_x_of(H, g.p1_bits), b = kh_bucket_of_x(x, g.b2), w = kh_below_w(g.b2);
+    const uint32_t xoff = x - (uint32_t)kh_xlo(b, g.b2);
+    const uint32_t z = w < 32 ? (uint32_t)((H << (g.p1_bits + 32)) >> (32 + w)) : 0u;  // the 32 - w hash bits behind x
+    return (w < 32 ? xoff << (32 - w) : xoff) | z;
+}
+// the placement hash back from (region, window)
+__host__ __device__ __forceinline__ u64 kh_hash_of_below(u64 region, uint32_t low, RegionGeom g) {
+    const uint32_t p1 = (uint32_t)(region / g.b2), b = (uint32_t)(region % g.b2), w = kh_below_w(g.b2);
+    const uint32_t x = (uint32_t)kh_xlo(b, g.b2) + (w < 32 ? low >> (32 - w) : low);
+    const u64 z = w < 32 ? (u64)(low << w) : 0ull;  // left-aligned in 32 bits
+    u64 H = ((u64)x << 32) | z;                    // x and what follows it, left-aligned in 64 bits ...
+    H >>= g.p1_bits;                               // ... behind the level-1 digit
+    if (g.p1_bits) H |= (u64)p1 << (64 - g.p1_bits);
+    return H;
+}
+// significant bits of that window for a k-mer table: 2k minus the bits the region index stands for
+__host__ __device__ inline int kh_below_bits(uint32_t k, uint32_t shard_shift, RegionGeom g) {
+    return 2 * (int)k - (int)shard_shift - (int)g.p1_bits - (int)kh_floor_log2(g.b2);
+}
+
+__device__ __forceinline__ RegionGeom rgeom(const TableGeom &tg) { return RegionGeom{tg.p1_bits, tg.b2}; }
 // placement hash of a key in this table
 __device__ __forceinline__ u64 table_hash(const TableGeom &tg, u64 key) { return kh_table_hash(key, tg.k) << tg.shard_shift; }
-__device__ __forceinline__ u64 region_of(const TableGeom &tg, u64 H) { return H >> (64 - tg.rbits); }
-__device__ __forceinline__ uint32_t start_of(const TableGeom &tg, u64 H) {
-    return (uint32_t)(H >> (64 - tg.rbits - REGION_BITS)) & REGION_START_MASK;
+__device__ __forceinline__ u64 region_of(const TableGeom &tg, u64 H) {
+    return (u64)kh_p1_of(H, tg.p1_bits) * tg.b2 + kh_bucket_of_x(kh_x_of(H, tg.p1_bits), tg.b2);
 }
+__device__ __forceinline__ uint32_t start_of(const TableGeom &tg, u64 H) { return kh_start_of_x(kh_x_of(H, tg.p1_bits), tg.b2); }
 
 __device__ __forceinline__ void count_add(Slot *s, u64 addend) {
     // fire-and-forget device-scope add (result unused -> no-return global_atomic_add_x2)

@@ -32,6 +32,7 @@ namespace {
 
 constexpr double LOAD_HARD = 0.80;    // never let distinct exceed this fraction of capacity
 constexpr double LOAD_TARGET = 0.50;  // load right after a growth
+constexpr double HINT_LOAD = 0.65;    // a capacity hint of n keys gets the smallest table that holds them at this load
 constexpr u64 MIN_CAP = 8ull * kh::REGION_SLOTS;
 constexpr u64 DEFAULT_CAP = 1ull << 20;
 constexpr u64 SUB_TILES = 1ull << 16;      // tiles per count launch (2^28 positions)
@@ -170,6 +171,11 @@ struct kh_ctx {
     u64 region_cap = 0;
     u64 *scan_partial = nullptr;
     u64 scan_cap = 0;
+    u64 *est_set = nullptr;          // scratch of distinct_sample_kernel (partition.hip.h): the set a few level-1 partitions are counted in
+    u64 est_set_cap = 0;
+    u64 est_keys = 0;                // distinct keys the current fresh range is expected to bring (from that sample; 0 = no estimate)
+    bool sized_by_sample = false;    // the table's size comes from such a sample (stats / trace)
+    bool estimate_on = true;         // KMERHIP_ESTIMATE=0: never (rounds 1-3's sizing: the hint, or the worst case)
     u64 part_batches = 0;
     double stage_ms[ST_N] = {0};
     struct StageEv { int stage; hipEvent_t a, b; };
@@ -177,8 +183,15 @@ struct kh_ctx {
 
     // ---- kh_push_text: device-side record scanning ----
     uint8_t *txt_raw = nullptr;   u64 txt_raw_cap = 0;   // host text lands here
-    uint8_t *txt_out = nullptr;   u64 txt_out_cap = 0;   // flat bases for the count kernels
-    uint8_t *txt_qual = nullptr;  u64 txt_qual_cap = 0;
+    uint8_t *txt_acc[2] = {nullptr, nullptr};   u64 txt_acc_cap[2] = {0, 0};    // flat bases of the texts pushed, accumulated for the count kernels
+    uint8_t *txt_accq[2] = {nullptr, nullptr};  u64 txt_accq_cap[2] = {0, 0};   // ... and their qualities
+    int txt_cur = 0;                       // the buffer the scans append to
+    u64 txt_acc_len = 0;                   // bytes accumulated there and not counted yet (a multiple of 16)
+    bool txt_acc_qual = false;             // ... with qualities
+    hipEvent_t txt_acc_done[2] = {nullptr, nullptr};  // the count of that buffer's last content (on `stream`)
+    bool txt_acc_busy[2] = {false, false};
+    hipStream_t txt_scan_stream = nullptr; // the stream the accumulated scans ran on
+    u64 *txt_scan_partial = nullptr;  u64 txt_scan_cap = 0;  // scan scratch of the text stream
     u64 *txt_ls = nullptr;        u64 txt_ls_cap = 0;    // line starts
     uint8_t *txt_hdr = nullptr;   u64 txt_hdr_cap = 0;   // FASTA: line is a header
     uint32_t *txt_tnl = nullptr;  u64 txt_tnl_cap = 0;   // per-tile newline counts
@@ -187,12 +200,6 @@ struct kh_ctx {
     u64 *txt_tout = nullptr;      u64 txt_tout_cap = 0;
     uint32_t *txt_err = nullptr;  u64 txt_err_cap = 0;
     struct TxtHost { u64 total; u64 end_mark; uint32_t err; uint8_t first, last; } *h_txt = nullptr;  // pinned
-    hipEvent_t txt_raw_free = nullptr;
-    bool txt_raw_busy = false;
-    // kh_push_text leaves the COUNTING of its text (scanned into txt_out / txt_qual) to the next call that enters the
-    // context: the next kh_push_text then copies its text to the device while this one is counted (flush_text)
-    u64 txt_pending = 0;          // bases in txt_out still to be counted (0 = nothing pending)
-    bool txt_pending_qual = false;
     double text_ms = 0.0;
 
     bool poisoned = false;
@@ -240,6 +247,7 @@ int close_fresh_window(kh_ctx *c);
 int ensure_wide(kh_ctx *c);
 
 int flush_text(kh_ctx *c);
+int need_table(kh_ctx *c);
 int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool keep_window = false, bool narrow_ok = false) {
     if (!c) return KH_ERR_BAD_ARG;
     if (c->poisoned) return fail(c, KH_ERR_STATE, "context is poisoned by an earlier error");
@@ -252,7 +260,7 @@ int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool kee
         int rc = flush_acc(c, false);
         if (rc != KH_OK) return rc;
     }
-    if (flush_pending && c->txt_pending) {
+    if (flush_pending && c->txt_acc_len) {
         int rc = flush_text(c);
         if (rc != KH_OK) return rc;
     }
@@ -276,7 +284,40 @@ int alloc_table(kh_ctx *c, u64 cap, Slot **out) {
     return KH_OK;
 }
 
+// The 16-byte table exists only once something needs it (round 4).  A context whose batches all go through the partitioned
+// path with 32-bit payloads keeps its counts in the 8-byte image (ntab) from the first pass to kh_finish / kh_histogram /
+// kh_lookup / the packed exports: 16 bytes per slot -- 34 GB at the headline's size, 43 GB at configs[3]'s -- that are then
+// never allocated, never initialised, and are room for one batch's partition buffers instead of two batches'.
+// Allocated here it is uninitialised (table_dirty): whoever needs it cleared, clears it (clear_if_dirty); a widening or a
+// fresh region pass writes every slot anyway.
+int need_table(kh_ctx *c) {
+    if (c->table) return KH_OK;
+    hipError_t e = hipMalloc((void **)&c->table, c->cap * sizeof(Slot));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->table = nullptr;
+        return fail(c, KH_ERR_OOM, "hipMalloc(table)", e);
+    }
+    c->table_dirty = true;
+    return KH_OK;
+}
+// an EMPTY table of another size: nothing to move, nothing to allocate yet
+void resize_empty_table(kh_ctx *c, u64 newcap) {
+    if (c->table) (void)hipFree(c->table);  // (synchronises the device)
+    c->table = nullptr;
+    if (c->ntab) {
+        (void)hipFree(c->ntab);
+        c->ntab = nullptr;
+        c->ntab_cap = 0;
+    }
+    c->cap = newcap;
+    c->table_dirty = false;
+    c->rheads_valid = false;
+}
+
 int clear_if_dirty(kh_ctx *c) {
+    const int nrc = need_table(c);
+    if (nrc != KH_OK) return nrc;
     if (!c->table_dirty) return KH_OK;
     hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, c->table, c->cap);
     HIP_TRY(c, hipGetLastError());
@@ -303,6 +344,10 @@ int close_fresh_window(kh_ctx *c) {
 // The 8-byte image -> the 16-byte table (every slot of it is rewritten: a lazily reset wide table needs no clearing first).
 int ensure_wide(kh_ctx *c) {
     if (!c->narrow) return KH_OK;
+    {
+        const int nrc = need_table(c);
+        if (nrc != KH_OK) return nrc;
+    }
     hipLaunchKernelGGL(kh::ntable_widen_kernel, dim3(grid_for(c->cap)), dim3(kh::BLOCK), 0, c->stream, (const u64 *)c->ntab, c->cap,
                        c->narrow_g, c->table);
     HIP_TRY(c, hipGetLastError());
@@ -322,24 +367,50 @@ int sync_counters(kh_ctx *c) {
     return KH_OK;
 }
 
-u64 round_cap(double want) {  // a power-of-two number of regions (placement takes hash bits from the top)
+// The smallest table of at least `want` slots.  Up to 1024 regions: a power of two.  Beyond: 1024 x b2 regions
+// (kernels.hip.h TableGeom) with b2 in steps of at most an eighth -- every multiple of 8 from 64, of 16 from 128, of 32 from
+// 256, of 64 from 512 -- so that a table ends within 12.5 % of the load it was sized for, and so that b2 stays a multiple of
+// every power-of-two world size up to 8 (64 from b2 = 512): the hash-range shards of the multi-GPU merge nest in such a table
+// (merge_regions).  KMERHIP_POW2_TABLE=1: powers of two only, rounds 1-3's tables (A/B, tests).
+bool pow2_tables() {
+    static const bool v = [] { const char *e = getenv("KMERHIP_POW2_TABLE"); return e && e[0] == '1'; }();
+    return v;
+}
+u64 round_cap(double want) {
     u64 cap = MIN_CAP;
-    while ((double)cap < want) cap *= 2;
-    return cap;
+    while ((double)cap < want && cap < 1024ull * kh::REGION_SLOTS) cap *= 2;
+    if ((double)cap >= want) return cap;
+    if (pow2_tables()) {
+        while ((double)cap < want) cap *= 2;
+        return cap;
+    }
+    const double per_b2 = 1024.0 * kh::REGION_SLOTS;
+    u64 b2 = (u64)(want / per_b2);
+    if ((double)b2 * per_b2 < want) ++b2;
+    u64 step = 1;
+    if (b2 > 64) {
+        u64 top = 64;
+        while (top * 2 < b2) top *= 2;  // top < b2 <= 2 top
+        step = std::min<u64>(top / 8, 64);
+    } else {  // 1 .. 64: powers of two (tables of <= 2^28 slots: the granularity matters little there)
+        u64 q = 1;
+        while (q < b2) q *= 2;
+        b2 = q;
+    }
+    b2 = (b2 + step - 1) / step * step;
+    return b2 * 1024ull * kh::REGION_SLOTS;
 }
-
-uint32_t region_bits(u64 cap) {
-    uint32_t b = 0;
-    while (((u64)kh::REGION_SLOTS << (b + 1)) <= cap) ++b;  // 64-bit: a 2^32-slot table is legal
-    return b;
-}
+kh::RegionGeom geom_of_cap(u64 cap) { return kh::kh_geom_of_regions(cap / kh::REGION_SLOTS); }
+bool cap_is_pow2(u64 cap) { return (cap & (cap - 1)) == 0; }
 
 kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap);
 
 kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap) {
     kh::TableGeom tg;
     tg.table = table;
-    tg.rbits = region_bits(cap);
+    const kh::RegionGeom rg = geom_of_cap(cap);
+    tg.p1_bits = rg.p1_bits;
+    tg.b2 = rg.b2;
     tg.k = c->k;
     tg.shard_shift = c->shard_shift;
     tg.shard_index = c->shard_index;
@@ -355,6 +426,11 @@ int grow_to(kh_ctx *c, u64 newcap) {
         (void)hipFree(c->ntab);
         c->ntab = nullptr;
         c->ntab_cap = 0;
+    }
+    if (!c->table) {  // an empty table that was never needed: it just has another size now
+        resize_empty_table(c, newcap);
+        c->grows++;
+        return KH_OK;
     }
     rc = alloc_table(c, newcap, &nt);
     if (rc != KH_OK) return rc;
@@ -418,12 +494,13 @@ struct StageTimer {
     kh_ctx *c;
     int stage;
     hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(kh_ctx *ctx, int st) : c(ctx), stage(st) {
-        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, c->stream);
+    hipStream_t st_stream;
+    StageTimer(kh_ctx *ctx, int st, hipStream_t s = nullptr) : c(ctx), stage(st), st_stream(s ? s : ctx->stream) {
+        if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, st_stream);
     }
     void stop() {
         if (a && b) {
-            (void)hipEventRecord(b, c->stream);
+            (void)hipEventRecord(b, st_stream);
             c->stage_events.push_back({stage, a, b});
             a = b = nullptr;
         }
@@ -485,31 +562,42 @@ struct GeomChoice {
 
 GeomChoice make_geom(const kh_ctx *c, u64 cap) {
     GeomChoice gc;
-    const uint32_t rbits = region_bits(cap);
-    uint32_t p2 = std::min<uint32_t>(rbits, kh::MAX_P2_BITS);
-    uint32_t p1 = rbits - p2;
     const int hbits = 2 * (int)c->k - (int)c->shard_shift;  // significant bits of the placement hash
-    const int need = hbits - 32;  // level-1 bits needed for 32-bit payloads
-    if (need > (int)p1 && need <= (int)kh::MAX_P1_BITS && need <= (int)rbits) {
-        p1 = (uint32_t)need;
-        p2 = rbits - p1;
+    uint32_t p1, b2;
+    if (cap_is_pow2(cap)) {
+        uint32_t rbits = 0;
+        while (((u64)kh::REGION_SLOTS << (rbits + 1)) <= cap) ++rbits;  // 64-bit: a 2^32-slot table is legal
+        uint32_t p2 = std::min<uint32_t>(rbits, kh::MAX_P2_BITS);
+        p1 = rbits - p2;
+        const int need = hbits - 32;  // level-1 bits needed for 32-bit payloads
+        if (need > (int)p1 && need <= (int)kh::MAX_P1_BITS && need <= (int)rbits) {
+            p1 = (uint32_t)need;
+            p2 = rbits - p1;
+        }
+        // With more than 2^10 regions level 1 gets its full 1024 partitions, whatever the payload: the bins kernels are built
+        // around one lane per partition, level 2 then has <= 512 buckets per partition up to 2^19 regions (what the arena
+        // kernel and the unit-writing scatter take), and the written-out windows (window.hip.h) fix the digit at 10 bits.
+        // (Round 2 did this for 64-bit payloads only: k = 19 at the headline size got 512 partitions x 1024 buckets, i.e. the
+        // exact level 2 with the unaligned scatter -- 122 ms per step against k = 21's 75.)
+        if (rbits > kh::MAX_P1_BITS && c->shard_shift == 0 && c->k >= kh::MAX_P1_BITS) {
+            p1 = kh::MAX_P1_BITS;
+            p2 = rbits - p1;
+        }
+        gc.ok = p1 <= kh::MAX_P1_BITS && p2 <= kh::MAX_P2_BITS;
+        b2 = p2 <= 20 ? 1u << p2 : 0u;
+    } else {  // 1024 x b2 regions, b2 not a power of two: the partition passes use the table's own geometry
+        const kh::RegionGeom rg = geom_of_cap(cap);
+        p1 = rg.p1_bits;
+        b2 = rg.b2;
+        gc.ok = p1 == kh::MAX_P1_BITS && b2 <= kh::MAX_B2 && c->shard_shift == 0;
     }
-    // With more than 2^10 regions level 1 gets its full 1024 partitions, whatever the payload: the bins kernels are built
-    // around one lane per partition, level 2 then has <= 512 buckets per partition up to 2^19 regions (what the arena
-    // kernel and the unit-writing scatter take), and the written-out windows (window.hip.h) fix the digit at 10 bits.
-    // (Round 2 did this for 64-bit payloads only: k = 19 at the headline size got 512 partitions x 1024 buckets, i.e. the
-    // exact level 2 with the unaligned scatter -- 122 ms per step against k = 21's 75.)
-    if (rbits > kh::MAX_P1_BITS && c->shard_shift == 0 && c->k >= kh::MAX_P1_BITS) {
-        p1 = kh::MAX_P1_BITS;
-        p2 = rbits - p1;
-    }
-    gc.g.rbits = rbits;
     gc.g.p1_bits = p1;
-    gc.g.p2_bits = p2;
+    gc.g.b2 = b2 ? b2 : 1u;
+    gc.g.b2_magic = kh::part_magic_of(gc.g.b2);
+    gc.g.p2_bits = kh::part_p2_bits_of(gc.g.b2);
     gc.g.k = c->k;
     gc.g.shard_shift = c->shard_shift;
     gc.g.shard_index = c->shard_index;
-    gc.ok = p1 <= kh::MAX_P1_BITS && p2 <= kh::MAX_P2_BITS;
     gc.use32 = (hbits - (int)p1) <= 32 && c->pay_mode != 64;
     return gc;
 }
@@ -556,9 +644,7 @@ uint32_t qual_thr(const kh_ctx *c) {
 
 // count bits of a 32-bit exchange head for this table (shard.hip.h), or -1 if the format does not apply
 int head_count_bits(const kh_ctx *c, u64 regions) {
-    uint32_t rb = 0;
-    while ((1ull << rb) < regions) ++rb;
-    const int hb = 2 * (int)c->k - (int)rb;
+    const int hb = kh::kh_below_bits(c->k, 0, kh::kh_geom_of_regions(regions));  // hash bits below the region index of an UNSHARDED table
     return (hb >= 1 && hb <= 28) ? 32 - hb : -1;  // at least 4 count bits
 }
 
@@ -573,7 +659,7 @@ bool region_small_groups(const kh_ctx *c, u64 expect, u64 nregions) {
     // with 512 lanes; an hg-shaped input in 2^32 slots (0.62, 2.9 K per bucket) 27.4 vs 20.5 ms.
     const int forced = [] { const char *e = getenv("KMERHIP_REGION_NT"); return e ? atoi(e) : 0; }();
     if (forced) return forced == 512;
-    const double keys = c->hinted ? (double)c->hint_keys : (double)(c->distinct_known + expect);
+    const double keys = c->est_keys ? (double)(c->distinct_known + c->est_keys) : c->hinted ? (double)c->hint_keys : (double)(c->distinct_known + expect);
     return !(keys > 0.6 * (double)c->cap && expect / nregions > 16384);
 }
 template <>
@@ -593,9 +679,15 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
     const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
     c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
     // (a narrow FRESH pass must write every region of the image whatever the table held: dirty = 1)
-#define KH_REGION32(FRESH, NARROW, NT, DIRTY, CB, RH) \
-    hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW, NT>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, g, \
+    const bool pow2 = g.p2_bits != 0xFFFFFFFFu;  // (the power-of-two instances take digit and start by shifts: rounds 1-3's code)
+#define KH_REGION32_P(FRESH, NARROW, NT, DIRTY, CB, RH, P2) \
+    hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW, NT, P2>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, g, \
                        (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab, skip)
+#define KH_REGION32(FRESH, NARROW, NT, DIRTY, CB, RH)                     \
+    do {                                                                  \
+        if (pow2) KH_REGION32_P(FRESH, NARROW, NT, DIRTY, CB, RH, true);  \
+        else KH_REGION32_P(FRESH, NARROW, NT, DIRTY, CB, RH, false);      \
+    } while (0)
     // A fresh pass into a table that will end at load <= 0.6 runs in 512-lane workgroups, three per CU (at a higher load
     // the probing loop is most of the kernel and wants the waves of two 1024-lane workgroups; a pass over a filled table
     // keeps the old slots in registers: eight per lane would not fit).  Without a hint: the load it would end at if every
@@ -609,14 +701,29 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
     else if (narrow) KH_REGION32(false, true, kh::REGION_NT, 0u, 0u, (uint32_t *)nullptr);
     else KH_REGION32(false, false, kh::REGION_NT, 0u, 0u, (uint32_t *)nullptr);
 #undef KH_REGION32
+#undef KH_REGION32_P
 }
 
 // One partitioned batch: windows ending in PART_TILE tiles [tile0, tile0+ntiles).
 // PT = payload type carried through the partition buffers (partition.hip.h).
+// gc: the geometry of the partition passes.  Level 1 needs its p1_bits alone; `size_from_sample` (a fresh batch with 1024
+// level-1 partitions): once level 1 has run, the batch's distinct keys are estimated from a few of its partitions
+// (distinct_sample_kernel) and the table is made for THAT many keys -- gc.g.b2 is final only from there on.
+// range_scale: windows of the whole range / windows of this batch (the estimate of one batch is scaled up to the range).
+constexpr double LOAD_SIZED = 0.50;     // a table sized from the sample ends at this load, or a step below (round_cap rounds up) ...
+constexpr double LOAD_KEEP_MAX = 0.53;  // ... an existing table is kept up to this load (and 2^31 slots -- 512 buckets per partition, the
+constexpr double LOAD_KEEP_MIN = 0.36;  //     fast level-2 shape -- is preferred up to it), and down to this one
+u64 policy_cap(double keys) {
+    const u64 cap512 = 512ull * 1024 * kh::REGION_SLOTS;
+    const double want = keys / LOAD_SIZED;
+    if (want > (double)cap512 && keys / LOAD_KEEP_MAX <= (double)cap512) return cap512;
+    return round_cap(std::max(want, (double)(2048ull * kh::REGION_SLOTS)));
+}
+
 template <typename PT>
-int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 tile0, u64 ntiles) {
+int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u64 ntiles, bool size_from_sample, double range_scale) {
     constexpr bool CHUNKED = true;  // level 1 always goes into the chunk pool (partition.hip.h)
-    const u64 nregions = 1ull << g.rbits;
+    kh::PartGeom &g = gc.g;
     const u64 P1 = 1ull << g.p1_bits;
     const u64 n_all = ntiles * kh::PART_TILE;  // every window of these tiles
     const bool estimated = ra.survive < 1.0;
@@ -625,8 +732,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     // every workgroup's private ranges
     const u64 pool_chunks = (n_ub / kh::CHUNK_PAY) + (n_ub / kh::CHUNK_PAY) / 24 + (u64)PART_G1 * (P1 + kh::POOL_GRAB) + 1024;
     const u64 max_blocks = pool_chunks / kh::CPB + P1 + 1;
-    const u64 n2 = max_blocks << g.p2_bits;
     int rc;
+    // ---- what level 1 needs: the pool and its metadata (independent of the table's size) ----
     if (!c->moff) {  // fixed-size scratch, allocated once
         u64 z = 0;
         z = 0;
@@ -634,39 +741,23 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         z = 0;
         if ((rc = ensure_buf(c, &c->nch, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(nch)")) != KH_OK) return rc;
         z = 0;
-        if ((rc = ensure_buf(c, &c->info, &z, 4, "hipMalloc(info)")) != KH_OK) return rc;
+        if ((rc = ensure_buf(c, &c->info, &z, 8, "hipMalloc(info)")) != KH_OK) return rc;
         z = 0;
         if ((rc = ensure_buf(c, &c->pcount, &z, (u64)kh::MAX_P1, "hipMalloc(pcount)")) != KH_OK) return rc;
         z = 0;
         if ((rc = ensure_buf(c, &c->pstart, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(pstart)")) != KH_OK) return rc;
         z = 0;
         if ((rc = ensure_buf(c, &c->pool_next, &z, 1, "hipMalloc(pool_next)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->ptotal, &z, (u64)kh::MAX_P1, "hipMalloc(ptotal)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pcap, &z, (u64)kh::MAX_P1, "hipMalloc(pcap)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->ovf, &z, 4, "hipMalloc(ovf)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->heavy, &z, (u64)kh::MAX_P1, "hipMalloc(heavy)")) != KH_OK) return rc;
     }
     if ((rc = ensure_buf(c, &c->blocks, &c->blocks_cap, max_blocks, "hipMalloc(blocks)")) != KH_OK) return rc;
-    if (c->h2_cap < n2) {  // H2 and O2 grow together
-        u64 z = c->h2_cap;
-        if ((rc = ensure_buf(c, &c->H2, &z, n2, "hipMalloc(H2)")) != KH_OK) return rc;
-        z = c->O2 ? c->h2_cap + 1 : 0;
-        if ((rc = ensure_buf(c, &c->O2, &z, n2 + 1, "hipMalloc(O2)")) != KH_OK) return rc;
-        c->h2_cap = n2;
-    }
-    if (c->region_cap < nregions) {
-        u64 z = c->bstart ? c->region_cap + 1 : 0;
-        if ((rc = ensure_buf(c, &c->bstart, &z, nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
-        z = c->rfail ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rfail, &z, nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
-        z = c->rnew ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rnew, &z, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
-        z = c->rheads ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rheads, &z, nregions, "hipMalloc(rheads)")) != KH_OK) return rc;
-        z = c->rreal ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rreal, &z, nregions, "hipMalloc(rreal)")) != KH_OK) return rc;
-        z = c->bend ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->bend, &z, nregions, "hipMalloc(bend)")) != KH_OK) return rc;
-        z = c->hot_list ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->hot_list, &z, nregions, "hipMalloc(hot_list)")) != KH_OK) return rc;
-        c->region_cap = nregions;
-    }
     if (c->pool_cap < pool_chunks) {
         u64 z = c->chunk_part ? c->pool_cap : 0;
         if ((rc = ensure_buf(c, &c->chunk_part, &z, pool_chunks, "hipMalloc(chunk_part)")) != KH_OK) return rc;
@@ -676,57 +767,22 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if ((rc = ensure_buf(c, &c->plist, &z, pool_chunks, "hipMalloc(plist)")) != KH_OK) return rc;
         c->pool_cap = pool_chunks;
     }
-    // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
-    // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
-    const bool lines_on = [] { const char *e = getenv("KMERHIP_P2_LINES"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
-    const bool lines = lines_on && g.p2_bits >= 1 && g.p2_bits <= 9;
-    const uint32_t force_wide = [] { const char *e = getenv("KMERHIP_P2_FORCE_WIDE"); return (e && e[0] == '1') ? 1u : 0u; }();
-    // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
-    // each), 32..512 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
-    const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
-    const bool arena = arena_on && g.p1_bits >= 8 && g.p2_bits >= 5 && g.p2_bits <= 10;
-    const u64 arena_pay = arena ? (n_ub + nregions) + ((n_ub + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
-    // the overflow list: a sixteenth of the batch, plus what the workgroups RESERVE without using -- every workgroup that
-    // overflows at all takes private 8192-entry segments (part2_arena_kernel, OVF_SEG), so a batch in which most of the
-    // P1 partitions hold one moderately heavy bucket needs P1 segments before the first entry beyond them is "list full"
-    const u64 ovf_need = arena ? n_ub / 16 + 2 * P1 * 8192ull + (1ull << 20) : 0;
-    const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);
-    const u64 pad_ub = lines ? (max_blocks << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
-    // Heavy level-1 partitions (a homopolymer's, a satellite's: arena_plan_kernel) go through the exact kernels while the
-    // others take the arenas; their buckets follow the arenas in the same buffer: room for an eighth of the batch there
-    // (more than that in heavy partitions: the batch takes the exact path as a whole).
-    const u64 heavy_room = arena ? n_ub / 8 : 0;
-    const u64 heavy_base = (arena_pay + 31) & ~31ull;   // payload index behind the arenas (an upper bound of their total)
-    const u64 heavy_pad = (arena && lines) ? ((heavy_room / (kh::CPB * kh::CHUNK_PAY) + 2 * P1) << g.p2_bits) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;
-    // A: the level-1 pool.  B: the level-2 output -- exact path: every payload + sentinel padding; arenas: a quarter more
-    const u64 b_bytes = std::max((n_ub + pad_ub) * (u64)sizeof(PT), arena ? (heavy_base + heavy_room + heavy_pad + 64) * (u64)sizeof(PT) : 0);
+    const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);  // A: the level-1 pool
     if (c->key_cap < a_bytes) {  // (capacities in BYTES)
         u64 z = c->keysA ? c->key_cap : 0;
         if ((rc = ensure_buf(c, &c->keysA, &z, a_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
         c->key_cap = a_bytes;
     }
-    if (c->keyb_cap < b_bytes) {
-        u64 z = c->keysB ? c->keyb_cap : 0;
-        if ((rc = ensure_buf(c, &c->keysB, &z, b_bytes, "hipMalloc(keysB)")) != KH_OK) return rc;
-        c->keyb_cap = b_bytes;
-    }
-    PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);
-    if (arena || estimated) {
-        if (!c->ptotal) {
-            u64 z = 0;
-            if ((rc = ensure_buf(c, &c->ptotal, &z, (u64)kh::MAX_P1, "hipMalloc(ptotal)")) != KH_OK) return rc;
-            z = 0;
-            if ((rc = ensure_buf(c, &c->pcap, &z, (u64)kh::MAX_P1, "hipMalloc(pcap)")) != KH_OK) return rc;
-            z = 0;
-            if ((rc = ensure_buf(c, &c->ovf, &z, 4, "hipMalloc(ovf)")) != KH_OK) return rc;
-            z = 0;
-            if ((rc = ensure_buf(c, &c->heavy, &z, (u64)kh::MAX_P1, "hipMalloc(heavy)")) != KH_OK) return rc;
-        }
-        if (arena && c->ovf_cap < ovf_need) {
-            u64 z = c->ovf_list ? c->ovf_cap : 0;
-            if ((rc = ensure_buf(c, &c->ovf_list, &z, ovf_need, "hipMalloc(ovf_list)")) != KH_OK) return rc;
-            c->ovf_cap = ovf_need;
-        }
+    // the sample: enough partitions for ~2 M payloads (one partition of a large batch), a set with room for all of them
+    const uint32_t est_np = size_from_sample ? (uint32_t)std::min<u64>(16, std::max<u64>(1, (2ull << 20) / std::max<u64>(1, n_ub / P1))) : 0u;
+    constexpr uint32_t EST_P0 = 517;  // (not partition 0: the hash of A^k is 0 -- its partition is the one a homopolymer makes heavy)
+    u64 est_slots = 0;
+    uint32_t est_sub = 0;  // ... and of a large batch's partition only the keys with est_sub zero bits behind the level-1 digit
+    if (size_from_sample) {
+        while (est_sub < 6 && (n_ub / P1) >> (est_sub + 1) >= (1ull << 19)) ++est_sub;
+        est_slots = 1ull << 16;
+        while (est_slots < 3 * (u64)est_np * ((n_ub / P1 >> est_sub) + 1)) est_slots *= 2;
+        if ((rc = ensure_buf(c, &c->est_set, &c->est_set_cap, est_slots, "hipMalloc(distinct sample)")) != KH_OK) return rc;
     }
 
     const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
@@ -736,6 +792,9 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
     cs.pay = c->keysA;
     cs.plist = c->plist;
     cs.fill8 = c->fill8;
+    const uint32_t force_wide = [] { const char *e = getenv("KMERHIP_P2_FORCE_WIDE"); return (e && e[0] == '1') ? 1u : 0u; }();
+    bool have_total = false;  // the host knows how many payloads level 1 produced (it synchronised to read them)
+    u64 batch_total = 0;
 
     {
         {
@@ -763,7 +822,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             l1.tiles_per_block = tpb;
             l1.k = c->k;
             l1.thr = thr;
-            l1.g = g;
+            l1.g = g;  // (level 1 reads p1_bits, k and the shard fields: not b2)
             l1.pool = c->keysA;
             l1.chunk_part = c->chunk_part;
             l1.fill8 = c->fill8;
@@ -784,35 +843,146 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
 #endif
         {
             StageTimer t(c, ST_MISC);
-            if (arena || estimated) HIP_TRY(c, hipMemsetAsync(c->ptotal, 0, kh::MAX_P1 * sizeof(u64), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->ptotal, 0, kh::MAX_P1 * sizeof(u64), c->stream));
             hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
-                               (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, (arena || estimated) ? c->ptotal : (u64 *)nullptr);
+                               (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, c->ptotal);
             if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
+            // (the plan's moff / mbase depend on b2: it runs again below once that is final; this run sets the chunk list's cursors)
             hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
                                c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)nullptr);
             hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
                                (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
-            HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
+            if (size_from_sample) {
+                u64 *est_out = c->info + 4;  // [distinct, payloads seen, no room]
+                HIP_TRY(c, hipMemsetAsync(est_out, 0, 3 * sizeof(u64), c->stream));
+                HIP_TRY(c, hipMemsetAsync(c->est_set, 0xFF, est_slots * sizeof(u64), c->stream));
+                hipLaunchKernelGGL(kh::distinct_sample_kernel<PT>, dim3(1024), dim3(kh::BLOCK), 0, c->stream, cs, (const u64 *)c->pstart,
+                                   EST_P0 % (uint32_t)(P1 - est_np + 1), est_np, est_sub, c->est_set, est_slots - 1, est_out);
+            }
         }
-        if (estimated) {
+        if (estimated || size_from_sample) {
             // Everything behind the pool is sized for n_ub payloads, an estimate: are there more?  (The pool itself has
             // slack -- a partial chunk per workgroup and partition -- so level 1 may well have found room for them: what
             // counts is the total, from chunk_hist_kernel; and payloads level 1 found no room for are in ctr->failed,
             // which is 0 on entry.)  Nothing but the pool and its chunk lists has been written yet.
             std::vector<u64> pt(kh::MAX_P1);
-            u64 lost = 0, total = 0;
+            u64 lost = 0, total = 0, est[3] = {0, 0, 0};
             HIP_TRY(c, hipMemcpyAsync(pt.data(), c->ptotal, kh::MAX_P1 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipMemcpyAsync(&lost, &c->d_ctr->failed, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            if (size_from_sample) HIP_TRY(c, hipMemcpyAsync(est, c->info + 4, sizeof(est), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             for (u64 p = 0; p < P1; ++p) total += pt[p];
-            if (lost || total > n_ub) {
+            have_total = true;
+            batch_total = total;
+            if (estimated && (lost || total > n_ub)) {
                 HIP_TRY(c, hipMemsetAsync(&c->d_ctr->failed, 0, sizeof(u64), c->stream));
                 if (c->trace)
                     fprintf(stderr, "[kmerhip] sized for %.3f of the windows (%llu payloads), found %llu%s: again at full size\n", ra.survive, n_ub,
                             total, lost ? " and more that did not fit the pool" : "");
                 return KH_RETRY_FULL_SIZE;
             }
+            if (size_from_sample) {
+                // distinct keys of the batch: the sample's, scaled by payloads (its partitions hold est[1] of `total`) -- and of the
+                // range, scaled by windows: an upper bound (later batches repeat keys of this one)
+                double keys = (double)total;  // no usable sample: as if every payload were a new key (round 3's sizing)
+                if (est[2] == 0 && est[1] > 0) keys = (double)est[0] * ((double)total / (double)est[1]);  // (est[1]: the payloads counted: the same share of `total` as the keys)
+                c->est_keys = (u64)(keys * range_scale) + 1;
+                const double load_now = (double)c->est_keys / (double)c->cap;
+                u64 newcap = c->cap;
+                // (a capacity hint is the caller's word on ALL the keys to come, this range being perhaps the first of many: a hinted
+                //  table is never made smaller, only larger when the sample says the hint cannot be right)
+                if (load_now > LOAD_KEEP_MAX || (!c->hinted && (load_now < LOAD_KEEP_MIN || c->cap < 2048ull * kh::REGION_SLOTS))) newcap = policy_cap((double)c->est_keys);
+                if (c->hinted && newcap < c->cap) newcap = c->cap;
+                // two levels of partitioning reach 1024 x 1024 regions: beyond that (more than ~3 G keys in one range) the table
+                // grows by rehash after the batch and later batches take the direct path, as before
+                newcap = std::min<u64>(newcap, (u64)kh::MAX_P1 * kh::MAX_B2 * kh::REGION_SLOTS);
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess) {  // never beyond a third of what is free (the partition buffers of this batch come next)
+                    const u64 room = ((u64)fr + (c->table ? c->cap * sizeof(Slot) : 0) + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
+                    while (newcap > c->cap && newcap * sizeof(Slot) > room) newcap = round_cap((double)newcap * 0.8);
+                }
+                if (c->trace)
+                    fprintf(stderr, "[kmerhip] %llu payloads, ~%llu distinct (sample: %llu of %llu in %u partition(s)%s): table %llu -> %llu slots, load %.3f\n", total,
+                            c->est_keys, est[0], est[1], est_np, est[2] ? ", VOID" : "", c->cap, newcap, (double)c->est_keys / (double)newcap);
+                if (newcap != c->cap) {
+                    // the table is empty (a lazily reset one may hold stale slots: the same to us): it just has another size now
+                    resize_empty_table(c, newcap);
+                    c->sized_by_sample = true;
+                    const GeomChoice g2 = make_geom(c, c->cap);
+                    if (!g2.ok || g2.g.p1_bits != g.p1_bits || g2.use32 != gc.use32) return fail(c, KH_ERR_STATE, "table geometry changed under a running batch");
+                    gc = g2;
+                }
+            }
         }
+    }
+    // ---- what depends on the table's size ----
+    // (level 2's output is sized from the payloads level 1 really produced where the host has just read that number)
+    const u64 n_pay = have_total ? std::min(n_ub, batch_total) : n_ub;
+    const u64 nregions = kh::part_regions(g);
+    const u64 n2 = max_blocks * g.b2;
+    if (c->h2_cap < n2) {  // H2 and O2 grow together
+        u64 z = c->h2_cap;
+        if ((rc = ensure_buf(c, &c->H2, &z, n2, "hipMalloc(H2)")) != KH_OK) return rc;
+        z = c->O2 ? c->h2_cap + 1 : 0;
+        if ((rc = ensure_buf(c, &c->O2, &z, n2 + 1, "hipMalloc(O2)")) != KH_OK) return rc;
+        c->h2_cap = n2;
+    }
+    if (c->region_cap < nregions) {
+        u64 z = c->bstart ? c->region_cap + 1 : 0;
+        if ((rc = ensure_buf(c, &c->bstart, &z, nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
+        z = c->rfail ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rfail, &z, nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
+        z = c->rnew ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rnew, &z, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
+        z = c->rheads ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rheads, &z, nregions, "hipMalloc(rheads)")) != KH_OK) return rc;
+        z = c->rreal ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->rreal, &z, nregions, "hipMalloc(rreal)")) != KH_OK) return rc;
+        z = c->bend ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->bend, &z, nregions, "hipMalloc(bend)")) != KH_OK) return rc;
+        z = c->hot_list ? c->region_cap : 0;
+        if ((rc = ensure_buf(c, &c->hot_list, &z, nregions, "hipMalloc(hot_list)")) != KH_OK) return rc;
+        c->region_cap = nregions;
+    }
+    // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
+    // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
+    const bool lines_on = [] { const char *e = getenv("KMERHIP_P2_LINES"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
+    const bool lines = lines_on && g.b2 >= 2 && g.b2 <= 512;
+    // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
+    // each), 32..1024 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
+    const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
+    const bool arena = arena_on && g.p1_bits >= 8 && g.b2 >= 32 && g.b2 <= kh::MAX_B2;
+    const u64 arena_pay = arena ? (n_pay + nregions) + ((n_pay + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
+    // the overflow list: a sixteenth of the batch, plus what the workgroups RESERVE without using -- every workgroup that
+    // overflows at all takes private 8192-entry segments (part2_arena_kernel, OVF_SEG), so a batch in which most of the
+    // P1 partitions hold one moderately heavy bucket needs P1 segments before the first entry beyond them is "list full"
+    const u64 ovf_need = arena ? n_pay / 16 + 2 * P1 * 8192ull + (1ull << 20) : 0;
+    const u64 pad_ub = lines ? (max_blocks * g.b2) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
+    // Heavy level-1 partitions (a homopolymer's, a satellite's: arena_plan_kernel) go through the exact kernels while the
+    // others take the arenas; their buckets follow the arenas in the same buffer: room for an eighth of the batch there
+    // (more than that in heavy partitions: the batch takes the exact path as a whole).
+    const u64 heavy_room = arena ? n_pay / 8 : 0;
+    const u64 heavy_base = (arena_pay + 31) & ~31ull;   // payload index behind the arenas (an upper bound of their total)
+    const u64 heavy_pad = (arena && lines) ? ((heavy_room / (kh::CPB * kh::CHUNK_PAY) + 2 * P1) * g.b2) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;
+    // B: the level-2 output -- exact path: every payload + sentinel padding; arenas: a quarter more
+    const u64 b_bytes = std::max((n_pay + pad_ub) * (u64)sizeof(PT), arena ? (heavy_base + heavy_room + heavy_pad + 64) * (u64)sizeof(PT) : 0);
+    if (c->keyb_cap < b_bytes) {
+        u64 z = c->keysB ? c->keyb_cap : 0;
+        if ((rc = ensure_buf(c, &c->keysB, &z, b_bytes, "hipMalloc(keysB)")) != KH_OK) return rc;
+        c->keyb_cap = b_bytes;
+    }
+    PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);
+    if (arena && c->ovf_cap < ovf_need) {
+        u64 z = c->ovf_list ? c->ovf_cap : 0;
+        if ((rc = ensure_buf(c, &c->ovf_list, &z, ovf_need, "hipMalloc(ovf_list)")) != KH_OK) return rc;
+        c->ovf_cap = ovf_need;
+    }
+    {
+        StageTimer t(c, ST_MISC);
+        if (size_from_sample)  // (b2 is final now: the plan's matrix offsets again)
+            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
+                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)nullptr);
+        HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
     }
     const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
     bool arena_done = false, heavy_exact = false;
@@ -827,12 +997,22 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
             const u64 room = [&] { const char *e = getenv("KMERHIP_L2_HEAVY_ROOM"); return e ? std::min<u64>(heavy_room, strtoull(e, nullptr, 10)) : heavy_room; }();
             hipLaunchKernelGGL(kh::arena_plan_kernel, dim3((unsigned)std::min<u64>(64, (nregions + 1023) / 1024)), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
                                c->ovf, skew_x, c->heavy, room);
-            if (g.p2_bits == 10)  // 2^20 regions: 1024 buckets per partition, 128-byte bins, 64-byte units
-                hipLaunchKernelGGL((kh::part2_arena_kernel<PT, 64, 1024>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
-                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy);
-            else
-                hipLaunchKernelGGL((kh::part2_arena_kernel<PT, sizeof(PT) == 4 ? KH_ARENA_UNITB : 64, 512>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g,
-                                   (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy);
+#define KH_ARENA(UB, NBK, P2)                                                                                                              \
+    hipLaunchKernelGGL((kh::part2_arena_kernel<PT, UB, NBK, P2>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g, \
+                       (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy)
+            const bool pow2 = g.p2_bits != 0xFFFFFFFFu;
+            constexpr int UB512 = sizeof(PT) == 4 ? KH_ARENA_UNITB : 64;
+            if (g.b2 > 768) {  // 769 .. 1024 buckets per partition: the 128 KiB of bins shared out among them, 64-byte units, four buckets per lane group
+                if (pow2) KH_ARENA(64, 1024, true);
+                else KH_ARENA(64, 1024, false);
+            } else if (g.b2 > 512) {  // 513 .. 768: three buckets per lane group
+                KH_ARENA(64, 768, false);
+            } else if (pow2) {
+                KH_ARENA(UB512, 512, true);
+            } else {
+                KH_ARENA(UB512, 512, false);
+            }
+#undef KH_ARENA
         }
         u64 hov[4] = {0, 0, 0, 0};
         HIP_TRY(c, hipMemcpyAsync(hov, c->ovf, sizeof(hov), hipMemcpyDeviceToHost, c->stream));
@@ -878,7 +1058,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         if (lines)  // whole aligned 64-byte units only (32-bit payloads, 2..512 buckets per partition)
             hipLaunchKernelGGL((kh::part2_scatter_lines_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::P2L_NT), 0, c->stream,
                                (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB);
-        if (g.p2_bits <= 9)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
+        if (g.b2 <= 512)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
             hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 512>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
                                (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
         else
@@ -926,6 +1106,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, const kh::PartGeom &g, u64 t
         }
     }
     if (!nar && c->narrow && (rc = ensure_wide(c)) != KH_OK) return rc;
+    if (!nar && (rc = need_table(c)) != KH_OK) return rc;  // (a fresh pass writes every region of it: uninitialised is fine)
     if (nar) c->narrow_g = g;
     // A bucket holding more than a thousandth of the batch (and a million payloads) would keep ONE workgroup of the region
     // pass busy for as long as the whole pass takes: the pass skips it, hot_buckets_kernel counts it afterwards (below).
@@ -1149,7 +1330,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     bool part = false;
     if (c->path_mode == 2) part = true;
     else if (c->path_mode == 0) part = windows >= PART_MIN_WINDOWS && (double)c->cap <= 7.0 * (double)windows;
-    if (part && (ra.use_qual || (!c->hinted && windows >= (64ull << 20)))) {
+    if (part && (ra.use_qual || windows >= (64ull << 20))) {
         // A quality-masked range: most windows may be gone (-Q 20 on typical reads keeps 0.4 of them at k = 31) -- and so may
         // those of an unhinted one (FASTQ text as the device scanner leaves it: headers and quality lines are masked positions,
         // 0.4 of the windows are k-mers; the table of an unhinted context is sized from the windows).  Count the
@@ -1178,7 +1359,16 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         }
         if (c->trace) fprintf(stderr, "[kmerhip] %s range: %.3f of the windows expected to survive\n", ra.use_qual ? "quality-masked" : "unhinted", ra.survive);
     }
-    if (part && !c->hinted) {
+    // A fresh range with 1024 level-1 partitions ahead of it: partition_batch sizes the table itself, from the distinct keys of
+    // a few level-1 partitions, once level 1 has run (round 4) -- hinted or not.  All that is needed here is a table of more
+    // than 1024 regions, so that level 1 gets its 10-bit digit.
+    const bool sample = part && c->estimate_on && c->table_empty && c->shard_shift == 0 && c->k >= kh::MAX_P1_BITS && windows >= PART_MIN_WINDOWS;
+    c->est_keys = 0;
+    if (sample && c->cap < 2048ull * kh::REGION_SLOTS) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        resize_empty_table(c, 2048ull * kh::REGION_SLOTS);
+    }
+    if (part && !c->hinted && !sample) {
         // No capacity hint: this batch may bring up to `windows` NEW keys.  A region pass that overflows
         // falls back to re-inserting the overflowing buckets through device atomics -- correct, but
         // ~30x slower than the pass itself -- so room for the worst case is made first: an empty table
@@ -1191,7 +1381,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         u64 limit = c->cap;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
-            const u64 bytes = ((u64)fr + c->cap * sizeof(Slot)) / 4;
+            const u64 bytes = ((u64)fr + (c->table ? c->cap * sizeof(Slot) : 0)) / 4;
             u64 lim = MIN_CAP;
             while (lim * 2 * sizeof(Slot) <= bytes) lim *= 2;
             limit = std::max(limit, lim);
@@ -1204,17 +1394,8 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         const u64 want = std::min(round_cap((double)(c->distinct_known + expect) / LOAD_PART), limit);
         if (want > c->cap) {
             if (c->table_empty) {
-                Slot *nt = nullptr;
-                int rc = alloc_table(c, want, &nt);
-                if (rc == KH_OK) {
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    (void)hipFree(c->table);
-                    c->table = nt;
-                    c->cap = want;
-                    c->table_dirty = false;
-                } else {
-                    c->poisoned = false;  // a smaller table still works: the overflow path grows on demand
-                }
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                resize_empty_table(c, want);
             } else {
                 StageTimer t(c, ST_GROW);
                 int rc = grow_to(c, want);
@@ -1232,8 +1413,11 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     }
     if (!c->part_budget) {
         size_t fr = 0, tot = 0;
-        u64 budget = 160ull << 30;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * 0.75));
+        // (up to 0.78 of what is free: the 8-byte table image -- 8 bytes per slot, allocated after level 2 -- and the small arrays
+        //  take the rest.  Round 3 stopped at 160 GiB / 0.75: configs[3]'s 125 M reads then ran as two batches, the second one a
+        //  pass over a filled table that re-reads and re-writes all of it: 36 ms of region pass where one fresh pass takes 24)
+        u64 budget = 224ull << 30;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * 0.78));
         const char *e = getenv("KMERHIP_PART_BUDGET_GB");
         if (e && atof(e) > 0) budget = (u64)(atof(e) * (double)(1ull << 30));
         c->part_budget = std::max<u64>(budget, 64ull << 20);
@@ -1253,7 +1437,10 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         const u64 nb = (left + batch_tiles - 1) / batch_tiles;  // equal-sized batches
         batch_tiles = (left + nb - 1) / nb;
         const u64 nt = std::min(batch_tiles, left);
-        int rc = gc.use32 ? partition_batch<uint32_t>(c, ra, gc.g, t, nt) : partition_batch<u64>(c, ra, gc.g, t, nt);
+        GeomChoice gcb = gc;
+        const bool from_sample = sample && t == first_tile && gcb.g.p1_bits == kh::MAX_P1_BITS;
+        const double range_scale = (double)(end_tile - first_tile) / (double)nt;
+        int rc = gcb.use32 ? partition_batch<uint32_t>(c, ra, gcb, t, nt, from_sample, range_scale) : partition_batch<u64>(c, ra, gcb, t, nt, from_sample, range_scale);
         if (rc == KH_RETRY_FULL_SIZE) {  // the sample misjudged these tiles: the rest of the range is sized for every window
             ra.survive = 1.0;
             continue;
@@ -1499,6 +1686,7 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
         else if (!strcmp(pm, "partition")) c->path_mode = 2;
     }
     if (const char *py = getenv("KMERHIP_PAYLOAD")) c->pay_mode = atoi(py);
+    if (const char *es = getenv("KMERHIP_ESTIMATE")) c->estimate_on = !(es[0] == '0');
 
     int rc = KH_OK;
     do {
@@ -1512,10 +1700,12 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
         if (hipMalloc((void **)&c->d_ctr, sizeof(Counters)) != hipSuccess) { rc = KH_ERR_OOM; break; }
         if (hipHostMalloc((void **)&c->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) { rc = KH_ERR_OOM; break; }
         if (hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream) != hipSuccess) { rc = KH_ERR_HIP; break; }
-        u64 cap = cfg->capacity_hint ? round_cap((double)cfg->capacity_hint / 0.65) : DEFAULT_CAP;
-        rc = alloc_table(c, cap, &c->table);
-        if (rc != KH_OK) break;
-        c->cap = cap;
+        u64 cap = cfg->capacity_hint ? round_cap((double)cfg->capacity_hint / HINT_LOAD) : DEFAULT_CAP;
+        if (const char *e = getenv("KMERHIP_TABLE_REGIONS")) {  // (tests: a table of exactly this many regions, e.g. 1024 x 40)
+            const u64 nr = strtoull(e, nullptr, 10);
+            if (kh::kh_regions_valid(nr) && nr * kh::REGION_SLOTS >= MIN_CAP) cap = nr * kh::REGION_SLOTS;
+        }
+        c->cap = cap;  // (the table itself is allocated when something first needs it: need_table)
         if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = KH_ERR_HIP; break; }
     } while (0);
     if (rc != KH_OK) {
@@ -1541,8 +1731,8 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->merge_off, c->chunk_part, c->fill8, c->plist,
-                       c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_out, c->txt_qual, c->txt_ls, c->txt_hdr,
+                       c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->est_set, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_acc[0], c->txt_acc[1], c->txt_accq[0], c->txt_accq[1], c->txt_scan_partial, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)
         if (q) (void)hipFree(q);
@@ -1551,7 +1741,8 @@ extern "C" void kh_destroy(kh_ctx *c) {
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_txt) (void)hipHostFree(c->h_txt);
-    if (c->txt_raw_free) (void)hipEventDestroy(c->txt_raw_free);
+    for (int i = 0; i < 2; ++i)
+        if (c->txt_acc_done[i]) (void)hipEventDestroy(c->txt_acc_done[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1561,11 +1752,11 @@ extern "C" int kh_reset(kh_ctx *c) {
         c->win_open = false;
         if (c->win_dirty) c->table_dirty = true;
     }
-    int rc = enter(c, false, true, false, true);
+    int rc = enter(c, false, false, false, true);  // (touches no slot: the reset is lazy, and a table nobody has needed yet stays unallocated)
     if (rc != KH_OK) return rc;
     if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
     c->acc_len = c->acc_carry = 0;  // pushes not yet counted are forgotten with everything else
-    c->txt_pending = 0;
+    c->txt_acc_len = 0;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
     // Lazy: no table_init here (5.5 ms for a 34 GB table).  A partitioned batch into an empty table
@@ -1574,6 +1765,7 @@ extern "C" int kh_reset(kh_ctx *c) {
     c->narrow = false;         // (both images are stale now; the next fresh pass chooses again)
     c->narrow_banned = false;
     c->new_rate = -1.0;
+    c->est_keys = 0;
     c->rheads_valid = false;
     HIP_TRY(c, hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream));
     memset(c->h_ctr, 0, sizeof(Counters));  // (the host copy too: its k-mer total decides what may go into the 8-byte image)
@@ -1691,107 +1883,226 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
 }
 
 // ---- raw text: records are found on the device (rawparse.hip.h) ------------------------------
+// Round 4: scanned text ACCUMULATES on the device -- the flat bases (and qualities) of push after push, appended in one of
+// two buffers of up to an eighth of the free memory -- and is counted when a buffer is full or something looks at the table
+// (flush_text).  A file streamed through kh_push_text in 256 MiB chunks used to be 120 counting batches into a growing
+// table (device atomics for most of them, 17 G k-mers/s); now it is one or a few partitioned batches at the rate of the
+// resident benchmark, the first of them FRESH and its table sized from the level-1 sample (partition_batch).
+// The scan kernels run on the COPY stream, right behind the text's own transfer: copies and scans of later texts go on
+// while an accumulated buffer is being counted on the context's stream (the other buffer takes them).
 namespace {
 
 int text_fail(kh_ctx *c, const char *why) { return fail(c, KH_ERR_FORMAT, why); }
 
-// d_text: 16-byte aligned device text holding whole records.  raw_event: record c->txt_raw_free once
-// the scanning kernels (the only readers of d_text) are enqueued.
-int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, bool raw_event, bool defer_count = false) {
+// bytes of text one accumulation buffer may hold: per text byte there are two buffers' worth of flat bases (+ qualities)
+// and the partition buffers of its ~0.45 surviving windows (11 B each) -- an eighth (a tenth) of what is free
+u64 text_acc_limit(const kh_ctx *c, bool with_qual) {
+    u64 lim = 40ull << 30;
+    if (const char *e = getenv("KMERHIP_TEXT_ACC_MB")) {  // (tests: small buffers exercise the switch-over)
+        const u64 v = strtoull(e, nullptr, 10);
+        if (v) return std::max<u64>(1ull << 20, v << 20);
+    }
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        u64 held = c->key_cap + c->keyb_cap;
+        for (int i = 0; i < 2; ++i) held += c->txt_acc_cap[i] + c->txt_accq_cap[i];
+        lim = std::min<u64>(lim, ((u64)fr + held) / (with_qual ? 10 : 8));
+    } else {
+        (void)hipGetLastError();
+    }
+    return std::max<u64>(lim & ~((1ull << 20) - 1), 64ull << 20);
+}
+
+// exclusive scan on the text stream (its own scratch: the context's stream may be scanning for a counting batch meanwhile)
+int text_device_scan(kh_ctx *c, hipStream_t s, const uint32_t *in, u64 n, u64 *out) {
+    const u64 nb = (n + kh::SCAN_CHUNK - 1) / kh::SCAN_CHUNK;
+    if (c->txt_scan_cap < nb + 2) {
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->txt_scan_partial) (void)hipFree(c->txt_scan_partial);
+        c->txt_scan_partial = nullptr;
+        c->txt_scan_cap = 0;
+        if (hipMalloc((void **)&c->txt_scan_partial, (nb + 2) * 2 * sizeof(u64)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, KH_ERR_OOM, "hipMalloc(text scan)");
+        }
+        c->txt_scan_cap = (nb + 2) * 2;
+    }
+    hipLaunchKernelGGL(kh::scan_partials_kernel, dim3((unsigned)nb), dim3(kh::SCAN_NT), 0, s, in, n, c->txt_scan_partial);
+    hipLaunchKernelGGL(kh::scan_spine_kernel, dim3(1), dim3(1024), 0, s, c->txt_scan_partial, nb);
+    hipLaunchKernelGGL(kh::scan_apply_kernel, dim3((unsigned)nb), dim3(kh::SCAN_NT), 0, s, in, n, (const u64 *)c->txt_scan_partial, out);
+    HIP_TRY(c, hipGetLastError());
+    return KH_OK;
+}
+
+// d_text: 16-byte aligned device text holding whole records; s: the stream its bytes arrive on (the scan runs there).
+// Appends the flat form to the current accumulation buffer.
+int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s) {
     const bool fastq = format == KH_TEXT_FASTQ;
     const bool with_qual = fastq && c->minq >= 0;
     const u64 ntiles = (n + kh::RAW_TILE - 1) / kh::RAW_TILE;
-    const u64 padded = (n + 15) / 16 * 16 + 64;
+    const u64 need = (n + 15) / 16 * 16 + 64;  // (FASTQ: as many bytes as the text; FASTA: at most)
     int rc;
     if (!c->h_txt) {
         hipError_t e = hipHostMalloc((void **)&c->h_txt, sizeof(*c->h_txt), hipHostMallocDefault);
         if (e != hipSuccess) return fail(c, KH_ERR_OOM, "hipHostMalloc(text scan)", e);
     }
-    if ((rc = ensure_buf(c, &c->txt_tnl, &c->txt_tnl_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
-    if ((rc = ensure_buf(c, &c->txt_tbase, &c->txt_tbase_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
-    if ((rc = ensure_buf(c, &c->txt_err, &c->txt_err_cap, 4, "hipMalloc(text err)")) != KH_OK) return rc;
-    if ((rc = ensure_buf(c, &c->txt_out, &c->txt_out_cap, padded, "hipMalloc(text bases)")) != KH_OK) return rc;
-    if (with_qual && (rc = ensure_buf(c, &c->txt_qual, &c->txt_qual_cap, padded, "hipMalloc(text qualities)")) != KH_OK) return rc;
+    // room in the current buffer -- else what it holds is counted and the other buffer takes over
+    if (c->txt_acc_len && (c->txt_acc_qual != with_qual || c->txt_acc_len + need > c->txt_acc_cap[c->txt_cur])) {
+        if ((rc = flush_text(c)) != KH_OK) return rc;
+    }
+    const int cur = c->txt_cur;
+    if (c->txt_acc_busy[cur]) {  // its last content is still being counted on the context's stream
+        HIP_TRY(c, hipStreamWaitEvent(s, c->txt_acc_done[cur], 0));
+        c->txt_acc_busy[cur] = false;
+    }
+    if (c->txt_acc_cap[cur] < c->txt_acc_len + need || (with_qual && c->txt_accq_cap[cur] < c->txt_acc_len + need)) {
+        // (only ever grown when empty: its content cannot be moved.  A first text of n bytes gets room for 128 like it, within the limit)
+        const u64 lim = text_acc_limit(c, with_qual);
+        // (a text of 32 MiB or more is a chunk of a file being streamed: the whole limit at once -- one big batch instead of several)
+        u64 want = std::max<u64>(need, std::min<u64>(lim, std::max<u64>(n >= (32ull << 20) ? lim : 128 * need, c->txt_acc_cap[cur ^ 1])));
+        want = std::max<u64>(want, c->txt_acc_cap[cur]);
+        if (c->txt_acc_cap[cur] < want) {
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->txt_acc[cur]) (void)hipFree(c->txt_acc[cur]);
+            c->txt_acc[cur] = nullptr;
+            c->txt_acc_cap[cur] = 0;
+            hipError_t e = hipMalloc((void **)&c->txt_acc[cur], want);
+            if (e != hipSuccess && want > need) {  // (no room for the generous size: what this text needs, then)
+                (void)hipGetLastError();
+                want = need;
+                e = hipMalloc((void **)&c->txt_acc[cur], want);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, KH_ERR_OOM, "hipMalloc(text bases)", e);
+            }
+            c->txt_acc_cap[cur] = want;
+        }
+        if (with_qual && c->txt_accq_cap[cur] < c->txt_acc_cap[cur]) {
+            HIP_TRY(c, hipStreamSynchronize(s));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->txt_accq[cur]) (void)hipFree(c->txt_accq[cur]);
+            c->txt_accq[cur] = nullptr;
+            c->txt_accq_cap[cur] = 0;
+            hipError_t e = hipMalloc((void **)&c->txt_accq[cur], c->txt_acc_cap[cur]);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(c, KH_ERR_OOM, "hipMalloc(text qualities)", e);
+            }
+            c->txt_accq_cap[cur] = c->txt_acc_cap[cur];
+        }
+    }
+    uint8_t *const out = c->txt_acc[cur] + c->txt_acc_len;  // (16-byte aligned: lengths are kept multiples of 16)
+    uint8_t *const outq = with_qual ? c->txt_accq[cur] + c->txt_acc_len : nullptr;
+    // (scratch of the scan: sized per text, reallocated only when a larger text comes -- on the text stream)
+    auto tbuf = [&](auto **ptr, u64 *cap, u64 want, const char *what) -> int {
+        if (*cap >= want && *ptr) return KH_OK;
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (*ptr) (void)hipFree(*ptr);
+        *ptr = nullptr;
+        *cap = 0;
+        if (hipMalloc((void **)ptr, want * sizeof(**ptr)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, KH_ERR_OOM, what);
+        }
+        *cap = want;
+        return KH_OK;
+    };
+    if ((rc = tbuf(&c->txt_tnl, &c->txt_tnl_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
+    if ((rc = tbuf(&c->txt_tbase, &c->txt_tbase_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
+    if ((rc = tbuf(&c->txt_err, &c->txt_err_cap, (u64)4, "hipMalloc(text err)")) != KH_OK) return rc;
     const unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)GRID_CAP);
     u64 out_len = 0;
     {
-        StageTimer tm(c, ST_TEXT);
-        hipLaunchKernelGGL(kh::raw_nl_count_kernel, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles, c->txt_tnl);
-        if ((rc = device_scan(c, c->txt_tnl, ntiles, c->txt_tbase)) != KH_OK) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->txt_err, 0, sizeof(uint32_t), c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tbase + ntiles, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->first, d_text, 1, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->last, d_text + n - 1, 1, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        StageTimer tm(c, ST_TEXT, s);
+        hipLaunchKernelGGL(kh::raw_nl_count_kernel, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles, c->txt_tnl);
+        if ((rc = text_device_scan(c, s, c->txt_tnl, ntiles, c->txt_tbase)) != KH_OK) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->txt_err, 0, sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tbase + ntiles, sizeof(u64), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->first, d_text, 1, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->last, d_text + n - 1, 1, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
         const bool open_end = c->h_txt->last != '\n';           // no final newline: the text end closes the line
         const u64 nlines = c->h_txt->total + (open_end ? 1 : 0);
         if (c->h_txt->first != (fastq ? '@' : '>')) return text_fail(c, fastq ? "text does not start with '@'" : "text does not start with '>'");
         if (fastq && (nlines & 3)) return text_fail(c, "FASTQ line count is not a multiple of 4");
-        if ((rc = ensure_buf(c, &c->txt_ls, &c->txt_ls_cap, nlines + 2, "hipMalloc(line starts)")) != KH_OK) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->txt_ls, 0, sizeof(u64), c->stream));
-        hipLaunchKernelGGL(kh::raw_line_starts_kernel, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+        if ((rc = tbuf(&c->txt_ls, &c->txt_ls_cap, nlines + 2, "hipMalloc(line starts)")) != KH_OK) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->txt_ls, 0, sizeof(u64), s));
+        hipLaunchKernelGGL(kh::raw_line_starts_kernel, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
                            (const u64 *)c->txt_tbase, c->txt_ls);
         if (open_end) {
             c->h_txt->end_mark = n + 1;
-            HIP_TRY(c, hipMemcpyAsync(c->txt_ls + nlines, &c->h_txt->end_mark, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->txt_ls + nlines, &c->h_txt->end_mark, sizeof(u64), hipMemcpyHostToDevice, s));
         }
         if (fastq) {
             const u64 nrec = nlines / 4;
-            hipLaunchKernelGGL(kh::fastq_validate_kernel, dim3(grid_for(nrec)), dim3(kh::BLOCK), 0, c->stream, d_text,
+            hipLaunchKernelGGL(kh::fastq_validate_kernel, dim3(grid_for(nrec)), dim3(kh::BLOCK), 0, s, d_text,
                                (const u64 *)c->txt_ls, nrec, c->txt_err);
-            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
             if (c->h_txt->err) return text_fail(c, "not 4-line FASTQ ('@' / '+' markers or |seq| != |qual|)");
+            // (only a validated layout is marked: the quality gather reads |seq| bytes from the quality line's start)
             if (with_qual)
-                hipLaunchKernelGGL(kh::fastq_mark_kernel<true>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
-                                   (const u64 *)c->txt_tbase, (const u64 *)c->txt_ls, c->txt_out, c->txt_qual);
+                hipLaunchKernelGGL(kh::fastq_mark_kernel<true>, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
+                                   (const u64 *)c->txt_tbase, (const u64 *)c->txt_ls, out, outq);
             else
-                hipLaunchKernelGGL(kh::fastq_mark_kernel<false>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
-                                   (const u64 *)c->txt_tbase, (const u64 *)c->txt_ls, c->txt_out, (uint8_t *)nullptr);
+                hipLaunchKernelGGL(kh::fastq_mark_kernel<false>, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
+                                   (const u64 *)c->txt_tbase, (const u64 *)c->txt_ls, out, (uint8_t *)nullptr);
             out_len = n;
         } else {
-            if ((rc = ensure_buf(c, &c->txt_hdr, &c->txt_hdr_cap, nlines + 2, "hipMalloc(header flags)")) != KH_OK) return rc;
-            if ((rc = ensure_buf(c, &c->txt_tkeep, &c->txt_tkeep_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
-            if ((rc = ensure_buf(c, &c->txt_tout, &c->txt_tout_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
-            hipLaunchKernelGGL(kh::fasta_headers_kernel, dim3(grid_for(nlines + 1)), dim3(kh::BLOCK), 0, c->stream, d_text, n,
+            if ((rc = tbuf(&c->txt_hdr, &c->txt_hdr_cap, nlines + 2, "hipMalloc(header flags)")) != KH_OK) return rc;
+            if ((rc = tbuf(&c->txt_tkeep, &c->txt_tkeep_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
+            if ((rc = tbuf(&c->txt_tout, &c->txt_tout_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
+            hipLaunchKernelGGL(kh::fasta_headers_kernel, dim3(grid_for(nlines + 1)), dim3(kh::BLOCK), 0, s, d_text, n,
                                (const u64 *)c->txt_ls, nlines + 1, c->txt_hdr);
-            hipLaunchKernelGGL(kh::fasta_compact_kernel<0>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+            hipLaunchKernelGGL(kh::fasta_compact_kernel<0>, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
                                (const u64 *)c->txt_tbase, (const uint8_t *)c->txt_hdr, c->txt_tkeep, (const u64 *)nullptr,
                                (uint8_t *)nullptr, c->txt_err);
-            if ((rc = device_scan(c, c->txt_tkeep, ntiles, c->txt_tout)) != KH_OK) return rc;
-            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tout + ntiles, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if ((rc = text_device_scan(c, s, c->txt_tkeep, ntiles, c->txt_tout)) != KH_OK) return rc;
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tout + ntiles, sizeof(u64), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
             if (c->h_txt->err) return text_fail(c, "blank before a line end, or a CR not followed by LF, inside a FASTA record");
             out_len = c->h_txt->total;
-            hipLaunchKernelGGL(kh::fasta_compact_kernel<1>, dim3(grid), dim3(kh::BLOCK), 0, c->stream, d_text, n, ntiles,
+            hipLaunchKernelGGL(kh::fasta_compact_kernel<1>, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
                                (const u64 *)c->txt_tbase, (const uint8_t *)c->txt_hdr, (uint32_t *)nullptr,
-                               (const u64 *)c->txt_tout, c->txt_out, (uint32_t *)nullptr);
+                               (const u64 *)c->txt_tout, out, (uint32_t *)nullptr);
         }
         HIP_TRY(c, hipGetLastError());
+        if (out_len) {  // a separator behind the text, and on to the next multiple of 16
+            const u64 end = (c->txt_acc_len + out_len + 1 + 15) & ~15ull;
+            HIP_TRY(c, hipMemsetAsync(out + out_len, '\n', end - (c->txt_acc_len + out_len), s));
+            if (with_qual) HIP_TRY(c, hipMemsetAsync(outq + out_len, '\n', end - (c->txt_acc_len + out_len), s));
+            c->txt_acc_len = end;
+            c->txt_acc_qual = with_qual;
+            c->txt_scan_stream = s;
+        }
     }
-    if (raw_event) {
-        if (!c->txt_raw_free) HIP_TRY(c, hipEventCreateWithFlags(&c->txt_raw_free, hipEventDisableTiming));
-        HIP_TRY(c, hipEventRecord(c->txt_raw_free, c->stream));
-        c->txt_raw_busy = true;
-    }
-    if (out_len == 0) return KH_OK;
-    if (defer_count) {  // (kh_push_text: counted when the context is entered next -- under the next text's copy, if that is what comes)
-        c->txt_pending = out_len;
-        c->txt_pending_qual = with_qual;
-        return KH_OK;
-    }
-    return count_device_range(c, c->txt_out, with_qual ? c->txt_qual : nullptr, out_len, 0);
+    return KH_OK;
 }
 
 }  // namespace
 namespace {
-// counts the text kh_push_text has scanned and left in txt_out
+// counts what the text pushes have accumulated; the other buffer takes what comes next
 int flush_text(kh_ctx *c) {
-    const u64 n = c->txt_pending;
-    c->txt_pending = 0;
+    const u64 n = c->txt_acc_len;
     if (!n) return KH_OK;
-    return count_device_range(c, c->txt_out, c->txt_pending_qual ? c->txt_qual : nullptr, n, 0);
+    const int cur = c->txt_cur;
+    c->txt_acc_len = 0;
+    c->txt_cur ^= 1;
+    if (c->txt_scan_stream && c->txt_scan_stream != c->stream) {  // the scans that filled the buffer ran on the copy stream
+        hipEvent_t ready;
+        HIP_TRY(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(ready, c->txt_scan_stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
+        (void)hipEventDestroy(ready);
+    }
+    const int rc = count_device_range(c, c->txt_acc[cur], c->txt_acc_qual ? c->txt_accq[cur] : nullptr, n, 0);
+    if (!c->txt_acc_done[cur]) HIP_TRY(c, hipEventCreateWithFlags(&c->txt_acc_done[cur], hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->txt_acc_done[cur], c->stream));
+    c->txt_acc_busy[cur] = true;
+    return rc;
 }
 
 int text_args(kh_ctx *c, const uint8_t *text, u64 n, int format) {
@@ -1809,29 +2120,35 @@ extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n,
     if ((rc = text_args(c, d_text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
     if ((uintptr_t)d_text & 15) return fail(c, KH_ERR_BAD_ARG, "d_text must be 16-byte aligned");
-    rc = scan_text(c, d_text, n, format, false);
+    rc = scan_text(c, d_text, n, format, c->stream);
+    if (rc == KH_OK) rc = flush_text(c);  // (resident text: counted right away, as kh_push_device counts resident bases)
     if (rc == KH_OK) c->bases_pushed += n;
     return rc;
 }
 
 extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int format) {
-    // (what earlier calls left pending is counted below, once this text's copy is under way -- not by enter())
+    // (what earlier calls have accumulated stays where it is: it is counted when its buffer is full, or by whatever looks
+    //  at the table next)
     int rc = enter(c, false, false, false, true);
     if (rc != KH_OK) return rc;
     if ((rc = text_args(c, text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
     if ((rc = ensure_stage(c)) != KH_OK) return rc;
+    if (c->acc_len && (rc = flush_acc(c, false)) != KH_OK) return rc;  // (kh_push's own accumulation: counted first, so that its buffers stay bounded)
     if (c->txt_raw_cap < n + 64) {
         u64 want = std::max<u64>(1ull << 20, c->txt_raw_cap);
         while (want < n + 64) want *= 2;
-        if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
-        if ((rc = ensure_buf(c, &c->txt_raw, &c->txt_raw_cap, want, "hipMalloc(text)")) != KH_OK) return rc;
-        c->txt_raw_busy = false;
+        HIP_TRY(c, hipStreamSynchronize(c->cstream));  // (the last text's scan reads the old buffer)
+        if (c->txt_raw) (void)hipFree(c->txt_raw);
+        c->txt_raw = nullptr;
+        c->txt_raw_cap = 0;
+        if (hipMalloc((void **)&c->txt_raw, want) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, KH_ERR_OOM, "hipMalloc(text)");
+        }
+        c->txt_raw_cap = want;
     }
-    if (c->txt_raw_busy) {  // the previous text is still being scanned (its COUNTING does not read txt_raw)
-        HIP_TRY(c, hipStreamWaitEvent(c->cstream, c->txt_raw_free, 0));
-        c->txt_raw_busy = false;
-    }
+    // the text -> the device, on the copy stream (behind the previous text's scan, which read the same buffer)
     if (is_pinned_host(text)) {  // pinned / registered text: one DMA, no staging memcpy
         hipEvent_t t0, t1;
         HIP_TRY(c, hipEventCreate(&t0));
@@ -1857,22 +2174,10 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
         c->stage_used[p] = true;
         c->h2d_events.emplace_back(t0, t1);
     }
-    hipEvent_t ready;
-    HIP_TRY(c, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    HIP_TRY(c, hipEventRecord(ready, c->cstream));
-    // While the copy runs: count what the previous kh_push_text scanned (and what kh_push has accumulated).  The scan of
-    // THIS text -- the part that can refuse it -- stays inside this call; its counting is left to the next one.
-    rc = KH_OK;
-    if (c->acc_len) rc = flush_acc(c, false);
-    if (rc == KH_OK) rc = flush_text(c);
-    if (rc != KH_OK) {
-        (void)hipEventSynchronize(ready);  // (the caller gets its buffer back when we return)
-        (void)hipEventDestroy(ready);
-        return rc;
-    }
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
-    (void)hipEventDestroy(ready);
-    rc = scan_text(c, c->txt_raw, n, format, true, true);
+    // The scan -- the part that can refuse the text -- runs right behind the copy, on the same stream, and is over when this
+    // call returns (its first host read-back waits for the copy too: the caller may reuse its buffer).
+    rc = scan_text(c, c->txt_raw, n, format, c->cstream);
+    if (rc != KH_OK) (void)hipStreamSynchronize(c->cstream);  // (whatever happened: the caller gets its buffer back)
     if (rc == KH_OK) c->bases_pushed += n;
     return rc;
 }
@@ -2256,7 +2561,7 @@ kh::SlotSrc slot_src(const kh_ctx *c) {
     kh::SlotSrc s;
     s.table = c->table;
     s.ntab = c->narrow ? c->ntab : nullptr;
-    s.p2_bits = c->narrow ? c->narrow_g.p2_bits : 0;
+    s.geo = c->narrow ? kh::RegionGeom{c->narrow_g.p1_bits, c->narrow_g.b2} : geom_of_cap(c->cap);
     return s;
 }
 
@@ -2266,12 +2571,12 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
     if (rc != KH_OK) return rc;
     const bool packed = fmt != XF_WIDE;
     const u64 nregions = c->cap / kh::REGION_SLOTS;
-    if (fmt == XF_PACKED64 && 2 * (int)c->k - (int)region_bits(c->cap) > 32)
+    if (fmt == XF_PACKED64 && kh::kh_below_bits(c->k, 0, geom_of_cap(c->cap)) > 32)
         return fail(c, KH_ERR_RANGE, "packed export needs 2k - log2(table regions) <= 32");
     const int cb = fmt == XF_HEADS32 ? head_count_bits(c, nregions) : 0;
     if (cb < 0) return fail(c, KH_ERR_RANGE, "32-bit heads need 1 <= 2k - log2(table regions) <= 28");
     if (table_regions) *table_regions = nregions;
-    if (nparts < 1 || nparts > (uint32_t)kh::MAX_SENDERS || (nparts & (nparts - 1)) || nparts > nregions || !part_counts ||
+    if (nparts < 1 || nparts > (uint32_t)kh::MAX_SENDERS || (nparts & (nparts - 1)) || nparts > nregions || nregions % nparts || !part_counts ||
         !d_region_counts)
         return fail(c, KH_ERR_BAD_ARG, "bad nparts / NULL argument");
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "table is already a shard");
@@ -2327,7 +2632,7 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
     if (total && (!d_keys || (!packed && !d_counts))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
     if (total && fmt == XF_HEADS32) {
         hipLaunchKernelGGL(kh::region_compact_heads_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           slot_src(c), (const u64 *)c->merge_off, region_bits(c->cap), c->k, (uint32_t)cb,
+                           slot_src(c), (const u64 *)c->merge_off, c->k, (uint32_t)cb,
                            (uint32_t *)d_keys);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2340,7 +2645,7 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
         rc = zero_cursors(c);
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL(kh::region_compact_packed_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           slot_src(c), (const u64 *)c->merge_off, region_bits(c->cap), c->k, (u64 *)d_keys,
+                           slot_src(c), (const u64 *)c->merge_off, c->k, (u64 *)d_keys,
                            &c->d_ctr->big);
         HIP_TRY(c, hipGetLastError());
         u64 wide = 0;
@@ -2430,8 +2735,16 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     const bool packed = fmt != XF_WIDE;
     if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || (!packed && !d_counts) || !d_region_counts)
         return fail(c, KH_ERR_BAD_ARG, "bad nsenders / NULL argument");
-    if (sender_regions == 0 || (sender_regions & (sender_regions - 1)) || (sender_regions >> c->shard_shift) == 0)
-        return fail(c, KH_ERR_BAD_ARG, "sender_regions must be a power of two >= the shard count");
+    // The senders' tables: any geometry a table can have (a power of two, or 1024 x b2 regions) whose regions split evenly
+    // among the shards -- for 1024 x b2 that means b2 is a multiple of the shard count: a shard's range of sender regions then
+    // nests in any receiver table of nr x 2^d regions (target t <-> sender-local region t >> d), exactly as bit fields do
+    // for powers of two.  (Proof sketch: with C = b2 / shards, the sender-local region of a key is p1' C + floor(xr C / 2^(32 - s)),
+    // p1' and xr being the shard table's own level-1 digit and the bits behind it; a receiver with C 2^d buckets per p1' has
+    // t = p1' C 2^d + floor(xr C 2^d / 2^(32 - s)), and t >> d is the former.)
+    const kh::RegionGeom sgeo = kh::kh_geom_of_regions(sender_regions);
+    if (!kh::kh_regions_valid(sender_regions) || (sender_regions >> c->shard_shift) == 0 || (sender_regions & ((1ull << c->shard_shift) - 1)) ||
+        (sgeo.b2 > 1 && (sgeo.b2 & (sgeo.b2 - 1)) && sgeo.b2 % (1u << c->shard_shift)))
+        return fail(c, KH_ERR_BAD_ARG, "sender_regions must be a table geometry (a power of two, or a multiple of 1024) that splits evenly among the shards");
     const u64 nr = sender_regions >> c->shard_shift;  // sender regions inside this shard's hash range
     if (windowed && nr % c->win_n) return fail(c, KH_ERR_BAD_ARG, "region window: fewer sender regions in the shard than pieces");
     // per-sender offsets of every region segment (device scans), and the incoming total (host)
@@ -2456,27 +2769,31 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     }
     // a first piece sizes for all of them (pieces are equal shares of the hash range)
     const u64 expect = (windowed && c->table_empty) ? incoming * c->win_n : incoming;
-    if ((double)(c->distinct_known + expect) > LOAD_HARD * (double)c->cap) {
-        u64 newcap = c->cap;
-        while ((double)(c->distinct_known + expect) > LOAD_HARD * (double)newcap) newcap *= 2;
+    // the receiver's table must NEST with the senders' regions: nr x 2^d regions for some d (negative: coarser)
+    auto nests = [&](u64 cap) {
+        const u64 nt = cap / kh::REGION_SLOTS;
+        if (!kh::kh_regions_valid(nt)) return false;
+        const u64 hi = std::max(nt, nr), lo = std::min(nt, nr);
+        return hi % lo == 0 && ((hi / lo) & (hi / lo - 1)) == 0;
+    };
+    if ((double)(c->distinct_known + expect) > LOAD_HARD * (double)c->cap || !nests(c->cap)) {
+        const double need = (double)(c->distinct_known + expect) / LOAD_HARD;
+        u64 newcap = nr * kh::REGION_SLOTS;
+        while ((double)newcap < need || newcap < c->cap || newcap < MIN_CAP) newcap *= 2;
+        while (newcap / 2 >= MIN_CAP && (double)(newcap / 2) >= need && newcap / 2 >= c->cap && nests(newcap / 2)) newcap /= 2;
         if (c->win_open) {  // growing rehashes the whole table: the unwritten pieces must be empty first
             rc = close_fresh_window(c);
             if (rc != KH_OK) return rc;
         }
         if (c->table_empty) {
-            Slot *nt = nullptr;
-            rc = alloc_table(c, newcap, &nt);
-            if (rc != KH_OK) return rc;
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            (void)hipFree(c->table);
-            c->table = nt;
-            c->cap = newcap;
-            c->table_dirty = false;
+            resize_empty_table(c, newcap);
         } else {
             rc = grow_to(c, newcap);
             if (rc != KH_OK) return rc;
         }
     }
+    if ((rc = need_table(c)) != KH_OK) return rc;  // (uninitialised if new: a fresh merge writes every region -- `dirty` below)
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     const u64 nregions = c->cap / kh::REGION_SLOTS;
     if (c->region_cap < nregions) {
@@ -2491,19 +2808,17 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     kh::MergeArgs a;
     memset(&a, 0, sizeof(a));
     a.nsenders = nsenders;
-    uint32_t nr_bits = 0;
-    while ((1ull << nr_bits) < nr) ++nr_bits;
-    a.dshift = (int32_t)tg.rbits - (int32_t)nr_bits;  // target t <-> sender-local region t >> dshift
+    a.dshift = 0;  // target t <-> sender-local region t >> dshift (nests(): the ratio is a power of two)
+    for (u64 q = nregions; q > nr; q >>= 1) ++a.dshift;
+    for (u64 q = nr; q > nregions; q >>= 1) --a.dshift;
     for (uint32_t s = 0; s < nsenders; ++s) {
         a.src[s].keys = (const u64 *)d_keys[s];
         a.src[s].counts = packed ? nullptr : (const u64 *)d_counts[s];
         a.src[s].off = c->merge_off + (u64)s * (nr + 1);
     }
-    uint32_t sr_bits = 0;
-    while ((1ull << sr_bits) < sender_regions) ++sr_bits;
-    a.src_rbits = sr_bits;
+    a.sgeo = sgeo;
     a.src_region0 = (u64)c->shard_index * nr;
-    if (fmt == XF_PACKED64 && 2 * (int)c->k - (int)sr_bits > 32) return fail(c, KH_ERR_BAD_ARG, "packed pairs need 2k - log2(sender_regions) <= 32");
+    if (fmt == XF_PACKED64 && kh::kh_below_bits(c->k, 0, sgeo) > 32) return fail(c, KH_ERR_BAD_ARG, "packed pairs need 2k - log2(sender_regions) <= 32");
     if (fmt == XF_HEADS32) {
         const int cb = head_count_bits(c, sender_regions);
         if (cb < 0) return fail(c, KH_ERR_BAD_ARG, "32-bit heads need 1 <= 2k - log2(sender_regions) <= 28");
@@ -2532,7 +2847,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
         const uint8_t *none = nullptr;
         const uint32_t dirty = (uint32_t)(windowed ? (fresh && c->win_dirty) : c->table_dirty);
 #define KH_MERGE_LAUNCH(FRESH, FMT) \
-    hipLaunchKernelGGL((kh::shard_merge_kernel<FRESH, false, FMT>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, 0u, c->d_ctr, \
+    hipLaunchKernelGGL((kh::shard_merge_kernel<FRESH, false, FMT>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, kh::RegionGeom{0u, 1u}, c->d_ctr, \
                        FRESH ? dirty : 0u, (uint32_t)region0)
         if (fresh) {
             if (fmt == XF_WIDE) KH_MERGE_LAUNCH(true, 0);
@@ -2558,7 +2873,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
     if (c->h_ctr->part_failed) {  // some target regions overflowed: grow, then insert their pairs directly
-        const uint32_t old_rbits = tg.rbits;
+        const kh::RegionGeom old_geo{tg.p1_bits, tg.b2};
         StageTimer t(c, ST_GROW);
         rc = close_fresh_window(c);  // growing rehashes the whole table
         if (rc != KH_OK) return rc;
@@ -2566,7 +2881,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
         if (rc != KH_OK) return rc;
 #define KH_MERGE_DIRECT(FMT) \
     hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, FMT>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, \
-                       table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_rbits, c->d_ctr, 0u, \
+                       table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_geo, c->d_ctr, 0u, \
                        (uint32_t)region0)
         if (fmt == XF_WIDE) KH_MERGE_DIRECT(0);
         else if (fmt == XF_PACKED64) KH_MERGE_DIRECT(1);

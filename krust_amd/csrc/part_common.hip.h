@@ -26,6 +26,7 @@ constexpr int PART_TILE = PART_NT * CHUNK;       // 16384 positions / keys per b
 constexpr uint32_t MAX_P1 = 1024;
 constexpr uint32_t MAX_P1_BITS = 10;
 constexpr uint32_t MAX_P2_BITS = 10;             // <= 1024 regions per level-1 partition
+constexpr uint32_t MAX_B2 = 1u << MAX_P2_BITS;
 constexpr u64 PART2_CHUNK = 16ull * PART_TILE;   // payloads per level-2 workgroup (262144)
 #ifndef KH_REGION_NT
 #define KH_REGION_NT 1024  // (512: three workgroups per CU instead of two -- A/B builds)
@@ -40,13 +41,34 @@ constexpr int REGION_NT = KH_REGION_NT;          // lanes per workgroup in regio
 constexpr int REGION_RK = KH_REGION_RK;                     // keys prefetched per lane per round
 
 struct PartGeom {
-    uint32_t rbits;        // log2(regions) = p1_bits + p2_bits
     uint32_t p1_bits;      // level-1 partitions = 1 << p1_bits
-    uint32_t p2_bits;      // buckets per level-1 partition = 1 << p2_bits
+    uint32_t b2;           // buckets per level-1 partition (ANY number <= 1024 since round 4; regions = b2 << p1_bits).  For a
+                           // table with a power-of-two region count any split describes the same layout; otherwise
+                           // (p1_bits, b2) is the table's own geometry (kernels.hip.h TableGeom, kh_geom_of_regions)
+    u64 b2_magic;          // ceil(2^40 / b2): r / b2 == (r * b2_magic) >> 40 for every region index r < 2^22 (part_div_b2)
+    uint32_t p2_bits;      // log2(b2) where b2 is a power of two (the hot kernels then take digit and start by shifts: their POW2
+                           // instances are rounds 1-3's code, instruction for instruction), 0xFFFFFFFF otherwise
     uint32_t k;
     uint32_t shard_shift;  // as TableGeom: placement hash = kh_table_hash << shard_shift
     uint32_t shard_index;
 };
+__host__ __device__ inline u64 part_regions(const PartGeom &g) { return (u64)g.b2 << g.p1_bits; }
+__host__ inline u64 part_magic_of(uint32_t b2) { return ((1ull << 40) + b2 - 1) / b2; }
+__host__ inline uint32_t part_p2_bits_of(uint32_t b2) {
+    if (b2 & (b2 - 1)) return 0xFFFFFFFFu;
+    uint32_t b = 0;
+    while ((1u << b) < b2) ++b;
+    return b;
+}
+// bucket of a 32-bit payload: POW2 -- the top p2_bits bits; else the fast-range (kernels.hip.h)
+template <bool POW2>
+__device__ __forceinline__ uint32_t part_bucket32(uint32_t pay, const PartGeom &g) {
+    if constexpr (POW2) return g.p2_bits ? (pay >> (32 - g.p2_bits)) : 0u;
+    else return kh_bucket_of_x(pay, g.b2);
+}
+// region index -> (level-1 partition, bucket)
+__device__ __forceinline__ uint32_t part_div_b2(const PartGeom &g, u64 r) { return (uint32_t)((r * g.b2_magic) >> 40); }
+__device__ __forceinline__ RegionGeom rgeom(const PartGeom &g) { return RegionGeom{g.p1_bits, g.b2}; }
 
 template <int MODE = KH_MUL_AUTO>
 __device__ __forceinline__ u64 part_hash(const PartGeom &g, u64 key) { return kh_table_hash<MODE>(key, g.k) << g.shard_shift; }
@@ -64,18 +86,15 @@ template <>
 struct Pay<u64> {  // the key itself
     __device__ static __forceinline__ u64 make(u64 key, u64 H, const PartGeom &g) { return key; }
     __device__ static __forceinline__ uint32_t p2(u64 pay, const PartGeom &g) {
-        const u64 H = part_hash(g, pay);
-        return g.p2_bits ? (uint32_t)((H << g.p1_bits) >> (64 - g.p2_bits)) : 0u;
+        return kh_bucket_of_x(kh_x_of(part_hash(g, pay), g.p1_bits), g.b2);
     }
     __device__ static __forceinline__ u64 key(u64 pay, uint32_t p1, const PartGeom &g) { return pay; }
 };
 
 template <>
-struct Pay<uint32_t> {  // bits [p1_bits, p1_bits+32) of H
-    __device__ static __forceinline__ uint32_t make(u64 key, u64 H, const PartGeom &g) { return (uint32_t)((H << g.p1_bits) >> 32); }
-    __device__ static __forceinline__ uint32_t p2(uint32_t pay, const PartGeom &g) {
-        return g.p2_bits ? (pay >> (32 - g.p2_bits)) : 0u;
-    }
+struct Pay<uint32_t> {  // x: bits [p1_bits, p1_bits+32) of H
+    __device__ static __forceinline__ uint32_t make(u64 key, u64 H, const PartGeom &g) { return kh_x_of(H, g.p1_bits); }
+    __device__ static __forceinline__ uint32_t p2(uint32_t pay, const PartGeom &g) { return kh_bucket_of_x(pay, g.b2); }
     __device__ static __forceinline__ u64 hash(uint32_t pay, uint32_t p1, const PartGeom &g) {
         const u64 top = g.p1_bits ? ((u64)p1 << (64 - g.p1_bits)) : 0ull;
         return top | ((u64)pay << (32 - g.p1_bits));

@@ -89,6 +89,61 @@ __global__ __launch_bounds__(1024) void chunk_list_kernel(const uint16_t *__rest
         if (tag[j] != 0xFFFFFFFFu) plist[s_base[tag[j] >> 16] + (tag[j] & 0xFFFFu)] = (uint32_t)(lo + (u64)j * 1024 + tid);
 }
 
+// ---- how many DISTINCT keys does the batch hold?  (round 4) --------------------------------------------------------------
+// Level 1 splits the batch by the top 10 bits of a bijective hash: a partition holds every occurrence of an exact 1/1024
+// of the key space, whatever the table will look like.  So the distinct payloads of a few partitions, counted exactly, times
+// 1024 / (partitions sampled) is the batch's distinct k-mer count to ~0.1 % -- known BEFORE the table's geometry is needed
+// (level 2 is the first kernel that depends on it).  The host sizes the table from it (kmerhip.hip, partition_batch): no
+// capacity hint, no worst-case table, and the load the region pass sees is the one it was tuned for.
+// An open-addressing SET in global memory (u64 slots, ~0 = free; value = payload, with the partition above a 32-bit one):
+// one plain load settles the ~11 of 12 payloads that are copies, a compare-and-swap the rest.  sub_bits: of the sampled
+// partitions' keys only those whose next sub_bits hash bits are zero are counted -- still every occurrence of an exact share
+// of the key space, so that a large batch's sample stays ~1 M payloads and its set in the L2.  out[0] += new values,
+// out[1] += payloads counted, out[2] += values that found no room within 128 probes (the estimate is then void).
+template <typename PT>
+__global__ __launch_bounds__(BLOCK) void distinct_sample_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, uint32_t p_first, uint32_t np,
+                                                                uint32_t sub_bits, u64 *__restrict__ set, u64 set_mask, u64 *__restrict__ out) {
+    const u64 c0 = pstart[p_first], c1 = pstart[p_first + np];
+    uint32_t nd = 0, nf = 0;
+    u64 seen = 0;
+    uint32_t p = p_first;
+    for (u64 ci = c0 + blockIdx.x; ci < c1; ci += gridDim.x) {  // one chunk (<= 256 payloads) per iteration
+        while (pstart[p + 1] <= ci) ++p;                         // (uniform: the chunk's partition)
+        const uint32_t chunk = cs.plist[ci];
+        const uint32_t fill = (uint32_t)cs.fill8[chunk] + 1u;
+        if (threadIdx.x >= fill) continue;
+        const PT pay = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + threadIdx.x];
+        if (sizeof(PT) == 8 && (u64)pay == KH_EMPTY_KEY) continue;
+        if (sub_bits) {  // (a 32-bit payload IS hash bits; an 8-byte one is the key: any fixed function of it will do)
+            const uint32_t sel = sizeof(PT) == 4 ? (uint32_t)pay >> (32 - sub_bits) : (uint32_t)(kh_mix64((u64)pay) >> 40) >> (24 - sub_bits);
+            if (sel) continue;
+        }
+        ++seen;
+        const u64 v = sizeof(PT) == 4 ? ((u64)(p - p_first) << 32) | (u64)pay : (u64)pay;
+        u64 h = kh_mix64(v) & set_mask;
+        uint32_t probes = 0;
+        for (; probes < 128; ++probes, h = (h + 1) & set_mask) {
+            u64 cur = set[h];
+            if (cur == ~0ull) {
+                cur = atomicCAS((unsigned long long *)&set[h], ~0ull, (unsigned long long)v);
+                if (cur == ~0ull) {
+                    ++nd;
+                    break;
+                }
+            }
+            if (cur == v) break;
+        }
+        nf += probes == 128;
+    }
+    const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    seen = wave_sum(seen);
+    if (lane_id() == 0) {
+        if (d) atomicAdd(&out[0], d);
+        if (seen) atomicAdd(&out[1], seen);
+        if (f) atomicAdd(&out[2], f);
+    }
+}
+
 // Level-2 plan over chunk lists.  pstart = exclusive scan of pcount (P1 + 1 entries).  Same outputs as
 // part2_plan_kernel; info[2] is left to the level-2 scan (the grand total is not known yet).
 // only (optional): plan blocks for the partitions with only[p] != 0 alone -- the heavy partitions of a batch whose other
@@ -134,7 +189,7 @@ __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__r
     if (tid == 0) {
         s_bbase[P1] = b;
         info[0] = b;
-        info[1] = b << g.p2_bits;
+        info[1] = b * g.b2;
         info[2] = 0;
         info[3] = wide ? 1 : 0;
     }
@@ -143,14 +198,14 @@ __global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__r
         const u64 lo = pstart[tid], hi = lo + nchunks_of(tid);
         const u64 b0 = s_bbase[tid];
         const uint32_t n = (uint32_t)(s_bbase[tid + 1] - b0);
-        moff[tid] = b0 << g.p2_bits;
+        moff[tid] = b0 * g.b2;
         nch[tid] = n;
         for (uint32_t c = 0; c < n; ++c) {
             if (b0 + c >= max_blocks) break;
             Part2Block pb;
             pb.lo = lo + (u64)c * CPB;
             pb.hi = pb.lo + CPB < hi ? pb.lo + CPB : hi;
-            pb.mbase = (b0 << g.p2_bits) + c;
+            pb.mbase = b0 * g.b2 + c;
             pb.mstride = n;
             pb.p1 = (uint32_t)tid;
             blocks[b0 + c] = pb;
@@ -276,7 +331,7 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restri
     }
     __syncthreads();
     if (pad > 1 && info[3]) pad = 1;  // (the unit-writing kernel stands down for this batch: no padding)
-    if (tid < (1 << g.p2_bits)) H2[pb.mbase + (u64)tid * pb.mstride] = (s_hist[tid] + pad - 1) / pad * pad;
+    if ((uint32_t)tid < g.b2) H2[pb.mbase + (u64)tid * pb.mstride] = (s_hist[tid] + pad - 1) / pad * pad;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -317,7 +372,7 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
     if (only_if_wide && !info[3]) return;  // launched behind part2_scatter_lines_kernel: runs only where that one stood down
     const Part2Block pb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
-    const int P2 = 1 << g.p2_bits;
+    const int P2 = (int)g.b2;
     p2_stage_chunks<CHUNKED>(cs, pb, s_chk, s_cfill, tid, PART2_NT);
     // lane tid owns buckets tid + q * PART2_NT: their running output cursors live in registers
     u64 gcur[OWN];
@@ -372,7 +427,7 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
 #if KH_ABL2 & 28  /* timing experiment: the same scatter pattern and byte volume, but every write one whole aligned 128 / 64 / 32-byte unit */
         for (uint32_t i = tid; i < (uint32_t)PART2_TILE; i += PART2_NT) {
             constexpr uint32_t LP = ((KH_ABL2 & 4) ? 128 : (KH_ABL2 & 8) ? 64 : 32) / sizeof(PT);
-            const uint32_t b = (i / LP) & (uint32_t)(P2 - 1);
+            const uint32_t b = (i / LP) % (uint32_t)P2;
             out[((s_dst[b] + s_lofs[b]) & ~(u64)(LP - 1)) + (i % LP)] = s_stage[i];
         }
 #else
@@ -423,12 +478,12 @@ struct P2L {
     static constexpr int PER = TILE / P2L_NT;
 };
 
-// sentinel of bucket `digit`: 32-bit payloads -- a payload carrying ANOTHER level-2 digit (needs p2_bits >= 1);
+// sentinel of bucket `digit`: 32-bit payloads -- a payload of ANOTHER bucket (needs b2 >= 2);
 // 64-bit payloads (keys) -- the empty key
 template <typename PT>
-__device__ __forceinline__ PT p2_sentinel(uint32_t digit, uint32_t p2_bits) {
+__device__ __forceinline__ PT p2_sentinel(uint32_t digit, uint32_t b2) {
     if (sizeof(PT) == 8) return (PT)KH_EMPTY_KEY;
-    return (PT)((digit ^ 1u) << (32 - p2_bits));
+    return (PT)kh_xlo(digit ? digit - 1u : 1u, b2);  // the first payload of a neighbouring bucket
 }
 
 template <typename PT, bool CHUNKED>
@@ -453,7 +508,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
     if ((u64)blockIdx.x >= info[0] || info[3]) return;  // info[3]: a partition too large for 32-bit offsets (see the plan kernel)
     const Part2Block pb = blocks[blockIdx.x];
     const int tid = threadIdx.x;
-    const int P2 = 1 << g.p2_bits;
+    const int P2 = (int)g.b2;
     p2_stage_chunks<CHUNKED>(cs, pb, s_chk, s_cfill, tid, NT);
     // lane b < 512 owns bucket b: its output cursor (always on a unit boundary, relative to the block's base
     // position = bucket 0's segment: the segments of the higher buckets lie above it) and its carried count
@@ -597,7 +652,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
     for (uint32_t x = tid; x < (uint32_t)NBK * UNIT; x += NT) {
         const uint32_t b = x / UNIT, i = x % UNIT;
         const uint2 m = s_ofs[b];
-        if (m.x && b < (uint32_t)P2) out[gbase + m.y + i] = i < m.x ? s_buf[res_fin + b * UNIT + i] : p2_sentinel<PT>(b, g.p2_bits);
+        if (m.x && b < (uint32_t)P2) out[gbase + m.y + i] = i < m.x ? s_buf[res_fin + b * UNIT + i] : p2_sentinel<PT>(b, g.b2);
     }
 }
 
@@ -634,7 +689,7 @@ __global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict_
     __shared__ u64 s_scan[1024];
     const int tid = threadIdx.x;
     const int P1 = 1 << g.p1_bits;
-    const uint32_t P2 = 1u << g.p2_bits;
+    const uint32_t P2 = g.b2;
     const u64 mine = tid < P1 ? ptotal[tid] : 0ull;
     u64 tot = 0;
     (void)block_scan_1024(mine, s_scan, tid, &tot);
@@ -669,7 +724,7 @@ __global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict_
     // bstart[] of every bucket: this workgroup's share (the launch has one workgroup per 1024 buckets, or fewer: they stride)
     const u64 nb = (u64)P1 * P2;
     for (u64 r = (u64)blockIdx.x * 1024 + tid; r < nb; r += (u64)gridDim.x * 1024) {
-        const uint32_t p = (uint32_t)(r >> g.p2_bits), bk = (uint32_t)r & (P2 - 1);
+        const uint32_t p = part_div_b2(g, r), bk = (uint32_t)r - p * P2;
         bstart[r] = s_base[p] + (u64)bk * s_cap[p];
     }
     if (blockIdx.x == 0 && tid == 0) bstart[nb] = s_base[P1];
@@ -688,7 +743,7 @@ struct OvfEntry {
 // unhinted 2-billion-key input gets; round 2 sent those to the exact path with the unaligned scatter).  The 128 KiB of
 // bins are shared out among the partition's buckets either way: 32 4-byte (16 8-byte) payloads per bin at 1024, units of
 // 64 bytes there, and the ranks that do not fit such a small bin (Poisson tail of ~8 arrivals per flush) take the overflow list.
-template <typename PT, int UNITB, int NBK>
+template <typename PT, int UNITB, int NBK, bool POW2>
 __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
                                                              const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
                                                              PT *__restrict__ out, u64 *__restrict__ bend,
@@ -699,7 +754,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin at 512 buckets (256 bytes)
     constexpr uint32_t TOTAL = P2L_NBK * CAP;                 // payloads all bins hold together (128 KiB)
     constexpr uint32_t UW = UNITB / 16;                       // 16-byte words per unit
-    static_assert(NBK == 512 || (NBK == 1024 && UNITB == 64), "1024 buckets: 128-byte bins, 64-byte units");
+    static_assert(NBK == 512 || ((NBK == 768 || NBK == 1024) && UNITB == 64), "more than 512 buckets: smaller bins, 64-byte units");
     __shared__ __attribute__((aligned(16))) PT s_bin[TOTAL + UNIT];  // 128 KiB (+ a trash unit)
     __shared__ uint32_t s_cnt[NBK];
     __shared__ uint32_t s_chk[CPB];
@@ -716,8 +771,9 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     if (tid == 0) s_skip = ovf[1] != 0 || heavy[p] != 0;  // (a heavy partition: the exact kernels take it, see arena_plan_kernel)
     __syncthreads();
     if (s_skip) return;
-    const uint32_t P2 = 1u << g.p2_bits;
-    const uint32_t capr = TOTAL >> g.p2_bits;  // payloads per bin: the 128 KiB are shared out among the partition's P2 buckets
+    const uint32_t P2 = g.b2;
+    // payloads per bin: the 128 KiB are shared out among the partition's P2 buckets (whole 16-byte words)
+    const uint32_t capr = POW2 ? TOTAL >> g.p2_bits : (TOTAL / P2) & ~(16u / (uint32_t)sizeof(PT) - 1u);
     if (tid == 0) {
         s_ovf_next = 0;
         s_ovf_end = 0;
@@ -739,11 +795,14 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #ifndef KH_ARENA_POS_LDS
 #define KH_ARENA_POS_LDS 0  // 1: positions in LDS for 512 buckets too (A/B builds)
 #endif
-    constexpr bool POS_LDS = NBK == 1024 || KH_ARENA_POS_LDS;
+    // Round 4 (any number of buckets up to 1024, kernels.hip.h TableGeom): NBK = 768 for 513 .. 768 buckets -- three buckets per
+    // lane group instead of four, 40-48 payloads per bin instead of 32.
+    constexpr bool POS_LDS = NBK > 512 || KH_ARENA_POS_LDS != 0;  // (in registers they spill there: 222 / 518 VGPRs at 768 / 1024 buckets, -Rpass-analysis)
+    constexpr bool BASE_CALC = POS_LDS;
     __shared__ uint32_t s_apos[POS_LDS ? NBK : 1];
     const uint32_t acap = pcap[p];
     const u64 pbase = bstart[(u64)p * P2];
-    u64 abase_r[POS_LDS ? 1 : NB];
+    u64 abase_r[BASE_CALC ? 1 : NB];
     uint32_t apos_r[POS_LDS ? 1 : NB];
     if constexpr (POS_LDS) {
         if (tid < NBK) s_apos[tid] = 0;
@@ -751,12 +810,12 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #pragma unroll
         for (uint32_t it = 0; it < NB; ++it) {
             const uint32_t ob = og + it * (NT / LP);
-            abase_r[it] = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
+            if constexpr (!BASE_CALC) abase_r[it] = ob < P2 ? bstart[(u64)p * P2 + ob] : 0;
             apos_r[it] = 0;
         }
     }
     auto abase_of = [&](uint32_t it, uint32_t ob) -> u64 {
-        if constexpr (POS_LDS) return pbase + (u64)ob * acap;
+        if constexpr (BASE_CALC) return pbase + (u64)ob * acap;
         else return abase_r[it];
     };
     if (tid < NBK) s_cnt[tid] = 0;
@@ -879,7 +938,8 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
                     const bool ok = (have >> (h * HALF + j)) & 1u;
-                    dg[j] = Pay<PT>::p2(pay[h * HALF + j], g);
+                    if constexpr (sizeof(PT) == 4) dg[j] = part_bucket32<POW2>((uint32_t)pay[h * HALF + j], g);
+                    else dg[j] = Pay<PT>::p2(pay[h * HALF + j], g);
                     rk[j] = ok ? atomicAdd(&s_cnt[dg[j]], 1u) : 0xFFFFFFFFu;
                 }
                 uint32_t omask = 0;
@@ -968,10 +1028,10 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 // 16-byte table (the same hash bits), linear probing inside the region.  The key of slot i:
 __device__ __forceinline__ u64 narrow_key(const PartGeom &g, u64 slot_index, uint32_t pay) {
     const uint32_t r = (uint32_t)(slot_index >> REGION_BITS);
-    return Pay<uint32_t>::key(pay, r >> g.p2_bits, g);
+    return Pay<uint32_t>::key(pay, part_div_b2(g, r), g);
 }
 __device__ __forceinline__ uint32_t narrow_start(const PartGeom &g, uint32_t pay) {
-    return (pay >> (32 - g.p2_bits - REGION_BITS)) & REGION_START_MASK;
+    return kh_start_of_x(pay, g.b2);
 }
 // count[pay] += addend in the narrow image of one region; false = the count might leave 32 bits (nothing changed).
 // `guard` = an upper bound of everything the running kernel may still add to one key (the length of its list): a count
@@ -1032,7 +1092,7 @@ __global__ __launch_bounds__(BLOCK) void ovf_agg_insert_kernel(TableGeom tg, Par
                 const u64 key = s_key[i];
                 const uint32_t region = (uint32_t)(key >> 32), pay = (uint32_t)key;
                 if constexpr (NARROW) (void)narrow_upsert(ntab + (u64)region * REGION_SLOTS, g, pay, (u64)cnt, 0ull, nd, nf);
-                else upsert(tg, Pay<uint32_t>::key(pay, region >> g.p2_bits, g), (u64)cnt, nd, nf);
+                else upsert(tg, Pay<uint32_t>::key(pay, part_div_b2(g, region), g), (u64)cnt, nd, nf);
                 s_key[i] = FREE;
                 s_cnt[i] = 0;
             }
@@ -1148,8 +1208,8 @@ __global__ __launch_bounds__(BLOCK) void ntable_lookup_kernel(const u64 *__restr
             continue;
         }
         const u64 H = part_hash(g, key);
-        const u64 region = g.rbits ? (H >> (64 - g.rbits)) : 0ull;
         const uint32_t pay = Pay<uint32_t>::make(key, H, g);
+        const u64 region = (u64)kh_p1_of(H, g.p1_bits) * g.b2 + kh_bucket_of_x(pay, g.b2);
         const u64 *reg = ntab + region * REGION_SLOTS;
         uint32_t off = narrow_start(g, pay);
         u64 res = 0;
@@ -1184,7 +1244,7 @@ __global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeo
         const bool valid = e.region != 0xFFFFFFFFu;
         bool mine = valid;
         const u64 key = NARROW ? (((u64)e.region << 32) | (uint32_t)e.pay)  // (identity inside the image: region + payload)
-                               : (mine ? Pay<PT>::key((PT)e.pay, e.region >> g.p2_bits, g) : 0ull);
+                               : (mine ? Pay<PT>::key((PT)e.pay, part_div_b2(g, e.region), g) : 0ull);
         // skew guard as in count_direct_kernel: an overflow list is mostly copies of a few heavy keys
         u64 weight = 1;
         int first = -1;
@@ -1233,14 +1293,14 @@ __global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeo
 __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restrict__ O2, u64 o2_total_index,
                                                             const u64 *__restrict__ moff, const uint32_t *__restrict__ nch,
                                                             PartGeom g, u64 *__restrict__ bstart) {
-    const u64 nregions = 1ull << g.rbits;
+    const u64 nregions = part_regions(g);
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
     if (r > nregions) return;
     if (r == nregions) {
         bstart[r] = O2[o2_total_index];  // grand total of the level-2 scan
         return;
     }
-    const uint32_t p1 = (uint32_t)(r >> g.p2_bits), p2 = (uint32_t)r & ((1u << g.p2_bits) - 1u);
+    const uint32_t p1 = part_div_b2(g, r), p2 = (uint32_t)r - p1 * g.b2;
     // an empty level-1 partition has no chunks: its buckets all start where the partition starts,
     // which is the O2 value at the next partition's first entry (or the grand total)
     bstart[r] = nch[p1] ? O2[moff[p1] + (u64)p2 * nch[p1]] : O2[moff[p1]];
@@ -1252,10 +1312,10 @@ __global__ __launch_bounds__(256) void bucket_bounds_heavy_kernel(const u64 *__r
                                                                   const uint32_t *__restrict__ nch, PartGeom g,
                                                                   const uint8_t *__restrict__ heavy, u64 base,
                                                                   u64 *__restrict__ bstart, u64 *__restrict__ bend) {
-    const u64 nregions = 1ull << g.rbits;
+    const u64 nregions = part_regions(g);
     const u64 r = (u64)blockIdx.x * 256 + threadIdx.x;
     if (r >= nregions) return;
-    const uint32_t p1 = (uint32_t)(r >> g.p2_bits), p2 = (uint32_t)r & ((1u << g.p2_bits) - 1u);
+    const uint32_t p1 = part_div_b2(g, r), p2 = (uint32_t)r - p1 * g.b2;
     if (!heavy[p1]) return;
     const u64 n = nch[p1];  // (> 0: a heavy partition has chunks)
     // the partition's [bucket][block] matrix is contiguous in the scan: bucket p2 + 1 starts where bucket p2 ends, and
@@ -1441,6 +1501,32 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(T
 
 constexpr uint32_t R32_FREE = 0xFFFFFFFFu;  // free marker of the 32-bit LDS image
 
+// Where a payload of region (p1, digit) starts probing, and whether a payload of the bucket's data IS one of the region's
+// (sentinels -- payloads of another bucket -- pad the exact level 2's segments).  POW2: b2 = 2^p2_bits, digit and start are
+// bit fields of the payload (rounds 1-3's instructions); else the two words of payload * b2 (kernels.hip.h TableGeom).
+template <bool POW2>
+struct R32Geo {
+    uint32_t b2, digit, sshift, dshift, dmask;
+    __device__ __forceinline__ uint32_t start(uint32_t pay) const {
+        if constexpr (POW2) return (pay >> sshift) & REGION_START_MASK;
+        else return kh_start_of_x(pay, b2);
+    }
+    __device__ __forceinline__ bool mine(uint32_t pay) const {
+        if constexpr (POW2) return (((pay >> dshift) ^ digit) & dmask) == 0;
+        else return kh_bucket_of_x(pay, b2) == digit;
+    }
+};
+template <bool POW2>
+__device__ __forceinline__ R32Geo<POW2> r32_geo(const PartGeom &g, uint32_t digit) {
+    R32Geo<POW2> q;
+    q.b2 = g.b2;
+    q.digit = digit;
+    q.sshift = POW2 ? 32 - g.p2_bits - REGION_BITS : 0;
+    q.dshift = (POW2 && g.p2_bits) ? 32 - g.p2_bits : 0;
+    q.dmask = (POW2 && g.p2_bits) ? 0xFFFFFFFFu : 0u;  // (no level-2 digit: nothing to check, no sentinels exist)
+    return q;
+}
+
 // One round of lane-decoupled probing over the lanes' private payload queues (see
 // region_count_kernel32).  GUARD = skew guard for buckets far above the mean size: a bucket
 // dominated by one key (poly-A, satellites) would send every lane's increment to one LDS word, so
@@ -1452,16 +1538,16 @@ constexpr uint32_t R32_FREE = 0xFFFFFFFFu;  // free marker of the 32-bit LDS ima
 constexpr uint32_t R32_QBLOCK = (REGION_RK + 1) * 64;
 __device__ __forceinline__ uint32_t r32_qbase(int tid) { return ((uint32_t)tid >> 6) * R32_QBLOCK + ((uint32_t)tid & 63u); }
 
-template <bool GUARD>
+template <bool GUARD, bool POW2>
 __device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t *s_q, uint32_t *s_pay,
                                                      uint32_t *s_add, uint32_t *s_special, uint32_t *s_fail, int tid,
-                                                     uint32_t sshift, uint32_t &nd) {
+                                                     const R32Geo<POW2> &rg, uint32_t &nd) {
     uint32_t idx = 0, pay = 0, off = 0, probes = 0, weight = 1;
     const uint32_t qb = r32_qbase(tid);
     bool active = nk > 0;
     if (active) {
         pay = s_q[qb];
-        off = (pay >> sshift) & REGION_START_MASK;
+        off = rg.start(pay);
     }
     for (;;) {
         const u64 amask = __ballot(active);
@@ -1511,7 +1597,7 @@ __device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t
             weight = 1;
             if (active) {
                 pay = s_q[qb + idx * 64];
-                off = (pay >> sshift) & REGION_START_MASK;
+                off = rg.start(pay);
                 probes = 0;
             }
         }
@@ -1566,13 +1652,14 @@ __device__ __forceinline__ bool r32_group_free(const R32Group &c, uint32_t &fo) 
     return any;
 }
 
+template <bool POW2>
 __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t *s_q, uint32_t *s_pay,
-                                                    uint32_t *s_add, uint32_t *s_fail, int tid, uint32_t sshift, uint32_t &nd) {
+                                                    uint32_t *s_add, uint32_t *s_fail, int tid, const R32Geo<POW2> &rg, uint32_t &nd) {
     uint32_t idx = 0, probes = 0;
     const uint32_t qb = r32_qbase(tid);
     bool active = nk > 0;
     uint32_t pay = s_q[qb];  // (every queue slot holds a loaded payload, real or clamped)
-    uint32_t grp = (pay >> sshift) & REGION_START_MASK;
+    uint32_t grp = rg.start(pay);
     while (__ballot(active) != 0) {
         const R32Group c = r32_group_load(s_pay, grp);
         uint32_t o, fo;
@@ -1602,7 +1689,7 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
             active = idx < nk;
             probes = 0;
             pay = s_q[qb + (active ? idx : 0u) * 64];
-            grp = (pay >> sshift) & REGION_START_MASK;
+            grp = rg.start(pay);
         }
     }
 }
@@ -1629,7 +1716,7 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
 // three workgroups in different phases beat two: 21.1 -> 19.2 ms (S50M at load 0.58: 12.2 -> 11.2; S10M at 0.44: 4.1 -> 3.3);
 // at load 0.61 with 30 K payloads per bucket the loop wants the waves: 36.4 -> 40.9 ms (but at 0.62 with 2.9 K per bucket:
 // 27.4 -> 20.5).  kmerhip.hip (region_small_groups) chooses.
-template <bool FRESH, bool NARROW, int NT = REGION_NT>
+template <bool FRESH, bool NARROW, int NT = REGION_NT, bool POW2 = false>
 __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(TableGeom tg, PartGeom g, const uint32_t *__restrict__ pays, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
@@ -1675,20 +1762,18 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
         }
         return;
     }
-    const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
-    // H = [p1 | payload << (32 - p1_bits) ...]: the in-region start is the REGION_BITS bits that
-    // follow the p2 digit at the top of the payload
-    const uint32_t sshift = 32 - g.p2_bits - REGION_BITS;
+    const uint32_t p1 = part_div_b2(g, r);
+    // H = [p1 | payload << (32 - p1_bits) ...]: bucket and in-region start are the high and the low word of
+    // payload * b2 (kh_bucket_of_x / kh_start_of_x; for b2 = 2^j the top j bits of the payload and the REGION_BITS behind them)
+    const uint32_t b2 = g.b2;
     Slot *reg = tg.table + r * REGION_SLOTS;
     const uint32_t *__restrict__ src = pays + lo;
     const uint32_t n = (uint32_t)(hi - lo);  // < 2^32 - 1 (checked above)
     const bool hot = (hi - lo) > hot_threshold;  // far above the mean bucket: skewed keys likely
-    // can a payload of this region equal the free marker 0xFFFFFFFF?  Only if its level-2 digit is all ones.
-    const uint32_t p2mask = (1u << g.p2_bits) - 1u;
-    const bool may_special = g.p2_bits == 0 || ((uint32_t)r & p2mask) == p2mask;
-    const uint32_t dshift = g.p2_bits ? 32 - g.p2_bits : 0;   // a real payload has the region's own digit on top
-    const uint32_t digit = g.p2_bits ? ((uint32_t)r & p2mask) : 0u;
-    const uint32_t dmask = g.p2_bits ? 0xFFFFFFFFu : 0u;      // (no level-2 digit: nothing to check, no sentinels exist)
+    // can a payload of this region equal the free marker 0xFFFFFFFF?  Only in a partition's last bucket.
+    const uint32_t digit = (uint32_t)r - p1 * b2;             // the region's bucket: a real payload x has (x * b2) >> 32 == digit
+    const R32Geo<POW2> rg = r32_geo<POW2>(g, digit);
+    const bool may_special = digit == b2 - 1u;                // (0xFFFFFFFF falls into the LAST bucket; b2 == 1: the only one)
     uint32_t nreal = 0;
     uint32_t kbuf[REGION_RK];
 #pragma unroll
@@ -1710,7 +1795,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             if (oldn[q] >> 32) {  // live: the payload is stored as it is probed for
                 w = (uint32_t)oldn[q];
                 if (w == R32_FREE) {  // (see below: the slot must not look free)
-                    if (g.p2_bits) w = 0u;
+                    if (b2 > 1) w = 0u;
                     else unrepresentable = true;
                 }
             }
@@ -1731,7 +1816,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
                     // bits, so 0 can neither arrive nor be probed for: it marks the slot as taken.  Without a
                     // level-2 digit (tables of <= 1024 regions) there is no such value: fail the region, its
                     // bucket then goes through the direct path.
-                    if (g.p2_bits) w = 0u;
+                    if (b2 > 1) w = 0u;
                     else unrepresentable = true;
                 }
             }
@@ -1774,11 +1859,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             uint32_t rq = 0;  // real payloads, compacted into the lane's queue (sentinels dropped)
 #pragma unroll
             for (int j = 0; j < REGION_RK; ++j)
-                if ((uint32_t)j < nk && (((pj[j] >> dshift) ^ digit) & dmask) == 0) s_q[r32_qbase(tid) + 64 * rq++] = pj[j];
+                if ((uint32_t)j < nk && rg.mine(pj[j])) s_q[r32_qbase(tid) + 64 * rq++] = pj[j];
             nreal += rq;
-            if (hot) region32_probe_round<true>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
-            else if (may_special) region32_probe_round<false>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, sshift, nd);
-            else region32_probe_lean(rq, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
+            if (hot) region32_probe_round<true, POW2>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, rg, nd);
+            else if (may_special) region32_probe_round<false, POW2>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, rg, nd);
+            else region32_probe_lean<POW2>(rq, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
         } else {
             // First probe of all eight payloads as straight-line code: the eight slot reads are in flight
             // together and a payload that finds its key right there (most of them: a key comes ~12 times, and at
@@ -1807,7 +1892,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
                 uint32_t oj[FP];
                 R32Group cj[FP];
 #pragma unroll
-                for (int j = 0; j < FP; ++j) oj[j] = (pj[h + j] >> sshift) & REGION_START_MASK;
+                for (int j = 0; j < FP; ++j) oj[j] = rg.start(pj[h + j]);
 #pragma unroll
                 for (int j = 0; j < FP; ++j) cj[j] = r32_group_load(s_pay, oj[j]);
 #pragma unroll
@@ -1815,7 +1900,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
                     // (predicated, not branched: the exec-mask bookkeeping of sixteen small branches per round cost
                     //  as many scalar instructions as the kernel has vector ones)
                     const uint32_t pay = pj[h + j];
-                    const bool valid = (uint32_t)(h + j) < nk && (((pay >> dshift) ^ digit) & dmask) == 0;
+                    const bool valid = (uint32_t)(h + j) < nk && rg.mine(pay);
                     nreal += valid;
                     uint32_t o;
                     const bool hit = r32_group_find(cj[j], pay, o) && valid;
@@ -1831,7 +1916,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             }
             const uint32_t r = wrun > lane ? (wrun - lane + 63u) >> 6 : 0u;  // this lane's share: rows 0 .. r-1 of its column
 #if !(KH_ABLR & 1)  /* timing experiment otherwise: no probing loop behind the straight-line first probe */
-            region32_probe_lean(r, s_q, s_pay, s_add, &s_fail, tid, sshift, nd);
+            region32_probe_lean<POW2>(r, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
 #endif
         }
     }
@@ -1844,7 +1929,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
         // The payload equal to the free marker was only counted.  One lane places it now by plain
         // linear probing over the combined image (old keys from HBM, new claims from s_pay).
         const u64 key = Pay<uint32_t>::key(R32_FREE, p1, g);
-        uint32_t off = (R32_FREE >> sshift) & REGION_START_MASK;
+        uint32_t off = rg.start(R32_FREE);
         uint32_t probes = 0;
         bool is_new = false;
         for (; probes < REGION_SLOTS; ++probes, off = (off + 1) & REGION_MASK) {
@@ -1987,13 +2072,13 @@ __global__ __launch_bounds__(BLOCK) void failed_buckets_insert_kernel(TableGeom 
     const u64 r = blockIdx.x;
     if (!rfail[r]) return;
     const u64 lo = bstart[r], hi = bend[r];
-    const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
+    const uint32_t p1 = part_div_b2(g, r), digit = (uint32_t)r - p1 * g.b2;
     uint32_t nd = 0, nf = 0;
     u64 real = 0;
     for (u64 i = lo + threadIdx.x; i < hi; i += BLOCK) {
         const PT v = pays[i];
-        // 32-bit payloads: a payload with another level-2 digit is a sentinel (line padding), not a k-mer
-        if (sizeof(PT) == 4 && g.p2_bits && (uint32_t)((u64)v >> (32 - g.p2_bits)) != ((uint32_t)r & ((1u << g.p2_bits) - 1u))) continue;
+        // 32-bit payloads: a payload of another bucket is a sentinel (line padding), not a k-mer
+        if (sizeof(PT) == 4 && kh_bucket_of_x((uint32_t)v, g.b2) != digit) continue;
         if (sizeof(PT) == 8 && (u64)v == KH_EMPTY_KEY) continue;  // 64-bit payloads: the empty key pads the segments
         ++real;
         upsert(tg, Pay<PT>::key(v, p1, g), 1ull, nd, nf);
@@ -2053,8 +2138,7 @@ __global__ __launch_bounds__(BLOCK) void hot_buckets_kernel(TableGeom tg, PartGe
     for (u64 b = 0; b < nhot; ++b) {
         const u64 r = list[b];
         const u64 lo = bstart[r], n = bend[r] - lo;
-        const uint32_t p1 = (uint32_t)(r >> g.p2_bits);
-        const uint32_t digit = g.p2_bits ? ((uint32_t)r & ((1u << g.p2_bits) - 1u)) : 0u;
+        const uint32_t p1 = part_div_b2(g, r), digit = (uint32_t)r - p1 * g.b2;
         auto apply = [&]() {  // the LDS table -> the table in HBM; leaves it empty (all threads)
             __syncthreads();
             for (int i = tid; i < HOT_TAB; i += BLOCK) {
@@ -2087,7 +2171,7 @@ __global__ __launch_bounds__(BLOCK) void hot_buckets_kernel(TableGeom tg, PartGe
                     if (i >= s1) continue;
                     const PT v = pays[lo + i];
                     // a payload with another level-2 digit (32-bit) / the empty key (64-bit) pads the segments: not a k-mer
-                    if (sizeof(PT) == 4 && g.p2_bits && (uint32_t)((u64)v >> (32 - g.p2_bits)) != digit) continue;
+                    if (sizeof(PT) == 4 && kh_bucket_of_x((uint32_t)v, g.b2) != digit) continue;
                     if (sizeof(PT) == 8 && (u64)v == KH_EMPTY_KEY) continue;
                     ++real;
                     if (v == FREE) {

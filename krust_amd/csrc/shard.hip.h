@@ -14,10 +14,12 @@ namespace kh {
 // What an export reads: the 16-byte table, or (ntab != nullptr) its 8-byte image -- count << 32 | the 32-bit payload
 // of the partition passes, whose bits below the level-2 digit ARE the hash bits below the region index that the packed
 // and the heads formats carry (round 3: a rank's table can stay in the narrow form through the exchange).
+// Round 4: tables of any multiple of 1024 regions -- the window is kernels.hip.h kh_below_region (for a power-of-two table
+// the 32 hash bits below the region index, as before).
 struct SlotSrc {
     const Slot *table;
     const u64 *ntab;
-    uint32_t p2_bits;  // narrow: the level-2 digit on top of every payload (the image's geometry)
+    RegionGeom geo;    // the table's geometry; narrow: the geometry the image's payloads are relative to (the same layout)
 };
 struct SlotVal {
     bool live;
@@ -39,10 +41,26 @@ __device__ __forceinline__ SlotVal slot_read(const SlotSrc &src, u64 i) {
     }
     return v;
 }
-// bits [rbits, rbits + 32) of the slot's table hash
-__device__ __forceinline__ uint32_t slot_hash_below_region(const SlotSrc &src, const SlotVal &v, uint32_t rbits, uint32_t k) {
-    if (src.ntab) return (uint32_t)v.key_or_pay << src.p2_bits;
-    return (uint32_t)((kh_table_hash(v.key_or_pay, k) << rbits) >> 32);
+// The 32-bit window of hash bits below the region index (kernels.hip.h kh_below_region) of a slot of region r.  What
+// depends on the region alone -- its bucket's first x -- is computed once per workgroup (one workgroup per region):
+struct BelowCtx {
+    uint32_t xlo, w;
+};
+__device__ __forceinline__ BelowCtx below_ctx(const SlotSrc &src, u64 r) {
+    BelowCtx b;
+    b.xlo = (uint32_t)kh_xlo((uint32_t)(r % src.geo.b2), src.geo.b2);
+    b.w = kh_below_w(src.geo.b2);
+    return b;
+}
+__device__ __forceinline__ uint32_t slot_hash_below_region(const SlotSrc &src, const SlotVal &v, const BelowCtx &bc, uint32_t k) {
+    if (src.ntab) {  // the payload IS x, and no hash bits follow it (32-bit payloads: 2k - p1_bits <= 32)
+        const uint32_t xoff = (uint32_t)v.key_or_pay - bc.xlo;
+        return bc.w < 32 ? xoff << (32 - bc.w) : xoff;
+    }
+    const u64 H = kh_table_hash(v.key_or_pay, k);
+    const uint32_t xoff = kh_x_of(H, src.geo.p1_bits) - bc.xlo;
+    const uint32_t z = bc.w < 32 ? (uint32_t)((H << (src.geo.p1_bits + 32)) >> (32 + bc.w)) : 0u;
+    return (bc.w < 32 ? xoff << (32 - bc.w) : xoff) | z;
 }
 
 // rcount[r] = live slots of region r.  One workgroup per region.
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__res
 // key whenever 2k - rbits <= 32 (the hash is a bijection); halves the bytes on the xGMI links.
 // *wide is raised if a count does not fit 32 bits (the caller then uses the unpacked export).
 __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc src, const u64 *__restrict__ roff,
-                                                                      uint32_t rbits, uint32_t k, u64 *__restrict__ pairs,
+                                                                      uint32_t k, u64 *__restrict__ pairs,
                                                                       u64 *__restrict__ wide) {
     __shared__ uint32_t s_cur;
     const u64 r = blockIdx.x;
@@ -99,6 +117,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc sr
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
     bool too_wide = false;
+    const BelowCtx bc = below_ctx(src, r);
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {
         const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
         const bool live = s.live;
@@ -109,14 +128,14 @@ __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc sr
         wbase = (uint32_t)__shfl((int)wbase, __builtin_ctzll(m), 64);
         if (live) {
             too_wide |= (s.count >> 32) != 0;
-            pairs[base + wbase + mbcnt(m)] = (s.count << 32) | slot_hash_below_region(src, s, rbits, k);
+            pairs[base + wbase + mbcnt(m)] = (s.count << 32) | slot_hash_below_region(src, s, bc, k);
         }
     }
     if (__any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
 }
 
 // ---- 32-bit "heads" -------------------------------------------------------------------------------
-// The narrowest exchange unit: one u32 = [hb = 2k - rbits hash bits | cb = 32 - hb bits: addend - 1].
+// The narrowest exchange unit: one u32 = [hb = kh_below_bits() hash bits (2k - log2 regions, rounded up) | cb = 32 - hb bits: addend - 1].
 // A pair whose count exceeds 2^cb travels as several heads of the same key -- the receiver simply
 // adds them up, so there is no escape mechanism -- and a table with a count above 64 x 2^cb is
 // declared not representable (*wide), which bounds the blow-up.  S100M (k = 21, 2^19 regions):
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(BLOCK) void region_head_count_kernel(SlotSrc src, u
 
 // Heads of region r go to [roff[r], roff[r+1]) (any order inside the region).
 __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src, const u64 *__restrict__ roff,
-                                                                     uint32_t rbits, uint32_t k, uint32_t cb,
+                                                                     uint32_t k, uint32_t cb,
                                                                      uint32_t *__restrict__ heads) {
     __shared__ uint32_t s_cur;
     const u64 r = blockIdx.x;
@@ -155,6 +174,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
     const uint32_t cmask = (1u << cb) - 1u;
+    const BelowCtx bc = below_ctx(src, r);
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {  // uniform trip count
         const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
         const bool live = s.live;
@@ -172,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src
         if (lane_id() == 63) wbase = atomicAdd(&s_cur, wtotal);
         wbase = (uint32_t)__shfl((int)wbase, 63, 64);
         if (live) {
-            const uint32_t hw = slot_hash_below_region(src, s, rbits, k) & ~cmask;  // the hb hash bits, top-aligned
+            const uint32_t hw = slot_hash_below_region(src, s, bc, k) & ~cmask;  // the hb hash bits, top-aligned
             u64 o = base + wbase + (incl - nh);
             u64 left = s.count;
             for (uint32_t h = 0; h < nh; ++h) {
@@ -205,7 +225,7 @@ struct MergeArgs {
     uint32_t nsenders;
     int32_t dshift;  // target region t reads sender-local region t >> dshift (dshift >= 0), or the
                      // 2^-dshift sender-local regions starting at t << -dshift (dshift < 0)
-    uint32_t src_rbits;   // packed formats: region bits of the senders' tables
+    RegionGeom sgeo;      // packed formats: geometry of the senders' (unsharded) tables
     uint32_t head_cmask;  // heads: (1 << cb) - 1
     u64 src_region0;      // packed formats: the senders' region index of this shard's first region
 };
@@ -217,7 +237,7 @@ struct MergeArgs {
 template <bool FRESH, bool DIRECT, int FMT>
 __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, MergeArgs a, uint8_t *__restrict__ rfail,
                                                               uint32_t *__restrict__ rnew, const uint8_t *__restrict__ only_failed,
-                                                              uint32_t old_rbits, Counters *ctr, uint32_t dirty,
+                                                              RegionGeom old_geo, Counters *ctr, uint32_t dirty,
                                                               uint32_t region0) {
     __shared__ u64 s_key[DIRECT ? 1 : REGION_SLOTS];
     __shared__ u64 s_cnt[DIRECT ? 1 : REGION_SLOTS];
@@ -225,10 +245,11 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     __shared__ u64 s_seg_lo[MAX_SENDERS];
     __shared__ uint32_t s_seg_len[MAX_SENDERS];
     const int tid = threadIdx.x;
-    // In DIRECT mode the grid still walks the ORIGINAL target regions (old_rbits); tg is the grown table.
+    // In DIRECT mode the grid still walks the ORIGINAL target regions (old_geo); tg is the grown table.
     const u64 t = (u64)blockIdx.x + region0;  // region0: first target region of this call's window (kh_set_region_window)
     if (DIRECT && !only_failed[t]) return;
-    const uint32_t match_bits = DIRECT ? old_rbits : tg.rbits;
+    const RegionGeom match = DIRECT ? old_geo : rgeom(tg);  // the geometry whose region t this workgroup stands for
+    auto target_of = [&](u64 H) -> u64 { return (u64)kh_p1_of(H, match.p1_bits) * match.b2 + kh_bucket_of_x(kh_x_of(H, match.p1_bits), match.b2); };
     Slot *reg = tg.table + t * REGION_SLOTS;
     if (!DIRECT) {
         const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
@@ -252,20 +273,36 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
     const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
     constexpr bool PACKED = FMT != 0;
+    // What a sender region stands for in the packed formats: its level-1 digit at the top of the hash and the first x of
+    // its bucket (kernels.hip.h kh_hash_of_below, with the divisions done once per segment)
+    struct SegBase {
+        u64 htop;
+        uint32_t xlo;
+    };
+    const uint32_t sw = kh_below_w(a.sgeo.b2);
+    auto seg_base = [&](u64 rs) -> SegBase {  // rs: the senders' (global) region index
+        SegBase sb;
+        const uint32_t p1 = (uint32_t)(rs / a.sgeo.b2), b = (uint32_t)(rs % a.sgeo.b2);
+        sb.htop = a.sgeo.p1_bits ? (u64)p1 << (64 - a.sgeo.p1_bits) : 0ull;
+        sb.xlo = (uint32_t)kh_xlo(b, a.sgeo.b2);
+        return sb;
+    };
     // one incoming unit: raw0 = key / packed pair / head, raw1 = count (FMT 0 only)
-    auto take = [&](u64 raw0, u64 raw1, u64 Hregion) {
+    auto take = [&](u64 raw0, u64 raw1, const SegBase &sb) {
         u64 key, H, addend;
         if (PACKED) {
             const uint32_t low = FMT == 1 ? (uint32_t)raw0 : ((uint32_t)raw0 & ~a.head_cmask);
             addend = FMT == 1 ? (raw0 >> 32) : (u64)((uint32_t)raw0 & a.head_cmask) + 1;
-            const u64 Hs = Hregion | ((u64)low << (32 - a.src_rbits));  // the sender's (unsharded) table hash
+            const uint32_t x = sb.xlo + (sw < 32 ? low >> (32 - sw) : low);
+            const u64 below = ((u64)x << 32) | (sw < 32 ? (u64)(uint32_t)(low << sw) : 0ull);
+            const u64 Hs = sb.htop | (below >> a.sgeo.p1_bits);  // the sender's (unsharded) table hash
             H = Hs << tg.shard_shift;
-            if ((H >> (64 - match_bits)) != t) return;  // the segment also feeds the sibling targets
+            if (target_of(H) != t) return;  // the segment also feeds the sibling targets
             key = kh_table_unhash(Hs, tg.k);
         } else {
             key = raw0;
             H = table_hash(tg, key);
-            if ((H >> (64 - match_bits)) != t) return;
+            if (target_of(H) != t) return;
             addend = raw1;
         }
         if (DIRECT) {
@@ -305,7 +342,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
             s_seg_len[tid] = (uint32_t)(a.src[tid].off[rl0 + 1] - lo);  // a region holds <= 4096 keys x <= 64 heads
         }
         __syncthreads();
-        const u64 Hregion = (PACKED && a.src_rbits) ? (a.src_region0 + rl0) << (64 - a.src_rbits) : 0;
+        const SegBase sb = PACKED ? seg_base(a.src_region0 + rl0) : SegBase{0ull, 0u};
         for (uint32_t s0 = 0; s0 < a.nsenders; s0 += 4) {
             uint32_t len[4], maxlen = 0;
             u64 lo[4];
@@ -331,7 +368,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (idx < len[q]) take(r0[q], r1[q], Hregion);
+                    if (idx < len[q]) take(r0[q], r1[q], sb);
             }
         }
     } else {
@@ -339,8 +376,8 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
             for (u64 rl = rl0; rl < rl0 + (PACKED ? nrl : 1); ++rl) {  // PACKED: segment by segment (the region index is part of the key)
                 const MergeSrc src = a.src[s];
                 const u64 lo = src.off[rl], hi = src.off[PACKED ? rl + 1 : rl0 + nrl];
-                const u64 Hregion = (PACKED && a.src_rbits) ? (a.src_region0 + rl) << (64 - a.src_rbits) : 0;
-                for (u64 i = lo + tid; i < hi; i += 1024) take(load0(src, i), FMT == 0 ? src.counts[i] : 0ull, Hregion);
+                const SegBase sb = PACKED ? seg_base(a.src_region0 + rl) : SegBase{0ull, 0u};
+                for (u64 i = lo + tid; i < hi; i += 1024) take(load0(src, i), FMT == 0 ? src.counts[i] : 0ull, sb);
             }
     }
     if (DIRECT) {

@@ -340,7 +340,11 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
     keys = attempt(lambda: torch.empty(max(n_local, 1), dtype=torch.int64, device=dev))
     lap("setup")
     pow2 = world & (world - 1) == 0
-    regions_ok = pow2 and world <= 64 and nreg >= world
+    # (a table of 1024 x b2 regions, b2 not a power of two, nests with its hash-range shards only if the world divides b2:
+    #  krust_amd/csrc/kmerhip.hip merge_regions)
+    b2 = nreg >> 10 if nreg > 1024 else 1
+    geo_ok = b2 & (b2 - 1) == 0 or b2 % max(world, 1) == 0
+    regions_ok = pow2 and world <= 64 and nreg >= world and nreg % world == 0 and geo_ok
     rcnt = attempt(lambda: torch.empty(nreg, dtype=torch.int32, device=dev)) if regions_ok else None
 
     def export(fmt):
@@ -359,7 +363,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
 
     npieces = default_pieces() if pieces is None else int(pieces)
     piped = (regions_ok and packed and npieces > 1 and npieces & (npieces - 1) == 0 and npieces <= 64
-             and (nreg // world) >= 64 * npieces)
+             and (nreg // world) >= 64 * npieces and (nreg // world) % npieces == 0)
     exported, my_fmt = None, 0
     if regions_ok and packed:
         if piped:

@@ -376,9 +376,9 @@ struct Session {
         std::function<int()> stopper = stop_workers;
         Joiner joiner{stopper};
 
-        // (256 MiB chunks.  Larger ones mean fewer partitioned passes -- every pass rewrites the table -- but the chunk buffers
-        //  are pinned, and pinning runs at ~5 GB/s: two 1 GiB buffers cost 0.38 s, more than the passes they saved; measured
-        //  on a 3.2 GB FASTQ, profiles/README.md r03.)
+        // (128 MiB chunks.  The chunk buffers are pinned, and pinning runs at ~5 GB/s: two 256 MiB buffers cost 0.12 s of every
+        //  run.  The size of a chunk no longer decides the size of a counting batch: since round 4 the library accumulates the
+        //  scanned chunks on the device and counts tens of GB at a time -- kmerhip.hip, scan_text.)
         const size_t chunk = text_chunk_bytes();
         // The chunk buffer is PINNED memory (kh_host_alloc): kh_push_text then DMAs from it -- no staging memcpy inside the
         // library -- and a plain file is read into it by several pread() calls side by side (one read() moves ~6 GB/s
@@ -579,11 +579,11 @@ struct Session {
         // (a chunk's read runs beside the previous chunk's push, ~10 ms per 256 MiB since the library counts one text under the
         //  next one's copy: four pread()s side by side take as long, eight leave a margin -- measured, profiles/README.md r03b)
         const unsigned hw = std::thread::hardware_concurrency();
-        return std::max(1u, std::min(8u, hw ? hw : 1u));
+        return std::max(1u, std::min(12u, hw ? hw : 1u));
     }
     static size_t text_chunk_bytes() {
         const char *e = getenv("KMERUST_TEXT_CHUNK_KB");  // tests use small chunks to exercise the cuts
-        return (e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256 << 10) << 10;
+        return (e && atol(e) > 0 ? (size_t)atol(e) : (size_t)128 << 10) << 10;  // (128 MiB: pinning costs ~0.2 s per GiB, and the device accumulates the chunks anyway)
     }
     // Largest p > 0 with a record starting at p ('>' at a line start); 0 if none.
     static size_t fasta_cut(const uint8_t *b, size_t n) {

@@ -92,3 +92,22 @@ def test_kernels_named_by_the_bench_line_exist_and_were_profiled():
     b = _bench(tag)
     if "kernels" in b["roofline"]:     # (lines written since round 3 carry the names themselves)
         assert all(n in stats for n in b["roofline"]["kernels"].values())
+
+
+def test_the_bench_line_describes_its_own_roofline_and_hint():
+    """the line says which terms `roofline.achieved` prices (compaction excluded), what the memory
+    system moved per peak second beside it (`traffic_frac`), and where the capacity hint came from -- bench.py builds
+    these keys, and BASELINE.md states the same formula."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    st = {"kmers": 1000, "distinct": 100, "table_slots": 4096}
+    rf = bench.roofline_of(st, 5000, 1.0, {"level1": 0.4, "level2": 0.3, "region": 0.3}, 21)
+    assert rf["formula"]["compaction_term_included"] is False and rf["formula"]["per_kmer"] == 24 and rf["formula"]["per_distinct"] == 8
+    assert rf["alg_bytes_per_step"] == 5000 + 24 * 1000 + 8 * 100
+    assert "traffic_frac" in rf and "traffic" in rf
+    src = _read("bench.py")
+    for key in ('"capacity_hint"', '"capacity_hint_source"', '"unhinted"', '"table_load"', '"traffic_frac"'):
+        assert key in src, key
+    assert "8·N_distinct" in _read("BASELINE.md") and "24·N_distinct" not in _read("BASELINE.md")

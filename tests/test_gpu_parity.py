@@ -1405,3 +1405,64 @@ def test_count_beyond_32_bits(K, monkeypatch, hot):
         exp[0] = want0
         assert dict(zip(keys.tolist(), cnts.tolist())) == exp
         assert dc.histogram()[-1] == (want0, 1)
+
+
+# ---------------------------------------------------------------------------
+# round 4: tables of any multiple of 1024 regions (kernels.hip.h TableGeom)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("k,minq", [(21, None), (19, 20), (31, None), (25, 20)], ids=["k21", "k19q20", "k31", "k25q20"])
+@pytest.mark.parametrize("b2", [3, 40, 96, 520, 640, 1000])
+def test_tables_of_1024_x_b2_regions(K, monkeypatch, b2, k, minq):
+    """A table of 1024 x b2 regions for b2 that are NOT powers of two (KMERHIP_TABLE_REGIONS forces the geometry a large
+    input would get from round_cap): region = p1 * b2 + ((x * b2) >> 32), start from the product's low word.  b2 = 3: the
+    exact level 2 (count -> scan -> unit scatter); 40, 96: the arena kernel's 512-bucket form; 520, 640, 1000: its 1024-bucket
+    form with the bins shared out among b2 buckets.  Both payload widths, with and without -Q.  Counted by the partitioned path in three pushes
+    (fresh pass, then passes over a filled table) and, into a second table of the same geometry, by the direct path;
+    then every consumer of the layout: results (through the 8-byte image where there is one), histogram, lookups, min-count,
+    and growth by rehash into a larger table (a push through the direct path that doubles it)."""
+    monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * b2))
+    n_reads = 60_000 if b2 < 500 else 400_000
+    bases, qual = O.synth_reads(SEED + b2, 1 << 21, 150, 0, n_reads)
+    m = O.OracleMap()
+    total = m.scan_flat(bases, k, qual=qual if minq is not None else None, min_quality=minq, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    import torch
+    tb, tq = torch.from_numpy(bases).cuda(), torch.from_numpy(qual).cuda()
+    torch.cuda.synchronize()
+    for path in ("partition", "direct"):
+        with K.DeviceCounter(k, min_quality=minq, capacity_hint=len(m), path=path) as dc:
+            cut = [0, (n_reads // 2) * 151, (n_reads // 2 + 1) * 151, n_reads * 151]
+            for a, b in zip(cut, cut[1:]):
+                dc.push_device(tb.data_ptr() + a, tq.data_ptr() + a if minq is not None else None, b - a)
+            st = dc.finish()
+            assert st["table_slots"] == 1024 * b2 * 4096, st
+            assert st["kmers"] == total and st["distinct"] == len(m)
+            keys, cnts = dc.result()
+            assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c), f"{path}: map differs from the oracle"
+            assert dc.histogram() == m.histogram()
+            probe = np.concatenate([want_k[:: max(1, len(want_k) // 5000)], np.array([0, (1 << (2 * k)) - 1 if k < 32 else 2**64 - 1], dtype=np.uint64)])
+            got = dc.lookup(probe)
+            exp = np.array([m.get(int(x)) for x in probe], dtype=np.uint64)
+            assert np.array_equal(got, exp)
+            k2, c2 = dc.result(min_count=3)
+            sel = want_c >= 3
+            assert np.array_equal(k2, want_k[sel]) and np.array_equal(c2, want_c[sel])
+    # growth: a table of 1024 x 3 regions (12.6 M slots) that these keys outgrow -- rehash into 1024 x 6, from the direct path
+    # and from the partitioned one (whose regions overflow first: the failed buckets' re-insert)
+    if b2 == 640:
+        bases2, qual2 = O.synth_reads(SEED + 77, 1 << 24, 150, 0, 1_200_000)
+        m2 = O.OracleMap()
+        total2 = m2.scan_flat(bases2, k, qual=qual2 if minq is not None else None, min_quality=minq, nthreads=NCPU)
+        w2k, w2c = m2.arrays()
+        assert len(m2) > 0.8 * 1024 * 3 * 4096
+        tb2, tq2 = torch.from_numpy(bases2).cuda(), torch.from_numpy(qual2).cuda()
+        monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * 3))
+        monkeypatch.setenv("KMERHIP_ESTIMATE", "0")   # (the sample would size the table before the region pass: no overflow to handle)
+        for path in ("direct", "partition"):
+            with K.DeviceCounter(k, min_quality=minq, capacity_hint=1000, path=path) as dc:
+                dc.push_device(tb2.data_ptr(), tq2.data_ptr() if minq is not None else None, tb2.numel())
+                st = dc.finish()
+                assert st["grows"] >= 1 and st["table_slots"] > 1024 * 3 * 4096
+                assert st["kmers"] == total2 and st["distinct"] == len(m2)
+                keys, cnts = dc.result()
+                assert np.array_equal(keys, w2k) and np.array_equal(cnts, w2c), path

@@ -331,3 +331,31 @@ def test_prop_fasta_text(text_counters, text, k):
 @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 def test_prop_fastq_text(text_counters, text, k, minq):
     assert _device_dict(text_counters(k, minq), text, "fastq") == expect(text, "fastq", k, minq)
+
+
+@pytest.mark.parametrize("fmt,minq", [("fastq", 20), ("fastq", None), ("fasta", None)])
+def test_text_accumulates_on_the_device_and_switches_buffers(monkeypatch, fmt, minq):
+    """Round 4: scanned text accumulates in one of two device buffers and is counted when a buffer is full (or something
+    looks at the table).  KMERHIP_TEXT_ACC_MB=1 makes the buffers 1 MiB: forty chunks of ~150 KB fill and switch them
+    several times, the count of one buffer running while the next chunks are scanned into the other -- with a lookup in
+    the middle (counts what has accumulated) and a chunk LARGER than a buffer (gets a buffer of its own size)."""
+    monkeypatch.setenv("KMERHIP_TEXT_ACC_MB", "1")
+    rng = np.random.default_rng(77)
+    k = 21
+    chunks = []
+    for i in range(40):
+        n = 3_000_000 if i == 25 else 150_000
+        chunks.append(make_fastq(rng, n // 300, 100, 200) if fmt == "fastq" else make_fasta(rng, max(2, n // 5000), 2000, 8000, 70))
+    want = {}
+    with native.DeviceCounter(k, min_quality=minq) as dc:
+        for i, part in enumerate(chunks):
+            dc.push_text(part, fmt)
+            for kk, v in expect(part, fmt, k, minq).items():
+                want[kk] = want.get(kk, 0) + v
+            if i == 13:
+                some = np.array(list(want)[:200], dtype=np.uint64)
+                assert dc.lookup(some).tolist() == [want[int(x)] for x in some]
+        st = dc.finish()
+        keys, counts = dc.result()
+    assert st["kmers"] == sum(want.values())
+    assert dict(zip(keys.tolist(), counts.tolist())) == want
