@@ -495,6 +495,8 @@ def cli_leg(krust_amd, torch, dev, local_rank, reads=10_000_000, k=21):
         #  instead of 0.1-0.3 right after that -- `create_s` of the runs below says which it was: give the driver a moment)
         time.sleep(3.0)
         for rep in range(3):   # (the first run pages the binary and the ROCm libraries in)
+            if rep:
+                time.sleep(3.0)  # (the previous process's few hundred GB of HBM are still being reclaimed: see above)
             t0 = time.perf_counter()
             p = subprocess.run([exe, str(k), path, "--format", "histogram", "-q"], capture_output=True, env=env, timeout=600)
             wall = time.perf_counter() - t0

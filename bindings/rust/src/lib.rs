@@ -24,7 +24,7 @@ pub mod sys {
         pub capacity_hint: u64,
         pub stream: *mut c_void,
         pub flags: u32,
-        pub reserved: u32,
+        pub input_mib: u32,
     }
 
     #[repr(C)]
@@ -213,7 +213,7 @@ impl HipKmerMap {
             capacity_hint: 0,
             stream: std::ptr::null_mut(),
             flags: 0,
-            reserved: 0,
+            input_mib: 0,
         };
         let mut ctx = std::ptr::null_mut();
         check(std::ptr::null(), unsafe { sys::kh_create(&mut ctx, &cfg) })?;
@@ -354,7 +354,7 @@ impl HipKmerMapGroup {
             capacity_hint: 0,
             stream: std::ptr::null_mut(),
             flags: 0,
-            reserved: 0,
+            input_mib: 0,
         };
         let mut group = std::ptr::null_mut();
         check(std::ptr::null(), unsafe { sys::kh_group_create(&mut group, &cfg, devices.as_ptr(), devices.len() as u32) })?;

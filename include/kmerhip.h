@@ -77,7 +77,9 @@ typedef struct kh_config {
                                 kh_push_device yourself) -- unless KH_FLAG_CALLER_STREAM says that NULL means
                                 the legacy default stream itself (what torch.cuda.current_stream() usually is) */
     uint32_t flags;          /* KH_FLAG_* */
-    uint32_t reserved;
+    uint32_t input_mib;      /* expected total input of this context in MiB (the size of the file about to be pushed), 0 = unknown.
+                                Never needed: it lets kh_push_text size its device-side accumulation for THIS input instead
+                                of for an eighth of the free memory (a small file then costs a small allocation) */
 } kh_config;
 
 #define KH_FLAG_TRACE 1u           /* print phase timings to stderr (also env KMERHIP_TRACE=1) */

@@ -43,7 +43,8 @@
 
 namespace {
 
-double merge_timeout_s() {
+// KMERHIP_MERGE_TIMEOUT_S: read when a communicator (or a hub) is set up, kept there
+double merge_timeout_env() {
     const char *e = getenv("KMERHIP_MERGE_TIMEOUT_S");
     const double v = e ? atof(e) : 300.0;
     return v > 0 ? v : 300.0;
@@ -61,6 +62,7 @@ struct LocalHub {
     uint32_t arrived = 0;
     u64 generation = 0;
     bool poisoned = false;                       // a rank gave up: every barrier returns false from now on
+    double timeout_s = 300.0;                    // KMERHIP_MERGE_TIMEOUT_S, as read when the ranks were set up
     std::vector<const void *> base;              // posted per rank
     std::vector<std::vector<u64>> off, len;      // [rank][peer], bytes
     std::vector<std::vector<u64>> small;         // all-gather postings
@@ -77,7 +79,7 @@ struct LocalHub {
             cv.notify_all();
             return true;
         }
-        const bool woke = cv.wait_for(lk, std::chrono::duration<double>(merge_timeout_s()), [&] { return generation != gen || poisoned; });
+        const bool woke = cv.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return generation != gen || poisoned; });
         if (generation != gen) return true;  // (the barrier completed, whatever happened since)
         if (!woke) {
             poisoned = true;
@@ -338,7 +340,7 @@ struct DevBuf {  // scratch of one merge; freed when it goes out of scope
     }
 };
 
-uint32_t merge_pieces_default() {
+uint32_t merge_pieces_default() {  // (a tunable of the exchange: how many shares the pipeline works in; any value gives the same shards)
     const char *e = getenv("KMERHIP_MERGE_PIECES");
     const int v = e ? atoi(e) : 4;
     return v >= 1 ? (uint32_t)v : 1u;
@@ -349,6 +351,9 @@ struct Fault {
     int rank = -1, code = KH_ERR_STATE;
     std::string point;
     Fault() {
+#if !KH_TESTING
+        return;  // (the product library has no failure injection: krust_amd/lib/libkmerhip_testing.so does)
+#endif
         const char *e = getenv("KMERHIP_FAULT");
         if (!e || !*e) return;
         const std::string s(e);
@@ -370,6 +375,10 @@ struct Fault {
 int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     Comm *cm = c->comm;
     (void)hipSetDevice(c->device);  // (enter() may have failed before it got there)
+#if KH_TESTING
+    cm->timeout_s = merge_timeout_env();  // (tests change the bound between merges of one group)
+    if (cm->hub) cm->hub->timeout_s = cm->timeout_s;
+#endif
     const uint32_t W = cm->nranks, R = cm->rank;
     const double t_begin = now_ms();
     double t_export = 0, t_wait = 0, t_merge = 0;
@@ -885,7 +894,8 @@ int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id
     cm->nranks = nranks;
     cm->rank = rank;
     cm->hub = hub;
-    cm->timeout_s = merge_timeout_s();
+    cm->timeout_s = merge_timeout_env();
+    if (hub) hub->timeout_s = cm->timeout_s;
     c->comm = cm;
     int rc = KH_OK;
     if (hipStreamCreateWithFlags(&cm->xs, hipStreamNonBlocking) != hipSuccess) rc = fail(c, KH_ERR_HIP, "hipStreamCreate(exchange)");

@@ -9,6 +9,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,9 +61,84 @@ enum { ST_DIRECT = 0, ST_P1_COUNT, ST_P1_SCATTER, ST_P2_COUNT, ST_P2_SCATTER, ST
 
 namespace {
 struct Comm;  // exchange.hip.h: RCCL communicator (or the process-local hub) of this rank
+
+// ---- environment knobs (round 4: ONE place) -----------------------------------------------------------------------------
+// Read ONCE, at kh_create, into the context.  Two kinds:
+//   * tunables of the product library: how much memory, how many threads, how long to wait, what to print, which insert path.
+//     None of them can change a count.
+//   * switches of the TEST build (-DKH_TESTING=1: krust_amd/lib/libkmerhip_testing.so, what tests/ load): force a kernel
+//     variant, a table geometry, a fallback, an injected failure.  They exist so that every path can be driven against the
+//     oracle; the product library does not compile them in -- there is no environment variable that makes it take an
+//     ablation path or fail a merge.  (The test build also re-reads them at every call: tests flip them between batches.)
+#ifndef KH_TESTING
+#define KH_TESTING 0
+#endif
+struct Knobs {
+    // product
+    bool trace = false;              // KMERHIP_TRACE=1
+    int path = 0;                    // KMERHIP_PATH=direct|partition: 1 | 2 (0: chosen per push)
+    double part_budget_gb = 0;       // KMERHIP_PART_BUDGET_GB
+    u64 acc_max_mb = 0;              // KMERHIP_ACC_MAX_MB
+    u64 text_acc_mb = 0;             // KMERHIP_TEXT_ACC_MB
+    int copy_threads = 0;            // KMERHIP_COPY_THREADS
+    bool estimate = true;            // KMERHIP_ESTIMATE=0: size tables from the hint / the worst case, never from the level-1 sample
+    bool pow2_table = false;         // KMERHIP_POW2_TABLE=1: tables of 2^n regions only (rounds 1-3's)
+    // test build only
+    int payload = 0;                 // KMERHIP_PAYLOAD=64
+    u64 table_regions = 0;           // KMERHIP_TABLE_REGIONS
+    int region_nt = 0;               // KMERHIP_REGION_NT
+    bool p2_force_wide = false;      // KMERHIP_P2_FORCE_WIDE=1
+    bool generic_k = false;          // KMERHIP_GENERIC_K=1
+    bool p1_legacy = false;          // KMERHIP_P1_BINS=0
+    bool p2_lines = true;            // KMERHIP_P2_LINES=0
+    bool l2_arena = true;            // KMERHIP_L2_ARENA=0
+    u64 l2_ovf_cap = ~0ull;          // KMERHIP_L2_OVF_CAP
+    int l2_skew_x = -1;              // KMERHIP_L2_SKEW_X (-1: default 2)
+    u64 l2_heavy_room = ~0ull;       // KMERHIP_L2_HEAVY_ROOM
+    bool narrow = true;              // KMERHIP_NARROW=0
+    u64 hot_cut = 0;                 // KMERHIP_HOT_CUT (0: default; ~0: no bucket is hot)
+    int ovf_agg = -1;                // KMERHIP_OVF_AGG
+    double survival = 0;             // KMERHIP_SURVIVAL
+    bool stop_after_p1 = false, stop_after_p2 = false;  // ablation builds (KH_ABL*)
+};
+inline const char *env_of(const char *name) {
+    const char *e = getenv(name);
+    return (e && *e) ? e : nullptr;
+}
+void read_knobs(Knobs &k) {
+    k = Knobs();
+    if (const char *e = env_of("KMERHIP_TRACE")) k.trace = e[0] != '0';
+    if (const char *e = env_of("KMERHIP_PATH")) k.path = !strcmp(e, "direct") ? 1 : !strcmp(e, "partition") ? 2 : 0;
+    if (const char *e = env_of("KMERHIP_PART_BUDGET_GB")) k.part_budget_gb = atof(e);
+    if (const char *e = env_of("KMERHIP_ACC_MAX_MB")) k.acc_max_mb = strtoull(e, nullptr, 10);
+    if (const char *e = env_of("KMERHIP_TEXT_ACC_MB")) k.text_acc_mb = strtoull(e, nullptr, 10);
+    if (const char *e = env_of("KMERHIP_COPY_THREADS")) k.copy_threads = atoi(e);
+    if (const char *e = env_of("KMERHIP_ESTIMATE")) k.estimate = e[0] != '0';
+    if (const char *e = env_of("KMERHIP_POW2_TABLE")) k.pow2_table = e[0] == '1';
+#if KH_TESTING
+    if (const char *e = env_of("KMERHIP_PAYLOAD")) k.payload = atoi(e);
+    if (const char *e = env_of("KMERHIP_TABLE_REGIONS")) k.table_regions = strtoull(e, nullptr, 10);
+    if (const char *e = env_of("KMERHIP_REGION_NT")) k.region_nt = atoi(e);
+    if (const char *e = env_of("KMERHIP_P2_FORCE_WIDE")) k.p2_force_wide = e[0] == '1';
+    if (const char *e = env_of("KMERHIP_GENERIC_K")) k.generic_k = e[0] != '0';
+    if (const char *e = env_of("KMERHIP_P1_BINS")) k.p1_legacy = e[0] == '0';
+    if (const char *e = env_of("KMERHIP_P2_LINES")) k.p2_lines = e[0] != '0';
+    if (const char *e = env_of("KMERHIP_L2_ARENA")) k.l2_arena = e[0] != '0';
+    if (const char *e = env_of("KMERHIP_L2_OVF_CAP")) k.l2_ovf_cap = strtoull(e, nullptr, 10);
+    if (const char *e = env_of("KMERHIP_L2_SKEW_X")) k.l2_skew_x = atoi(e);
+    if (const char *e = env_of("KMERHIP_L2_HEAVY_ROOM")) k.l2_heavy_room = strtoull(e, nullptr, 10);
+    if (const char *e = env_of("KMERHIP_NARROW")) k.narrow = e[0] != '0';
+    if (const char *e = env_of("KMERHIP_HOT_CUT")) k.hot_cut = (e[0] == '0' && !e[1]) ? ~0ull : strtoull(e, nullptr, 10);
+    if (const char *e = env_of("KMERHIP_OVF_AGG")) k.ovf_agg = atoi(e);
+    if (const char *e = env_of("KMERHIP_SURVIVAL")) k.survival = atof(e);
+    k.stop_after_p1 = env_of("KMERHIP_STOP_AFTER_P1") != nullptr;
+    k.stop_after_p2 = env_of("KMERHIP_STOP_AFTER_P2") != nullptr;
+#endif
+}
 }
 
 struct kh_ctx {
+    Knobs knobs;
     int device = 0;
     Comm *comm = nullptr;
     hipStream_t stream = nullptr;
@@ -192,6 +268,7 @@ struct kh_ctx {
     bool txt_acc_busy[2] = {false, false};
     hipStream_t txt_scan_stream = nullptr; // the stream the accumulated scans ran on
     u64 *txt_scan_partial = nullptr;  u64 txt_scan_cap = 0;  // scan scratch of the text stream
+    u64 expect_bytes = 0;                  // kh_config::input_mib: what the caller expects to push in total (0 = unknown)
     u64 *txt_ls = nullptr;        u64 txt_ls_cap = 0;    // line starts
     uint8_t *txt_hdr = nullptr;   u64 txt_hdr_cap = 0;   // FASTA: line is a header
     uint32_t *txt_tnl = nullptr;  u64 txt_tnl_cap = 0;   // per-tile newline counts
@@ -250,6 +327,9 @@ int flush_text(kh_ctx *c);
 int need_table(kh_ctx *c);
 int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool keep_window = false, bool narrow_ok = false) {
     if (!c) return KH_ERR_BAD_ARG;
+#if KH_TESTING
+    read_knobs(c->knobs);  // (tests flip the switches between calls on one context; the product library reads them once, at kh_create)
+#endif
     if (c->poisoned) return fail(c, KH_ERR_STATE, "context is poisoned by an earlier error");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->win_open && !keep_window) {
@@ -372,10 +452,8 @@ int sync_counters(kh_ctx *c) {
 // 256, of 64 from 512 -- so that a table ends within 12.5 % of the load it was sized for, and so that b2 stays a multiple of
 // every power-of-two world size up to 8 (64 from b2 = 512): the hash-range shards of the multi-GPU merge nest in such a table
 // (merge_regions).  KMERHIP_POW2_TABLE=1: powers of two only, rounds 1-3's tables (A/B, tests).
-bool pow2_tables() {
-    static const bool v = [] { const char *e = getenv("KMERHIP_POW2_TABLE"); return e && e[0] == '1'; }();
-    return v;
-}
+bool g_pow2_tables = false;  // (process-wide: set from the knobs of the last context created -- a sizing policy, not state)
+bool pow2_tables() { return g_pow2_tables; }
 u64 round_cap(double want) {
     u64 cap = MIN_CAP;
     while ((double)cap < want && cap < 1024ull * kh::REGION_SLOTS) cap *= 2;
@@ -534,9 +612,15 @@ int drain_events(kh_ctx *c) {
 }
 
 // ---- device scratch management for the partitioned path --------------------------------------
+double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 template <typename T>
 int ensure_buf(kh_ctx *c, T **ptr, u64 *cap, u64 need, const char *what) {
     if (*cap >= need && *ptr) return KH_OK;
+    const double t0 = c->trace ? wall_ms() : 0.0;
+    struct Tr {
+        kh_ctx *c; double t0; const char *what; u64 bytes;
+        ~Tr() { if (c->trace && wall_ms() - t0 > 5.0) fprintf(stderr, "[kmerhip] %s: %.1f MB took %.1f ms\n", what, (double)bytes / 1e6, wall_ms() - t0); }
+    } tr{c, t0, what, need * sizeof(T)};
     if (*ptr) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         (void)hipFree(*ptr);
@@ -599,6 +683,7 @@ GeomChoice make_geom(const kh_ctx *c, u64 cap) {
     gc.g.shard_shift = c->shard_shift;
     gc.g.shard_index = c->shard_index;
     gc.use32 = (hbits - (int)p1) <= 32 && c->pay_mode != 64;
+    gc.g.defer = (gc.use32 && kh::p1_fast_ok(gc.g)) ? 1u : 0u;  // (level 1's FAST kernels leave the last Feistel round to level 2)
     return gc;
 }
 
@@ -657,7 +742,7 @@ bool region_small_groups(const kh_ctx *c, u64 expect, u64 nregions) {
     // above load 0.6 (the hint's load, or -- without one -- as if every payload room was made for were a new key) with
     // more than 16 K payloads per bucket.  Measured: 125 M reads into 2^31 slots (0.61, 30 K per bucket) 36.4 vs 40.9 ms
     // with 512 lanes; an hg-shaped input in 2^32 slots (0.62, 2.9 K per bucket) 27.4 vs 20.5 ms.
-    const int forced = [] { const char *e = getenv("KMERHIP_REGION_NT"); return e ? atoi(e) : 0; }();
+    const int forced = c->knobs.region_nt;
     if (forced) return forced == 512;
     const double keys = c->est_keys ? (double)(c->distinct_known + c->est_keys) : c->hinted ? (double)c->hint_keys : (double)(c->distinct_known + expect);
     return !(keys > 0.6 * (double)c->cap && expect / nregions > 16384);
@@ -792,7 +877,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     cs.pay = c->keysA;
     cs.plist = c->plist;
     cs.fill8 = c->fill8;
-    const uint32_t force_wide = [] { const char *e = getenv("KMERHIP_P2_FORCE_WIDE"); return (e && e[0] == '1') ? 1u : 0u; }();
+    const uint32_t force_wide = c->knobs.p2_force_wide ? 1u : 0u;
     bool have_total = false;  // the host knows how many payloads level 1 produced (it synchronised to read them)
     u64 batch_total = 0;
 
@@ -830,13 +915,13 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
             l1.pool_chunks = pool_chunks;
             l1.ctr = c->d_ctr;
             // KMERHIP_GENERIC_K=1: the C++ window where a written-out one exists; KMERHIP_P1_BINS=0: round 1's tile-sorting kernel (both for A/B)
-            l1.generic_k = [] { const char *e = getenv("KMERHIP_GENERIC_K"); return e && e[0] && e[0] != '0'; }();
-            l1.legacy = [] { const char *e = getenv("KMERHIP_P1_BINS"); return e && e[0] == '0'; }();
+            l1.generic_k = c->knobs.generic_k;
+            l1.legacy = c->knobs.p1_legacy;
             if (sizeof(PT) == 4) kh::launch_level1_32(l1, nullptr);
             else kh::launch_level1_64(l1, nullptr);
         }
 #if KH_ABL
-        if (getenv("KMERHIP_STOP_AFTER_P1")) {  // ablation builds only: time level 1 alone (its output is garbage)
+        if (c->knobs.stop_after_p1) {  // ablation builds only: time level 1 alone (its output is garbage)
             HIP_TRY(c, hipGetLastError());
             return sync_counters(c);
         }
@@ -885,7 +970,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
                 // distinct keys of the batch: the sample's, scaled by payloads (its partitions hold est[1] of `total`) -- and of the
                 // range, scaled by windows: an upper bound (later batches repeat keys of this one)
                 double keys = (double)total;  // no usable sample: as if every payload were a new key (round 3's sizing)
-                if (est[2] == 0 && est[1] > 0) keys = (double)est[0] * ((double)total / (double)est[1]);  // (est[1]: the payloads counted: the same share of `total` as the keys)
+                // (scaled by KEY SPACE -- the sample is every occurrence of an exact 1 / (1024 / np x 2^sub) of it -- not by payloads: a
+                //  sampled partition that holds a repeat family's heavy keys has more payloads, not more keys; an hg-shaped input
+                //  came out 21 % low that way)
+                if (est[2] == 0 && est[1] > 0) keys = std::min((double)total, (double)est[0] * ((double)P1 / (double)est_np) * (double)(1u << est_sub));
                 c->est_keys = (u64)(keys * range_scale) + 1;
                 const double load_now = (double)c->est_keys / (double)c->cap;
                 u64 newcap = c->cap;
@@ -946,11 +1034,11 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     }
     // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
     // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
-    const bool lines_on = [] { const char *e = getenv("KMERHIP_P2_LINES"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
+    const bool lines_on = c->knobs.p2_lines;
     const bool lines = lines_on && g.b2 >= 2 && g.b2 <= 512;
     // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
     // each), 32..1024 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
-    const bool arena_on = [] { const char *e = getenv("KMERHIP_L2_ARENA"); return !(e && e[0] == '0'); }();  // (read per batch: tests flip it)
+    const bool arena_on = c->knobs.l2_arena;
     const bool arena = arena_on && g.p1_bits >= 8 && g.b2 >= 32 && g.b2 <= kh::MAX_B2;
     const u64 arena_pay = arena ? (n_pay + nregions) + ((n_pay + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
     // the overflow list: a sixteenth of the batch, plus what the workgroups RESERVE without using -- every workgroup that
@@ -986,15 +1074,15 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     }
     const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
     bool arena_done = false, heavy_exact = false;
-    const u64 ovf_test_cap = [] { const char *e = getenv("KMERHIP_L2_OVF_CAP"); return e ? (u64)strtoull(e, nullptr, 10) : ~0ull; }();
+    const u64 ovf_test_cap = c->knobs.l2_ovf_cap;
     const u64 ovf_lim = std::min(c->ovf_cap, ovf_test_cap);
     if (arena) {
         {
             StageTimer t(c, ST_P2_SCATTER);
             // (test knobs: KMERHIP_L2_SKEW_X = how many times the mean a partition may hold before it counts as heavy, 0 = no
             //  limit; KMERHIP_L2_OVF_CAP = entries the overflow list may take; KMERHIP_L2_HEAVY_ROOM = payloads of room for heavy partitions)
-            const uint32_t skew_x = [] { const char *e = getenv("KMERHIP_L2_SKEW_X"); return e ? (uint32_t)atoi(e) : 2u; }();
-            const u64 room = [&] { const char *e = getenv("KMERHIP_L2_HEAVY_ROOM"); return e ? std::min<u64>(heavy_room, strtoull(e, nullptr, 10)) : heavy_room; }();
+            const uint32_t skew_x = c->knobs.l2_skew_x >= 0 ? (uint32_t)c->knobs.l2_skew_x : 2u;
+            const u64 room = std::min<u64>(heavy_room, c->knobs.l2_heavy_room);
             hipLaunchKernelGGL(kh::arena_plan_kernel, dim3((unsigned)std::min<u64>(64, (nregions + 1023) / 1024)), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
                                c->ovf, skew_x, c->heavy, room);
 #define KH_ARENA(UB, NBK, P2)                                                                                                              \
@@ -1006,7 +1094,11 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
                 if (pow2) KH_ARENA(64, 1024, true);
                 else KH_ARENA(64, 1024, false);
             } else if (g.b2 > 512) {  // 513 .. 768: three buckets per lane group
-                KH_ARENA(64, 768, false);
+#ifndef KH_ARENA_UNITB_768
+#define KH_ARENA_UNITB_768 64  // (128: whole lines while a bin holds >= 48 payloads, i.e. up to 682 buckets -- A/B builds)
+#endif
+                if (KH_ARENA_UNITB_768 == 128 && sizeof(PT) == 4 && g.b2 <= 682) KH_ARENA(128, 768, false);
+                else KH_ARENA(64, 768, false);
             } else if (pow2) {
                 KH_ARENA(UB512, 512, true);
             } else {
@@ -1066,7 +1158,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
                                (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
     }
 #if KH_ABL2 || KH_ABL3
-    if (getenv("KMERHIP_STOP_AFTER_P2")) {  // ablation builds only: time level 2 alone (its output is garbage)
+    if (c->knobs.stop_after_p2) {  // ablation builds only: time level 2 alone (its output is garbage)
         HIP_TRY(c, hipGetLastError());
         return sync_counters(c);
     }
@@ -1088,7 +1180,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     const bool was_empty = c->table_empty;
     // The 8-byte table image (see kh_ctx::ntab): a fresh pass with 32-bit payloads writes it, a pass over a table that is
     // in that form updates it.  KMERHIP_NARROW=0: always the 16-byte table (A/B).
-    const bool narrow_on = [] { const char *e = getenv("KMERHIP_NARROW"); return !(e && e[0] == '0'); }();
+    const bool narrow_on = c->knobs.narrow;
     bool nar = sizeof(PT) == 4 && narrow_on && !c->narrow_banned && !c->shard_shift && (c->table_empty || c->narrow);
     if (nar && c->ntab_cap != c->cap) {
         if (c->ntab) {
@@ -1114,8 +1206,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     // hint that was far too small: there every bucket is large, and the region pass's overflow handling is what sizes the
     // table) -- so at most a 64th of the buckets can be hot.  KMERHIP_HOT_CUT=n: another threshold (tests); 0 = no bucket is hot.
     const u64 hot_cut = [&] {
-        const char *e = getenv("KMERHIP_HOT_CUT");
-        if (e) return e[0] == '0' && !e[1] ? ~0ull : (u64)strtoull(e, nullptr, 10);
+        if (c->knobs.hot_cut) return c->knobs.hot_cut;
         return std::max<u64>(std::max<u64>(n_all >> 10, 1ull << 20), 64 * (n_all / nregions));
     }();
     if (hot_cut != ~0ull) {
@@ -1137,7 +1228,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         // (a long list is mostly copies -- bursts of a tandem repeat's payloads, a repeat family's: summed in LDS first; 4-byte
         //  payloads, and on the 8-byte image only where no count can leave 32 bits: the table's k-mers so far plus this batch's
         //  windows stay below 2^32.  KMERHIP_OVF_AGG=0: never; =1: for lists of any length -- tests)
-        const int agg_env = [] { const char *e = getenv("KMERHIP_OVF_AGG"); return e ? atoi(e) : -1; }();
+        const int agg_env = c->knobs.ovf_agg;
         const bool ovf_agg = sizeof(PT) == 4 && agg_env != 0 && (agg_env == 1 || c->ovf_pending >= (1u << 16)) &&
                              (!nar || c->h_ctr->kmers + n_all < 0xFFFFFFFFull);
         if (c->ovf_pending && ovf_agg) {
@@ -1305,6 +1396,20 @@ int direct_range(kh_ctx *c, const RangeArgs &ra, u64 first_tile, u64 end_tile) {
     return KH_OK;
 }
 
+// bytes the two partition buffers (and the overflow list) of a batch may take: decided at the context's first partitioned range
+void ensure_part_budget(kh_ctx *c) {
+    if (c->part_budget) return;
+    size_t fr = 0, tot = 0;
+    // (up to 0.78 of what is free: the 8-byte table image -- 8 bytes per slot, allocated after level 2 -- and the small arrays
+    //  take the rest.  Round 3 stopped at 160 GiB / 0.75: configs[3]'s 125 M reads then ran as two batches, the second one a
+    //  pass over a filled table that re-reads and re-writes all of it: 36 ms of region pass where one fresh pass takes 24)
+    u64 budget = 224ull << 30;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * 0.78));
+    else (void)hipGetLastError();
+    if (c->knobs.part_budget_gb > 0) budget = (u64)(c->knobs.part_budget_gb * (double)(1ull << 30));
+    c->part_budget = std::max<u64>(budget, 64ull << 20);
+}
+
 // Count all windows of the device buffer [d_bases, d_bases+n) that end at offset >= wlo_off.
 int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual, u64 n, u64 wlo_off) {
     if (n == 0) return KH_OK;
@@ -1330,16 +1435,19 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     bool part = false;
     if (c->path_mode == 2) part = true;
     else if (c->path_mode == 0) part = windows >= PART_MIN_WINDOWS && (double)c->cap <= 7.0 * (double)windows;
-    if (part && (ra.use_qual || windows >= (64ull << 20))) {
+    if (part) ensure_part_budget(c);
+    // (an unmasked range whose every window fits one batch with room to spare needs no estimate of the survivors: the sample
+    //  costs a kernel and a host round trip, 0.3 ms of the headline's 68)
+    const bool tight = part && (double)windows * 11.0 > 0.85 * (double)c->part_budget;
+    if (part && (ra.use_qual || (windows >= (64ull << 20) && (tight || !c->hinted)))) {
         // A quality-masked range: most windows may be gone (-Q 20 on typical reads keeps 0.4 of them at k = 31) -- and so may
         // those of an unhinted one (FASTQ text as the device scanner leaves it: headers and quality lines are masked positions,
         // 0.4 of the windows are k-mers; the table of an unhinted context is sized from the windows).  Count the
         // survivors of every 64th 4096-position tile and size pool, arenas and batches from that instead of from "every
         // window" -- configs[2] then runs as one batch instead of two.  KMERHIP_SURVIVAL=x: use x instead of the sample
         // (tests: a far too small x exercises the retry); =1: size for every window.
-        const char *e = getenv("KMERHIP_SURVIVAL");
-        if (e && atof(e) > 0) {
-            ra.survive = std::min(1.0, atof(e));
+        if (c->knobs.survival > 0) {
+            ra.survive = std::min(1.0, c->knobs.survival);
         } else {
             const u64 t0 = ra.wlo / kh::TILE, t1 = (ra.vend + kh::TILE - 1) / kh::TILE, stride = 64;
             const u64 nsamp = (t1 - t0 + stride - 1) / stride;
@@ -1411,17 +1519,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         int rc = sync_counters(c);
         if (rc != KH_OK) return rc;
     }
-    if (!c->part_budget) {
-        size_t fr = 0, tot = 0;
-        // (up to 0.78 of what is free: the 8-byte table image -- 8 bytes per slot, allocated after level 2 -- and the small arrays
-        //  take the rest.  Round 3 stopped at 160 GiB / 0.75: configs[3]'s 125 M reads then ran as two batches, the second one a
-        //  pass over a filled table that re-reads and re-writes all of it: 36 ms of region pass where one fresh pass takes 24)
-        u64 budget = 224ull << 30;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * 0.78));
-        const char *e = getenv("KMERHIP_PART_BUDGET_GB");
-        if (e && atof(e) > 0) budget = (u64)(atof(e) * (double)(1ull << 30));
-        c->part_budget = std::max<u64>(budget, 64ull << 20);
-    }
+    ensure_part_budget(c);
     const u64 first_tile = ra.wlo / kh::PART_TILE;
     const u64 end_tile = (ra.vend + kh::PART_TILE - 1) / kh::PART_TILE;
     const u64 distinct_before = c->distinct_known;
@@ -1469,11 +1567,12 @@ unsigned usable_cpus() {
     return t < 1 ? 1u : t;
 }
 
+int g_copy_threads = 0;  // KMERHIP_COPY_THREADS of the first context created (the staging threads are a property of the process)
 void staged_memcpy(void *dst, const void *src, size_t n) {
     static const unsigned hw = [] {
         unsigned t = usable_cpus();
         if (t > 6) t = 6;  // (measured on the box, 15 GB pushes / 17 GB results: 6 threads 30 / 24 GB/s, 12 threads 20 / 14 GB/s)
-        if (const char *e = getenv("KMERHIP_COPY_THREADS")) t = (unsigned)atoi(e);
+        if (g_copy_threads > 0) t = (unsigned)g_copy_threads;
         return t < 1 ? 1u : t;
     }();
     const size_t min_part = 4u << 20;
@@ -1560,10 +1659,7 @@ u64 acc_stride(u64 cap) { return HALO + cap + 64; }  // one of the two halves (b
 u64 acc_limit(const kh_ctx *c) {
     size_t fr = 0, tot = 0;
     u64 lim = ACC_MAX;
-    if (const char *e = getenv("KMERHIP_ACC_MAX_MB")) {  // (tests: small buffers exercise the seams)
-        const u64 v = strtoull(e, nullptr, 10);
-        if (v) lim = std::max<u64>(ACC_MIN, v << 20);
-    }
+    if (c->knobs.acc_max_mb) lim = std::max<u64>(ACC_MIN, c->knobs.acc_max_mb << 20);  // (small buffers exercise the seams)
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
         // what a batch of `lim` bases takes besides the table: two accumulation buffers with their quality halves (4 x)
         // and the partition buffers and overflow list of its ~lim windows (11 B per window with 4-byte payloads, 20 with
@@ -1676,17 +1772,17 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
     c->k = cfg->k;
     c->minq = cfg->min_quality;
     c->flags = cfg->flags;
-    const char *tr = getenv("KMERHIP_TRACE");
-    c->trace = (cfg->flags & KH_FLAG_TRACE) || (tr && tr[0] && tr[0] != '0');
+    read_knobs(c->knobs);
+    g_pow2_tables = c->knobs.pow2_table;
+    if (!g_copy_threads) g_copy_threads = c->knobs.copy_threads;
+    c->trace = (cfg->flags & KH_FLAG_TRACE) || c->knobs.trace;
+    c->expect_bytes = (u64)cfg->input_mib << 20;
     c->hinted = cfg->capacity_hint != 0;
     c->hint_keys = cfg->capacity_hint;
     c->path_mode = (cfg->flags & KH_FLAG_FORCE_DIRECT) ? 1 : (cfg->flags & KH_FLAG_FORCE_PARTITION) ? 2 : 0;
-    if (const char *pm = getenv("KMERHIP_PATH")) {
-        if (!strcmp(pm, "direct")) c->path_mode = 1;
-        else if (!strcmp(pm, "partition")) c->path_mode = 2;
-    }
-    if (const char *py = getenv("KMERHIP_PAYLOAD")) c->pay_mode = atoi(py);
-    if (const char *es = getenv("KMERHIP_ESTIMATE")) c->estimate_on = !(es[0] == '0');
+    if (c->knobs.path) c->path_mode = c->knobs.path;
+    c->pay_mode = c->knobs.payload;
+    c->estimate_on = c->knobs.estimate;
 
     int rc = KH_OK;
     do {
@@ -1701,10 +1797,8 @@ extern "C" int kh_create(kh_ctx **out, const kh_config *cfg) {
         if (hipHostMalloc((void **)&c->h_ctr, sizeof(Counters), hipHostMallocDefault) != hipSuccess) { rc = KH_ERR_OOM; break; }
         if (hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), c->stream) != hipSuccess) { rc = KH_ERR_HIP; break; }
         u64 cap = cfg->capacity_hint ? round_cap((double)cfg->capacity_hint / HINT_LOAD) : DEFAULT_CAP;
-        if (const char *e = getenv("KMERHIP_TABLE_REGIONS")) {  // (tests: a table of exactly this many regions, e.g. 1024 x 40)
-            const u64 nr = strtoull(e, nullptr, 10);
+        if (const u64 nr = c->knobs.table_regions)  // (test build: a table of exactly this many regions, e.g. 1024 x 40)
             if (kh::kh_regions_valid(nr) && nr * kh::REGION_SLOTS >= MIN_CAP) cap = nr * kh::REGION_SLOTS;
-        }
         c->cap = cap;  // (the table itself is allocated when something first needs it: need_table)
         if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = KH_ERR_HIP; break; }
     } while (0);
@@ -1898,10 +1992,7 @@ int text_fail(kh_ctx *c, const char *why) { return fail(c, KH_ERR_FORMAT, why); 
 // and the partition buffers of its ~0.45 surviving windows (11 B each) -- an eighth (a tenth) of what is free
 u64 text_acc_limit(const kh_ctx *c, bool with_qual) {
     u64 lim = 40ull << 30;
-    if (const char *e = getenv("KMERHIP_TEXT_ACC_MB")) {  // (tests: small buffers exercise the switch-over)
-        const u64 v = strtoull(e, nullptr, 10);
-        if (v) return std::max<u64>(1ull << 20, v << 20);
-    }
+    if (c->knobs.text_acc_mb) return std::max<u64>(1ull << 20, c->knobs.text_acc_mb << 20);  // (small buffers exercise the switch-over)
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
         u64 held = c->key_cap + c->keyb_cap;
@@ -1936,7 +2027,7 @@ int text_device_scan(kh_ctx *c, hipStream_t s, const uint32_t *in, u64 n, u64 *o
 
 // d_text: 16-byte aligned device text holding whole records; s: the stream its bytes arrive on (the scan runs there).
 // Appends the flat form to the current accumulation buffer.
-int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s) {
+int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s, bool counted_at_once = false) {
     const bool fastq = format == KH_TEXT_FASTQ;
     const bool with_qual = fastq && c->minq >= 0;
     const u64 ntiles = (n + kh::RAW_TILE - 1) / kh::RAW_TILE;
@@ -1950,6 +2041,19 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s
     if (c->txt_acc_len && (c->txt_acc_qual != with_qual || c->txt_acc_len + need > c->txt_acc_cap[c->txt_cur])) {
         if ((rc = flush_text(c)) != KH_OK) return rc;
     }
+    if (c->txt_acc_len == 0) {
+        // a fresh accumulation: the buffer that exists and is idle, rather than a new allocation (after a reset the other
+        // buffer would be "next": tens of GB allocated for nothing -- and a process that allocates while another one's
+        // memory is still being reclaimed waits for that: 4 s of a bench step, measured)
+        for (int i = 0; i < 2; ++i)
+            if (c->txt_acc_busy[i] && hipEventQuery(c->txt_acc_done[i]) == hipSuccess) c->txt_acc_busy[i] = false;
+        (void)hipGetLastError();
+        const int o = c->txt_cur ^ 1;
+        const bool cur_ok = !c->txt_acc_busy[c->txt_cur] && c->txt_acc_cap[c->txt_cur] >= need && (!with_qual || c->txt_accq_cap[c->txt_cur] >= need);
+        const bool oth_ok = !c->txt_acc_busy[o] && c->txt_acc_cap[o] >= need && (!with_qual || c->txt_accq_cap[o] >= need);
+        if (!cur_ok && oth_ok) c->txt_cur = o;
+        else if (cur_ok && oth_ok && c->txt_acc_cap[o] > c->txt_acc_cap[c->txt_cur]) c->txt_cur = o;
+    }
     const int cur = c->txt_cur;
     if (c->txt_acc_busy[cur]) {  // its last content is still being counted on the context's stream
         HIP_TRY(c, hipStreamWaitEvent(s, c->txt_acc_done[cur], 0));
@@ -1958,12 +2062,18 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s
     if (c->txt_acc_cap[cur] < c->txt_acc_len + need || (with_qual && c->txt_accq_cap[cur] < c->txt_acc_len + need)) {
         // (only ever grown when empty: its content cannot be moved.  A first text of n bytes gets room for 128 like it, within the limit)
         const u64 lim = text_acc_limit(c, with_qual);
-        // (a text of 32 MiB or more is a chunk of a file being streamed: the whole limit at once -- one big batch instead of several)
-        u64 want = std::max<u64>(need, std::min<u64>(lim, std::max<u64>(n >= (32ull << 20) ? lim : 128 * need, c->txt_acc_cap[cur ^ 1])));
+        // How much: what the caller says it will push (kh_config::input_mib); else, for a text of 32 MiB or more -- a chunk of a
+        // file being streamed -- the whole limit (one big batch instead of several), for a small one 128 like it.  A resident
+        // text (kh_push_text_device) is counted at once: exactly its size.
+        u64 want = c->expect_bytes ? c->expect_bytes + (c->expect_bytes >> 6) + need : (n >= (32ull << 20) ? lim : 128 * need);
+        if (counted_at_once) want = need;
+        want = std::max<u64>(need, std::min<u64>(lim, std::max<u64>(want, counted_at_once ? 0 : c->txt_acc_cap[cur ^ 1])));
         want = std::max<u64>(want, c->txt_acc_cap[cur]);
         if (c->txt_acc_cap[cur] < want) {
+            const double ta = wall_ms();
             HIP_TRY(c, hipStreamSynchronize(s));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const double tb = wall_ms();
             if (c->txt_acc[cur]) (void)hipFree(c->txt_acc[cur]);
             c->txt_acc[cur] = nullptr;
             c->txt_acc_cap[cur] = 0;
@@ -1978,6 +2088,7 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s
                 return fail(c, KH_ERR_OOM, "hipMalloc(text bases)", e);
             }
             c->txt_acc_cap[cur] = want;
+            if (c->trace) fprintf(stderr, "[kmerhip] text accumulation buffer %d: %.1f GB (sync %.1f ms, alloc %.1f ms)\n", cur, (double)want / 1e9, tb - ta, wall_ms() - tb);
         }
         if (with_qual && c->txt_accq_cap[cur] < c->txt_acc_cap[cur]) {
             HIP_TRY(c, hipStreamSynchronize(s));
@@ -2098,7 +2209,9 @@ int flush_text(kh_ctx *c) {
         HIP_TRY(c, hipStreamWaitEvent(c->stream, ready, 0));
         (void)hipEventDestroy(ready);
     }
+    const double t0 = wall_ms();
     const int rc = count_device_range(c, c->txt_acc[cur], c->txt_acc_qual ? c->txt_accq[cur] : nullptr, n, 0);
+    if (c->trace) fprintf(stderr, "[kmerhip] %.2f GB of accumulated text counted (host side of it: %.1f ms)\n", (double)n / 1e9, wall_ms() - t0);
     if (!c->txt_acc_done[cur]) HIP_TRY(c, hipEventCreateWithFlags(&c->txt_acc_done[cur], hipEventDisableTiming));
     HIP_TRY(c, hipEventRecord(c->txt_acc_done[cur], c->stream));
     c->txt_acc_busy[cur] = true;
@@ -2120,7 +2233,7 @@ extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n,
     if ((rc = text_args(c, d_text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
     if ((uintptr_t)d_text & 15) return fail(c, KH_ERR_BAD_ARG, "d_text must be 16-byte aligned");
-    rc = scan_text(c, d_text, n, format, c->stream);
+    rc = scan_text(c, d_text, n, format, c->stream, true);
     if (rc == KH_OK) rc = flush_text(c);  // (resident text: counted right away, as kh_push_device counts resident bases)
     if (rc == KH_OK) c->bases_pushed += n;
     return rc;

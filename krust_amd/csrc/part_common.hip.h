@@ -46,6 +46,7 @@ struct PartGeom {
                            // table with a power-of-two region count any split describes the same layout; otherwise
                            // (p1_bits, b2) is the table's own geometry (kernels.hip.h TableGeom, kh_geom_of_regions)
     u64 b2_magic;          // ceil(2^40 / b2): r / b2 == (r * b2_magic) >> 40 for every region index r < 2^22 (part_div_b2)
+    uint32_t defer;        // 1: the pool's 32-bit payloads lack the last Feistel round (hash_p1_pay32 below): level 2 finishes them
     uint32_t p2_bits;      // log2(b2) where b2 is a power of two (the hot kernels then take digit and start by shifts: their POW2
                            // instances are rounds 1-3's code, instruction for instruction), 0xFFFFFFFF otherwise
     uint32_t k;
@@ -115,18 +116,39 @@ __device__ __forceinline__ uint32_t p1_of_hash(u64 H, const PartGeom &g) {
 __host__ __device__ inline bool p1_fast_ok(const PartGeom &g) {
     return g.shard_shift == 0 && g.p1_bits <= g.k && 2 * g.k - g.p1_bits >= 1 && 2 * g.k - g.p1_bits <= 32 && g.k < 32;
 }
+// Round 4: THE LAST FEISTEL ROUND IS LEVEL 2'S.  Written as a ^= F(b), b ^= F(a), a ^= F(b), b ^= F(a) on (a, b) = (L, R) of
+// the key, the hash is a << k | b -- and a, which holds the level-1 digit and everything level 1's addresses are made of, is
+// final after the THIRD round; the fourth only changes b.  Level 1 is bound by its instruction stream (21 of its 26.5 ms are
+// VALU issue), level 2 by the memory system with the VALU idle half the time: so a level-1 kernel on the FAST path stores
+// y = (a_low ++ b') -- the payload with b one round short -- and whoever reads the pool (the level-2 kernels: l2_finish)
+// applies x = y ^ F(a) << ..., a = digit ++ a_low, which is the payload defined above, bit for bit.  PartGeom::defer says so.
+// MEASURED (profiles/README.md r04, A/B builds, S100M): level 1 26.43 -> 25.42 ms at k = 21 (25.8 at k = 17, 26.9 at k = 13: one
+// round of twelve instructions fewer per window, as predicted) -- and level 2 21.8 -> 23.8 ms: the arena kernel is at its 128
+// registers with 14 spilled, and five more vector instructions per payload cost it more than level 1 gained.  Net +1 ms per
+// step, so the DEFAULT IS OFF (0); the code stays as the measurement's record and for a level 2 with registers to spare.
+#ifndef KH_L1_DEFER_ROUND
+#define KH_L1_DEFER_ROUND 0
+#endif
 template <int MODE>
 __device__ __forceinline__ void hash_p1_pay32(const uint32_t k, const uint32_t p1_bits, u64 key, uint32_t &p1, uint32_t &pay) {
     const uint32_t mask = (1u << k) - 1u;
-    uint32_t L = (uint32_t)(key >> k) & mask, R = (uint32_t)key & mask, t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC0, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC1, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC2, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC3, k)) & mask; L = R; R = t;
-    p1 = L >> (k - p1_bits);
-    pay = ((L << k) | R) << (32u - (2u * k - p1_bits));  // L's top p1_bits fall off the 32-bit word
+    uint32_t a = (uint32_t)(key >> k) & mask, b = (uint32_t)key & mask;
+    a = (a ^ kh_feistel_f<MODE>(b, KH_FC0, k)) & mask;
+    b = (b ^ kh_feistel_f<MODE>(a, KH_FC1, k)) & mask;
+    a = (a ^ kh_feistel_f<MODE>(b, KH_FC2, k)) & mask;
+#if !KH_L1_DEFER_ROUND
+    b = (b ^ kh_feistel_f<MODE>(a, KH_FC3, k)) & mask;
+#endif
+    p1 = a >> (k - p1_bits);
+    pay = ((a << k) | b) << (32u - (2u * k - p1_bits));  // a's top p1_bits fall off the 32-bit word
 }
-
+// what level 2 does to a deferred payload y of level-1 partition p1 (valid under p1_fast_ok)
+__device__ __forceinline__ uint32_t pay32_finish(uint32_t y, uint32_t p1, uint32_t k, uint32_t p1_bits) {
+    const uint32_t nb = 2u * k - p1_bits;  // significant bits of the payload, left-aligned in 32
+    const uint32_t alow = k > p1_bits ? y >> (32u - (k - p1_bits)) : 0u;
+    const uint32_t a = (p1 << (k - p1_bits)) | alow;
+    return y ^ (kh_feistel_f<KH_MUL_AUTO>(a, KH_FC3, k) << (32u - nb));
+}
 // ---- level-2 work unit and the two level-1 output layouts it can read -----------------------------
 struct Part2Block {
     u64 lo, hi;        // dense source: payload range in the level-1 output;
@@ -181,7 +203,13 @@ __device__ __forceinline__ bool p2_load(const PT *__restrict__ dense, const Chun
     const uint32_t off = ec & (CHUNK_PAY - 1);
     const uint32_t have = s_cfill[ec >> 8];
     out = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (off < have ? off : 0)];
-    return e < n && off < have;
+    return e < n && off < have;  // (the caller finishes the payload: l2_finish)
+}
+// a payload as read from the level-1 pool -> the payload every later stage means (see hash_p1_pay32)
+template <typename PT>
+__device__ __forceinline__ PT l2_finish(PT v, uint32_t p1, const PartGeom &g) {
+    if constexpr (sizeof(PT) == 4) return (KH_L1_DEFER_ROUND && g.defer) ? (PT)pay32_finish((uint32_t)v, p1, g.k, g.p1_bits) : v;
+    else return v;
 }
 template <bool CHUNKED>
 __device__ __forceinline__ uint32_t p2_count_of(const Part2Block &pb) {

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(PART_NT) void part2_count_kernel(const PT *__restri
             ok |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, base + (uint32_t)j * PART_NT + tid, n, v[j]) << j;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (ok & (1u << j)) atomicAdd(&s_hist[Pay<PT>::p2(v[j], g)], 1u);
+            if (ok & (1u << j)) atomicAdd(&s_hist[Pay<PT>::p2(l2_finish(v[j], pb.p1, g), g)], 1u);
     }
     __syncthreads();
     if (pad > 1 && info[3]) pad = 1;  // (the unit-writing kernel stands down for this batch: no padding)
@@ -394,6 +394,8 @@ __global__ __launch_bounds__(PART2_NT, (NBK == 512 && sizeof(PT) == 4) ? 4 : 2) 
         have |= (uint32_t)p2_load<CHUNKED, PT>(pays, cs, pb, s_chk, s_cfill, (uint32_t)j * PART2_NT + tid, n, pay[j]) << j;
     for (uint32_t base = 0; base < n; base += PART2_TILE) {
         uint32_t tag[P2_PER];
+#pragma unroll
+        for (int j = 0; j < P2_PER; ++j) pay[j] = l2_finish(pay[j], pb.p1, g);
 #pragma unroll
         for (int j = 0; j < P2_PER; ++j) tag[j] = (have & (1u << j)) ? (Pay<PT>::p2(pay[j], g) << 16) : 0xFFFFFFFFu;
 #pragma unroll
@@ -556,6 +558,8 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
     auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
         const uint32_t res_old = RES0 + par * RES_SZ, res_new = RES0 + (par ^ 1u) * RES_SZ;
         uint32_t tag[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) pay[j] = l2_finish(pay[j], pb.p1, g);
 #pragma unroll
         for (int j = 0; j < PER; ++j) tag[j] = (have & (1u << j)) ? (Pay<PT>::p2(pay[j], g) << 16) : 0xFFFFFFFFu;
 #pragma unroll
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin at 512 buckets (256 bytes)
     constexpr uint32_t TOTAL = P2L_NBK * CAP;                 // payloads all bins hold together (128 KiB)
     constexpr uint32_t UW = UNITB / 16;                       // 16-byte words per unit
-    static_assert(NBK == 512 || ((NBK == 768 || NBK == 1024) && UNITB == 64), "more than 512 buckets: smaller bins, 64-byte units");
+    static_assert(NBK == 512 || NBK == 768 || (NBK == 1024 && UNITB == 64), "1024 buckets: 128-byte bins, 64-byte units");
     __shared__ __attribute__((aligned(16))) PT s_bin[TOTAL + UNIT];  // 128 KiB (+ a trash unit)
     __shared__ uint32_t s_cnt[NBK];
     __shared__ uint32_t s_chk[CPB];
@@ -938,6 +942,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
                     const bool ok = (have >> (h * HALF + j)) & 1u;
+                    pay[h * HALF + j] = l2_finish(pay[h * HALF + j], p, g);  // (level 1 left the last Feistel round to us)
                     if constexpr (sizeof(PT) == 4) dg[j] = part_bucket32<POW2>((uint32_t)pay[h * HALF + j], g);
                     else dg[j] = Pay<PT>::p2(pay[h * HALF + j], g);
                     rk[j] = ok ? atomicAdd(&s_cnt[dg[j]], 1u) : 0xFFFFFFFFu;

@@ -122,6 +122,21 @@ KH_HD void win_outputs_ref(uint64_t key, uint32_t &p1, uint32_t &pay32) {
 #define KH_WIN_ROUNDS32 \
     KH_WIN_ROUND32("v122", "v123", "%[f0]") KH_WIN_ROUND32("v123", "v122", "%[f1]") \
     KH_WIN_ROUND32("v122", "v123", "%[f2]") KH_WIN_ROUND32("v123", "v122", "%[f3]")
+// 32-bit payloads (round 4): THREE rounds.  L = v122 -- the level-1 digit, the addresses -- is final after the third; the
+// fourth, which only changes R, is left to level 2 (part_common.hip.h hash_p1_pay32 / pay32_finish: level 1 is bound by its
+// instruction stream, level 2 is not -- or so it seemed).  KH_L1_DEFER_ROUND=1 builds it; the default is the four-round window.
+#ifndef KH_L1_DEFER_ROUND
+#define KH_L1_DEFER_ROUND 0  // (measured: level 1 -1.0 ms, level 2 +2.0 ms -- see part_common.hip.h)
+#endif
+#if KH_L1_DEFER_ROUND
+#define KH_WIN_ROUNDS24_P32 \
+    KH_WIN_ROUND24("v122", "v123", "0x3779b1") KH_WIN_ROUND24("v123", "v122", "0xebca77") KH_WIN_ROUND24("v122", "v123", "0xb2ae3d")
+#define KH_WIN_ROUNDS32_P32 \
+    KH_WIN_ROUND32("v122", "v123", "%[f0]") KH_WIN_ROUND32("v123", "v122", "%[f1]") KH_WIN_ROUND32("v122", "v123", "%[f2]")
+#else
+#define KH_WIN_ROUNDS24_P32 KH_WIN_ROUNDS24
+#define KH_WIN_ROUNDS32_P32 KH_WIN_ROUNDS32
+#endif
 #define KH_WIN_ROUNDS32_K32 \
     KH_WIN_ROUND32_K32("v122", "v123", "%[f0]") KH_WIN_ROUND32_K32("v123", "v122", "%[f1]") \
     KH_WIN_ROUND32_K32("v122", "v123", "%[f2]") KH_WIN_ROUND32_K32("v123", "v122", "%[f3]")
@@ -170,15 +185,15 @@ __device__ __forceinline__ void win_hash32(uint32_t flo, uint32_t fhi, uint32_t 
     "v_min_u32 v120, %[flo], %[rlo]\n v_lshrrev_b32 v122, %[k], v120\n v_and_b32 v123, %[km], v120\n"
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the declaration)
     if constexpr (K == 21) {
-        asm(KH_W32_CANON64 KH_WIN_ROUNDS24 KH_W32_PAY0 KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON64 KH_WIN_ROUNDS24_P32 KH_W32_PAY0 KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W32_OPERANDS);
     } else if constexpr (K >= 17) {
-        asm(KH_W32_CANON64 KH_WIN_ROUNDS24 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON64 KH_WIN_ROUNDS24_P32 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W32_OPERANDS);
     } else if constexpr (K == 16) {
-        asm(KH_W32_CANON32 KH_WIN_ROUNDS24 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON32 KH_WIN_ROUNDS24_P32 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
     } else if constexpr (K >= 12) {
-        asm(KH_W32_CANON32 KH_WIN_ROUNDS32 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON32 KH_WIN_ROUNDS32_P32 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
     } else {
-        asm(KH_W32_CANON32 KH_WIN_ROUNDS32 KH_W32_PAY KH_WIN_ADDR("v_lshlrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON32 KH_WIN_ROUNDS32_P32 KH_W32_PAY KH_WIN_ADDR("v_lshlrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
     }
 #else
     (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)PL; (void)PR; (void)CS; (void)BS;

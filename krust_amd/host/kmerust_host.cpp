@@ -236,7 +236,8 @@ struct Session {
     kh_ctx *ctx = nullptr;  // ctxs[0]
     uint32_t k;
     size_t next_ctx = 0;
-    Session(const KmerCounter &kc, bool use_qual) : k((uint32_t)kc.k_) {
+    // input_bytes: the size of the (plain) file about to be counted, 0 = unknown -- kh_config::input_mib
+    Session(const KmerCounter &kc, bool use_qual, uint64_t input_bytes = 0) : k((uint32_t)kc.k_) {
         if (!kc.k_set_) throw Error("k-mer length not set");
         Lap lap(timing().create_s);
         kh_config cfg;
@@ -246,6 +247,7 @@ struct Session {
         cfg.min_quality = use_qual ? kc.min_quality_ : -1;
         cfg.device = kc.device_;
         cfg.capacity_hint = kc.capacity_hint_;
+        cfg.input_mib = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (input_bytes + (1u << 20) - 1) >> 20);
         if (kc.devices_.size() > 1) {
             std::vector<int32_t> devs(kc.devices_.begin(), kc.devices_.end());
             const int rc = kh_group_create(&group, &cfg, devs.data(), (uint32_t)devs.size());
@@ -697,6 +699,13 @@ KmerCounter &KmerCounter::k(size_t kk) {
     return *this;
 }
 
+// size of a plain (uncompressed, regular) input file; 0 for stdin, gzip and anything stat() does not know
+static uint64_t plain_file_bytes(const std::string &path) {
+    if (is_stdin_path(path) || lower_ext(path) == "gz") return 0;
+    struct stat sb;
+    return (stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode)) ? (uint64_t)sb.st_size : 0;
+}
+
 static bool wants_quality(const KmerCounter &, SequenceFormat resolved, int min_quality, const std::string &path) {
     // run.rs:543: both Some; the CLI path for stdin ignores -Q (src/main.rs:145-152, run.rs:195-197)
     return min_quality >= 0 && resolved == SequenceFormat::Fastq && !is_stdin_path(path);
@@ -705,7 +714,7 @@ static bool wants_quality(const KmerCounter &, SequenceFormat resolved, int min_
 PackedCounts KmerCounter::count_packed(const std::string &path, bool apply_min_count) const {
     const SequenceFormat f = resolve_format(input_format_, is_stdin_path(path) ? nullptr : &path);
     const bool q = wants_quality(*this, f, min_quality_, path);
-    Session s(*this, q);
+    Session s(*this, q, plain_file_bytes(path));
     s.count_file(path, f, q);
     return s.result(apply_min_count ? min_count_ : 1);
 }
@@ -721,7 +730,7 @@ std::unordered_map<std::string, uint64_t> KmerCounter::count(const std::string &
 std::vector<std::pair<uint64_t, uint64_t>> KmerCounter::histogram(const std::string &path) const {
     const SequenceFormat f = resolve_format(input_format_, is_stdin_path(path) ? nullptr : &path);
     const bool q = wants_quality(*this, f, min_quality_, path);
-    Session s(*this, q);
+    Session s(*this, q, plain_file_bytes(path));
     s.count_file(path, f, q);
     return s.histogram(min_count_);  // computed on the device, after the min_count filter (run.rs:447-450)
 }

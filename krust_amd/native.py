@@ -30,7 +30,7 @@ TEXT_FASTA, TEXT_FASTQ = 1, 2
 class KhConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("k", C.c_uint32), ("min_quality", C.c_int32),
                 ("device", C.c_int32), ("capacity_hint", C.c_uint64), ("stream", C.c_void_p),
-                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32), ("input_mib", C.c_uint32)]
 
 
 class KhStats(C.Structure):

@@ -29,9 +29,11 @@ def test_library_exports_every_declared_symbol(K):
     from krust_amd import native
     declared = _declared()
     assert declared, "header parse failed"
-    raw = C.CDLL(native.LIB_PATH)
-    for name in declared:
-        assert hasattr(raw, name), f"{name} declared in kmerhip.h but not exported"
+    libdir = os.path.dirname(native.LIB_PATH)
+    for so in ("libkmerhip.so", "libkmerhip_testing.so"):  # the product library and the test build (the same ABI, tests/conftest.py)
+        raw = C.CDLL(os.path.join(libdir, so))
+        for name in declared:
+            assert hasattr(raw, name), f"{name} declared in kmerhip.h but not exported by {so}"
     assert sorted(native.SYMBOLS) == declared, "native.py binding list out of sync with kmerhip.h"
     assert K.lib().kh_abi_version() == 1
 

@@ -342,3 +342,54 @@ def test_a_rank_whose_context_is_poisoned_joins_the_first_gather(K, monkeypatch)
         assert res[1][0] == K.native.KH_ERR_STATE and "poisoned" in res[1][1], res[1]
         for r in (0, 2):
             assert res[r][0] == K.native.KH_ERR_PEER and "rank 1 failed" in res[r][1], res[r]
+
+
+@pytest.mark.parametrize("world,k,b2,pieces", [(2, 21, 40, None), (4, 19, 24, "2"), (8, 21, 40, None), (2, 31, 6, None), (4, 21, 100, "1")])
+def test_group_merge_of_tables_with_1024_x_b2_regions(K, monkeypatch, world, k, b2, pieces):
+    """Round 4: tables of 1024 x b2 regions, b2 not a power of two (what a large input gets: 640 at 125 M reads).  Ownership is
+    still the top bits of the hash, a rank's share of the sender regions still nests in the receiver's table when the world
+    divides b2 (kmerhip.hip merge_regions), and the exchange units carry x - xlo(bucket) instead of a bit field
+    (kernels.hip.h kh_below_region).  KMERHIP_TABLE_REGIONS forces the geometry on every rank; every shard against the
+    oracle, through the heads / packed / wide routes, one shot and in pieces."""
+    monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * b2))
+    if pieces is None:
+        monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    else:
+        monkeypatch.setenv("KMERHIP_MERGE_PIECES", pieces)
+    n_reads = 120_000
+    full_b, _ = O.synth_reads(SEED + b2, 1 << 20, 150, 0, n_reads, with_qual=False)
+    fk, fc = oracle_arrays(full_b, k)
+    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    per = n_reads // world
+    with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000, path="partition" if b2 >= 40 else None) as g:
+        for r, dc in enumerate(g.counters):
+            lo, hi = r * per, (n_reads if r == world - 1 else (r + 1) * per)
+            dc.push(full_b[lo * 151: hi * 151])
+        assert all(dc.finish()["table_slots"] == 1024 * b2 * 4096 for dc in g.counters)
+        infos = g.merge()
+        assert all(i["path"].startswith("regions") for i in infos), infos   # b2 is a multiple of the world: the shards nest
+        for r, (dc, info) in enumerate(zip(g.counters, infos)):
+            keys, cnts = dc.result()
+            sel = owners == r
+            assert np.array_equal(keys, fk[sel]) and np.array_equal(cnts, fc[sel]), f"shard {r} differs from the oracle"
+            assert info["owned_distinct"] == int(sel.sum())
+            assert np.array_equal(dc.lookup(keys[:1000]), cnts[:1000])
+
+
+def test_a_world_that_does_not_divide_b2_takes_the_generic_route(K, monkeypatch):
+    """1024 x 6 regions among 4 ranks: 6 / 4 is not an integer, a shard's regions do not nest -- every rank sees that from the
+    same numbers and the merge takes the owner-partitioned route (correct, slower)."""
+    monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * 6))
+    k, world, n_reads = 21, 4, 40_000
+    full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
+    fk, fc = oracle_arrays(full_b, k)
+    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    per = n_reads // world
+    with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
+        for r, dc in enumerate(g.counters):
+            dc.push(full_b[r * per * 151: (r + 1) * per * 151])
+        infos = g.merge()
+        assert all(i["path"] == "pairs" for i in infos), infos
+        for r, dc in enumerate(g.counters):
+            keys, cnts = dc.result()
+            assert np.array_equal(keys, fk[owners == r]) and np.array_equal(cnts, fc[owners == r])
