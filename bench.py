@@ -493,10 +493,12 @@ def cli_leg(krust_amd, torch, dev, local_rank, reads=10_000_000, k=21):
         runs = []
         # (this process has just freed a few hundred GB of HBM; a new process's runtime start-up has been seen to take 1-4 s
         #  instead of 0.1-0.3 right after that -- `create_s` of the runs below says which it was: give the driver a moment)
-        time.sleep(3.0)
+        # (measured, tools/cli_s100m_probe.py: started 0-3 s after a process that held ~230 GB of HBM has exited, a new process's
+        #  hipMalloc of its partition buffers takes 1-5 s -- the driver is still reclaiming; after 10 s it takes milliseconds)
+        pause = 10.0 if reads >= 40_000_000 else 3.0
+        subprocess.run(["cat", path], stdout=subprocess.DEVNULL)  # (the file was written slice by slice: read once, it streams at the page cache's rate)
         for rep in range(3):   # (the first run pages the binary and the ROCm libraries in)
-            if rep:
-                time.sleep(3.0)  # (the previous process's few hundred GB of HBM are still being reclaimed: see above)
+            time.sleep(pause)
             t0 = time.perf_counter()
             p = subprocess.run([exe, str(k), path, "--format", "histogram", "-q"], capture_output=True, env=env, timeout=600)
             wall = time.perf_counter() - t0
@@ -743,8 +745,8 @@ def main():
             plan = [("headline twin WITHOUT a capacity hint (S100M, k=21)", dict(reads=reads, k=21, min_quality=None, hint=0, steps=3, verify=True)),
                     ("configs[1] S10M: 10 M x 150 bp, k=21", dict(reads=10_000_000, k=21, min_quality=None, steps=3)),
                     ("configs[1] twin WITHOUT a capacity hint (S10M, k=21)", dict(reads=10_000_000, k=21, min_quality=None, hint=0, steps=3)),
-                    ("configs[2] S100M: 100 M x 150 bp, k=31, -Q 20", dict(reads=100_000_000, k=31, min_quality=20)),
-                    ("k=19 twin of the headline (S100M, k=19): the level-1 window is generated for every k", dict(reads=100_000_000, k=19, min_quality=None)),
+                    ("configs[2] S100M: 100 M x 150 bp, k=31, -Q 20 (no capacity hint)", dict(reads=100_000_000, k=31, min_quality=20, hint=0)),
+                    ("k=19 twin of the headline (S100M, k=19, no capacity hint): the level-1 window is generated for every k", dict(reads=100_000_000, k=19, min_quality=None, hint=0)),
                     ("configs[3] rank 3's share of S1B: 125 M x 150 bp, k=21, with the a-priori capacity hint",
                      dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, steps=2)),
                     ("configs[3] the same share, no capacity hint",

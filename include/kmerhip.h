@@ -88,6 +88,11 @@ typedef struct kh_config {
                                       default: chosen per push from batch and table size
                                       (env KMERHIP_PATH=direct|partition overrides) */
 #define KH_FLAG_CALLER_STREAM 8u   /* launch on cfg->stream even when it is NULL (= the legacy default stream) */
+#define KH_FLAG_DEFER_TEXT_SCAN 16u /* kh_push_text returns when its text is on the device; the record scan -- and with it a
+                                      KH_ERR_FORMAT refusal -- happens during the NEXT call that enters the context (the next
+                                      kh_push_text scans it beside its own transfer; kh_finish at the latest).  A refusal then
+                                      concerns the PREVIOUS text (the current one is dropped with it): for callers that restart
+                                      the whole input on KH_ERR_FORMAT, as the kmerust command line does */
 
 /* indices into kh_stats.stage_ms */
 #define KH_NUM_STAGES 8

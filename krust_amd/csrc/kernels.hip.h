@@ -141,20 +141,31 @@ __host__ __device__ __forceinline__ uint32_t kh_start_of_x(uint32_t x, uint32_t 
 }
 // smallest x of bucket b (b <= b2: b = b2 gives 2^32): ceil(b * 2^32 / b2)
 __host__ __device__ __forceinline__ u64 kh_xlo(uint32_t b, uint32_t b2) { return (((u64)b << 32) + b2 - 1) / b2; }
+// ... among the x a k-mer table can hold: with 2k < p1_bits + 32 hash bits the low zs = p1_bits + 32 - 2k bits of every x are
+// zero, so the smallest x of the bucket is kh_xlo rounded UP to a multiple of 2^zs -- and x minus THAT keeps its low zs bits
+// zero (the exchange units count on it: their count field lives there).  zs = kh_x_zero_bits(k, p1_bits).
+__host__ __device__ __forceinline__ uint32_t kh_x_zero_bits(uint32_t k, uint32_t p1_bits) {
+    const int z = (int)p1_bits + 32 - 2 * (int)k;
+    return z <= 0 ? 0u : (z >= 32 ? 31u : (uint32_t)z);
+}
+__host__ __device__ __forceinline__ uint32_t kh_xlo_k(uint32_t b, uint32_t b2, uint32_t zs) {
+    const u64 m = (1ull << zs) - 1;
+    return (uint32_t)((kh_xlo(b, b2) + m) & ~m);
+}
 // "The hash bits below the region index" as a 32-bit window -- what the exchange units (shard.hip.h) carry: the top
 // w = 32 - floor(log2 b2) bits hold x - xlo(bucket) (< 2^w), the bits below them are the hash bits that follow x.
 // For b2 = 2^j: bits [p1_bits + j, p1_bits + j + 32) of H, as in rounds 1-3.
 __host__ __device__ __forceinline__ uint32_t kh_below_w(uint32_t b2) { return 32u - kh_floor_log2(b2); }
-__host__ __device__ __forceinline__ uint32_t kh_below_region(u64 H, RegionGeom g) {
+__host__ __device__ __forceinline__ uint32_t kh_below_region(u64 H, RegionGeom g, uint32_t k) {
     const uint32_t x = kh_x_of(H, g.p1_bits), b = kh_bucket_of_x(x, g.b2), w = kh_below_w(g.b2);
-    const uint32_t xoff = x - (uint32_t)kh_xlo(b, g.b2);
+    const uint32_t xoff = x - kh_xlo_k(b, g.b2, kh_x_zero_bits(k, g.p1_bits));
     const uint32_t z = w < 32 ? (uint32_t)((H << (g.p1_bits + 32)) >> (32 + w)) : 0u;  // the 32 - w hash bits behind x
     return (w < 32 ? xoff << (32 - w) : xoff) | z;
 }
 // the placement hash back from (region, window)
-__host__ __device__ __forceinline__ u64 kh_hash_of_below(u64 region, uint32_t low, RegionGeom g) {
+__host__ __device__ __forceinline__ u64 kh_hash_of_below(u64 region, uint32_t low, RegionGeom g, uint32_t k) {
     const uint32_t p1 = (uint32_t)(region / g.b2), b = (uint32_t)(region % g.b2), w = kh_below_w(g.b2);
-    const uint32_t x = (uint32_t)kh_xlo(b, g.b2) + (w < 32 ? low >> (32 - w) : low);
+    const uint32_t x = kh_xlo_k(b, g.b2, kh_x_zero_bits(k, g.p1_bits)) + (w < 32 ? low >> (32 - w) : low);
     const u64 z = w < 32 ? (u64)(low << w) : 0ull;  // left-aligned in 32 bits
     u64 H = ((u64)x << 32) | z;                    // x and what follows it, left-aligned in 64 bits ...
     H >>= g.p1_bits;                               // ... behind the level-1 digit

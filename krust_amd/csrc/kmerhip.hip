@@ -258,7 +258,11 @@ struct kh_ctx {
     std::vector<StageEv> stage_events;
 
     // ---- kh_push_text: device-side record scanning ----
-    uint8_t *txt_raw = nullptr;   u64 txt_raw_cap = 0;   // host text lands here
+    uint8_t *txt_raw2[2] = {nullptr, nullptr};  u64 txt_raw2_cap[2] = {0, 0};  // host text lands here (two: KH_FLAG_DEFER_TEXT_SCAN copies one while the other is scanned)
+    int txt_raw_next = 0;
+    hipStream_t sstream = nullptr;         // KH_FLAG_DEFER_TEXT_SCAN: the stream the scans run on, beside the copy stream
+    hipEvent_t txt_copied[2] = {nullptr, nullptr};
+    struct { bool on = false; int r = 0; u64 n = 0; int format = 0; } txt_unscanned;  // a text on the device whose scan is still to come
     uint8_t *txt_acc[2] = {nullptr, nullptr};   u64 txt_acc_cap[2] = {0, 0};    // flat bases of the texts pushed, accumulated for the count kernels
     uint8_t *txt_accq[2] = {nullptr, nullptr};  u64 txt_accq_cap[2] = {0, 0};   // ... and their qualities
     int txt_cur = 0;                       // the buffer the scans append to
@@ -324,6 +328,7 @@ int close_fresh_window(kh_ctx *c);
 int ensure_wide(kh_ctx *c);
 
 int flush_text(kh_ctx *c);
+int scan_unscanned(kh_ctx *c);
 int need_table(kh_ctx *c);
 int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool keep_window = false, bool narrow_ok = false) {
     if (!c) return KH_ERR_BAD_ARG;
@@ -338,6 +343,10 @@ int enter(kh_ctx *c, bool flush_pending = true, bool need_table = true, bool kee
     }
     if (flush_pending && c->acc_len) {
         int rc = flush_acc(c, false);
+        if (rc != KH_OK) return rc;
+    }
+    if (flush_pending && c->txt_unscanned.on) {  // (KH_FLAG_DEFER_TEXT_SCAN: the last text's scan -- and its verdict -- is still to come)
+        int rc = scan_unscanned(c);
         if (rc != KH_OK) return rc;
     }
     if (flush_pending && c->txt_acc_len) {
@@ -1826,7 +1835,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
                        c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->est_set, c->merge_off, c->chunk_part, c->fill8, c->plist,
-                       c->pcount, c->pstart, c->pool_next, c->txt_raw, c->txt_acc[0], c->txt_acc[1], c->txt_accq[0], c->txt_accq[1], c->txt_scan_partial, c->txt_ls, c->txt_hdr,
+                       c->pcount, c->pstart, c->pool_next, c->txt_raw2[0], c->txt_raw2[1], c->txt_acc[0], c->txt_acc[1], c->txt_accq[0], c->txt_accq[1], c->txt_scan_partial, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)
         if (q) (void)hipFree(q);
@@ -1835,8 +1844,14 @@ extern "C" void kh_destroy(kh_ctx *c) {
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
     if (c->h_txt) (void)hipHostFree(c->h_txt);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (c->txt_acc_done[i]) (void)hipEventDestroy(c->txt_acc_done[i]);
+        if (c->txt_copied[i]) (void)hipEventDestroy(c->txt_copied[i]);
+    }
+    if (c->sstream) {
+        (void)hipStreamSynchronize(c->sstream);
+        (void)hipStreamDestroy(c->sstream);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1851,6 +1866,8 @@ extern "C" int kh_reset(kh_ctx *c) {
     if (c->cstream) HIP_TRY(c, hipStreamSynchronize(c->cstream));
     c->acc_len = c->acc_carry = 0;  // pushes not yet counted are forgotten with everything else
     c->txt_acc_len = 0;
+    if (c->sstream) HIP_TRY(c, hipStreamSynchronize(c->sstream));
+    c->txt_unscanned.on = false;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drain_events(c);
     // Lazy: no table_init here (5.5 ms for a 34 GB table).  A partitioned batch into an empty table
@@ -2239,6 +2256,17 @@ extern "C" int kh_push_text_device(kh_ctx *c, const uint8_t *d_text, uint64_t n,
     return rc;
 }
 
+namespace {
+// KH_FLAG_DEFER_TEXT_SCAN: the text copied by the previous kh_push_text is scanned now (on the scan stream, behind its copy)
+int scan_unscanned(kh_ctx *c) {
+    if (!c->txt_unscanned.on) return KH_OK;
+    c->txt_unscanned.on = false;
+    const int r = c->txt_unscanned.r;
+    HIP_TRY(c, hipStreamWaitEvent(c->sstream, c->txt_copied[r], 0));
+    return scan_text(c, c->txt_raw2[r], c->txt_unscanned.n, c->txt_unscanned.format, c->sstream);
+}
+}  // namespace
+
 extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int format) {
     // (what earlier calls have accumulated stays where it is: it is counted when its buffer is full, or by whatever looks
     //  at the table next)
@@ -2248,26 +2276,34 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
     if (n == 0) return KH_OK;
     if ((rc = ensure_stage(c)) != KH_OK) return rc;
     if (c->acc_len && (rc = flush_acc(c, false)) != KH_OK) return rc;  // (kh_push's own accumulation: counted first, so that its buffers stay bounded)
-    if (c->txt_raw_cap < n + 64) {
-        u64 want = std::max<u64>(1ull << 20, c->txt_raw_cap);
+    const bool defer = (c->flags & KH_FLAG_DEFER_TEXT_SCAN) != 0;
+    if (defer && !c->sstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sstream, hipStreamNonBlocking));
+    // the raw buffer: always [0] when the scan follows the copy on one stream; alternating when the previous text is scanned
+    // beside this one's copy
+    const int r = defer ? c->txt_raw_next : 0;
+    if (defer) c->txt_raw_next ^= 1;
+    if (c->txt_raw2_cap[r] < n + 64) {
+        u64 want = std::max<u64>(1ull << 20, c->txt_raw2_cap[r]);
         while (want < n + 64) want *= 2;
-        HIP_TRY(c, hipStreamSynchronize(c->cstream));  // (the last text's scan reads the old buffer)
-        if (c->txt_raw) (void)hipFree(c->txt_raw);
-        c->txt_raw = nullptr;
-        c->txt_raw_cap = 0;
-        if (hipMalloc((void **)&c->txt_raw, want) != hipSuccess) {
+        HIP_TRY(c, hipStreamSynchronize(c->cstream));  // (the last text's scan read the old buffer)
+        if (c->sstream) HIP_TRY(c, hipStreamSynchronize(c->sstream));
+        if (c->txt_raw2[r]) (void)hipFree(c->txt_raw2[r]);
+        c->txt_raw2[r] = nullptr;
+        c->txt_raw2_cap[r] = 0;
+        if (hipMalloc((void **)&c->txt_raw2[r], want) != hipSuccess) {
             (void)hipGetLastError();
             return fail(c, KH_ERR_OOM, "hipMalloc(text)");
         }
-        c->txt_raw_cap = want;
+        c->txt_raw2_cap[r] = want;
     }
-    // the text -> the device, on the copy stream (behind the previous text's scan, which read the same buffer)
+    uint8_t *const raw = c->txt_raw2[r];
+    // the text -> the device, on the copy stream (behind the previous text's scan where that read the same buffer)
     if (is_pinned_host(text)) {  // pinned / registered text: one DMA, no staging memcpy
         hipEvent_t t0, t1;
         HIP_TRY(c, hipEventCreate(&t0));
         HIP_TRY(c, hipEventCreate(&t1));
         HIP_TRY(c, hipEventRecord(t0, c->cstream));
-        HIP_TRY(c, hipMemcpyAsync(c->txt_raw, text, n, hipMemcpyHostToDevice, c->cstream));
+        HIP_TRY(c, hipMemcpyAsync(raw, text, n, hipMemcpyHostToDevice, c->cstream));
         HIP_TRY(c, hipEventRecord(t1, c->cstream));
         c->h2d_events.emplace_back(t0, t1);
     } else
@@ -2281,18 +2317,33 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
         HIP_TRY(c, hipEventCreate(&t0));
         HIP_TRY(c, hipEventCreate(&t1));
         HIP_TRY(c, hipEventRecord(t0, c->cstream));
-        HIP_TRY(c, hipMemcpyAsync(c->txt_raw + off, c->h_stage[p], len, hipMemcpyHostToDevice, c->cstream));
+        HIP_TRY(c, hipMemcpyAsync(raw + off, c->h_stage[p], len, hipMemcpyHostToDevice, c->cstream));
         HIP_TRY(c, hipEventRecord(t1, c->cstream));
         HIP_TRY(c, hipEventRecord(c->stage_done[p], c->cstream));
         c->stage_used[p] = true;
         c->h2d_events.emplace_back(t0, t1);
     }
-    // The scan -- the part that can refuse the text -- runs right behind the copy, on the same stream, and is over when this
-    // call returns (its first host read-back waits for the copy too: the caller may reuse its buffer).
-    rc = scan_text(c, c->txt_raw, n, format, c->cstream);
-    if (rc != KH_OK) (void)hipStreamSynchronize(c->cstream);  // (whatever happened: the caller gets its buffer back)
-    if (rc == KH_OK) c->bases_pushed += n;
-    return rc;
+    if (!defer) {
+        // The scan -- the part that can refuse the text -- runs right behind the copy, on the same stream, and is over when this
+        // call returns (its first host read-back waits for the copy too: the caller may reuse its buffer).
+        rc = scan_text(c, raw, n, format, c->cstream);
+        if (rc != KH_OK) (void)hipStreamSynchronize(c->cstream);  // (whatever happened: the caller gets its buffer back)
+        if (rc == KH_OK) c->bases_pushed += n;
+        return rc;
+    }
+    // KH_FLAG_DEFER_TEXT_SCAN: while this text travels, the PREVIOUS one is scanned on the scan stream (kernels and host
+    // round trips beside the DMA); this one's scan -- and a refusal of it -- is the next call's business (or kh_finish's)
+    if (!c->txt_copied[r]) HIP_TRY(c, hipEventCreateWithFlags(&c->txt_copied[r], hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->txt_copied[r], c->cstream));
+    rc = scan_unscanned(c);
+    (void)hipEventSynchronize(c->txt_copied[r]);  // the caller may reuse its buffer
+    if (rc != KH_OK) return rc;  // the previous text was refused (or its scan failed): this one is dropped with it -- the caller starts over
+    c->txt_unscanned.on = true;
+    c->txt_unscanned.r = r;
+    c->txt_unscanned.n = n;
+    c->txt_unscanned.format = format;
+    c->bases_pushed += n;
+    return KH_OK;
 }
 
 extern "C" int kh_finish(kh_ctx *c, kh_stats *st) {

@@ -46,9 +46,9 @@ __device__ __forceinline__ SlotVal slot_read(const SlotSrc &src, u64 i) {
 struct BelowCtx {
     uint32_t xlo, w;
 };
-__device__ __forceinline__ BelowCtx below_ctx(const SlotSrc &src, u64 r) {
+__device__ __forceinline__ BelowCtx below_ctx(const SlotSrc &src, u64 r, uint32_t k) {
     BelowCtx b;
-    b.xlo = (uint32_t)kh_xlo((uint32_t)(r % src.geo.b2), src.geo.b2);
+    b.xlo = kh_xlo_k((uint32_t)(r % src.geo.b2), src.geo.b2, kh_x_zero_bits(k, src.geo.p1_bits));
     b.w = kh_below_w(src.geo.b2);
     return b;
 }
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc sr
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
     bool too_wide = false;
-    const BelowCtx bc = below_ctx(src, r);
+    const BelowCtx bc = below_ctx(src, r, k);
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {
         const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
         const bool live = s.live;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src
     if (threadIdx.x == 0) s_cur = 0;
     __syncthreads();
     const uint32_t cmask = (1u << cb) - 1u;
-    const BelowCtx bc = below_ctx(src, r);
+    const BelowCtx bc = below_ctx(src, r, k);
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {  // uniform trip count
         const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
         const bool live = s.live;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
         SegBase sb;
         const uint32_t p1 = (uint32_t)(rs / a.sgeo.b2), b = (uint32_t)(rs % a.sgeo.b2);
         sb.htop = a.sgeo.p1_bits ? (u64)p1 << (64 - a.sgeo.p1_bits) : 0ull;
-        sb.xlo = (uint32_t)kh_xlo(b, a.sgeo.b2);
+        sb.xlo = kh_xlo_k(b, a.sgeo.b2, kh_x_zero_bits(tg.k, a.sgeo.p1_bits));
         return sb;
     };
     // one incoming unit: raw0 = key / packed pair / head, raw1 = count (FMT 0 only)

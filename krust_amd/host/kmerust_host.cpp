@@ -248,6 +248,9 @@ struct Session {
         cfg.device = kc.device_;
         cfg.capacity_hint = kc.capacity_hint_;
         cfg.input_mib = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (input_bytes + (1u << 20) - 1) >> 20);
+        // (a chunk's record scan runs beside the next chunk's transfer; a refusal then comes one call late -- count_file_text
+        //  starts the whole file over on a refusal anyway)
+        cfg.flags |= KH_FLAG_DEFER_TEXT_SCAN;
         if (kc.devices_.size() > 1) {
             std::vector<int32_t> devs(kc.devices_.begin(), kc.devices_.end());
             const int rc = kh_group_create(&group, &cfg, devs.data(), (uint32_t)devs.size());
@@ -378,9 +381,10 @@ struct Session {
         std::function<int()> stopper = stop_workers;
         Joiner joiner{stopper};
 
-        // (128 MiB chunks.  The chunk buffers are pinned, and pinning runs at ~5 GB/s: two 256 MiB buffers cost 0.12 s of every
-        //  run.  The size of a chunk no longer decides the size of a counting batch: since round 4 the library accumulates the
-        //  scanned chunks on the device and counts tens of GB at a time -- kmerhip.hip, scan_text.)
+        // (256 MiB chunks.  The chunk buffers are pinned, and pinning runs at ~5 GB/s: two 256 MiB buffers cost ~0.1 s of every
+        //  run; a chunk of half the size halves that but pays the per-chunk scan overhead twice as often: 0.87 s of pushes for
+        //  a 31.6 GB file at 128 MiB.  The size of a chunk no longer decides the size of a counting batch: since round 4 the
+        //  library accumulates the scanned chunks on the device and counts tens of GB at a time -- kmerhip.hip, scan_text.)
         const size_t chunk = text_chunk_bytes();
         // The chunk buffer is PINNED memory (kh_host_alloc): kh_push_text then DMAs from it -- no staging memcpy inside the
         // library -- and a plain file is read into it by several pread() calls side by side (one read() moves ~6 GB/s
@@ -567,7 +571,13 @@ struct Session {
             memmove(buf.data(), buf.data() + cut, have - cut);
             have -= cut;
         }
-        const int rc = stop_workers();
+        int rc = stop_workers();
+        // the last chunk's scan (KH_FLAG_DEFER_TEXT_SCAN) has not given its verdict yet: kh_finish brings it
+        for (size_t i = 0; i < ctxs.size() && rc == KH_OK; ++i) {
+            Lap lap(timing().finish_s);
+            rc = kh_finish(ctxs[i], nullptr);
+            if (rc != KH_OK && rc != KH_ERR_FORMAT) failed_ctx = ctxs[i];
+        }
         if (rc == KH_ERR_FORMAT) {
             if (pushed) reset_all();
             return false;
@@ -585,7 +595,7 @@ struct Session {
     }
     static size_t text_chunk_bytes() {
         const char *e = getenv("KMERUST_TEXT_CHUNK_KB");  // tests use small chunks to exercise the cuts
-        return (e && atol(e) > 0 ? (size_t)atol(e) : (size_t)128 << 10) << 10;  // (128 MiB: pinning costs ~0.2 s per GiB, and the device accumulates the chunks anyway)
+        return (e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256 << 10) << 10;  // (256 MiB: a chunk costs ~1 ms of scan kernels and host round trips beside its 4.7 ms of DMA)
     }
     // Largest p > 0 with a record starting at p ('>' at a line start); 0 if none.
     static size_t fasta_cut(const uint8_t *b, size_t n) {

@@ -53,7 +53,7 @@ class KhMergeInfo(C.Structure):
 ROUTES = ("none", "dense", "regions-heads", "regions-packed", "regions", "pairs")  # KH_ROUTE_*
 # names of kh_stats.stage_ms[i] (KH_STAGE_* of the header); bench.py maps them to the kernels that ran
 STAGES = ("direct", "unused", "level1", "level2_count", "level2", "region", "misc", "grow")
-FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION, FLAG_CALLER_STREAM = 1, 2, 4, 8
+FLAG_TRACE, FLAG_FORCE_DIRECT, FLAG_FORCE_PARTITION, FLAG_CALLER_STREAM, FLAG_DEFER_TEXT_SCAN = 1, 2, 4, 8, 16
 
 
 # every symbol include/kmerhip.h declares: name -> (restype, argtypes)
@@ -175,7 +175,8 @@ class DeviceCounter:
     Stands where the reference has `KmerMap` (src/run.rs:491-583): build()/
     build_with_quality() -> push()/push_device(); into_hashmap() -> result()."""
 
-    def __init__(self, k, min_quality=None, capacity_hint=0, device=-1, stream=None, trace=False, path=None):
+    def __init__(self, k, min_quality=None, capacity_hint=0, device=-1, stream=None, trace=False, path=None, defer_text_scan=False,
+                 input_bytes=0):
         """stream: None = the context creates its own non-blocking stream (NOT ordered with torch's streams:
         synchronise buffers you hand over yourself); an integer = launch on that hipStream_t, where 0 is the
         legacy default stream (torch.cuda.current_stream().cuda_stream is usually 0)."""
@@ -184,7 +185,9 @@ class DeviceCounter:
         cfg = KhConfig(C.sizeof(KhConfig), int(k), -1 if min_quality is None else int(min_quality),
                        int(device), int(capacity_hint), stream or None,
                        (FLAG_TRACE if trace else 0) | (FLAG_CALLER_STREAM if stream is not None else 0)
-                       | {None: 0, "auto": 0, "direct": FLAG_FORCE_DIRECT, "partition": FLAG_FORCE_PARTITION}[path], 0)
+                       | (FLAG_DEFER_TEXT_SCAN if defer_text_scan else 0)
+                       | {None: 0, "auto": 0, "direct": FLAG_FORCE_DIRECT, "partition": FLAG_FORCE_PARTITION}[path],
+                       min(0xFFFFFFFF, (int(input_bytes) + (1 << 20) - 1) >> 20))
         h = _P()
         rc = lib().kh_create(C.byref(h), C.byref(cfg))
         if rc != KH_OK:

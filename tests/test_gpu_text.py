@@ -359,3 +359,42 @@ def test_text_accumulates_on_the_device_and_switches_buffers(monkeypatch, fmt, m
         keys, counts = dc.result()
     assert st["kmers"] == sum(want.values())
     assert dict(zip(keys.tolist(), counts.tolist())) == want
+
+
+def test_deferred_text_scan_reports_one_call_late_and_counts_the_same():
+    """KH_FLAG_DEFER_TEXT_SCAN (what the kmerust command line sets): kh_push_text returns when its text is on the device;
+    the PREVIOUS text is scanned beside the transfer, this one during the next call (kh_finish at the latest).  Same table
+    as without the flag; a refusal arrives one call late and concerns the previous text -- the text of the call that
+    reports it is dropped too, nothing of either is counted; after a reset the context works again."""
+    rng = np.random.default_rng(911)
+    k, minq = 21, 20
+    parts = [make_fastq(rng, 900, 60, 180) for _ in range(6)]
+    want = {}
+    for p in parts:
+        for kk, v in expect(p, "fastq", k, minq).items():
+            want[kk] = want.get(kk, 0) + v
+    with native.DeviceCounter(k, min_quality=minq, defer_text_scan=True) as dc:
+        for p in parts:
+            dc.push_text(p, "fastq")
+        st = dc.finish()                       # scans the last text, counts everything
+        keys, counts = dc.result()
+        assert st["kmers"] == sum(want.values()) and dict(zip(keys.tolist(), counts.tolist())) == want
+        # a refused layout: reported by the NEXT call
+        dc.reset()
+        dc.push_text(parts[0], "fastq")
+        dc.push_text(b"@r\nACGT\n-\nIIII\n", "fastq")            # returns OK: not scanned yet (parts[0] was, beside its copy)
+        with pytest.raises(native.KmerHipError) as e:
+            dc.push_text(parts[1], "fastq")                      # the bad text's verdict; parts[1] is dropped with it
+        assert e.value.status == native.KH_ERR_FORMAT
+        st = dc.finish()
+        e0 = expect(parts[0], "fastq", k, minq)
+        assert st["kmers"] == sum(e0.values())                   # only the first text was ever counted
+        # ... or by kh_finish when nothing else comes
+        dc.reset()
+        dc.push_text(b"@r\nACGT\n-\nIIII\n", "fastq")
+        with pytest.raises(native.KmerHipError) as e:
+            dc.finish()
+        assert e.value.status == native.KH_ERR_FORMAT
+        dc.reset()
+        dc.push_text(parts[2], "fastq")
+        assert dc.finish()["kmers"] == sum(expect(parts[2], "fastq", k, minq).values())
