@@ -144,9 +144,11 @@ int kh_push_device(kh_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual, u
  * between FASTQ records, a missing '@' / '+' / '>' marker, |seq| != |qual|, blanks at line ends of
  * a FASTA record): the caller then parses that text itself and uses kh_push.
  * kh_push_text returns when `text` has been copied and scanned (the caller may reuse it; a refusal is always about
- * THIS call's text); like kh_push it may leave the counting to the next call that enters the context -- the next
- * kh_push_text copies its text to the device meanwhile -- so an error of the counting itself (KH_ERR_OOM,
- * KH_ERR_TABLE_FULL: errors that poison the context) can surface one call later, at the latest in kh_finish.
+ * THIS call's text -- unless the context was created with KH_FLAG_DEFER_TEXT_SCAN).  The scanned, flat form of the texts
+ * ACCUMULATES on the device (up to an eighth of the free memory, or kh_config.input_mib) and is counted when that is
+ * full or when anything looks at the table (kh_finish, kh_result_*, kh_lookup, kh_push_device ...): a file streamed in
+ * chunks is counted in one or a few large batches.  So an error of the counting itself (KH_ERR_OOM, KH_ERR_TABLE_FULL:
+ * errors that poison the context) can surface in a later call, at the latest in kh_finish.
  * kh_push_text_device: d_text must be 16-byte aligned. */
 #define KH_TEXT_FASTA 1
 #define KH_TEXT_FASTQ 2

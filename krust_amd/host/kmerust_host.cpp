@@ -250,7 +250,7 @@ struct Session {
         cfg.input_mib = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (input_bytes + (1u << 20) - 1) >> 20);
         // (a chunk's record scan runs beside the next chunk's transfer; a refusal then comes one call late -- count_file_text
         //  starts the whole file over on a refusal anyway)
-        cfg.flags |= KH_FLAG_DEFER_TEXT_SCAN;
+        if (const char *e = getenv("KMERUST_DEFER_SCAN"); !(e && e[0] == '0')) cfg.flags |= KH_FLAG_DEFER_TEXT_SCAN;
         if (kc.devices_.size() > 1) {
             std::vector<int32_t> devs(kc.devices_.begin(), kc.devices_.end());
             const int rc = kh_group_create(&group, &cfg, devs.data(), (uint32_t)devs.size());
