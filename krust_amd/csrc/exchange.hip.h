@@ -896,6 +896,7 @@ int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id
     cm->hub = hub;
     cm->timeout_s = merge_timeout_env();
     if (hub) hub->timeout_s = cm->timeout_s;
+    c->part_budget = 0;  // (decided again at the next partitioned range: a rank of a merge leaves room for the exchange)
     c->comm = cm;
     int rc = KH_OK;
     if (hipStreamCreateWithFlags(&cm->xs, hipStreamNonBlocking) != hipSuccess) rc = fail(c, KH_ERR_HIP, "hipStreamCreate(exchange)");

@@ -1415,8 +1415,12 @@ void ensure_part_budget(kh_ctx *c) {
     // (up to 0.78 of what is free: the 8-byte table image -- 8 bytes per slot, allocated after level 2 -- and the small arrays
     //  take the rest.  Round 3 stopped at 160 GiB / 0.75: configs[3]'s 125 M reads then ran as two batches, the second one a
     //  pass over a filled table that re-reads and re-writes all of it: 36 ms of region pass where one fresh pass takes 24)
+    // A rank of a multi-GPU merge (a communicator is attached) leaves room for what kh_merge_across allocates while the
+    // partition buffers are still there: send and receive buffers (16 B per local key) and the shard's 16-byte table -- about
+    // 49 B per local key, 64 GB at configs[3]'s size -- hence 0.55 there: configs[3]'s share then runs as two batches.
     u64 budget = 224ull << 30;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * 0.78));
+    const double share = c->comm ? 0.55 : 0.78;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * share));
     else (void)hipGetLastError();
     if (c->knobs.part_budget_gb > 0) budget = (u64)(c->knobs.part_budget_gb * (double)(1ull << 30));
     c->part_budget = std::max<u64>(budget, 64ull << 20);
@@ -2748,6 +2752,12 @@ extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
     if (sh >= 2 * c->k) return fail(c, KH_ERR_BAD_ARG, "more shards than k-mers");
     c->shard_shift = sh;
     c->shard_index = index;
+    if (c->ntab) {  // (a shard table is never kept as the 8-byte image: its 8 bytes per slot are room for the shard's 16-byte table)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->ntab);
+        c->ntab = nullptr;
+        c->ntab_cap = 0;
+    }
     return KH_OK;
 }
 

@@ -381,10 +381,12 @@ struct Session {
         std::function<int()> stopper = stop_workers;
         Joiner joiner{stopper};
 
-        // (256 MiB chunks.  The chunk buffers are pinned, and pinning runs at ~5 GB/s: two 256 MiB buffers cost ~0.1 s of every
-        //  run; a chunk of half the size halves that but pays the per-chunk scan overhead twice as often: 0.87 s of pushes for
-        //  a 31.6 GB file at 128 MiB.  The size of a chunk no longer decides the size of a counting batch: since round 4 the
-        //  library accumulates the scanned chunks on the device and counts tens of GB at a time -- kmerhip.hip, scan_text.)
+        // (128 MiB chunks.  The chunk buffers are pinned, and pinning runs at ~5 GB/s: two 256 MiB buffers cost ~0.1 s of every
+        //  run, two of 128 MiB half that.  Measured on a 31.6 GB FASTQ (tools/cli_s100m_probe.py): the pushes take 0.75-0.78 s at
+        //  64, 128 and 256 MiB alike -- 41 GB/s, what one host buffer DMAs at; a chunk's scan runs beside the next chunk's
+        //  transfer (KH_FLAG_DEFER_TEXT_SCAN) -- so the smaller buffers win: 1.21 s against 1.32 s of wall time.  The size of a
+        //  chunk no longer decides the size of a counting batch: since round 4 the library accumulates the scanned chunks on the
+        //  device and counts tens of GB at a time -- kmerhip.hip, scan_text.)
         const size_t chunk = text_chunk_bytes();
         // The chunk buffer is PINNED memory (kh_host_alloc): kh_push_text then DMAs from it -- no staging memcpy inside the
         // library -- and a plain file is read into it by several pread() calls side by side (one read() moves ~6 GB/s
@@ -595,7 +597,7 @@ struct Session {
     }
     static size_t text_chunk_bytes() {
         const char *e = getenv("KMERUST_TEXT_CHUNK_KB");  // tests use small chunks to exercise the cuts
-        return (e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256 << 10) << 10;  // (256 MiB: a chunk costs ~1 ms of scan kernels and host round trips beside its 4.7 ms of DMA)
+        return (e && atol(e) > 0 ? (size_t)atol(e) : (size_t)128 << 10) << 10;  // (128 MiB: see count_file_text)
     }
     // Largest p > 0 with a record starting at p ('>' at a line start); 0 if none.
     static size_t fasta_cut(const uint8_t *b, size_t n) {
