@@ -170,7 +170,7 @@ def cpu_baseline(host_bases, k, target_seconds):
 # here against the __global__ kernels of krust_amd/csrc and against the committed rocprofv3 trace of this command.
 def payload_bytes(k):
     """Bytes per k-mer in the partition buffers at bench table sizes (>= 2^10 regions): 4 while the 2k - 10 hash bits
-    below the level-1 digit fit 32 (k <= 21), the 8-byte key otherwise (make_geom, kmerhip.hip)."""
+    below the level-1 digit fit 32 (k <= 21), the 8-byte key otherwise (make_geom, krust_amd/csrc/kmerhip.hip)."""
     return 4 if 2 * k - 10 <= 32 else 8
 
 

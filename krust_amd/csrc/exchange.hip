@@ -1,6 +1,6 @@
-// exchange.hip.h -- the multi-GPU exchange behind the C ABI: kh_comm_* / kh_merge_across / kh_group_*.
+// exchange.hip -- the multi-GPU exchange behind the C ABI: kh_comm_* / kh_merge_across / kh_group_*.
 //
-// Included by kmerhip.hip (same translation unit: it drives the export / merge entry points defined there).
+// A translation unit of its own over ctx.hip.h: it drives the export / merge entry points of merge.hip.
 // north_star: "reads shard naturally per GPU across the 8 x MI355X node with a final RCCL reduce of per-GPU
 // hash tables over xGMI".  A hash table is not element-wise reducible, so the "reduce" is an all-to-all of
 // region segments to owner = top bits of the table hash, then an LDS rebuild of every owner's shard
@@ -14,7 +14,8 @@
 // Transport: RCCL when every rank has its own device; a process-local hub (device-to-device copies between
 // the threads' contexts) when a kh_group lists a device twice -- the 1-GPU test box -- because RCCL refuses
 // duplicate devices.  Both sit behind `Xport`, so the merge sequence is one piece of code.
-#pragma once
+#include "ctx.hip.h"
+#include "shard.hip.h"
 
 #include <rccl/rccl.h>
 
@@ -41,7 +42,7 @@
 // or a rank that cannot go on, poisons the hub and every barrier returns at once.
 // KMERHIP_FAULT="rank:point[:status]" (tests) makes `rank` fail at a named point of the sequence.
 
-namespace {
+namespace khi {
 
 // KMERHIP_MERGE_TIMEOUT_S: read when a communicator (or a hub) is set up, kept there
 double merge_timeout_env() {
@@ -443,7 +444,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
     if (lrc == KH_OK) lrc = inject("start");
     const u64 n_local = lrc == KH_OK ? c->h_ctr->distinct : 0;
-    const u64 nreg = c->cap / kh::REGION_SLOTS;
+    u64 nreg = c->cap / kh::REGION_SLOTS;
     mi.local_distinct = n_local;
     int rc;
 
@@ -473,6 +474,26 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         mi.sent_units = mi.recv_units = n;
         if (lrc == KH_OK) mi.owned_distinct = c->h_ctr->distinct;
         return finish(lrc);
+    }
+
+    // ---- one table geometry for every rank (round 4) ----
+    // A table is sized from its own rank's level-1 sample (batch.hip): two ranks whose estimates fall on either side of a size
+    // step hold tables of different geometry, whose regions do not correspond -- such a world used to take the generic route.
+    // The smaller tables are re-laid-out to the largest one first (grow_to: one rehash pass over a table's keys), so that the
+    // region routes below apply.  (A rank that cannot -- out of memory -- says so in the next gather like any other failure.)
+    if ((rc = gather(lrc, {nreg}, "the table sizes")) != KH_OK) return done(rc);
+    {
+        u64 target = 0;
+        for (uint32_t r = 0; r < W; ++r) target = std::max(target, all[r]);
+        if (nreg < target && kh::kh_regions_valid(target)) {
+            const double t0 = now_ms();
+            lrc = grow_to(c, target * kh::REGION_SLOTS);
+            if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
+            if (lrc == KH_OK) nreg = c->cap / kh::REGION_SLOTS;
+            t_export += now_ms() - t0;
+            if (c->trace) fprintf(stderr, "[kmerhip] merge: rank %u re-laid its table out to %llu regions (the largest of the world) in %.1f ms\n", R,
+                                  (unsigned long long)target, now_ms() - t0);
+        }
     }
 
     const bool pow2 = (W & (W - 1)) == 0;
@@ -933,7 +954,8 @@ int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id
     return rc;
 }
 
-}  // namespace
+}  // namespace khi
+using namespace khi;
 
 // =============================================================================================
 // C ABI

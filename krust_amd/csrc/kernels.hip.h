@@ -14,6 +14,10 @@
 
 #include "kmer_bits.h"
 
+// A kernel that is not a template: every translation unit that includes its header gets a copy of its own (the units that do
+// not launch it drop theirs), so that the headers can be shared between units.
+#define KH_GLOBAL [[maybe_unused]] static __global__
+
 namespace kh {
 
 typedef unsigned long long u64;
@@ -606,7 +610,7 @@ __global__ __launch_bounds__(BLOCK) void survival_sample_kernel(
 // ---------------------------------------------------------------------------------------------
 // table maintenance
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void table_init_kernel(Slot *table, u64 cap) {
+KH_GLOBAL __launch_bounds__(BLOCK) void table_init_kernel(Slot *table, u64 cap) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint4 e = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride)
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(BLOCK) void table_init_kernel(Slot *table, u64 cap)
 }
 
 // ctr->cursor += number of live slots with count >= min_count
-__global__ __launch_bounds__(BLOCK) void table_count_kernel(const Slot *table, u64 cap, u64 min_count, Counters *ctr) {
+KH_GLOBAL __launch_bounds__(BLOCK) void table_count_kernel(const Slot *table, u64 cap, u64 min_count, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     u64 n = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
@@ -676,7 +680,7 @@ __device__ __forceinline__ void compact_tiles(u64 cap, u64 *__restrict__ keys, u
         __syncthreads();  // (s_wave / s_base are reused by the next tile)
     }
 }
-__global__ __launch_bounds__(BLOCK) void table_compact_kernel(const Slot *table, u64 cap, u64 min_count, u64 *keys,
+KH_GLOBAL __launch_bounds__(BLOCK) void table_compact_kernel(const Slot *table, u64 cap, u64 min_count, u64 *keys,
                                                               u64 *counts, u64 out_cap, Counters *ctr) {
     compact_tiles(cap, keys, counts, out_cap, ctr, [&](u64 i, u64 &key, u64 &count) {
         const uint4 v = *reinterpret_cast<const uint4 *>(&table[i]);
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(BLOCK) void table_compact_kernel(const Slot *table,
 }
 
 // count[key] += addend for n (key, addend) pairs: rehash-free merge of another table's pairs.
-__global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(TableGeom tg, const u64 *keys,
+KH_GLOBAL __launch_bounds__(BLOCK) void table_merge_pairs_kernel(TableGeom tg, const u64 *keys,
                                                                   const u64 *counts, u64 n, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(BLOCK) void table_merge_pairs_kernel(TableGeom tg, 
 
 // ---- dense form for small k (2k <= 26 bits of key space): element-wise reducible ------------------
 // dense[key] = count of every live pair (dense[] is zeroed by the host first; keys are unique).
-__global__ __launch_bounds__(BLOCK) void table_to_dense_kernel(const Slot *__restrict__ table, u64 cap, u64 *__restrict__ dense,
+KH_GLOBAL __launch_bounds__(BLOCK) void table_to_dense_kernel(const Slot *__restrict__ table, u64 cap, u64 *__restrict__ dense,
                                                                u64 n_entries) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(BLOCK) void table_to_dense_kernel(const Slot *__res
 }
 
 // count[key] += dense[key] for every key with a non-zero entry that shard `owner` of `nparts` owns.
-__global__ __launch_bounds__(BLOCK) void table_merge_dense_kernel(TableGeom tg, const u64 *__restrict__ dense, u64 n_entries,
+KH_GLOBAL __launch_bounds__(BLOCK) void table_merge_dense_kernel(TableGeom tg, const u64 *__restrict__ dense, u64 n_entries,
                                                                   uint32_t owner, uint32_t nparts, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(BLOCK) void table_merge_dense_kernel(TableGeom tg, 
 }
 
 // Move every live pair of `old` into `nt` (table growth).
-__global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, TableGeom tg,
+KH_GLOBAL __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u64 oldcap, TableGeom tg,
                                                              Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
@@ -743,7 +747,7 @@ __global__ __launch_bounds__(BLOCK) void table_rehash_kernel(const Slot *old, u6
     if (lane_id() == 0 && f) atomicAdd(&ctr->failed, f);
 }
 
-__global__ __launch_bounds__(BLOCK) void table_lookup_kernel(TableGeom tg, const u64 *keys, u64 n, u64 *out) {
+KH_GLOBAL __launch_bounds__(BLOCK) void table_lookup_kernel(TableGeom tg, const u64 *keys, u64 n, u64 *out) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(BLOCK) void table_lookup_kernel(TableGeom tg, const
 constexpr uint32_t HIST_LDS = 2048;
 constexpr uint32_t HIST_DENSE = 1u << 16;
 
-__global__ __launch_bounds__(BLOCK) void table_hist_kernel(const Slot *table, u64 cap, u64 min_count, u64 *dense,
+KH_GLOBAL __launch_bounds__(BLOCK) void table_hist_kernel(const Slot *table, u64 cap, u64 min_count, u64 *dense,
                                                            u64 *big, u64 big_cap, Counters *ctr) {
     __shared__ uint32_t s_bins[HIST_LDS];
     for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) s_bins[i] = 0;
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(BLOCK) void table_hist_kernel(const Slot *table, u6
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t MAX_PARTS = 256;
 
-__global__ __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u64 cap, uint32_t k, uint32_t nparts,
+KH_GLOBAL __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u64 cap, uint32_t k, uint32_t nparts,
                                                             u64 *part_counts) {
     __shared__ uint32_t s_cnt[MAX_PARTS];
     for (uint32_t i = threadIdx.x; i < nparts; i += BLOCK) s_cnt[i] = 0;
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(BLOCK) void owner_count_kernel(const Slot *table, u
 }
 
 // cursors[p] starts at the exclusive prefix of part_counts; wave-aggregated per owner.
-__global__ __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table, u64 cap, uint32_t k, uint32_t nparts,
+KH_GLOBAL __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table, u64 cap, uint32_t k, uint32_t nparts,
                                                               u64 *cursors, u64 *keys, u64 *counts, u64 out_cap) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     const u64 first = (u64)blockIdx.x * BLOCK + threadIdx.x;
@@ -848,7 +852,7 @@ __global__ __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table,
 // ---------------------------------------------------------------------------------------------
 // deterministic synthetic reads: one lane per 16 output bytes, one 16-byte store each
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void synth_reads_kernel(u64 seed, u64 genome_len, uint32_t read_len,
+KH_GLOBAL __launch_bounds__(BLOCK) void synth_reads_kernel(u64 seed, u64 genome_len, uint32_t read_len,
                                                             u64 first_read, u64 n_reads, uint8_t *bases,
                                                             uint8_t *qual) {
     const u64 kg = kh_stream_key(seed, 0), ks = kh_stream_key(seed, 1), kd = kh_stream_key(seed, 2),

@@ -33,7 +33,7 @@ namespace kh {
 // ---- chunk list: chunk ids ordered by partition ---------------------------------------------------
 // pcount[p] += chunks owned by partition p among ids [0, nchunks)
 // ptotal (optional): ptotal[p] += payloads in those chunks
-__global__ __launch_bounds__(1024) void chunk_hist_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
+KH_GLOBAL __launch_bounds__(1024) void chunk_hist_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
                                                           u64 pool_chunks, uint32_t *__restrict__ pcount,
                                                           const uint8_t *__restrict__ fill8, u64 *__restrict__ ptotal) {
     __shared__ uint32_t s_h[MAX_P1];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(1024) void chunk_hist_kernel(const uint16_t *__rest
 
 // plist[pstart[p] + rank] = chunk id.  cursors[] starts as a copy of pstart[] (low 32 bits suffice:
 // a pool holds far fewer than 2^32 chunks).  One workgroup per 16384 chunk ids.
-__global__ __launch_bounds__(1024) void chunk_list_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
+KH_GLOBAL __launch_bounds__(1024) void chunk_list_kernel(const uint16_t *__restrict__ chunk_part, const u64 *__restrict__ pool_next,
                                                           u64 pool_chunks, uint32_t *__restrict__ cursors,
                                                           uint32_t *__restrict__ plist) {
     __shared__ uint32_t s_h[MAX_P1];
@@ -165,7 +165,7 @@ __device__ __forceinline__ u64 block_scan_1024(u64 v, u64 *s_scan, int tid, u64 
     return incl - v;
 }
 
-__global__ __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__restrict__ pstart, PartGeom g,
+KH_GLOBAL __launch_bounds__(1024) void part2_plan_chunked_kernel(const u64 *__restrict__ pstart, PartGeom g,
                                                                   Part2Block *__restrict__ blocks, u64 max_blocks,
                                                                   u64 *__restrict__ moff, uint32_t *__restrict__ nch,
                                                                   u64 *__restrict__ info, uint32_t *__restrict__ cursors,
@@ -224,7 +224,7 @@ constexpr int SCAN_NT = 256;
 constexpr int SCAN_PER = 16;
 constexpr int SCAN_CHUNK = SCAN_NT * SCAN_PER;  // 4096 entries per workgroup
 
-__global__ __launch_bounds__(SCAN_NT) void scan_partials_kernel(const uint32_t *__restrict__ in, u64 n, u64 *__restrict__ partial) {
+KH_GLOBAL __launch_bounds__(SCAN_NT) void scan_partials_kernel(const uint32_t *__restrict__ in, u64 n, u64 *__restrict__ partial) {
     __shared__ u64 s_w[SCAN_NT / 64];
     const u64 base = (u64)blockIdx.x * SCAN_CHUNK;
     u64 s = 0;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(SCAN_NT) void scan_partials_kernel(const uint32_t *
 }
 
 // single workgroup: in-place exclusive scan of partial[0..nb), total -> partial[nb]
-__global__ __launch_bounds__(1024) void scan_spine_kernel(u64 *__restrict__ partial, u64 nb) {
+KH_GLOBAL __launch_bounds__(1024) void scan_spine_kernel(u64 *__restrict__ partial, u64 nb) {
     __shared__ u64 s_w[16];
     __shared__ u64 s_carry;
     const int tid = threadIdx.x;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(1024) void scan_spine_kernel(u64 *__restrict__ part
     if (tid == 0) partial[nb] = s_carry;
 }
 
-__global__ __launch_bounds__(SCAN_NT) void scan_apply_kernel(const uint32_t *__restrict__ in, u64 n,
+KH_GLOBAL __launch_bounds__(SCAN_NT) void scan_apply_kernel(const uint32_t *__restrict__ in, u64 n,
                                                              const u64 *__restrict__ partial, u64 *__restrict__ out) {
     __shared__ u64 s_w[SCAN_NT / 64];
     const int tid = threadIdx.x;
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_scatter_lines_kernel(const PT *_
 // chunks, any number of workgroups) and their buckets follow the arenas in the same buffer.  ovf[2] = heavy partitions,
 // ovf[3] = payloads in them; ovf[1] = 2 only if those exceed heavy_room payloads (the room the host has reserved behind
 // the arenas): then the batch does take the exact path as a whole.
-__global__ __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict__ ptotal, PartGeom g, u64 *__restrict__ bstart,
+KH_GLOBAL __launch_bounds__(1024) void arena_plan_kernel(const u64 *__restrict__ ptotal, PartGeom g, u64 *__restrict__ bstart,
                                                           uint32_t *__restrict__ pcap, u64 *__restrict__ ovf, uint32_t skew_x,
                                                           uint8_t *__restrict__ heavy, u64 heavy_room) {
     __shared__ u64 s_base[MAX_P1 + 1];
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(BLOCK) void ovf_agg_insert_kernel(TableGeom tg, Par
 }
 
 // ntab -> the 16-byte table (every slot of it is written)
-__global__ __launch_bounds__(BLOCK) void ntable_widen_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, Slot *__restrict__ table) {
+KH_GLOBAL __launch_bounds__(BLOCK) void ntable_widen_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, Slot *__restrict__ table) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
         const u64 sl = ntab[i];
@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(BLOCK) void ntable_widen_kernel(const u64 *__restri
     }
 }
 // the narrow twins of table_count_kernel / table_compact_kernel / table_hist_kernel / table_lookup_kernel (kernels.hip.h)
-__global__ __launch_bounds__(BLOCK) void ntable_count_kernel(const u64 *__restrict__ ntab, u64 cap, u64 min_count, Counters *ctr) {
+KH_GLOBAL __launch_bounds__(BLOCK) void ntable_count_kernel(const u64 *__restrict__ ntab, u64 cap, u64 min_count, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     u64 n = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(BLOCK) void ntable_count_kernel(const u64 *__restri
     n = wave_sum(n);
     if (lane_id() == 0 && n) atomicAdd(&ctr->cursor, n);
 }
-__global__ __launch_bounds__(BLOCK) void ntable_compact_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, u64 min_count, u64 *keys,
+KH_GLOBAL __launch_bounds__(BLOCK) void ntable_compact_kernel(const u64 *__restrict__ ntab, u64 cap, PartGeom g, u64 min_count, u64 *keys,
                                                                u64 *counts, u64 out_cap, Counters *ctr) {
     compact_tiles(cap, keys, counts, out_cap, ctr, [&](u64 i, u64 &key, u64 &count) {
         const u64 sl = ntab[i];
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(BLOCK) void ntable_compact_kernel(const u64 *__rest
         return live;
     });
 }
-__global__ __launch_bounds__(BLOCK) void ntable_hist_kernel(const u64 *__restrict__ ntab, u64 cap, u64 min_count, u64 *dense, u64 *big,
+KH_GLOBAL __launch_bounds__(BLOCK) void ntable_hist_kernel(const u64 *__restrict__ ntab, u64 cap, u64 min_count, u64 *dense, u64 *big,
                                                             u64 big_cap, Counters *ctr) {
     __shared__ uint32_t s_bins[HIST_LDS];
     for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) s_bins[i] = 0;
@@ -1204,7 +1204,7 @@ __global__ __launch_bounds__(BLOCK) void ntable_hist_kernel(const u64 *__restric
         if (v) atomicAdd(&dense[i], (u64)v);
     }
 }
-__global__ __launch_bounds__(BLOCK) void ntable_lookup_kernel(const u64 *__restrict__ ntab, PartGeom g, const u64 *keys, u64 n, u64 *out) {
+KH_GLOBAL __launch_bounds__(BLOCK) void ntable_lookup_kernel(const u64 *__restrict__ ntab, PartGeom g, const u64 *keys, u64 n, u64 *out) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeo
 }
 
 // bstart[r] = first payload of region r's bucket in the level-2 output, r in [0, R]; bstart[R] = total
-__global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restrict__ O2, u64 o2_total_index,
+KH_GLOBAL __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restrict__ O2, u64 o2_total_index,
                                                             const u64 *__restrict__ moff, const uint32_t *__restrict__ nch,
                                                             PartGeom g, u64 *__restrict__ bstart) {
     const u64 nregions = part_regions(g);
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const u64 *__restric
 
 // The same for the HEAVY partitions of an arena batch: their buckets were written by the exact kernels into the buffer
 // behind the arenas (at payload offset `base`); start and end of every bucket of a heavy partition, nothing for the others.
-__global__ __launch_bounds__(256) void bucket_bounds_heavy_kernel(const u64 *__restrict__ O2, const u64 *__restrict__ moff,
+KH_GLOBAL __launch_bounds__(256) void bucket_bounds_heavy_kernel(const u64 *__restrict__ O2, const u64 *__restrict__ moff,
                                                                   const uint32_t *__restrict__ nch, PartGeom g,
                                                                   const uint8_t *__restrict__ heavy, u64 base,
                                                                   u64 *__restrict__ bstart, u64 *__restrict__ bend) {
@@ -2044,7 +2044,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
 }
 
 // Folds the per-region results of one region_count pass into the context counters.
-__global__ __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restrict__ bstart, const uint8_t *__restrict__ rfail,
+KH_GLOBAL __launch_bounds__(BLOCK) void region_reduce_kernel(const u64 *__restrict__ bstart, const uint8_t *__restrict__ rfail,
                                                               const uint32_t *__restrict__ rnew, const u64 *__restrict__ rreal,
                                                               u64 nregions, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
@@ -2109,7 +2109,7 @@ constexpr int HOT_SLICE = 16384;  // payloads per slice
 constexpr int HOT_TAB = 4096;     // entries of the LDS table (applied when more than half are taken)
 constexpr int HOT_GRID = 1024;
 
-__global__ __launch_bounds__(BLOCK) void hot_list_kernel(const u64 *__restrict__ bstart, const u64 *__restrict__ bend, u64 nregions, u64 cut,
+KH_GLOBAL __launch_bounds__(BLOCK) void hot_list_kernel(const u64 *__restrict__ bstart, const u64 *__restrict__ bend, u64 nregions, u64 cut,
                                                          uint32_t *__restrict__ list, Counters *ctr) {
     const u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x;
     if (r < nregions && bend[r] - bstart[r] > cut) {

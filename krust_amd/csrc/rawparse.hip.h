@@ -57,7 +57,7 @@ __device__ __forceinline__ uint4 load16_guard(const uint8_t *__restrict__ raw, u
 }
 
 // tile_nl[t] = number of '\n' in tile t
-__global__ __launch_bounds__(BLOCK) void raw_nl_count_kernel(const uint8_t *__restrict__ raw, u64 n, u64 ntiles,
+KH_GLOBAL __launch_bounds__(BLOCK) void raw_nl_count_kernel(const uint8_t *__restrict__ raw, u64 n, u64 ntiles,
                                                              uint32_t *__restrict__ tile_nl) {
     __shared__ uint32_t s_w[4];
     for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BLOCK) void raw_nl_count_kernel(const uint8_t *__re
 }
 
 // LS[i + 1] = position after the i-th newline (LS[0] = 0 is written by the host)
-__global__ __launch_bounds__(BLOCK) void raw_line_starts_kernel(const uint8_t *__restrict__ raw, u64 n, u64 ntiles,
+KH_GLOBAL __launch_bounds__(BLOCK) void raw_line_starts_kernel(const uint8_t *__restrict__ raw, u64 n, u64 ntiles,
                                                                 const u64 *__restrict__ tile_base, u64 *__restrict__ LS) {
     __shared__ uint32_t s_w[4];
     for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BLOCK) void raw_line_starts_kernel(const uint8_t *_
 
 // ---- FASTQ ---------------------------------------------------------------------------------------
 // One lane per record r (lines 4r .. 4r+3).  err[0] |= 1 on a layout these kernels do not take.
-__global__ __launch_bounds__(BLOCK) void fastq_validate_kernel(const uint8_t *__restrict__ raw, const u64 *__restrict__ LS,
+KH_GLOBAL __launch_bounds__(BLOCK) void fastq_validate_kernel(const uint8_t *__restrict__ raw, const u64 *__restrict__ LS,
                                                                u64 nrecords, uint32_t *__restrict__ err) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     bool bad = false;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void fastq_mark_kernel(const uint8_t *__rest
 
 // ---- FASTA ---------------------------------------------------------------------------------------
 // hdr[L] = line L starts with '>'
-__global__ __launch_bounds__(BLOCK) void fasta_headers_kernel(const uint8_t *__restrict__ raw, u64 n, const u64 *__restrict__ LS,
+KH_GLOBAL __launch_bounds__(BLOCK) void fasta_headers_kernel(const uint8_t *__restrict__ raw, u64 n, const u64 *__restrict__ LS,
                                                               u64 nlines, uint8_t *__restrict__ hdr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 L = (u64)blockIdx.x * BLOCK + threadIdx.x; L < nlines; L += stride) {

@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t slot_hash_below_region(const SlotSrc &src, c
 }
 
 // rcount[r] = live slots of region r.  One workgroup per region.
-__global__ __launch_bounds__(BLOCK) void region_live_count_kernel(SlotSrc src, uint32_t *__restrict__ rcount) {
+KH_GLOBAL __launch_bounds__(BLOCK) void region_live_count_kernel(SlotSrc src, uint32_t *__restrict__ rcount) {
     __shared__ uint32_t s_n;
     const u64 r = blockIdx.x;
     if (threadIdx.x == 0) s_n = 0;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(BLOCK) void region_live_count_kernel(SlotSrc src, u
 }
 
 // Live pairs of region r go to [roff[r], roff[r+1]) (any order inside the region).
-__global__ __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__restrict__ table, const u64 *__restrict__ roff,
+KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__restrict__ table, const u64 *__restrict__ roff,
                                                                u64 *__restrict__ keys, u64 *__restrict__ counts) {
     __shared__ uint32_t s_cur;
     const u64 r = blockIdx.x;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__res
 // table hash.  The receiver knows the region index of every segment, so these 32 bits identify the
 // key whenever 2k - rbits <= 32 (the hash is a bijection); halves the bytes on the xGMI links.
 // *wide is raised if a count does not fit 32 bits (the caller then uses the unpacked export).
-__global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc src, const u64 *__restrict__ roff,
+KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc src, const u64 *__restrict__ roff,
                                                                       uint32_t k, u64 *__restrict__ pairs,
                                                                       u64 *__restrict__ wide) {
     __shared__ uint32_t s_cur;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc sr
 // 23 hash bits + 9 count bits, 4 bytes per pair instead of 16.
 __device__ __forceinline__ uint32_t heads_of(u64 count, uint32_t cb) { return (uint32_t)((count + (1ull << cb) - 1) >> cb); }
 
-__global__ __launch_bounds__(BLOCK) void region_head_count_kernel(SlotSrc src, uint32_t cb,
+KH_GLOBAL __launch_bounds__(BLOCK) void region_head_count_kernel(SlotSrc src, uint32_t cb,
                                                                   uint32_t *__restrict__ rcount, u64 *__restrict__ wide) {
     __shared__ uint32_t s_n;
     const u64 r = blockIdx.x;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BLOCK) void region_head_count_kernel(SlotSrc src, u
 }
 
 // Heads of region r go to [roff[r], roff[r+1]) (any order inside the region).
-__global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src, const u64 *__restrict__ roff,
+KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src, const u64 *__restrict__ roff,
                                                                      uint32_t k, uint32_t cb,
                                                                      uint32_t *__restrict__ heads) {
     __shared__ uint32_t s_cur;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src
 
 // Region window of an export (kh_set_region_window): every owner's range of `per` regions is cut into
 // pieces of `wper`; the counts of all pieces but `piece` become zero.
-__global__ __launch_bounds__(BLOCK) void region_window_mask_kernel(uint32_t *__restrict__ rcount, u64 nregions, u64 per, u64 wper,
+KH_GLOBAL __launch_bounds__(BLOCK) void region_window_mask_kernel(uint32_t *__restrict__ rcount, u64 nregions, u64 per, u64 wper,
                                                                    uint32_t piece) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     for (u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x; r < nregions; r += stride)
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
 }
 
 // distinct += sum(rnew), part_failed += number of failed target regions
-__global__ __launch_bounds__(BLOCK) void shard_reduce_kernel(const uint8_t *__restrict__ rfail, const uint32_t *__restrict__ rnew,
+KH_GLOBAL __launch_bounds__(BLOCK) void shard_reduce_kernel(const uint8_t *__restrict__ rfail, const uint32_t *__restrict__ rnew,
                                                              u64 nregions, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     u64 d = 0, nf = 0;

@@ -78,7 +78,7 @@ class PeerFailure(RuntimeError):
 
 
 def _checked_gather(values, err, group, where):
-    """The gather every stretch of the merge ends in (exchange.hip.h, xp_gather): this rank's status in front of its
+    """The gather every stretch of the merge ends in (exchange.hip, xp_gather): this rank's status in front of its
     values.  A rank that failed locally (err = its exception) reports here and re-raises; every other rank raises
     PeerFailure from the SAME call -- nobody walks on into an all-to-all a peer will never post."""
     vals = [0] * len(values) if err is not None else [int(v) for v in values]
@@ -290,7 +290,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
 
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    # Shape of every stretch below (as in exchange.hip.h): local, fallible steps run under `attempt`, which keeps the
+    # Shape of every stretch below (as in exchange.hip): local, fallible steps run under `attempt`, which keeps the
     # first exception; the stretch ends in _checked_gather, where every rank learns about it and all leave together.
     err = [None]
 
@@ -341,7 +341,7 @@ def merge_across_ranks(counter, group=None, packed=True, dense=True, phase_times
     lap("setup")
     pow2 = world & (world - 1) == 0
     # (a table of 1024 x b2 regions, b2 not a power of two, nests with its hash-range shards only if the world divides b2:
-    #  krust_amd/csrc/kmerhip.hip merge_regions)
+    #  krust_amd/csrc/merge.hip merge_regions)
     b2 = nreg >> 10 if nreg > 1024 else 1
     geo_ok = b2 & (b2 - 1) == 0 or b2 % max(world, 1) == 0
     regions_ok = pow2 and world <= 64 and nreg >= world and nreg % world == 0 and geo_ok

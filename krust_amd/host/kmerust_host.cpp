@@ -386,7 +386,7 @@ struct Session {
         //  64, 128 and 256 MiB alike -- 41 GB/s, what one host buffer DMAs at; a chunk's scan runs beside the next chunk's
         //  transfer (KH_FLAG_DEFER_TEXT_SCAN) -- so the smaller buffers win: 1.21 s against 1.32 s of wall time.  The size of a
         //  chunk no longer decides the size of a counting batch: since round 4 the library accumulates the scanned chunks on the
-        //  device and counts tens of GB at a time -- kmerhip.hip, scan_text.)
+        //  device and counts tens of GB at a time -- input.hip, scan_text.)
         const size_t chunk = text_chunk_bytes();
         // The chunk buffer is PINNED memory (kh_host_alloc): kh_push_text then DMAs from it -- no staging memcpy inside the
         // library -- and a plain file is read into it by several pread() calls side by side (one read() moves ~6 GB/s

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # The suite drives every path of the library -- kernel variants, table geometries, fallbacks, injected failures -- through
-# environment switches that only the TEST build of the library compiles in (krust_amd/csrc/kmerhip.hip, Knobs;
+# environment switches that only the TEST build of the library compiles in (krust_amd/csrc/ctx.hip.h, Knobs;
 # `make -C krust_amd/csrc` builds both).  The product library (libkmerhip.so: what bench.py, smoke() and the kmerust binary
 # load) has none of them; tests/test_gpu_product_lib.py holds it to the oracle as it ships.  Set before krust_amd is imported.
 if os.path.exists(os.path.join(ROOT, "krust_amd", "lib", "libkmerhip_testing.so")):

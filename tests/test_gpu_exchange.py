@@ -1,4 +1,4 @@
-"""The exchange behind the C ABI (kh_comm_init / kh_merge_across / kh_group_*, krust_amd/csrc/exchange.hip.h):
+"""The exchange behind the C ABI (kh_comm_init / kh_merge_across / kh_group_*, krust_amd/csrc/exchange.hip):
 north_star's "final RCCL reduce of per-GPU hash tables" reachable without Python or PyTorch.
 
 On the 1-GPU box:
@@ -348,7 +348,7 @@ def test_a_rank_whose_context_is_poisoned_joins_the_first_gather(K, monkeypatch)
 def test_group_merge_of_tables_with_1024_x_b2_regions(K, monkeypatch, world, k, b2, pieces):
     """Round 4: tables of 1024 x b2 regions, b2 not a power of two (what a large input gets: 640 at 125 M reads).  Ownership is
     still the top bits of the hash, a rank's share of the sender regions still nests in the receiver's table when the world
-    divides b2 (kmerhip.hip merge_regions), and the exchange units carry x - xlo(bucket) instead of a bit field
+    divides b2 (merge.hip merge_regions), and the exchange units carry x - xlo(bucket) instead of a bit field
     (kernels.hip.h kh_below_region).  KMERHIP_TABLE_REGIONS forces the geometry on every rank; every shard against the
     oracle, through the heads / packed / wide routes, one shot and in pieces."""
     monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * b2))
@@ -393,3 +393,28 @@ def test_a_world_that_does_not_divide_b2_takes_the_generic_route(K, monkeypatch)
         for r, dc in enumerate(g.counters):
             keys, cnts = dc.result()
             assert np.array_equal(keys, fk[owners == r]) and np.array_equal(cnts, fc[owners == r])
+
+
+@pytest.mark.parametrize("world,k", [(2, 21), (4, 31)])
+def test_ranks_with_tables_of_different_sizes_agree_on_the_largest(K, world, k):
+    """Tables are sized from each rank's own input (growth, or the level-1 sample): ranks can arrive at the merge with
+    different geometries, whose regions do not correspond.  The merge's first gather is the table sizes; the smaller tables
+    are re-laid-out to the largest (exchange.hip, "one table geometry for every rank") and the region routes apply.  Here
+    rank 0 has eight times the reads of the others and no rank has a hint."""
+    n_reads = 110_000
+    full_b, _ = O.synth_reads(SEED + 5, 1 << 22, 150, 0, n_reads, with_qual=False)
+    fk, fc = oracle_arrays(full_b, k)
+    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    small = 10_000
+    cuts = [0, n_reads - small * (world - 1)] + [n_reads - small * (world - 1 - i) for i in range(1, world)]
+    with K.DeviceGroup(k, [0] * world) as g:
+        for r, dc in enumerate(g.counters):
+            dc.push(full_b[cuts[r] * 151: cuts[r + 1] * 151])
+        slots = [dc.finish()["table_slots"] for dc in g.counters]
+        assert slots[0] > slots[1], slots
+        infos = g.merge()
+        assert all(i["path"].startswith("regions") for i in infos), infos
+        for r, dc in enumerate(g.counters):
+            keys, cnts = dc.result()
+            sel = owners == r
+            assert np.array_equal(keys, fk[sel]) and np.array_equal(cnts, fc[sel]), f"shard {r} differs from the oracle"
