@@ -102,7 +102,25 @@ struct LocalHub {
         poisoned = false;
         arrived = 0;
     }
+    // A rank that leaves a POISONED merge does not know where its peers are: one of them may still enqueue a copy out of this
+    // rank's send buffer (it checks the poison flag at the next barrier only).  Such a rank's scratch is therefore not freed
+    // but kept here until every rank has left the merge (kh_group_merge, after the join; or the group's end).
+    std::vector<void *> kept;
+    void keep(void *p) {
+        std::lock_guard<std::mutex> lk(m);
+        kept.push_back(p);
+    }
+    void release_kept() {
+        std::vector<void *> k;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            k.swap(kept);
+        }
+        for (void *p : k) (void)hipFree(p);
+    }
+    ~LocalHub() { release_kept(); }
 };
+thread_local LocalHub *tl_hub = nullptr;  // the hub of the merge this thread is inside (DevBuf's destructor asks it)
 
 struct Comm {
     uint32_t nranks = 1, rank = 0;
@@ -322,12 +340,15 @@ int xp_allreduce_sum_u64(kh_ctx *c, u64 *d_buf, u64 n) {
 
 struct DevBuf {  // scratch of one merge; freed when it goes out of scope
     void *p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    int alloc(kh_ctx *c, u64 bytes, const char *what) {
-        if (p) (void)hipFree(p);
+    void release() {
+        if (!p) return;
+        if (tl_hub && tl_hub->is_poisoned()) tl_hub->keep(p);  // (a peer may still be reading it: LocalHub::keep)
+        else (void)hipFree(p);
         p = nullptr;
+    }
+    ~DevBuf() { release(); }
+    int alloc(kh_ctx *c, u64 bytes, const char *what) {
+        release();
         hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
         if (e != hipSuccess) {
             (void)hipGetLastError();
@@ -381,6 +402,10 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     if (cm->hub) cm->hub->timeout_s = cm->timeout_s;
 #endif
     const uint32_t W = cm->nranks, R = cm->rank;
+    struct HubScope {
+        explicit HubScope(LocalHub *h) { tl_hub = h; }
+        ~HubScope() { tl_hub = nullptr; }
+    } hub_scope(cm->hub);  // (declared before every DevBuf of the merge: destroyed after them)
     const double t_begin = now_ms();
     double t_export = 0, t_wait = 0, t_merge = 0;
     kh_merge_info mi;
@@ -1073,6 +1098,11 @@ extern "C" int kh_group_merge(kh_group *g, kh_merge_info *infos) {
     std::vector<std::thread> th;
     for (uint32_t i = 0; i < n; ++i) th.emplace_back([&, i] { rcs[i] = kh_merge_across(g->ctx[i], infos ? infos + i : nullptr); });
     for (auto &t : th) t.join();
+    if (g->hub) {  // every rank has left the merge: what a failed one's ranks kept alive for their peers can go
+        for (kh_ctx *c : g->ctx)
+            if (c && hipSetDevice(c->device) == hipSuccess) (void)hipDeviceSynchronize();
+        g->hub->release_kept();
+    }
     for (int r : rcs)  // the status of a rank that failed ITSELF says more than its peers' KH_ERR_PEER
         if (r != KH_OK && r != KH_ERR_PEER) return r;
     for (int r : rcs)
