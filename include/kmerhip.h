@@ -288,6 +288,8 @@ int kh_merge_pairs(kh_ctx *ctx, const uint64_t *keys, const uint64_t *counts, ui
  * ncclSend / ncclRecv groups on an own stream -- in KMERHIP_MERGE_PIECES (default 4) pieces, so that the
  * export of piece i + 1 and the LDS merge of piece i - 1 overlap the transfer of piece i -- and leaves this
  * context holding its hash-range shard (kh_set_shard state; kh_reset makes it a full table again).
+ * Ranks need not arrive with tables of one size (each is sized from its own input): the merge starts with a gather
+ * of the sizes, and a rank whose table is smaller than the largest re-lays it out to that size first.
  * One rank per context; ranks may be processes (one per GPU) or threads of one process (kh_group_*).
  *
  * Failure is collective too.  Every small all-gather of the sequence carries each rank's status, no transfer starts
