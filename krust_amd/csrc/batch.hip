@@ -82,7 +82,8 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
     const bool pow2 = g.p2_bits != 0xFFFFFFFFu;  // (the power-of-two instances take digit and start by shifts: rounds 1-3's code)
 #define KH_REGION32_P(FRESH, NARROW, NT, DIRTY, CB, RH, P2) \
     hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW, NT, P2>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, g, \
-                       (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab, skip)
+                       (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab, skip, \
+                       bend == (const u64 *)c->bend ? (const uint8_t *)c->heavy : (const uint8_t *)nullptr)  /* (arena level 2: which partitions the exact kernels took) */
 #define KH_REGION32(FRESH, NARROW, NT, DIRTY, CB, RH)                     \
     do {                                                                  \
         if (pow2) KH_REGION32_P(FRESH, NARROW, NT, DIRTY, CB, RH, true);  \

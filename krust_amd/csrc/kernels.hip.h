@@ -18,6 +18,11 @@
 // not launch it drop theirs), so that the headers can be shared between units.
 #define KH_GLOBAL [[maybe_unused]] static __global__
 
+// The wave's condition mask as it stands.  (__ballot / __any of the HIP headers take an int: the compiler turns the predicate
+// into 0 / 1 and compares that again -- a v_cndmask and a v_cmp per call, eight calls per payload round in the region pass.)
+__device__ __forceinline__ unsigned long long kh_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool kh_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 namespace kh {
 
 typedef unsigned long long u64;
@@ -553,12 +558,12 @@ __global__ __launch_bounds__(BLOCK) void count_direct_kernel(
                 bool mine = ok & (1u << jj);
                 nk += mine;
                 u64 weight = 1;
-                const u64 vmask = __ballot(mine);
+                const u64 vmask = kh_ballot(mine);
                 if (vmask) {
                     const int first = __builtin_ctzll(vmask);
                     const u64 lead = __shfl(key[jj], first, 64);
                     const bool same = mine && key[jj] == lead;
-                    const u64 smask = __ballot(same);
+                    const u64 smask = kh_ballot(same);
                     if (__builtin_popcountll(smask) > 1) {
                         if ((int)lane_id() == first) weight = (u64)__builtin_popcountll(smask);
                         else if (same) mine = false;
@@ -649,7 +654,7 @@ __device__ __forceinline__ void compact_tiles(u64 cap, u64 *__restrict__ keys, u
             k[j] = 0;
             c[j] = 0;
             const bool lv = i < cap && load(i, k[j], c[j]);
-            const u64 m = __ballot(lv);
+            const u64 m = kh_ballot(lv);
             off[j] = wtotal + mbcnt(m);
             wtotal += (uint32_t)__builtin_popcountll(m);
             live |= (lv ? 1u : 0u) << j;
@@ -829,11 +834,11 @@ KH_GLOBAL __launch_bounds__(BLOCK) void owner_scatter_kernel(const Slot *table, 
         if (i < cap) s = table[i];
         const bool live = (s.key != KH_EMPTY_KEY);
         const uint32_t own = live ? kh_owner_of(s.key, k, nparts) : 0xFFFFFFFFu;
-        u64 todo = __ballot(live);
+        u64 todo = kh_ballot(live);
         while (todo) {  // one round per distinct owner present in the wave
             const int leader = __builtin_ctzll(todo);
             const uint32_t p = (uint32_t)__shfl((int)own, leader, 64);
-            const u64 m = __ballot(live && own == p);
+            const u64 m = kh_ballot(live && own == p);
             u64 base = 0;
             if ((int)lane_id() == leader) base = atomicAdd(&cursors[p], (u64)__builtin_popcountll(m));
             base = __shfl(base, leader, 64);

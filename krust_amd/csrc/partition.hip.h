@@ -26,6 +26,7 @@
 // Reference counterpart: none (the reference is src/run.rs:526-571 + DashMap); results are the
 // same multiset of (key,count) as the direct path.
 #pragma once
+#include <type_traits>
 #include "part_common.hip.h"
 
 namespace kh {
@@ -895,12 +896,22 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 const uint32_t nun = c / UNIT, r = c % UNIT;
                 for (uint32_t u = 0; u < nun; ++u) {
                     if (apos + UNIT <= acap) {
-                        uint4 x[UW / LP];
-#pragma unroll
-                        for (uint32_t q = 0; q < UW / LP; ++q) x[q] = bin4[UW * u + oi + LP * q];
                         uint4 *d = reinterpret_cast<uint4 *>(out + abase + apos);
+                        // (named values, not a local array: the compiler kept `uint4 x[2]` on the stack and stored its
+                        //  second word to scratch with every unit -- 16 dead bytes per lane and unit, found in the ISA)
+                        if constexpr (UW / LP == 2) {
+                            const uint4 x0 = bin4[UW * u + oi], x1 = bin4[UW * u + oi + LP];
+                            d[oi] = x0;
+                            d[oi + LP] = x1;
+                        } else if constexpr (UW / LP == 1) {
+                            d[oi] = bin4[UW * u + oi];
+                        } else {
+                            uint4 x[UW / LP];
 #pragma unroll
-                        for (uint32_t q = 0; q < UW / LP; ++q) d[oi + LP * q] = x[q];
+                            for (uint32_t q = 0; q < UW / LP; ++q) x[q] = bin4[UW * u + oi + LP * q];
+#pragma unroll
+                            for (uint32_t q = 0; q < UW / LP; ++q) d[oi + LP * q] = x[q];
+                        }
                         apos += UNIT;
                     } else if (oi == 0) {
                         u64 at;
@@ -954,7 +965,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                     s_bin[r < capr ? dg[j] * capr + r : TOTAL] = pay[h * HALF + j];
                     omask |= (r != 0xFFFFFFFFu && r >= capr) ? (1u << j) : 0u;
                 }
-                if (__any(omask != 0)) {  // ranks that did not fit their bins (a heavy bucket): straight to the overflow list
+                if (kh_any(omask != 0)) {  // ranks that did not fit their bins (a heavy bucket): straight to the overflow list
                     const uint32_t k = (uint32_t)__builtin_popcount(omask);
                     u64 at = 0;
                     if (k && ovf_take(k, at)) {
@@ -1254,12 +1265,12 @@ __global__ __launch_bounds__(BLOCK) void ovf_insert_kernel(TableGeom tg, PartGeo
         u64 weight = 1;
         int first = -1;
         bool absorbed = false;
-        const u64 vmask = __ballot(mine);
+        const u64 vmask = kh_ballot(mine);
         if (vmask) {
             first = __builtin_ctzll(vmask);
             const u64 lead = __shfl(key, first, 64);
             const bool same = mine && key == lead;
-            const u64 smask = __ballot(same);
+            const u64 smask = kh_ballot(same);
             if (__builtin_popcountll(smask) > 1) {
                 if ((int)lane_id() == first) weight = (u64)__builtin_popcountll(smask);
                 else if (same) {
@@ -1428,12 +1439,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(T
             u64 key = kbuf[j];
             // skew guard for hot buckets (all lanes): lanes holding the first valid lane's key hand it their increment
             u64 weight = 1;
-            const u64 vmask = hot ? __ballot(key != KH_EMPTY_KEY) : 0ull;
+            const u64 vmask = hot ? kh_ballot(key != KH_EMPTY_KEY) : 0ull;
             if (vmask) {
                 const int first = __builtin_ctzll(vmask);
                 const u64 lead = __shfl(key, first, 64);
                 const bool same = key == lead;  // lead is a real key, so EMPTY lanes never match
-                const u64 smask = __ballot(same);
+                const u64 smask = kh_ballot(same);
                 if (__builtin_popcountll(smask) > 1) {
                     if ((int)lane_id() == first) weight = (u64)__builtin_popcountll(smask);
                     else if (same) key = KH_EMPTY_KEY;
@@ -1516,6 +1527,12 @@ struct R32Geo {
         if constexpr (POW2) return (pay >> sshift) & REGION_START_MASK;
         else return kh_start_of_x(pay, b2);
     }
+    // the same as a BYTE offset into a 4-byte-per-slot LDS array (the straight-line first probe addresses LDS by bytes: the
+    // shift folds into the field extraction)
+    __device__ __forceinline__ uint32_t start_b(uint32_t pay) const {
+        if constexpr (POW2) return (pay >> (sshift - 2u)) & (REGION_START_MASK << 2);  // (sshift >= 10: p2_bits <= 10)
+        else return kh_start_of_x(pay, b2) << 2;
+    }
     __device__ __forceinline__ bool mine(uint32_t pay) const {
         if constexpr (POW2) return (((pay >> dshift) ^ digit) & dmask) == 0;
         else return kh_bucket_of_x(pay, b2) == digit;
@@ -1555,14 +1572,14 @@ __device__ __forceinline__ void region32_probe_round(uint32_t nk, const uint32_t
         off = rg.start(pay);
     }
     for (;;) {
-        const u64 amask = __ballot(active);
+        const u64 amask = kh_ballot(active);
         if (amask == 0) break;
         bool placed = false;
         if (GUARD) {  // all lanes take part
             const int first = __builtin_ctzll(amask);
             const uint32_t lead = (uint32_t)__shfl((int)pay, first, 64);
             const bool same = active && pay == lead;
-            const u64 smask = __ballot(same);
+            const u64 smask = kh_ballot(same);
             if (__builtin_popcountll(smask) > 1) {
                 uint32_t wsum = same ? weight : 0u;
 #pragma unroll
@@ -1632,6 +1649,32 @@ __device__ __forceinline__ R32Group r32_group_load(const uint32_t *s_pay, uint32
     }
     return c;
 }
+// (byte-addressed twins for the straight-line first probe: gb = 4 x the group's first slot)
+__device__ __forceinline__ R32Group r32_group_load_b(const uint32_t *s_pay, uint32_t gb) {
+    R32Group c;
+    const char *const b = reinterpret_cast<const char *>(s_pay) + gb;
+    if constexpr (REGION_GROUP == 4) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(b);
+        c.v[0] = x.x; c.v[1] = x.y; c.v[2] = x.z; c.v[3] = x.w;
+    } else if constexpr (REGION_GROUP == 2) {
+        const uint2 x = *reinterpret_cast<const uint2 *>(b);
+        c.v[0] = x.x; c.v[1] = x.y;
+    } else {
+        c.v[0] = *reinterpret_cast<const uint32_t *>(b);
+    }
+    return c;
+}
+__device__ __forceinline__ bool r32_group_find_b(const R32Group &c, uint32_t pay, uint32_t &o4) {
+    bool any = c.v[0] == pay;
+    o4 = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < REGION_GROUP; ++i) {
+        const bool m = c.v[i] == pay;
+        any = any || m;
+        o4 = m ? 4u * i : o4;
+    }
+    return any;
+}
 // is `pay` in the group, and where (o: its slot's offset inside the group; a payload sits in at most one slot)
 __device__ __forceinline__ bool r32_group_find(const R32Group &c, uint32_t pay, uint32_t &o) {
     bool any = c.v[0] == pay;
@@ -1665,13 +1708,13 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
     bool active = nk > 0;
     uint32_t pay = s_q[qb];  // (every queue slot holds a loaded payload, real or clamped)
     uint32_t grp = rg.start(pay);
-    while (__ballot(active) != 0) {
+    while (kh_ballot(active) != 0) {
         const R32Group c = r32_group_load(s_pay, grp);
         uint32_t o, fo;
         bool hit = r32_group_find(c, pay, o) && active;
         const bool claim = r32_group_free(c, fo) && active && !hit;
         bool again = false;
-        if (__ballot(claim) != 0) {  // uniform; rare once the region's keys are in
+        if (kh_ballot(claim) != 0) {  // uniform; rare once the region's keys are in
             if (claim) {
                 const uint32_t old = atomicCAS(&s_pay[grp + fo], R32_FREE, pay);
                 if (old == R32_FREE) ++nd;
@@ -1726,7 +1769,10 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    uint32_t head_cb, uint32_t *__restrict__ rheads, Counters *ctr,
-                                                                   u64 *__restrict__ rreal, u64 *__restrict__ ntab, u64 skip_threshold) {
+                                                                   u64 *__restrict__ rreal, u64 *__restrict__ ntab, u64 skip_threshold,
+                                                                   const uint8_t *__restrict__ arena_heavy) {
+    // arena_heavy: nullptr, or -- when the batch's level 2 was the arena kernel -- its per-partition "left to the exact
+    // kernels" flags: a partition that is not flagged has buckets without sentinels (see first_probe below).
     // rreal[r] = payloads of the bucket that are k-mers (the bucket may hold SENTINELS, payloads with another
     // level-2 digit that pad its segments to whole lines: part2_scatter_lines_kernel; they are skipped here)
     // head_cb != 0 (FRESH only): also leave in rheads[r] the number of 32-bit exchange heads the region
@@ -1779,6 +1825,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
     const uint32_t digit = (uint32_t)r - p1 * b2;             // the region's bucket: a real payload x has (x * b2) >> 32 == digit
     const R32Geo<POW2> rg = r32_geo<POW2>(g, digit);
     const bool may_special = digit == b2 - 1u;                // (0xFFFFFFFF falls into the LAST bucket; b2 == 1: the only one)
+    const bool no_sentinels = arena_heavy != nullptr && arena_heavy[p1] == 0;  // (uniform)
     uint32_t nreal = 0;
     uint32_t kbuf[REGION_RK];
 #pragma unroll
@@ -1858,7 +1905,14 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             const u64 i64 = base + (u64)(REGION_RK + j) * NT + tid;
             kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
         }
-        if (hot || may_special || !FRESH) {
+#ifndef KH_REGION_R1_LOOP
+#define KH_REGION_R1_LOOP 1  // (0: A/B builds -- the first round takes the straight-line first probe like the others)
+#endif
+        // The FIRST round of a fresh pass finds the region's image empty: a first probe cannot hit there (every payload would
+        // go on to the queue and the loop anyway), so the round skips it and goes through the lanes' own queues -- which are
+        // balanced there, eight items each.
+        const bool first_round = KH_REGION_R1_LOOP && FRESH && base == 0;
+        if (hot || may_special || !FRESH || first_round) {
             // (the pass over a filled table keeps the old slots in registers; the straight-line first probe below
             // would push it over the 64 registers that two workgroups per CU allow)
             uint32_t rq = 0;  // real payloads, compacted into the lane's queue (sentinels dropped)
@@ -1890,35 +1944,53 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             if (n) continue;
 #endif
             constexpr int FP = KH_REGION_FP;
-            uint32_t wrun = 0;  // items queued by the wave so far (wave-uniform)
             const uint32_t lane = (uint32_t)tid & 63u, wq = ((uint32_t)tid >> 6) * R32_QBLOCK;
+            const uint32_t dummy_b = 4u * (REGION_SLOTS + (uint32_t)tid);
+            // CHECK = false: a FULL round of a bucket that holds no sentinels (the arena level 2 writes none) -- every lane has
+            // REGION_RK payloads and all of them are the region's: no validity test per payload (3 of the ~18 vector
+            // instructions a payload costs here)
+            auto first_probe = [&](auto chk) -> uint32_t {
+                constexpr bool CHECK = decltype(chk)::value;
+                uint32_t wrun = 0;  // items queued by the wave so far (wave-uniform)
 #pragma unroll
-            for (int h = 0; h < REGION_RK; h += FP) {
-                uint32_t oj[FP];
-                R32Group cj[FP];
+                for (int h = 0; h < REGION_RK; h += FP) {
+                    uint32_t oj[FP];
+                    R32Group cj[FP];
 #pragma unroll
-                for (int j = 0; j < FP; ++j) oj[j] = rg.start(pj[h + j]);
+                    for (int j = 0; j < FP; ++j) oj[j] = rg.start_b(pj[h + j]);  // (byte offsets)
 #pragma unroll
-                for (int j = 0; j < FP; ++j) cj[j] = r32_group_load(s_pay, oj[j]);
+                    for (int j = 0; j < FP; ++j) cj[j] = r32_group_load_b(s_pay, oj[j]);
 #pragma unroll
-                for (int j = 0; j < FP; ++j) {
-                    // (predicated, not branched: the exec-mask bookkeeping of sixteen small branches per round cost
-                    //  as many scalar instructions as the kernel has vector ones)
-                    const uint32_t pay = pj[h + j];
-                    const bool valid = (uint32_t)(h + j) < nk && rg.mine(pay);
-                    nreal += valid;
-                    uint32_t o;
-                    const bool hit = r32_group_find(cj[j], pay, o) && valid;
+                    for (int j = 0; j < FP; ++j) {
+                        // (predicated, not branched: the exec-mask bookkeeping of sixteen small branches per round cost
+                        //  as many scalar instructions as the kernel has vector ones)
+                        const uint32_t pay = pj[h + j];
+                        bool valid = true;
+                        if constexpr (CHECK) {
+                            valid = (uint32_t)(h + j) < nk && rg.mine(pay);
+                            nreal += valid;
+                        }
+                        uint32_t o4;
+                        const bool hit = r32_group_find_b(cj[j], pay, o4) && valid;
 #if !(KH_ABLR & 2)  /* timing experiment otherwise: no count updates in the first probe */
-                    atomicAdd(&s_add[hit ? oj[j] + o : REGION_SLOTS + (uint32_t)tid], 1u);  // no-return ds_add_u32; misses add to a private dummy word
+                        // no-return ds_add_u32; misses add to a private dummy word
+                        atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_add) + (hit ? (oj[j] | o4) : dummy_b)), 1u);
 #endif
-                    const bool queue = valid && !hit;
-                    const u64 qm = __ballot(queue);
-                    const uint32_t pos = wrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
-                    s_q[wq + (queue ? pos : (uint32_t)REGION_RK * 64u + lane)] = pay;  // (row REGION_RK is a dummy row)
-                    wrun += (uint32_t)__builtin_popcountll(qm);
+                        const bool queue = valid && !hit;
+                        const u64 qm = kh_ballot(queue);
+                        const uint32_t pos = wrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                        s_q[wq + (queue ? pos : (uint32_t)REGION_RK * 64u + lane)] = pay;  // (row REGION_RK is a dummy row)
+                        wrun += (uint32_t)__builtin_popcountll(qm);
+                    }
                 }
-            }
+                if constexpr (!CHECK) nreal += REGION_RK;
+                return wrun;
+            };
+#ifndef KH_REGION_NOCHECK
+#define KH_REGION_NOCHECK 1  // (0: A/B builds -- every round tests every payload)
+#endif
+            const bool plain = KH_REGION_NOCHECK && no_sentinels && rem >= (u64)REGION_RK * NT;  // uniform
+            const uint32_t wrun = plain ? first_probe(std::false_type{}) : first_probe(std::true_type{});
             const uint32_t r = wrun > lane ? (wrun - lane + 63u) >> 6 : 0u;  // this lane's share: rows 0 .. r-1 of its column
 #if !(KH_ABLR & 1)  /* timing experiment otherwise: no probing loop behind the straight-line first probe */
             region32_probe_lean<POW2>(r, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
@@ -2037,7 +2109,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
     if (FRESH && head_cb) {
         const uint32_t hw = (uint32_t)wave_sum((u64)nheads);
         if ((tid & 63) == 0 && hw) atomicAdd(&s_heads, hw);
-        if (__any(too_wide) && (tid & 63) == 0) atomicOr((unsigned long long *)&ctr->heads_wide, 1ull);
+        if (kh_any(too_wide) && (tid & 63) == 0) atomicOr((unsigned long long *)&ctr->heads_wide, 1ull);
         __syncthreads();
         if (tid == 0) rheads[r] = s_heads;
     }

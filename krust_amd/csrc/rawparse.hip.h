@@ -96,7 +96,7 @@ KH_GLOBAL __launch_bounds__(BLOCK) void fastq_validate_kernel(const uint8_t *__r
         if (qual_len && raw[e - 2] == '\r') --qual_len;
         bad |= raw[a] != '@' || raw[c] != '+' || seq_len != qual_len;
     }
-    if (__any(bad) && lane_id() == 0) atomicOr(err, 1u);
+    if (kh_any(bad) && lane_id() == 0) atomicOr(err, 1u);
 }
 
 // bases_out[pos] = raw[pos] on sequence lines (line index % 4 == 1, excluding CR / LF), '\n' elsewhere;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__r
         const uint32_t kpre = block_exclusive_scan_256((uint32_t)__builtin_popcount(keep), s_w, &ktotal);
         if (PASS == 0) {
             if (threadIdx.x == 0) tile_keep[t] = ktotal;
-            if (__any(bad) && lane_id() == 0) atomicOr(err, 2u);
+            if (kh_any(bad) && lane_id() == 0) atomicOr(err, 2u);
         } else {
             u64 o = tile_out[t] + kpre;
 #pragma unroll

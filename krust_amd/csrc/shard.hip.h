@@ -90,7 +90,7 @@ KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_kernel(const Slot *__rest
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {  // uniform trip count (4096 / 256)
         const Slot s = reg[i];
         const bool live = s.key != KH_EMPTY_KEY;
-        const u64 m = __ballot(live);
+        const u64 m = kh_ballot(live);
         if (m == 0) continue;
         uint32_t wbase = 0;
         if ((int)lane_id() == __builtin_ctzll(m)) wbase = atomicAdd(&s_cur, (uint32_t)__builtin_popcountll(m));
@@ -121,7 +121,7 @@ KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc src
     for (uint32_t i = threadIdx.x; i < REGION_SLOTS; i += BLOCK) {
         const SlotVal s = slot_read(src, r * REGION_SLOTS + i);
         const bool live = s.live;
-        const u64 m = __ballot(live);
+        const u64 m = kh_ballot(live);
         if (m == 0) continue;
         uint32_t wbase = 0;
         if ((int)lane_id() == __builtin_ctzll(m)) wbase = atomicAdd(&s_cur, (uint32_t)__builtin_popcountll(m));
@@ -131,7 +131,7 @@ KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc src
             pairs[base + wbase + mbcnt(m)] = (s.count << 32) | slot_hash_below_region(src, s, bc, k);
         }
     }
-    if (__any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
+    if (kh_any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
 }
 
 // ---- 32-bit "heads" -------------------------------------------------------------------------------
@@ -158,7 +158,7 @@ KH_GLOBAL __launch_bounds__(BLOCK) void region_head_count_kernel(SlotSrc src, ui
     }
     n = (uint32_t)wave_sum((u64)n);
     if (lane_id() == 0 && n) atomicAdd(&s_n, n);
-    if (__any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
+    if (kh_any(too_wide) && lane_id() == 0) atomicOr((unsigned long long *)wide, 1ull);
     __syncthreads();
     if (threadIdx.x == 0) rcount[r] = s_n;
 }
