@@ -300,15 +300,20 @@ __device__ __forceinline__ uint32_t swar_ge_bytes(uint32_t x, uint32_t y) {
     const uint32_t z = (x | 0x80808080u) - (y & 0x7F7F7F7Fu);  // bit 7: low 7 bits of x >= low 7 bits of y
     return ((x & ~y) | (~(x ^ y) & z)) & 0x80808080u;
 }
-// bytes b0..b3 (b0 = lowest address = FIRST base) -> 8 bits, first base most significant
-__device__ __forceinline__ uint32_t swar_codes4(uint32_t w) {
+// bytes b0..b3 (b0 = lowest address = FIRST base) -> 8 bits, first base most significant.
+// Round 4: the four 2-bit fields are gathered by ONE multiply -- field i sits at bit 8 i, the factor 2^30 + 2^20 + 2^10 + 1
+// moves it to bit 30 - 2 i of the product's top byte, and no other partial product lands in that byte (they fall below bit
+// 24 or beyond bit 31) -- where rounds 1-3 took three shifts and three ORs (the encoder was 110 of the ~945 vector
+// instructions a level-1 wave spends on a tile; ISA of part1_bins_kernel).  swar_codes4_top leaves the byte where the
+// multiply puts it (bits 24..31; junk below), for encode_raw to pick with v_perm_b32.
+__device__ __forceinline__ uint32_t swar_codes4_top(uint32_t w) {
     const uint32_t t = ((w >> 1) ^ (w >> 2)) & 0x03030303u;  // A,C,G,T -> 0,1,2,3 in every byte (either case)
-    return ((t >> 24) | (t >> 14) | (t >> 4) | (t << 6)) & 0xFFu;
+    return t * 0x40100401u;
 }
-// 0x80-per-byte flags -> 4 bits, first base most significant
-__device__ __forceinline__ uint32_t swar_flags4(uint32_t m) {
-    return ((m >> 4) & 8u) | ((m >> 13) & 4u) | ((m >> 22) & 2u) | (m >> 31);
-}
+__device__ __forceinline__ uint32_t swar_codes4(uint32_t w) { return swar_codes4_top(w) >> 24; }
+// 0x80-per-byte flags -> 4 bits, first base most significant (the same gather: flag i at bit 8 i after the shift, factor
+// 2^27 + 2^18 + 2^9 + 1, result in bits 24..27 of the product, nothing above)
+__device__ __forceinline__ uint32_t swar_flags4(uint32_t m) { return ((m >> 7) * 0x08040201u) >> 24; }
 __device__ __forceinline__ uint32_t swar_valid4(uint32_t w, uint32_t q, uint32_t thr4, bool qual) {
     // Accepted bytes are exactly ACGTacgt (src/kmer.rs:271-273).  Every byte has SOME 2-bit code; a
     // byte is a base iff, case folded, it equals the letter of its own code.  The four letters come
@@ -330,7 +335,9 @@ __device__ __forceinline__ void encode_raw(const RawChunk &r, u64 vbeg, u64 vend
     val = 0;
     if (!r.live) return;
     const uint32_t thr4 = thr * 0x01010101u;
-    code = (swar_codes4(r.w.x) << 24) | (swar_codes4(r.w.y) << 16) | (swar_codes4(r.w.z) << 8) | swar_codes4(r.w.w);
+    // (the top bytes of the four products, first word's first: two byte-selects and an OR)
+    code = __builtin_amdgcn_perm(swar_codes4_top(r.w.x), swar_codes4_top(r.w.y), 0x07030c0cu) |
+           __builtin_amdgcn_perm(swar_codes4_top(r.w.z), swar_codes4_top(r.w.w), 0x0c0c0703u);
     val = (swar_valid4(r.w.x, r.q.x, thr4, QUAL) << 12) | (swar_valid4(r.w.y, r.q.y, thr4, QUAL) << 8) |
           (swar_valid4(r.w.z, r.q.z, thr4, QUAL) << 4) | swar_valid4(r.w.w, r.q.w, thr4, QUAL);
     // data bounds, once per chunk instead of two 64-bit compares per base

@@ -1700,44 +1700,64 @@ __device__ __forceinline__ bool r32_group_free(const R32Group &c, uint32_t &fo) 
     return any;
 }
 
+// the first free slot of the group, as a byte offset (false: none)
+__device__ __forceinline__ bool r32_group_free_b(const R32Group &c, uint32_t &f4) {
+    bool any = false;
+    f4 = 0;
+#pragma unroll
+    for (int i = (int)REGION_GROUP - 1; i >= 0; --i) {
+        const bool f = c.v[i] == R32_FREE;
+        any = any || f;
+        f4 = f ? 4u * (uint32_t)i : f4;
+    }
+    return any;
+}
+
+// The probing loop.  Round 4, from its ISA (27 vector + ~30 scalar instructions per iteration, 45 % of the kernel's vector
+// instructions): everything is a BYTE offset (group, slot, the lane's place in its queue column: no shifts), "is the lane
+// still busy" is a compare of its own every iteration (a loop-carried predicate is rebuilt as 0 / 1 and compared again for
+// the ballot, and merged by four scalar instructions at every back edge), a claim is a plain divergent branch (the
+// "does anybody claim" ballot in front of it cost two vector instructions per iteration to skip a block the exec mask
+// skips by itself), and "the region is full" is the probe sequence coming back to its first group (no probe counter).
 template <bool POW2>
 __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t *s_q, uint32_t *s_pay,
                                                     uint32_t *s_add, uint32_t *s_fail, int tid, const R32Geo<POW2> &rg, uint32_t &nd) {
-    uint32_t idx = 0, probes = 0;
-    const uint32_t qb = r32_qbase(tid);
-    bool active = nk > 0;
-    uint32_t pay = s_q[qb];  // (every queue slot holds a loaded payload, real or clamped)
-    uint32_t grp = rg.start(pay);
-    while (kh_ballot(active) != 0) {
-        const R32Group c = r32_group_load(s_pay, grp);
-        uint32_t o, fo;
-        bool hit = r32_group_find(c, pay, o) && active;
-        const bool claim = r32_group_free(c, fo) && active && !hit;
+    constexpr uint32_t GB = 4u * REGION_GROUP, WRAP = REGION_MASK << 2;
+    const char *qp = reinterpret_cast<const char *>(s_q + r32_qbase(tid));  // the lane's column: row i is 256 i bytes on (rows 0 .. REGION_RK exist)
+    char *const payb = reinterpret_cast<char *>(s_pay);
+    char *const addb = reinterpret_cast<char *>(s_add);
+    uint32_t idx = 0;
+    uint32_t pay = *reinterpret_cast<const uint32_t *>(qp);  // (every queue slot holds a loaded payload, real or clamped)
+    uint32_t gb = rg.start_b(pay), gb0 = gb;                  // the group being looked at; the item's first one
+    for (;;) {
+        const bool active = idx < nk;
+        if (kh_ballot(active) == 0) break;
+        const R32Group c = r32_group_load_b(s_pay, gb);
+        uint32_t o4, f4;
+        bool hit = r32_group_find_b(c, pay, o4) && active;
+        const bool claim = r32_group_free_b(c, f4) && active && !hit;
         bool again = false;
-        if (kh_ballot(claim) != 0) {  // uniform; rare once the region's keys are in
-            if (claim) {
-                const uint32_t old = atomicCAS(&s_pay[grp + fo], R32_FREE, pay);
-                if (old == R32_FREE) ++nd;
-                hit = old == R32_FREE || old == pay;
-                o = fo;
-                again = !hit;  // another key took that slot meanwhile: look at the group again
-            }
+        if (claim) {  // (rare once the region's keys are in)
+            const uint32_t old = atomicCAS(reinterpret_cast<uint32_t *>(payb + (gb | f4)), R32_FREE, pay);
+            if (old == R32_FREE) ++nd;
+            hit = old == R32_FREE || old == pay;
+            o4 = f4;
+            again = !hit;  // another key took that slot meanwhile: look at the group again
         }
-        if (hit) atomicAdd(&s_add[grp + o], 1u);  // no-return ds_add_u32
-        const bool miss = active && !hit && !again;  // four slots, four other keys
-        probes += miss ? REGION_GROUP : 0u;
+        if (hit) atomicAdd(reinterpret_cast<uint32_t *>(addb + (gb | o4)), 1u);  // no-return ds_add_u32
+        const bool miss = active && !hit && !again;  // the group's slots hold other keys
+        const uint32_t nb = (gb + GB) & WRAP;
         bool done = hit;
-        if (miss && probes >= REGION_SLOTS) {  // region full
+        if (miss && nb == gb0) {  // every group seen: region full
             *s_fail = 1;
             done = true;
         }
-        grp = miss ? ((grp + REGION_GROUP) & REGION_MASK) : grp;
+        gb = miss ? nb : gb;
         if (done) {
             ++idx;
-            active = idx < nk;
-            probes = 0;
-            pay = s_q[qb + (active ? idx : 0u) * 64];
-            grp = rg.start(pay);
+            qp += 256;
+            pay = *reinterpret_cast<const uint32_t *>(qp);
+            gb = gb0 = rg.start_b(pay);
         }
     }
 }
