@@ -26,6 +26,10 @@ KNOBS = {
     "KMERHIP_P2_LINES": [None, None, "0"],
     "KMERHIP_GENERIC_K": [None, None, None, "1"],
     "KMERHIP_OVF_AGG": [None, "1", "1", "0"],
+    # round 4: the table's size comes from the level-1 sample unless told otherwise -- "0" brings back tables that are too
+    # small for what they get (regions that fill up, failed buckets re-inserted, growth); and tables of 1024 x b2 regions
+    "KMERHIP_ESTIMATE": [None, None, "0"],
+    "KMERHIP_TABLE_REGIONS": [None, None, None, None, "3072", "10240", "40960"],
 }
 
 
@@ -134,6 +138,8 @@ MID_KNOBS = {
     "KMERHIP_L2_ARENA": [None, None, None, "0"],
     "KMERHIP_PART_BUDGET_GB": [None, None, "0.6", "2"],
     "KMERHIP_OVF_AGG": [None, None, "1", "0"],
+    "KMERHIP_ESTIMATE": [None, None, None, "0"],
+    "KMERHIP_TABLE_REGIONS": [None, None, None, "20480", "81920"],
 }
 
 
