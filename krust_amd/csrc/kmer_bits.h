@@ -88,7 +88,13 @@ KH_HD bool kh_k_uses_mul24(uint32_t k) { return k >= 16 && k <= 24; }
 template <int MODE = KH_MUL_AUTO>
 KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
     uint32_t t;
-    if (MODE == KH_MUL_24 || (MODE == KH_MUL_AUTO && kh_k_uses_mul24(k))) {
+    if (MODE == KH_MUL_AUTO) {
+        // decided at run time WITHOUT a branch: the low word of r x c is the same from the 24-bit and from the 32-bit
+        // multiplier once the constant is chosen (r < 2^k <= 2^24 where the 24-bit one applies), so the choice is a
+        // uniform select of the constant.  (Round 4: the branch per round split every key of region_count_kernel64 and
+        // of the 64-bit level 2 into a dozen basic blocks -- 16 scalar branches per key.)
+        t = r * (kh_k_uses_mul24(k) ? ((c & 0xFFFFFFu) | 1u) : c);
+    } else if (MODE == KH_MUL_24) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // (__umul24() is a masked plain multiply to the compiler, re-selected as v_mul_u32_u24 only where
         // instruction selection can prove both operands 24-bit: in the extraction kernels two of the four rounds
