@@ -174,11 +174,10 @@ __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__r
         const uint4 v = load16_guard(raw, p0, n);
         uint32_t total;
         const u64 line0 = tile_base[t] + block_exclusive_scan_256(count_nl16(v), s_w, &total);
-        u64 line = line0;
-        bool header = p0 < n ? hdr[line] != 0 : false;
+        bool header = p0 < n ? hdr[line0] != 0 : false;  // (the line this lane's first byte is in)
         uint32_t keep = 0;  // bit j: byte j is kept
         bool bad = false;
-        const uint32_t after = (PASS == 0 && p0 + 16 < n) ? raw[p0 + 16] : '\n';  // the byte after this lane's 16
+        const uint32_t after = (p0 + 16 < n) ? raw[p0 + 16] : '\n';  // the byte after this lane's 16
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const uint32_t b = byte_of(v, j);
@@ -195,8 +194,11 @@ __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__r
                 bad |= !(nx == '\n' || p0 + j + 1 >= n);
             }
             if (b == '\n') {
-                ++line;
-                header = (p0 + j + 1 < n) ? hdr[line] != 0 : false;
+                // the next line is a header iff it starts with '>': hdr[] says the same (fasta_headers_kernel), but a load
+                // from it HERE is a dependent global load in the middle of a sixteen-step loop -- and with 61-byte lines some
+                // lane of the wave is at a line end in nearly every step (round 4: 6.1 ms per pass over a 3.1 GB text)
+                const uint32_t nx = j < 15 ? byte_of(v, (j + 1) & 15) : after;
+                header = (p0 + j + 1 < n) && nx == '>';
             }
         }
         uint32_t ktotal;
