@@ -719,11 +719,11 @@ void ensure_part_budget(kh_ctx *c) {
     // (up to 0.78 of what is free: the 8-byte table image -- 8 bytes per slot, allocated after level 2 -- and the small arrays
     //  take the rest.  Round 3 stopped at 160 GiB / 0.75: configs[3]'s 125 M reads then ran as two batches, the second one a
     //  pass over a filled table that re-reads and re-writes all of it: 36 ms of region pass where one fresh pass takes 24)
-    // A rank of a multi-GPU merge (a communicator is attached) leaves room for what kh_merge_across allocates while the
-    // partition buffers are still there: send and receive buffers (16 B per local key) and the shard's 16-byte table -- about
-    // 49 B per local key, 64 GB at configs[3]'s size -- hence 0.55 there: configs[3]'s share then runs as two batches.
+    // (A rank of a multi-GPU merge gets the same: kh_merge_across gives the partition buffers back before it allocates its
+    //  send / receive buffers and the shard's 16-byte table -- release_part_buffers.  For an hour of round 4 such a rank kept
+    //  0.55 instead, and configs[3]'s share ran as two batches there.)
     u64 budget = 224ull << 30;
-    const double share = c->comm ? 0.55 : 0.78;
+    const double share = 0.78;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * share));
     else (void)hipGetLastError();
     if (c->knobs.part_budget_gb > 0) budget = (u64)(c->knobs.part_budget_gb * (double)(1ull << 30));

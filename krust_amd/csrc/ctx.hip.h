@@ -307,6 +307,7 @@ kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap);
 int grow_to(kh_ctx *c, u64 newcap);
 int ensure_room(kh_ctx *c, u64 bound, bool allow_shrink_hint, bool *want_smaller);
 int drain_events(kh_ctx *c);
+int release_part_buffers(kh_ctx *c);  // the two partition buffers back to the device (they come back with the next partitioned batch)
 int device_scan(kh_ctx *c, const uint32_t *in, u64 n, u64 *out);
 int zero_cursors(kh_ctx *c);
 int read_cursor(kh_ctx *c, u64 *cursor, u64 *big);

@@ -293,6 +293,17 @@ int drain_events(kh_ctx *c) {
     return KH_OK;
 }
 
+int release_part_buffers(kh_ctx *c) {
+    if (!c->keysA && !c->keysB) return KH_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->keysA) (void)hipFree(c->keysA);
+    if (c->keysB) (void)hipFree(c->keysB);
+    c->keysA = c->keysB = nullptr;
+    c->key_cap = c->keyb_cap = 0;
+    c->part_budget = 0;  // (decided again at the next partitioned range)
+    return KH_OK;
+}
+
 GeomChoice make_geom(const kh_ctx *c, u64 cap) {
     GeomChoice gc;
     const int hbits = 2 * (int)c->k - (int)c->shard_shift;  // significant bits of the placement hash

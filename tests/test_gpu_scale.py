@@ -209,3 +209,27 @@ def test_configs3_merge_step_as_two_logical_ranks(K, shard_reads, monkeypatch):
         for dc in ranks:
             dc.close()
         torch.cuda.empty_cache()
+
+
+def test_a_world_of_one_rank_merges_the_full_size_table(K, shard_reads):
+    """kh_merge_across over RCCL with ONE rank: every key is the rank's own, so the merge must leave the table's content
+    as it was -- through the real transport (a send to itself), in pieces, at configs[3]'s size.  Round 4: a message of
+    2^30 bytes or more arrived half (the keys of the upper half of every piece were gone, silently, once a table held more
+    than 2^30 keys): messages are now 256 MiB at most (exchange.hip, xp_alltoallv).  Also: the rank -- a context with a
+    communicator -- still counts the shard in ONE partitioned batch (the merge gives the partition buffers back itself)."""
+    tb, nbytes, total, skeys, scnts = shard_reads
+    with K.DeviceCounter(21) as dc:
+        dc.comm_init(1, 0, K.comm_unique_id())
+        dc.push_device(tb.data_ptr(), None, nbytes)
+        st = dc.finish()
+        assert st["kmers"] == total and st["part_batches"] == 1, st
+        assert st["distinct"] > (1 << 30)              # (the size at which the transport's limit showed)
+        info = dc.merge_across()
+        assert info["path"].startswith("regions") and info["owned_distinct"] == st["distinct"], info
+        st2 = dc.finish()
+        assert st2["distinct"] == st["distinct"]
+        hist = dc.histogram()
+        assert sum(f for _, f in hist) == st["distinct"] and sum(c * f for c, f in hist) == total
+        assert np.array_equal(dc.lookup(skeys), scnts)
+    import torch
+    torch.cuda.empty_cache()
