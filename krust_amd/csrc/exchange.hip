@@ -355,6 +355,11 @@ struct DevBuf {  // scratch of one merge; freed when it goes out of scope
     int alloc(kh_ctx *c, u64 bytes, const char *what) {
         release();
         hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess && (c->keysA || c->keysB)) {  // the partition buffers of the counting that is over: room for this
+            (void)hipGetLastError();
+            p = nullptr;
+            if (release_part_buffers(c) == KH_OK) e = hipMalloc(&p, bytes ? bytes : 16);
+        }
         if (e != hipSuccess) {
             (void)hipGetLastError();
             p = nullptr;
@@ -472,8 +477,19 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     }
     int lrc = pre;
     if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
-    // the counting is over: its partition buffers (up to 0.78 of the device) are room for the exchange's buffers and the shard
-    if (lrc == KH_OK) lrc = release_part_buffers(c);
+    // The counting is over: its partition buffers (up to 0.78 of the device) are given back where the exchange would not fit
+    // beside them -- send and receive buffers (<= 16 B per local key together) and the shard's 16-byte table.  (Not always: a
+    // host that counts and merges in a loop would pay for 150 GB of hipMalloc per round.)
+    if (lrc == KH_OK) {
+        size_t fr = 0, tot = 0;
+        const u64 keys_now = c->h_ctr->distinct;
+        const u64 want = 16ull * keys_now + 16ull * (c->cap / W + kh::REGION_SLOTS) + (8ull << 30);
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            fr = 0;
+        }
+        if ((u64)fr < want) lrc = release_part_buffers(c);
+    }
     if (lrc == KH_OK) lrc = inject("start");
     const u64 n_local = lrc == KH_OK ? c->h_ctr->distinct : 0;
     u64 nreg = c->cap / kh::REGION_SLOTS;
