@@ -1032,7 +1032,10 @@ extern "C" int kh_merge_across(kh_ctx *c, kh_merge_info *info) {
         return fail(c, KH_ERR_RCCL, "the communicator was aborted by an earlier failed merge; create a new context and communicator");
     // (a finished merge leaves EVERY rank a shard: this refusal is collective by itself, nobody is waiting in a gather)
     if (c->shard_shift && !c->poisoned) return fail(c, KH_ERR_STATE, "the table is already a shard (merged before); kh_reset first");
-    int rc = enter(c);  // (counts what kh_push / kh_push_text left pending: may fail -- out of memory, table full -- on this rank alone)
+    // (counts what kh_push / kh_push_text left pending: may fail -- out of memory, table full -- on this rank alone.  The 8-byte
+    //  image stays what it is: the exports read it directly -- round 4: the default here widened it first, 13.5 ms and a 43 GB
+    //  allocation at configs[3]'s size, and every export then read the 16-byte table)
+    int rc = enter(c, true, true, false, true);
     if (c->comm && c->comm->nranks > 1) return merge_across_impl(c, info, rc);  // a failed pre-check is reported in the first gather
     if (rc != KH_OK) return rc;
     if (!c->comm) {  // a lone context is its own world

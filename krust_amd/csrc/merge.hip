@@ -193,7 +193,7 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
     if (c->win_n > 1 && (nregions / nparts) % c->win_n) return fail(c, KH_ERR_BAD_ARG, "region window: fewer regions per owner than pieces");
     rc = sync_counters(c);
     if (rc != KH_OK) return rc;
-    bool counted_by_region_pass = false;
+    bool counted_by_region_pass = false, keep_counts = false;
     if (fmt == XF_HEADS32 && c->rheads_valid && c->rheads_cb == (uint32_t)cb) {
         // the FRESH region pass that built this table left the head count of every region behind:
         // no counting pass over the 34 GB table
@@ -205,6 +205,12 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
                            slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big);
+        // (kept for the exports that follow -- the other pieces of a pipelined exchange, its unit counts: one pass over the table
+        //  instead of one per call; valid once the "too wide" flag below has come back clear, until anything touches the table)
+        if (c->rheads && c->region_cap >= nregions) {
+            HIP_TRY(c, hipMemcpyAsync(c->rheads, d_region_counts, nregions * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+            keep_counts = true;
+        }
     } else {
         hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
                            slot_src(c), d_region_counts);
@@ -233,6 +239,11 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
         rc = read_cursor(c, nullptr, &wide);
         if (rc != KH_OK) return rc;
         if (wide) return fail(c, KH_ERR_RANGE, "a count is too large for 32-bit heads");
+        if (keep_counts) {
+            c->rheads_valid = true;
+            c->rheads_wide = false;
+            c->rheads_cb = (uint32_t)cb;
+        }
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (uint32_t p = 0; p < nparts; ++p) part_counts[p] = bounds[p + 1] - bounds[p];
@@ -292,10 +303,17 @@ extern "C" int kh_region_unit_counts_device(kh_ctx *c, uint32_t unit_bytes, uint
             hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
                                slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big);
             HIP_TRY(c, hipGetLastError());
+            const bool keep = c->rheads && c->region_cap >= nregions;
+            if (keep) HIP_TRY(c, hipMemcpyAsync(c->rheads, d_region_counts, nregions * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
             u64 wide = 0;
             rc = read_cursor(c, nullptr, &wide);
             if (rc != KH_OK) return rc;
             if (wide) return fail(c, KH_ERR_RANGE, "a count is too large for 32-bit heads");
+            if (keep) {  // (as in export_regions)
+                c->rheads_valid = true;
+                c->rheads_wide = false;
+                c->rheads_cb = (uint32_t)cb;
+            }
         }
     } else {
         hipLaunchKernelGGL(kh::region_live_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
