@@ -152,11 +152,21 @@ extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
     if (sh >= 2 * c->k) return fail(c, KH_ERR_BAD_ARG, "more shards than k-mers");
     c->shard_shift = sh;
     c->shard_index = index;
-    if (c->ntab) {  // (a shard table is never kept as the 8-byte image: its 8 bytes per slot are room for the shard's 16-byte table)
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->ntab);
-        c->ntab = nullptr;
-        c->ntab_cap = 0;
+    if (c->ntab) {
+        // A shard table is never kept as the 8-byte image: where the shard's 16-byte table would not fit beside it, its 8 bytes
+        // per slot are the room.  (Not always: a host that counts and merges in a loop would free and allocate the image -- 21 GB
+        // at configs[3]'s size -- every round, and large allocations are what stalls on a nearly full device.)
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            fr = 0;
+        }
+        if ((u64)fr < 16ull * (c->cap >> sh) + (8ull << 30)) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->ntab);
+            c->ntab = nullptr;
+            c->ntab_cap = 0;
+        }
     }
     return KH_OK;
 }
