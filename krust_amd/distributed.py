@@ -31,6 +31,9 @@ def _host_staged(group):
 
 
 def _all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
+    # NOTE (round 4, tools/world1_merge_probe.py): over RCCL a message of 2^30 bytes or more arrived half.  The exchange inside
+    # the library (exchange.hip, xp_alltoallv) cuts its segments into 256 MiB messages; this harness sends a segment as ONE
+    # message -- fine for the sizes the tests run and for worlds of 4+ at the bench's sizes, not for two ranks with S100M tables.
     if out.is_cuda and _host_staged(group):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
