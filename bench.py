@@ -14,15 +14,24 @@ per GPU (rank r counts reads [r x 125 M, (r + 1) x 125 M): at N = 8 that IS the 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
+Prints ONE JSON line on rank 0 (contract in the task statement) -- SMALL: at most 6 KB, so that it fits whole into the
+8 KB tail the driver keeps of stdout (round 4's 23.5 KB line did not, and the driver recorded `parsed: null`).  The line
+(contract_line()) carries
   roofline      algorithmic HBM bytes of the counting kernels / their HIP-event duration, vs 8 TB/s; the kernels
                 are NAMED from what ran (kh_stats.stage_ms), and tests/test_docs_drift.py holds the names to the
                 source and to the committed rocprofv3 kernel trace
   verify        (N = 1, after the timed loop, outside it) exact counts of a 1/1024 key sample and the k-mer total
                 against the CPU oracle's scan of the same reads: the line says itself whether it is bit-exact
   cpu_baseline  the krust-equivalent threaded CPU port (oracle/) timed on this host's cores on a bounded sample
-                of the same reads, `optimised_cpu` beside it (rank 0, N=1 only).  A reported baseline only.
-  configs       BASELINE configs[1..4] (and a k = 19 twin of the headline) as sub-results with their own roofline
+                of the same reads, `optimised_value` beside it (rank 0, N=1 only).  A reported baseline only.
+  configs       BASELINE configs[1..4] (and a k = 19 twin of the headline): one flat row each
+  cli           the kmerust command line on S10M and S100M FASTQ files: wall seconds
+The FULL report (every sub-result's roofline, phase walls, samples, explanations) goes to gpurun_out/bench_full.json
+(BENCH_FULL_PATH overrides) and, as a pointer, `full_report` in the line.
+
+  --group N     N logical ranks as THREADS of this one process on ONE device (kh_group: the in-process hub instead of RCCL,
+                which refuses two ranks on one device): every line of the N > 1 accounting -- config.merge, per_rank,
+                conserved, rccl_nranks -- runs on a 1-GPU box.  A dry run of the code path, not a scaling measurement.
 """
 import argparse
 import json
@@ -58,6 +67,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--verify", action="store_true", help="(default at N = 1) check a 1/1024 key sample against the CPU oracle")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--group", type=int, default=0,
+                    help="N thread ranks on ONE device through kh_group_create / kh_group_merge (the N > 1 accounting on a 1-GPU box)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the end-to-end (host buffers in, results out) figures and the configs sub-results")
     return ap.parse_args()
@@ -518,8 +529,212 @@ def cli_leg(krust_amd, torch, dev, local_rank, reads=10_000_000, k=21):
             os.remove(path)
 
 
+def merge_dict(mi, impl):
+    """kh_merge_info -> config.merge of the line (one rank's view)."""
+    return {"impl": impl, "path": mi["path"], "local_distinct": mi["local_distinct"],
+            "sent_pairs": mi["sent_units"], "recv_pairs": mi["recv_units"], "unit_bytes": mi["unit_bytes"],
+            "owned_distinct": mi["owned_distinct"],
+            # what the TRANSPORT says the world is (ncclCommCount / the hub's size) and the library's own conservation verdict
+            "rccl_nranks": mi["nranks_seen"], "lib_conserved": bool(mi["conserved"]),
+            "sent_count_sum": mi["sent_count_sum"], "merged_count_sum": mi["merged_count_sum"],
+            "phase_ms": {"export": mi["export_ms"], "exchange_wait": mi["wait_ms"], "merge": mi["merge_ms"],
+                         "total": mi["total_ms"], "pieces": mi["pieces"]}}
+
+
+def _r(x, nd=4):
+    """Numbers of the contract line: enough digits to recompute every ratio, not seventeen."""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{nd + 2}g}") if abs(x) < 1e15 else x
+    return x
+
+
+LINE_LIMIT = 6144   # bytes: the whole line must fit the driver's 8 KB stdout tail
+
+
+def contract_line(full):
+    """The ONE line the driver parses, from the full report: the contract's keys, `roofline` and `cpu_baseline` as the task
+    statement defines them, and one flat row per sub-result.  Everything else stays in the full report."""
+    rf = full.get("roofline") or {}
+    dom = rf.get("dominant") or {}
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(line["value"], 6), _r(line["ms_per_step"], 5)
+    c = {k: cfg.get(k) for k in ("workload", "k", "reads_per_gpu", "kmers_per_step_per_gpu", "distinct_per_gpu", "table_slots", "table_load",
+                                  "capacity_hint", "parallelism", "mode") if cfg.get(k) is not None}
+    c["table_load"] = _r(c.get("table_load"))
+    mg = cfg.get("merge")
+    if mg:
+        c["merge"] = {k: mg.get(k) for k in ("impl", "path", "unit_bytes", "rccl_nranks", "lib_conserved", "conserved", "merged_occurrences",
+                                              "merged_distinct", "sent_pairs", "fallback_from_c_abi") if mg.get(k) is not None}
+        if mg.get("phase_ms"):
+            c["merge"]["phase_ms"] = {k: _r(v, 3) for k, v in mg["phase_ms"].items()}
+        if cfg.get("per_rank"):
+            c["per_rank"] = [[r["rank"], _r(r["count_kernel_ms"], 3), _r(r["export_ms"], 3), _r(r["exchange_wait_ms"], 3), _r(r["merge_ms"], 3),
+                              r["sent_units"], r["owned_distinct"]] for r in cfg["per_rank"]]
+            c["per_rank_columns"] = ["rank", "count_kernel_ms", "export_ms", "exchange_wait_ms", "merge_ms", "sent_units", "owned_distinct"]
+    if cfg.get("single_gpu_same_share"):
+        c["single_gpu_same_share"] = {k: _r(v, 5) for k, v in cfg["single_gpu_same_share"].items() if k != "what"}
+    line["config"] = c
+    line["roofline"] = {"bound": rf.get("bound"), "achieved": _r(rf.get("achieved"), 5), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                        "frac": _r(rf.get("frac")), "traffic": rf.get("traffic"), "traffic_frac": _r(rf.get("traffic_frac")),
+                        "alg_bytes_per_step": rf.get("alg_bytes_per_step"), "kernel_ms_per_step": _r(rf.get("kernel_ms_per_step"), 5),
+                        "kernel": rf.get("kernel"), "stages_ms": {k: _r(v, 4) for k, v in (rf.get("stages_ms") or {}).items()},
+                        "dominant": {"kernel": dom.get("kernel"), "ms": _r(dom.get("ms"), 4), "frac": _r(dom.get("frac"))} if dom else None}
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": (cb.get("sample") or "")[:160], "optimised_value": _r(cb.get("optimised_value"), 5),
+                                "optimised_cores": cb.get("optimised_cores")}
+    if full.get("verify") is not None:
+        v = full["verify"]
+        line["verify"] = {k: v.get(k) for k in ("ok", "sampled_keys", "cpu_total_kmers", "gpu_total_kmers") if v.get(k) is not None}
+    if full.get("unhinted"):
+        u = full["unhinted"]
+        line["unhinted"] = {"value": _r(u.get("value"), 6), "ratio_to_headline": _r(u.get("ratio_to_headline"), 5), "verify_ok": u.get("verify_ok")}
+    e2e = full.get("end_to_end") or {}
+    if e2e and "error" not in e2e:
+        pin = e2e.get("pinned") or {}
+        line["end_to_end"] = {"pageable_push_GBps": _r(e2e.get("push_GBps")), "pageable_kmers_per_s_push_only": _r(e2e.get("kmers_per_s_push_only"), 5),
+                              "pinned_push_GBps": _r(pin.get("push_GBps")), "pinned_kmers_per_s_pairs_out": _r(pin.get("kmers_per_s_pairs_out"), 5),
+                              "consistent": bool(e2e.get("consistent") and pin.get("consistent", True))}
+    rows = []
+    for x in full.get("configs") or []:
+        row = {"workload": (x.get("workload") or "")[:72]}
+        if "error" in x:
+            row["error"] = x["error"][:120]
+        else:
+            row.update({"value": _r(x.get("value"), 5), "ms_per_step": _r(x.get("ms_per_step"), 4), "frac": _r((x.get("roofline") or {}).get("frac")),
+                        "verify_ok": (x.get("verify") or {}).get("ok")})
+        rows.append(row)
+    if rows:
+        line["configs"] = rows
+    cli = full.get("cli")
+    if cli:
+        big = cli.get("s100m") or cli.get("large") or {}
+        line["cli"] = {"s10m_wall_s": _r(cli.get("wall_s")), "s100m_wall_s": _r(big.get("wall_s")), "s100m_kmers_per_s": _r(big.get("kmers_per_s"), 5),
+                       "s100m_reads": big.get("reads"), "ok": bool(cli.get("ok") and big.get("ok", True)) if "error" not in cli else False}
+        if "error" in cli:
+            line["cli"]["error"] = str(cli["error"])[:120]
+    line["full_report"] = full.get("full_report")
+    # never let an extra push the line over the limit: drop the optional blocks, largest first
+    for drop in ("end_to_end", "configs", "cli", "unhinted"):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        line["dropped_for_size"] = line.get("dropped_for_size", []) + [drop]
+    return line
+
+
+def emit(full):
+    """Full report -> gpurun_out/bench_full.json (BENCH_FULL_PATH overrides); contract line -> stdout, last and alone."""
+    path = os.environ.get("BENCH_FULL_PATH") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f)
+            f.write("\n")
+        full["full_report"] = os.path.relpath(path, ROOT)
+    except OSError as e:
+        full["full_report"] = f"not written: {e!r}"
+    line = json.dumps(contract_line(full))
+    assert len(line) <= LINE_LIMIT, len(line)
+    print(line, flush=True)
+
+
+def main_group(args):
+    """--group N: the N > 1 accounting of this file on ONE device.  N logical ranks are contexts of a kh_group (threads of this
+    process, the in-process hub as transport: RCCL refuses two ranks on one device); rank r counts reads [r x reads,
+    (r + 1) x reads) one after the other on the shared device, kh_group_merge runs the library's real merge sequence -- votes,
+    pipeline, digests, LDS merges -- and the line carries the same config.merge / per_rank / conserved / rccl_nranks keys as a
+    torchrun launch.  What it measures is the code path, not scaling: the ranks share one GPU's memory and CUs."""
+    import torch
+    import krust_amd
+    N = args.group
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    k = args.k
+    reads = args.reads or 10_000_000
+    stride = READ_LEN + 1
+    nbytes = reads * stride
+    with_qual = args.min_quality is not None
+    tbs, tqs = [], []
+    for r in range(N):
+        tb = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        tq = torch.empty(nbytes, dtype=torch.uint8, device=dev) if with_qual else None
+        krust_amd.synth_reads_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, SEED, GENOME_LEN, READ_LEN, r * reads, reads,
+                                     device=0, stream=torch.cuda.current_stream().cuda_stream)
+        tbs.append(tb)
+        tqs.append(tq)
+    torch.cuda.synchronize()
+    hint = args.capacity_hint or estimate_distinct(reads, k, N, with_qual)
+    with krust_amd.DeviceGroup(k, [0] * N, min_quality=args.min_quality, capacity_hint=hint) as grp:
+        def step():
+            sts = []
+            for r in range(N):
+                grp[r].reset()
+                grp[r].push_device(tbs[r].data_ptr(), tqs[r].data_ptr() if with_qual else None, nbytes)
+                sts.append(grp[r].finish())
+            return sts, grp.merge()
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sts, infos = step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        total_kmers = sum(int(st["kmers"]) for st in sts)
+        occ = dist_ = 0
+        for r in range(N):   # the key-sharded tables together hold every occurrence exactly once
+            hist = grp[r].histogram()
+            occ += sum(c * f for c, f in hist)
+            dist_ += sum(f for _, f in hist)
+        mg = merge_dict(infos[0], "kh_group_merge (C ABI; in-process hub: N thread ranks on one device)")
+        mg.update(merged_occurrences=occ, merged_distinct=dist_,
+                  conserved=bool(occ == total_kmers and all(i["conserved"] for i in infos)
+                                 and sum(i["sent_count_sum"] for i in infos) == sum(i["merged_count_sum"] for i in infos) == total_kmers))
+        if any(i["nranks_seen"] != N for i in infos):
+            raise RuntimeError(f"the transport saw {[i['nranks_seen'] for i in infos]} ranks, the group has {N}")
+        per_rank = [{"rank": r, "count_kernel_ms": sts[r]["count_kernel_ms"], "export_ms": i["export_ms"], "exchange_wait_ms": i["wait_ms"],
+                     "merge_ms": i["merge_ms"], "local_distinct": int(i["local_distinct"]), "sent_units": int(i["sent_units"]),
+                     "owned_distinct": int(i["owned_distinct"])} for r, i in enumerate(infos)]
+        st = sts[0]
+        rf = roofline_of(st, nbytes * (2 if with_qual else 1), st["count_kernel_ms"], st["stage_ms"], k)
+        verify = None
+        if not args.no_verify and reads <= 20_000_000:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            tot = 0
+            for r in range(N):
+                m = O.OracleMap()
+                tot += m.scan_flat(tbs[r].cpu().numpy(), k, qual=tqs[r].cpu().numpy() if with_qual else None, min_quality=args.min_quality,
+                                   sample_mask=1023, nthreads=2 * usable_cpus())
+            verify = {"ok": bool(tot == total_kmers == occ), "cpu_total_kmers": int(tot), "gpu_total_kmers": total_kmers,
+                      "what": "the k-mer total of all ranks' reads against the CPU oracle's scan, and against the merged shards' histograms"}
+    out = {"metric": "canonical k-mers/s at k=21, 100M x 150bp reads; bit-exact vs krust CPU",
+           "value": total_kmers * args.steps / elapsed, "unit": "k-mers/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+           "data": "synthetic",
+           "config": {"workload": f"--group {N}: {N} logical ranks x {reads} x {READ_LEN} bp reads on ONE GPU, k={k}: a dry run of the N > 1 accounting, not a scaling figure",
+                      "mode": f"group{N}", "k": k, "reads_per_gpu": reads, "kmers_per_step_per_gpu": int(st["kmers"]),
+                      "distinct_per_gpu": int(st["distinct"]), "table_slots": int(st["table_slots"]),
+                      "table_load": st["distinct"] / st["table_slots"], "capacity_hint": int(hint),
+                      "parallelism": f"reads sharded x{N} (thread ranks sharing one device); kh_group_merge",
+                      "merge": mg, "per_rank": per_rank},
+           "roofline": rf}
+    if verify is not None:
+        out["verify"] = verify
+    emit(out)
+
+
 def main():
     args = parse_args()
+    if args.group > 1:
+        return main_group(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -587,13 +802,8 @@ def main():
     def merge():
         if merge_impl == "c":
             # A failed merge raises on EVERY rank from this same call (kh_merge_across: status gathers, bounded waits,
-            # KH_ERR_PEER); the process then exits non-zero -- never re-exec, never hang.
-            mi = dc.merge_across()
-            return {"impl": "kh_merge_across (C ABI, RCCL)", "path": mi["path"], "local_distinct": mi["local_distinct"],
-                    "sent_pairs": mi["sent_units"], "recv_pairs": mi["recv_units"], "unit_bytes": mi["unit_bytes"],
-                    "owned_distinct": mi["owned_distinct"],
-                    "phase_ms": {"export": mi["export_ms"], "exchange_wait": mi["wait_ms"], "merge": mi["merge_ms"],
-                                 "total": mi["total_ms"], "pieces": mi["pieces"]}}
+            # KH_ERR_PEER; since round 5 also when what arrived is not what was sent); the process then exits non-zero.
+            return merge_dict(dc.merge_across(), "kh_merge_across (C ABI, RCCL)")
         out = dict(merge_across_ranks(dc, phase_times=True), impl="krust_amd.distributed (torch.distributed)")
         if merge_note:
             out["fallback_from_c_abi"] = merge_note
@@ -643,6 +853,9 @@ def main():
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)
         mg = dict(mg, merged_occurrences=int(chk[0].item()), merged_distinct=int(chk[1].item()),
                   conserved=bool(int(chk[0].item()) == total_kmers))
+        # the world RCCL itself reports (ncclCommCount inside the library) must be the world this run was launched with
+        if merge_impl == "c" and mg.get("rccl_nranks") != world:
+            raise RuntimeError(f"RCCL saw {mg.get('rccl_nranks')} ranks, the launcher {world}")
         # every rank's own figures of the last step: counting kernels, merge phases, what it sent and owns
         mine = torch.tensor([kernel_ms / args.steps, mg["phase_ms"].get("export", 0.0) if mg.get("phase_ms") else 0.0,
                              mg["phase_ms"].get("exchange_wait", 0.0) if mg.get("phase_ms") else 0.0,
@@ -654,8 +867,24 @@ def main():
         per_rank = [{"rank": r, "count_kernel_ms": float(v[0]), "export_ms": float(v[1]), "exchange_wait_ms": float(v[2]),
                      "merge_ms": float(v[3]), "local_distinct": int(v[4]), "sent_units": int(v[5]), "owned_distinct": int(v[6])}
                     for r, v in enumerate(rows)]
+        # The same share on ONE GPU, measured in this run: the rank's own reads counted with no merge (reset + push + finish),
+        # all ranks at once, rank 0's wall time.  The driver's N = 1 point is S100M (100 M reads); this is the N = 1 point of THIS
+        # workload (125 M reads per GPU), so that a 1 -> N curve can be read without mixing the two.
+        same_share = None
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            dc.reset()
+            dc.push_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, nbytes)
+            st1 = dc.finish()
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / 2
+        same_share = {"value": st1["kmers"] / dt1, "ms_per_step": dt1 * 1e3, "steps": 2, "kernel_ms_per_step": st1["count_kernel_ms"],
+                      "what": "rank 0's share counted alone on its GPU (no merge), measured after the timed loop of this run"}
+        fence()
     else:
         total_kmers = int(st["kmers"])
+        same_share = None
 
     verify = None
     do_verify = (args.verify or (world == 1 and not args.no_verify))
@@ -725,6 +954,7 @@ def main():
         if mg is not None:
             out["config"]["merge"] = mg
             out["config"]["per_rank"] = per_rank
+            out["config"]["single_gpu_same_share"] = same_share
         if verify is not None:
             out["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
@@ -791,7 +1021,7 @@ def main():
                         out["cli"][key]["phases"] = [r.get("phases") for r in big.get("runs", [])]
             except Exception as e:
                 out["cli"] = dict(out.get("cli") or {}, error=repr(e))
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     dc.close()
     if world > 1:

@@ -71,6 +71,10 @@ pub mod sys {
         pub wait_ms: f64,
         pub merge_ms: f64,
         pub total_ms: f64,
+        pub nranks_seen: u32,
+        pub conserved: u32,
+        pub sent_count_sum: u64,
+        pub merged_count_sum: u64,
     }
 
     #[repr(C)]

@@ -327,6 +327,15 @@ typedef struct kh_merge_info {
     double   wait_ms;         /* host wall time waiting for transfers / small collectives */
     double   merge_ms;        /* host wall time in the merge calls */
     double   total_ms;
+    /* conservation (round 5): the merge checks itself.  Every sender digests what it exports per destination (units, sum of
+     * the counts they carry, a wrapping checksum of the unit words), the digests travel with the small gathers, every receiver
+     * digests what ARRIVED per source and the merge kernels add up the counts they put into the shard: any difference fails
+     * the merge on every rank (KH_ERR_RCCL on the rank that saw it, KH_ERR_PEER on the others) -- a transport that loses
+     * half a message, or a merge kernel that drops a unit, cannot produce a quietly smaller table. */
+    uint32_t nranks_seen;      /* ranks the TRANSPORT reports (ncclCommCount; the process-local hub's size): == nranks */
+    uint32_t conserved;        /* 1: every check above held on this rank (always 1 when the call returned KH_OK) */
+    uint64_t sent_count_sum;   /* sum of the counts of all units this rank exported (its own share included) */
+    uint64_t merged_count_sum; /* sum of the counts this rank's merge put into its shard == occurrences it now holds */
 } kh_merge_info;
 int kh_merge_across(kh_ctx *ctx, kh_merge_info *info /* may be NULL */);
 

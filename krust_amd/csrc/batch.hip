@@ -302,8 +302,16 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
                 newcap = std::min<u64>(newcap, (u64)kh::MAX_P1 * kh::MAX_B2 * kh::REGION_SLOTS);
                 size_t fr = 0, tot = 0;
                 if (hipMemGetInfo(&fr, &tot) == hipSuccess) {  // never beyond a third of what is free (the partition buffers of this batch come next)
-                    const u64 room = ((u64)fr + (c->table ? c->cap * sizeof(Slot) : 0) + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
-                    while (newcap > c->cap && newcap * sizeof(Slot) > room) newcap = round_cap((double)newcap * 0.8);
+                    u64 room = ((u64)fr + (c->table ? c->cap * sizeof(Slot) : 0) + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
+                    if (c->knobs.table_room_mb) room = c->knobs.table_room_mb << 20;  // (test build: as if that were all the room)
+                    // (strictly smaller at every turn: round_cap() rounds UP, and 0.8 x a power of two -- every size up to 2^28 slots,
+                    //  every size with KMERHIP_POW2_TABLE=1 -- rounds back to where it came from: ADVICE r4, a loop without an end)
+                    while (newcap > c->cap && newcap * sizeof(Slot) > room) {
+                        u64 next = round_cap((double)newcap * 0.8);
+                        if (next >= newcap) next = round_cap((double)newcap * 0.5);
+                        if (next >= newcap) break;
+                        newcap = std::max(next, c->cap);
+                    }
                 }
                 if (c->trace)
                     fprintf(stderr, "[kmerhip] %llu payloads, ~%llu distinct (sample: %llu of %llu in %u partition(s)%s): table %llu -> %llu slots, load %.3f\n", total,
@@ -331,23 +339,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         if ((rc = ensure_buf(c, &c->O2, &z, n2 + 1, "hipMalloc(O2)")) != KH_OK) return rc;
         c->h2_cap = n2;
     }
-    if (c->region_cap < nregions) {
-        u64 z = c->bstart ? c->region_cap + 1 : 0;
-        if ((rc = ensure_buf(c, &c->bstart, &z, nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
-        z = c->rfail ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rfail, &z, nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
-        z = c->rnew ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rnew, &z, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
-        z = c->rheads ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rheads, &z, nregions, "hipMalloc(rheads)")) != KH_OK) return rc;
-        z = c->rreal ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rreal, &z, nregions, "hipMalloc(rreal)")) != KH_OK) return rc;
-        z = c->bend ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->bend, &z, nregions, "hipMalloc(bend)")) != KH_OK) return rc;
-        z = c->hot_list ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->hot_list, &z, nregions, "hipMalloc(hot_list)")) != KH_OK) return rc;
-        c->region_cap = nregions;
-    }
+    if ((rc = ensure_region_scratch(c, nregions)) != KH_OK) return rc;
     // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
     // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
     const bool lines_on = c->knobs.p2_lines;

@@ -100,6 +100,7 @@ struct Knobs {
     u64 hot_cut = 0;                 // KMERHIP_HOT_CUT (0: default; ~0: no bucket is hot)
     int ovf_agg = -1;                // KMERHIP_OVF_AGG
     double survival = 0;             // KMERHIP_SURVIVAL
+    u64 table_room_mb = 0;           // KMERHIP_TABLE_ROOM_MB: what the sample-sized table may take, as if the device had no more
     bool stop_after_p1 = false, stop_after_p2 = false;  // ablation builds (KH_ABL*)
 };
 inline const char *env_of(const char *name) {
@@ -203,6 +204,7 @@ struct kh_ctx {
     uint32_t rheads_cb = 0;
     u64 *bend = nullptr;             // arena path: end of every region's data (the exact path uses bstart + 1)
     uint32_t *hot_list = nullptr;    // [regions] buckets left to hot_buckets_kernel (partition.hip.h)
+    u64 *radd = nullptr;             // [regions] shard_merge_kernel: sum of the counts it put into every target region (conservation)
     u64 *ptotal = nullptr;           // [MAX_P1] payloads per level-1 partition
     uint32_t *pcap = nullptr;        // [MAX_P1] arena capacity of that partition's buckets
     uint8_t *heavy = nullptr;        // [MAX_P1] the partition is too heavy for one workgroup: the exact kernels take it
@@ -217,7 +219,7 @@ struct kh_ctx {
     uint32_t *pcount = nullptr;      // [MAX_P1] chunks per partition, then cursors
     u64 *pstart = nullptr;           // [MAX_P1 + 1]
     u64 *pool_next = nullptr;
-    u64 region_cap = 0;
+    u64 region_cap = 0;              // entries of EVERY [regions] array above: they grow together, ensure_region_scratch()
     u64 *scan_partial = nullptr;
     u64 scan_cap = 0;
     u64 *est_set = nullptr;          // scratch of distinct_sample_kernel (partition.hip.h): the set a few level-1 partitions are counted in
@@ -307,6 +309,7 @@ kh::TableGeom table_geom(const kh_ctx *c, Slot *table, u64 cap);
 int grow_to(kh_ctx *c, u64 newcap);
 int ensure_room(kh_ctx *c, u64 bound, bool allow_shrink_hint, bool *want_smaller);
 int drain_events(kh_ctx *c);
+int ensure_region_scratch(kh_ctx *c, u64 nregions);  // every [regions] scratch array of the context, grown together
 int release_part_buffers(kh_ctx *c);  // the two partition buffers back to the device (they come back with the next partitioned batch)
 int device_scan(kh_ctx *c, const uint32_t *in, u64 n, u64 *out);
 int zero_cursors(kh_ctx *c);

@@ -126,6 +126,7 @@ struct Comm {
     uint32_t nranks = 1, rank = 0;
     ncclComm_t nccl = nullptr;
     LocalHub *hub = nullptr;     // not owned
+    uint32_t seen = 0;           // ranks the transport itself reports: ncclCommCount, or the hub's size (kh_merge_info.nranks_seen)
     hipStream_t xs = nullptr;    // the exchange stream (transfers overlap the kernels on ctx->stream)
     u64 *d_small = nullptr;      // device staging of the small all-gathers: (1 + nranks) * SMALL_MAX u64
     u64 *h_small = nullptr;      // pinned twin
@@ -137,7 +138,7 @@ struct Comm {
     std::mutex abort_m;
     std::thread watchdog;
 };
-constexpr uint32_t SMALL_MAX = 128;  // u64 per rank in one small all-gather (status word included)
+constexpr uint32_t SMALL_MAX = 256;  // u64 per rank in one small all-gather (status word included; 3 digest words x 64 ranks fit)
 
 // ncclCommAbort, once.  Safe from the watchdog while the rank's own thread is blocked inside RCCL: that is what the call is for.
 void comm_abort(Comm *cm) {
@@ -372,6 +373,29 @@ struct DevBuf {  // scratch of one merge; freed when it goes out of scope
     }
 };
 
+// ---- conservation digests (round 5; shard.hip.h unit_digest_kernel) ----------------------------------
+// (units, sum of counts, checksum) of W unit segments of one buffer, into d_out[3 * W] (device), on the context's stream.
+// off / len in BYTES of the unit array; ub = bytes per unit (4 heads, 8 packed or the key array of wide pairs).
+int digest_units(kh_ctx *c, int fmt, const void *base, const u64 *counts, const u64 *off_bytes, const u64 *len_bytes, uint32_t W, u64 ub,
+                 uint32_t head_cmask, u64 *d_out) {
+    kh::DigestSegs segs;
+    memset(&segs, 0, sizeof(segs));
+    u64 maxlen = 0;
+    for (uint32_t p = 0; p < W; ++p) {
+        segs.off[p] = off_bytes[p] / ub;
+        segs.len[p] = len_bytes[p] / ub;
+        maxlen = std::max(maxlen, segs.len[p]);
+    }
+    HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)3 * W * sizeof(u64), c->stream));
+    if (!maxlen) return KH_OK;
+    const dim3 grid((unsigned)std::max<u64>(1, std::min<u64>(1024, (maxlen + kh::BLOCK * 16 - 1) / (kh::BLOCK * 16))), W), block(kh::BLOCK);
+    if (fmt == XF_HEADS32) hipLaunchKernelGGL((kh::unit_digest_kernel<2>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);
+    else if (fmt == XF_PACKED64) hipLaunchKernelGGL((kh::unit_digest_kernel<1>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);
+    else hipLaunchKernelGGL((kh::unit_digest_kernel<0>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);
+    HIP_TRY(c, hipGetLastError());
+    return KH_OK;
+}
+
 uint32_t merge_pieces_default() {  // (a tunable of the exchange: how many shares the pipeline works in; any value gives the same shards)
     const char *e = getenv("KMERHIP_MERGE_PIECES");
     const int v = e ? atoi(e) : 4;
@@ -421,6 +445,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     kh_merge_info mi;
     memset(&mi, 0, sizeof(mi));
     mi.nranks = W;
+    mi.nranks_seen = cm->seen;
     mi.pieces = 1;
     const Fault flt;
     auto inject = [&](const char *point) -> int {
@@ -454,8 +479,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     };
     // gather with timing; `where` names what would have come next
     std::vector<u64> all;
-    auto gather = [&](int lrc, std::initializer_list<u64> mine, const char *where) -> int {
-        const std::vector<u64> m(mine);
+    auto gather = [&](int lrc, const std::vector<u64> &m, const char *where) -> int {
         all.assign((size_t)W * std::max<size_t>(m.size(), 1), 0);
         const double t0 = now_ms();
         const int rc = xp_gather(c, lrc, m.data(), (uint32_t)m.size(), all.data(), where);
@@ -464,11 +488,96 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     };
     // the merge's last act: every rank learns whether every other one got through its merge kernels.  (Hub: also the
     // closing barrier -- every peer has finished copying out of this rank's send buffer before it is freed.)
+    // ---- conservation (round 5; kmerhip.h kh_merge_info) ----
+    // tx: what this rank exported, per destination; want_rx: what the senders announced for this rank (from the gathers the
+    // sequence has anyway); the receive side digests what arrived (d_rx) and verify_rx() compares -- and holds the sum of the
+    // counts the merge kernels took in (Counters::kmers of the shard, zero after kh_reset) to the same figures.
+    DevBuf dig;  // [0, 3W): scratch of the sender's digests; [3W (1 + i), 3W (2 + i)): the digests of what arrived in piece i
+    std::vector<u64> want_rx((size_t)3 * W, 0);
+    u64 tx_sum_total = 0, local_total = 0;
+    uint32_t rx_slots = 0;  // pieces whose arrival has been digested
+    auto d_tx = [&]() { return (u64 *)dig.p; };
+    auto d_rx = [&](uint32_t i) { return (u64 *)dig.p + (size_t)3 * W * (1 + i); };
+    // digests of one export's W segments (bytes so / sl inside `base`), read back: m[3 p + {units, counts, checksum}]
+    auto tx_digest = [&](int fmt, const void *base, const u64 *counts, const std::vector<u64> &so, const std::vector<u64> &sl, u64 ub, uint32_t cmask,
+                         std::vector<u64> &m) -> int {
+        m.assign((size_t)3 * W, 0);
+        int r = digest_units(c, fmt, base, counts, so.data(), sl.data(), W, ub, cmask, d_tx());
+        if (r != KH_OK) return r;
+        HIP_TRY(c, hipMemcpyAsync(m.data(), d_tx(), m.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (uint32_t p = 0; p < W; ++p) tx_sum_total += m[3 * p + 1];
+        return KH_OK;
+    };
+    // after a gather that carried every rank's tx digests (3 W words each): what they say this rank receives
+    auto note_announced = [&]() {
+        for (uint32_t s2 = 0; s2 < W; ++s2)
+            for (int j = 0; j < 3; ++j) want_rx[3 * s2 + j] += all[(size_t)s2 * 3 * W + 3 * R + j];
+    };
+    // (test build) KMERHIP_FAULT=rank:drop_half -- the upper half of what arrived is lost, as in round 4's transport incident
+    auto sabotage = [&](void *buf, u64 bytes) {
+        if ((int)R == flt.rank && flt.point == "drop_half" && bytes) (void)hipMemsetAsync((char *)buf + bytes / 2, 0, bytes - bytes / 2, c->stream);
+    };
+    // everything has been merged (kh_finish has run: the stream is idle, h_ctr current): arrived == announced == merged?
+    auto verify_rx = [&]() -> int {
+        std::vector<u64> got((size_t)3 * W, 0), h((size_t)3 * W * std::max(1u, rx_slots), 0);
+        if (rx_slots && hipMemcpy(h.data(), d_rx(0), (size_t)3 * W * rx_slots * sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(c, KH_ERR_HIP, "hipMemcpy(arrival digests)");
+        for (uint32_t i = 0; i < rx_slots; ++i)
+            for (size_t j = 0; j < (size_t)3 * W; ++j) got[j] += h[(size_t)3 * W * i + j];
+        u64 announced = 0;
+        for (uint32_t s2 = 0; s2 < W; ++s2) {
+            announced += want_rx[3 * s2 + 1];
+            if (got[3 * s2] != want_rx[3 * s2] || got[3 * s2 + 1] != want_rx[3 * s2 + 1] || got[3 * s2 + 2] != want_rx[3 * s2 + 2]) {
+                char buf[320];
+                snprintf(buf, sizeof(buf), "conservation: what arrived from rank %u differs from what it sent (units %llu / %llu, counts %llu / %llu, checksum %s): "
+                         "the transport lost or changed data", s2, (unsigned long long)got[3 * s2], (unsigned long long)want_rx[3 * s2],
+                         (unsigned long long)got[3 * s2 + 1], (unsigned long long)want_rx[3 * s2 + 1], got[3 * s2 + 2] == want_rx[3 * s2 + 2] ? "equal" : "different");
+                c->last_error = buf;
+                return KH_ERR_RCCL;
+            }
+        }
+        if (c->h_ctr->kmers != announced) {
+            char buf[256];
+            snprintf(buf, sizeof(buf), "conservation: the merge kernels took in counts summing to %llu, the units that arrived carry %llu",
+                     (unsigned long long)c->h_ctr->kmers, (unsigned long long)announced);
+            c->last_error = buf;
+            return KH_ERR_RCCL;
+        }
+        return KH_OK;
+    };
+    // all of this rank's exports are digested: do they carry what the table held?
+    auto verify_tx = [&]() -> int {
+        if (tx_sum_total == local_total) return KH_OK;
+        char buf[256];
+        snprintf(buf, sizeof(buf), "conservation: the exports carry counts summing to %llu, the table held %llu", (unsigned long long)tx_sum_total,
+                 (unsigned long long)local_total);
+        c->last_error = buf;
+        return KH_ERR_RCCL;
+    };
     auto finish = [&](int lrc) -> int {
         if (cm->hub && transfers && lrc == KH_OK && hipStreamSynchronize(cm->xs) != hipSuccess) lrc = fail(c, KH_ERR_HIP, "hipStreamSynchronize(exchange)");
-        const int rc = gather(lrc, {}, "the end of the merge");
-        if (rc == KH_OK) transfers = false;  // (every rank's copies are complete: see the line above)
-        return done(rc);
+        if (lrc == KH_OK) {
+            mi.sent_count_sum = tx_sum_total;
+            mi.merged_count_sum = c->h_ctr->kmers;
+        }
+        const int rc = gather(lrc, {mi.sent_count_sum, mi.merged_count_sum}, "the end of the merge");
+        if (rc != KH_OK) return done(rc);
+        transfers = false;  // (every rank's copies are complete: see the line above)
+        // the closing identity, from the gathered words (every rank decides the same): all that left == all that was merged
+        u64 sent = 0, merged = 0;
+        for (uint32_t r = 0; r < W; ++r) {
+            sent += all[2 * r];
+            merged += all[2 * r + 1];
+        }
+        if (sent != merged) {
+            char buf[256];
+            snprintf(buf, sizeof(buf), "conservation: the ranks exported counts summing to %llu and merged %llu", (unsigned long long)sent, (unsigned long long)merged);
+            c->last_error = buf;
+            return done(KH_ERR_RCCL);
+        }
+        mi.conserved = 1;
+        return done(KH_OK);
     };
 
     if (cm->nccl && (int)R == flt.rank && flt.point == "abort") {  // (tests: what a time-out does, without waiting for one)
@@ -491,7 +600,9 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         if ((u64)fr < want) lrc = release_part_buffers(c);
     }
     if (lrc == KH_OK) lrc = inject("start");
+    if (lrc == KH_OK) lrc = dig.alloc(c, (size_t)3 * W * (1 + 64) * sizeof(u64), "hipMalloc(digests)");
     const u64 n_local = lrc == KH_OK ? c->h_ctr->distinct : 0;
+    local_total = lrc == KH_OK ? c->h_ctr->kmers : 0;  // the sum of all counts of this rank's table
     u64 nreg = c->cap / kh::REGION_SLOTS;
     mi.local_distinct = n_local;
     int rc;
@@ -521,6 +632,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         mi.unit_bytes = 8;
         mi.sent_units = mi.recv_units = n;
         if (lrc == KH_OK) mi.owned_distinct = c->h_ctr->distinct;
+        tx_sum_total = local_total;  // (dense: what a rank adds to the all-reduce is its table; finish() holds the sum of the shards to the sum of these)
         return finish(lrc);
     }
 
@@ -545,6 +657,8 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     }
 
     const bool pow2 = (W & (W - 1)) == 0;
+    const int head_cb = head_count_bits(c, nreg);  // (< 0: heads do not apply to this table -- the vote then never agrees on them)
+    const uint32_t head_cmask = head_cb > 0 ? (1u << head_cb) - 1u : 0u;
     // (a table of 1024 x b2 regions, b2 not a power of two, splits into hash-range shards that nest only if W divides b2:
     //  kmerhip.hip merge_regions; round_cap() keeps b2 a multiple of 8 -- of 64 from 512 -- so this fails only for worlds
     //  of 16+ ranks with small tables, which then take the generic route)
@@ -745,9 +859,14 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
                     o += parts[p];
                     rl[p] = recv_mat[(size_t)p * npieces + i] * ub;
                 }
+                // what this piece carries, per destination: announced with the gather below, recomputed by the receivers
+                std::vector<u64> txm((size_t)3 * W, 0);  // (a rank that failed before its digest still posts as many words as its peers)
+                if (lrc == KH_OK) lrc = tx_digest(agreed == 2 ? XF_HEADS32 : XF_PACKED64, dst, nullptr, so, sl, ub, head_cmask, txm);
+                if (lrc == KH_OK && i + 1 == npieces) lrc = verify_tx();
                 // piece i leaves only when every rank has it ready (the gather queues behind transfer i - 1 on the exchange
                 // stream, which transfer i would do anyway; the export of piece i has overlapped transfer i - 1 by now)
-                if ((rc = gather(lrc, {}, "the transfer of a piece")) != KH_OK) return done(rc);
+                if ((rc = gather(lrc, txm, "the transfer of a piece")) != KH_OK) return done(rc);
+                note_announced();
                 mi.sent_units += o - parts[R];
                 used += o;
                 const double t0 = now_ms();
@@ -772,6 +891,14 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
                 t_wait += now_ms() - t0;
                 if (lrc != KH_OK) break;
                 t0 = now_ms();
+                {   // what arrived, per source (on the context's stream, in front of the merge that reads the same bytes)
+                    std::vector<u64> rl(W);
+                    for (uint32_t s2 = 0; s2 < W; ++s2) rl[s2] = recv_mat[(size_t)s2 * npieces + i] * ub;
+                    sabotage(flights[i].buf.p, flights[i].units * ub);
+                    lrc = digest_units(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, flights[i].buf.p, nullptr, flights[i].roff.data(), rl.data(), W, ub, head_cmask, d_rx(i));
+                    rx_slots = i + 1;
+                    if (lrc != KH_OK) break;
+                }
                 std::vector<const void *> kp(W);
                 std::vector<const uint32_t *> rp(W);
                 for (uint32_t s = 0; s < W; ++s) {
@@ -788,6 +915,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
                 (void)kh_set_region_window(c, 0, 1);
                 lrc = kh_finish(c, nullptr);
             }
+            if (lrc == KH_OK) lrc = verify_rx();
             mi.route = agreed == 2 ? KH_ROUTE_REGIONS_HEADS : KH_ROUTE_REGIONS_PACKED;
             mi.pieces = npieces;
             mi.unit_bytes = ub;
@@ -860,7 +988,23 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         if (lrc == KH_OK) lrc = rrc.alloc(c, nreg * sizeof(uint32_t), "hipMalloc(region counts in)");
         if (lrc == KH_OK && wide) lrc = rbuf2.alloc(c, rtot * 8, "hipMalloc(exchange receive counts)");
         if (lrc == KH_OK) lrc = inject("oneshot_alloc");
-        if ((rc = gather(lrc, {}, "the exchange")) != KH_OK) return done(rc);
+        const int xfmt = wide ? XF_WIDE : (agreed == 2 ? XF_HEADS32 : XF_PACKED64);
+        std::vector<u64> txm((size_t)3 * W, 0), seg_so(W), seg_sl(W), seg_ro(W), seg_rl(W);
+        {
+            u64 a2 = 0, b2 = 0;
+            for (uint32_t p = 0; p < W; ++p) {
+                seg_so[p] = a2 * ub;
+                seg_sl[p] = parts[p] * ub;
+                a2 += parts[p];
+                seg_ro[p] = b2 * ub;
+                seg_rl[p] = recv_units[p] * ub;
+                b2 += recv_units[p];
+            }
+        }
+        if (lrc == KH_OK) lrc = tx_digest(xfmt, sendbuf.p, wide ? (const u64 *)sendcnt.p : nullptr, seg_so, seg_sl, ub, head_cmask, txm);
+        if (lrc == KH_OK) lrc = verify_tx();
+        if ((rc = gather(lrc, txm, "the exchange")) != KH_OK) return done(rc);
+        note_announced();
         double t0 = now_ms();
         transfers = true;
         lrc = a2a_units(sendbuf.p, parts, recv_units, ub, rbuf.p);
@@ -874,6 +1018,11 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         if (lrc == KH_OK) lrc = xp_wait(c, nullptr, "exchange");  // the merge kernels run on the context's stream
         t_wait += now_ms() - t0;
         t0 = now_ms();
+        if (lrc == KH_OK) {
+            sabotage(rbuf.p, rtot * ub);
+            lrc = digest_units(c, xfmt, rbuf.p, wide ? (const u64 *)rbuf2.p : nullptr, seg_ro.data(), seg_rl.data(), W, ub, head_cmask, d_rx(0));
+            rx_slots = 1;
+        }
         if (lrc == KH_OK) lrc = kh_reset(c);
         if (lrc == KH_OK) lrc = kh_set_shard(c, R, W);
         if (lrc == KH_OK) lrc = inject("oneshot_merge");
@@ -891,6 +1040,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
             lrc = merge_regions(c, wide ? XF_WIDE : (agreed == 2 ? XF_HEADS32 : XF_PACKED64), W, nreg, kp.data(), wide ? cp.data() : nullptr, rp.data());
         }
         if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
+        if (lrc == KH_OK) lrc = verify_rx();
         t_merge += now_ms() - t0;
         mi.route = wide ? KH_ROUTE_REGIONS_WIDE : (agreed == 2 ? KH_ROUTE_REGIONS_HEADS : KH_ROUTE_REGIONS_PACKED);
         mi.unit_bytes = wide ? 16 : (uint32_t)ub;
@@ -915,7 +1065,22 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         lrc = rk.alloc(c, rtot * 8, "hipMalloc(exchange receive keys)");
         if (lrc == KH_OK) lrc = rcn.alloc(c, rtot * 8, "hipMalloc(exchange receive counts)");
         if (lrc == KH_OK) lrc = inject("generic_alloc");
-        if ((rc = gather(lrc, {}, "the exchange")) != KH_OK) return done(rc);
+        std::vector<u64> txm((size_t)3 * W, 0), seg_so(W), seg_sl(W), seg_ro(W), seg_rl(W);
+        {
+            u64 a2 = 0, b2 = 0;
+            for (uint32_t p = 0; p < W; ++p) {
+                seg_so[p] = a2 * 8;
+                seg_sl[p] = parts[p] * 8;
+                a2 += parts[p];
+                seg_ro[p] = b2 * 8;
+                seg_rl[p] = recv_units[p] * 8;
+                b2 += recv_units[p];
+            }
+        }
+        if (lrc == KH_OK) lrc = tx_digest(XF_WIDE, sendbuf.p, (const u64 *)sendcnt.p, seg_so, seg_sl, 8, 0u, txm);
+        if (lrc == KH_OK) lrc = verify_tx();
+        if ((rc = gather(lrc, txm, "the exchange")) != KH_OK) return done(rc);
+        note_announced();
         t0 = now_ms();
         transfers = true;
         lrc = a2a_units(sendbuf.p, parts, recv_units, 8, rk.p);
@@ -924,11 +1089,17 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         if (lrc == KH_OK) lrc = xp_wait(c, nullptr, "exchange");
         t_wait += now_ms() - t0;
         t0 = now_ms();
+        if (lrc == KH_OK) {
+            sabotage(rk.p, rtot * 8);
+            lrc = digest_units(c, XF_WIDE, rk.p, (const u64 *)rcn.p, seg_ro.data(), seg_rl.data(), W, 8, 0u, d_rx(0));
+            rx_slots = 1;
+        }
         if (lrc == KH_OK) lrc = kh_reset(c);
         if (lrc == KH_OK) lrc = inject("generic_merge");
         if (lrc == KH_OK) lrc = kh_merge_pairs_device(c, (const uint64_t *)rk.p, (const uint64_t *)rcn.p, rtot);
         if (lrc == KH_OK) lrc = kh_finish(c, nullptr);  // (also: the kernels are done with rk / rcn before they are freed)
         else (void)hipStreamSynchronize(c->stream);
+        if (lrc == KH_OK) lrc = verify_rx();
         t_merge += now_ms() - t0;
         mi.route = KH_ROUTE_PAIRS;
         mi.unit_bytes = 16;
@@ -970,6 +1141,7 @@ int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id
     int rc = KH_OK;
     if (hipStreamCreateWithFlags(&cm->xs, hipStreamNonBlocking) != hipSuccess) rc = fail(c, KH_ERR_HIP, "hipStreamCreate(exchange)");
     if (rc == KH_OK && hub) hub->xs[rank] = cm->xs;
+    if (hub) cm->seen = hub->n;
     if (rc == KH_OK && !hub) {
         const size_t n = (size_t)(1 + nranks) * SMALL_MAX * sizeof(u64);
         if (hipMalloc((void **)&cm->d_small, n) != hipSuccess || hipHostMalloc((void **)&cm->h_small, n, hipHostMallocDefault) != hipSuccess) {
@@ -981,6 +1153,9 @@ int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id
             if (r != ncclSuccess) {
                 cm->nccl = nullptr;
                 rc = rccl_fail(c, "ncclCommInitRank", r);
+            } else {
+                int cnt = 0;  // what RCCL itself says the world is (kh_merge_info.nranks_seen: the bench line asserts it == --gpus)
+                if (ncclCommCount(cm->nccl, &cnt) == ncclSuccess && cnt > 0) cm->seen = (uint32_t)cnt;
             }
         }
         if (rc == KH_OK) {
@@ -1031,7 +1206,9 @@ extern "C" int kh_merge_across(kh_ctx *c, kh_merge_info *info) {
     if (c->comm && c->comm->dead.load())  // (nobody can be waiting on a dead communicator: no gather to join)
         return fail(c, KH_ERR_RCCL, "the communicator was aborted by an earlier failed merge; create a new context and communicator");
     // (a finished merge leaves EVERY rank a shard: this refusal is collective by itself, nobody is waiting in a gather)
-    if (c->shard_shift && !c->poisoned) return fail(c, KH_ERR_STATE, "the table is already a shard (merged before); kh_reset first");
+    // (poisoned or not -- ADVICE r4: a poisoned shard used to walk into the first gather, where its peers, shards too, never came)
+    if (c->shard_shift) return fail(c, KH_ERR_STATE, c->poisoned ? "the table is already a shard (merged before) and the context is poisoned by an earlier error; kh_reset / a new context first"
+                                                                  : "the table is already a shard (merged before); kh_reset first");
     // (counts what kh_push / kh_push_text left pending: may fail -- out of memory, table full -- on this rank alone.  The 8-byte
     //  image stays what it is: the exports read it directly -- round 4: the default here widened it first, 13.5 ms and a 43 GB
     //  allocation at configs[3]'s size, and every export then read the 16-byte table)
@@ -1045,7 +1222,11 @@ extern "C" int kh_merge_across(kh_ctx *c, kh_merge_info *info) {
             info->pieces = 1;
         }
         rc = kh_finish(c, nullptr);
-        if (rc == KH_OK && info) info->local_distinct = info->owned_distinct = c->h_ctr->distinct;
+        if (rc == KH_OK && info) {
+            info->local_distinct = info->owned_distinct = c->h_ctr->distinct;
+            info->nranks_seen = info->conserved = 1;
+            info->sent_count_sum = info->merged_count_sum = c->h_ctr->kmers;
+        }
         return rc;
     }
     return merge_across_impl(c, info, KH_OK);

@@ -707,15 +707,21 @@ KH_GLOBAL __launch_bounds__(BLOCK) void table_merge_pairs_kernel(TableGeom tg, c
                                                                   const u64 *counts, u64 n, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
+    u64 ad = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const u64 key = keys[i];
         const u64 c = counts[i];
-        if (key != KH_EMPTY_KEY && c != 0) upsert(tg, key, c, nd, nf);
+        if (key != KH_EMPTY_KEY && c != 0) {
+            upsert(tg, key, c, nd, nf);
+            ad += c;
+        }
     }
     u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    ad = wave_sum(ad);
     if (lane_id() == 0) {
         if (d) atomicAdd(&ctr->distinct, d);
         if (f) atomicAdd(&ctr->failed, f);
+        if (ad) atomicAdd(&ctr->kmers, ad);  // (kmers == the sum of all counts in the table, merges included: round 5)
     }
 }
 
@@ -735,14 +741,20 @@ KH_GLOBAL __launch_bounds__(BLOCK) void table_merge_dense_kernel(TableGeom tg, c
                                                                   uint32_t owner, uint32_t nparts, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
     uint32_t nd = 0, nf = 0;
+    u64 ad = 0;
     for (u64 key = (u64)blockIdx.x * BLOCK + threadIdx.x; key < n_entries; key += stride) {
         const u64 c = dense[key];
-        if (c != 0 && kh_owner_of(key, tg.k, nparts) == owner) upsert(tg, key, c, nd, nf);
+        if (c != 0 && kh_owner_of(key, tg.k, nparts) == owner) {
+            upsert(tg, key, c, nd, nf);
+            ad += c;
+        }
     }
     u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+    ad = wave_sum(ad);
     if (lane_id() == 0) {
         if (d) atomicAdd(&ctr->distinct, d);
         if (f) atomicAdd(&ctr->failed, f);
+        if (ad) atomicAdd(&ctr->kmers, ad);
     }
 }
 

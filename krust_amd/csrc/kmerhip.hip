@@ -33,6 +33,7 @@ void read_knobs(Knobs &k) {
     if (const char *e = env_of("KMERHIP_HOT_CUT")) k.hot_cut = (e[0] == '0' && !e[1]) ? ~0ull : strtoull(e, nullptr, 10);
     if (const char *e = env_of("KMERHIP_OVF_AGG")) k.ovf_agg = atoi(e);
     if (const char *e = env_of("KMERHIP_SURVIVAL")) k.survival = atof(e);
+    if (const char *e = env_of("KMERHIP_TABLE_ROOM_MB")) k.table_room_mb = strtoull(e, nullptr, 10);
     k.stop_after_p1 = env_of("KMERHIP_STOP_AFTER_P1") != nullptr;
     k.stop_after_p2 = env_of("KMERHIP_STOP_AFTER_P2") != nullptr;
 #endif
@@ -268,6 +269,31 @@ int ensure_room(kh_ctx *c, u64 bound, bool allow_shrink_hint, bool *want_smaller
     return grow_to(c, newcap);
 }
 
+// The per-region scratch arrays of the partitioned path and of the shard merge.  ONE capacity for all of them: round 4 let the
+// merge raise region_cap after growing only the three arrays it uses itself, and a later partitioned batch into the same context
+// -- count little, merge into a larger geometry, kh_reset, count much -- then skipped the allocation of the others.
+int ensure_region_scratch(kh_ctx *c, u64 nregions) {
+    if (c->region_cap >= nregions && c->bstart) return KH_OK;
+    int rc;
+    const u64 have = c->region_cap;
+    u64 z = c->bstart ? have + 1 : 0;
+    if ((rc = ensure_buf(c, &c->bstart, &z, nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
+#define KH_REGION_ARRAY(field)                                                                    \
+    z = c->field ? have : 0;                                                                      \
+    if ((rc = ensure_buf(c, &c->field, &z, nregions, "hipMalloc(" #field ")")) != KH_OK) return rc
+    KH_REGION_ARRAY(rfail);
+    KH_REGION_ARRAY(rnew);
+    KH_REGION_ARRAY(rheads);
+    KH_REGION_ARRAY(rreal);
+    KH_REGION_ARRAY(bend);
+    KH_REGION_ARRAY(hot_list);
+    KH_REGION_ARRAY(radd);
+#undef KH_REGION_ARRAY
+    c->region_cap = nregions;
+    c->rheads_valid = false;  // (the array that held them is gone)
+    return KH_OK;
+}
+
 int drain_events(kh_ctx *c) {
     for (auto &e : c->stage_events) {
         float ms = 0.f;
@@ -447,7 +473,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->scan_partial, c->est_set, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->radd, c->scan_partial, c->est_set, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw2[0], c->txt_raw2[1], c->txt_acc[0], c->txt_acc[1], c->txt_accq[0], c->txt_accq[1], c->txt_scan_partial, c->txt_ls, c->txt_hdr,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)

@@ -433,15 +433,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     if ((rc = need_table(c)) != KH_OK) return rc;  // (uninitialised if new: a fresh merge writes every region -- `dirty` below)
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     const u64 nregions = c->cap / kh::REGION_SLOTS;
-    if (c->region_cap < nregions) {
-        u64 zz = c->bstart ? c->region_cap + 1 : 0;
-        if ((rc = ensure_buf(c, &c->bstart, &zz, nregions + 1, "hipMalloc(bstart)")) != KH_OK) return rc;
-        zz = c->rfail ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rfail, &zz, nregions, "hipMalloc(rfail)")) != KH_OK) return rc;
-        zz = c->rnew ? c->region_cap : 0;
-        if ((rc = ensure_buf(c, &c->rnew, &zz, nregions, "hipMalloc(rnew)")) != KH_OK) return rc;
-        c->region_cap = nregions;
-    }
+    if ((rc = ensure_region_scratch(c, nregions)) != KH_OK) return rc;
     kh::MergeArgs a;
     memset(&a, 0, sizeof(a));
     a.nsenders = nsenders;
@@ -484,7 +476,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
         const uint8_t *none = nullptr;
         const uint32_t dirty = (uint32_t)(windowed ? (fresh && c->win_dirty) : c->table_dirty);
 #define KH_MERGE_LAUNCH(FRESH, FMT) \
-    hipLaunchKernelGGL((kh::shard_merge_kernel<FRESH, false, FMT>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, none, kh::RegionGeom{0u, 1u}, c->d_ctr, \
+    hipLaunchKernelGGL((kh::shard_merge_kernel<FRESH, false, FMT>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, c->radd, none, kh::RegionGeom{0u, 1u}, c->d_ctr, \
                        FRESH ? dirty : 0u, (uint32_t)region0)
         if (fresh) {
             if (fmt == XF_WIDE) KH_MERGE_LAUNCH(true, 0);
@@ -497,7 +489,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
         }
 #undef KH_MERGE_LAUNCH
         hipLaunchKernelGGL(kh::shard_reduce_kernel, dim3(grid_for(nwin)), dim3(kh::BLOCK), 0, c->stream,
-                           (const uint8_t *)c->rfail + region0, (const uint32_t *)c->rnew + region0, (u64)nwin, c->d_ctr);
+                           (const uint8_t *)c->rfail + region0, (const uint32_t *)c->rnew + region0, (const u64 *)c->radd + region0, (u64)nwin, c->d_ctr);
     }
     HIP_TRY(c, hipGetLastError());
     c->table_empty = false;
@@ -518,7 +510,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
         if (rc != KH_OK) return rc;
 #define KH_MERGE_DIRECT(FMT) \
     hipLaunchKernelGGL((kh::shard_merge_kernel<false, true, FMT>), dim3((unsigned)nwin), dim3(1024), 0, c->stream, \
-                       table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, (const uint8_t *)c->rfail, old_geo, c->d_ctr, 0u, \
+                       table_geom(c, c->table, c->cap), a, c->rfail, c->rnew, c->radd, (const uint8_t *)c->rfail, old_geo, c->d_ctr, 0u, \
                        (uint32_t)region0)
         if (fmt == XF_WIDE) KH_MERGE_DIRECT(0);
         else if (fmt == XF_PACKED64) KH_MERGE_DIRECT(1);

@@ -236,12 +236,14 @@ struct MergeArgs {
 // FMT: 0 = {u64 key, u64 count} in two arrays, 1 = packed u64 (count << 32 | 32 hash bits), 2 = u32 heads
 template <bool FRESH, bool DIRECT, int FMT>
 __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, MergeArgs a, uint8_t *__restrict__ rfail,
-                                                              uint32_t *__restrict__ rnew, const uint8_t *__restrict__ only_failed,
+                                                              uint32_t *__restrict__ rnew, u64 *__restrict__ radd,
+                                                              const uint8_t *__restrict__ only_failed,
                                                               RegionGeom old_geo, Counters *ctr, uint32_t dirty,
                                                               uint32_t region0) {
     __shared__ u64 s_key[DIRECT ? 1 : REGION_SLOTS];
     __shared__ u64 s_cnt[DIRECT ? 1 : REGION_SLOTS];
     __shared__ uint32_t s_fail, s_new;
+    __shared__ u64 s_add;  // sum of the counts this region took in (conservation: ctr->kmers, through radd / shard_reduce_kernel)
     __shared__ u64 s_seg_lo[MAX_SENDERS];
     __shared__ uint32_t s_seg_len[MAX_SENDERS];
     const int tid = threadIdx.x;
@@ -267,9 +269,11 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     if (tid == 0) {
         s_fail = 0;
         s_new = 0;
+        s_add = 0;
     }
     __syncthreads();
     uint32_t nd = 0, nf = 0;
+    u64 nadd = 0;
     const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
     const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
     constexpr bool PACKED = FMT != 0;
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
             if (target_of(H) != t) return;
             addend = raw1;
         }
+        nadd += addend;
         if (DIRECT) {
             upsert(tg, key, addend, nd, nf);
             return;
@@ -381,15 +386,18 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
             }
     }
     if (DIRECT) {
-        const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf);
+        const u64 d = wave_sum((u64)nd), f = wave_sum((u64)nf), ad = wave_sum(nadd);
         if (lane_id() == 0) {
             if (d) atomicAdd(&ctr->distinct, d);
             if (f) atomicAdd(&ctr->failed, f);
+            if (ad) atomicAdd(&ctr->kmers, ad);
         }
         return;
     }
     const uint32_t dw = (uint32_t)wave_sum((u64)nd);
+    const u64 aw = wave_sum(nadd);
     if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
+    if ((tid & 63) == 0 && aw) atomicAdd(&s_add, aw);
     __syncthreads();
     if (s_fail) {
         if (FRESH && dirty)  // lazily reset table (kernels.hip.h / kh_reset): leave an EMPTY region, not garbage
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
         if (tid == 0) {
             rfail[t] = 1;
             rnew[t] = 0;
+            radd[t] = 0;  // (the DIRECT pass takes this region's units again, and counts them then)
         }
         return;
     }
@@ -408,23 +417,69 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     if (tid == 0) {
         rfail[t] = 0;
         rnew[t] = s_new;
+        radd[t] = s_add;
     }
 }
 
-// distinct += sum(rnew), part_failed += number of failed target regions
+// distinct += sum(rnew), kmers += sum(radd), part_failed += number of failed target regions
 KH_GLOBAL __launch_bounds__(BLOCK) void shard_reduce_kernel(const uint8_t *__restrict__ rfail, const uint32_t *__restrict__ rnew,
-                                                             u64 nregions, Counters *ctr) {
+                                                             const u64 *__restrict__ radd, u64 nregions, Counters *ctr) {
     const u64 stride = (u64)gridDim.x * BLOCK;
-    u64 d = 0, nf = 0;
+    u64 d = 0, nf = 0, ad = 0;
     for (u64 r = (u64)blockIdx.x * BLOCK + threadIdx.x; r < nregions; r += stride) {
         if (rfail[r]) ++nf;
-        else d += rnew[r];
+        else {
+            d += rnew[r];
+            ad += radd[r];
+        }
     }
     d = wave_sum(d);
     nf = wave_sum(nf);
+    ad = wave_sum(ad);
     if (lane_id() == 0) {
         if (d) atomicAdd(&ctr->distinct, d);
         if (nf) atomicAdd(&ctr->part_failed, nf);
+        if (ad) atomicAdd(&ctr->kmers, ad);
+    }
+}
+
+// ---- conservation digests of exchange units (round 5; exchange.hip) --------------------------------
+// What a sender announces about every segment it sends, and what the receiver recomputes from the bytes that arrived:
+// the number of units, the sum of the counts they carry (the same arithmetic as shard_merge_kernel's take()), and a wrapping
+// sum of the raw unit words.  blockIdx.y = segment; out[3 * seg + {0, 1, 2}] is ADDED to (zeroed by the host).
+// FMT as in shard_merge_kernel: 0 = keys + counts arrays, 1 = packed u64, 2 = u32 heads.
+struct DigestSegs {
+    u64 off[MAX_SENDERS];  // first unit of the segment (in units from `base`)
+    u64 len[MAX_SENDERS];  // units
+};
+template <int FMT>
+__global__ __launch_bounds__(BLOCK) void unit_digest_kernel(const void *__restrict__ base, const u64 *__restrict__ counts, DigestSegs segs,
+                                                            uint32_t head_cmask, u64 *__restrict__ out) {
+    const uint32_t seg = blockIdx.y;
+    const u64 lo = segs.off[seg], n = segs.len[seg];
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    u64 sum = 0, chk = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        if (FMT == 2) {
+            const uint32_t h = reinterpret_cast<const uint32_t *>(base)[lo + i];
+            sum += (u64)(h & head_cmask) + 1;
+            chk += h;
+        } else if (FMT == 1) {
+            const u64 v = reinterpret_cast<const u64 *>(base)[lo + i];
+            sum += v >> 32;
+            chk += v;
+        } else {
+            const u64 key = reinterpret_cast<const u64 *>(base)[lo + i], cn = counts[lo + i];
+            sum += cn;
+            chk += key + 0x9E3779B97F4A7C15ull * cn;
+        }
+    }
+    sum = wave_sum(sum);
+    chk = wave_sum(chk);
+    if (lane_id() == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&out[3 * seg + 0], n);
+        if (sum) atomicAdd(&out[3 * seg + 1], sum);
+        if (chk) atomicAdd(&out[3 * seg + 2], chk);
     }
 }
 

@@ -34,12 +34,30 @@ def _all_to_all(out, inp, out_splits=None, in_splits=None, group=None):
     # NOTE (round 4, tools/world1_merge_probe.py): over RCCL a message of 2^30 bytes or more arrived half.  The exchange inside
     # the library (exchange.hip, xp_alltoallv) cuts its segments into 256 MiB messages; this harness sends a segment as ONE
     # message -- fine for the sizes the tests run and for worlds of 4+ at the bench's sizes, not for two ranks with S100M tables.
+    _refuse_huge_messages(out, inp, out_splits, in_splits, group)
     if out.is_cuda and _host_staged(group):
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
         out.copy_(o)
     else:
         dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+MAX_MESSAGE_BYTES = 1 << 30
+
+
+def _refuse_huge_messages(out, inp, out_splits, in_splits, group):
+    """This harness sends a segment as ONE message.  Until tools/rccl/rccl_big_msg.hip has cleared the transport (round 4: a
+    message of >= 2^30 bytes arrived half), a segment that large is refused LOUDLY instead of risking a quietly smaller
+    table; kh_merge_across cuts its segments into 256 MiB messages and checks what arrived (exchange.hip)."""
+    if _host_staged(group):
+        return
+    world = dist.get_world_size(group)
+    for t, splits in ((inp, in_splits), (out, out_splits)):
+        sizes = splits if splits is not None else [t.numel() // world] * world
+        if sizes and max(int(x) for x in sizes) * t.element_size() >= MAX_MESSAGE_BYTES:
+            raise RuntimeError(f"krust_amd.distributed: a segment of {max(int(x) for x in sizes) * t.element_size()} bytes would travel as one RCCL "
+                               "message (>= 2^30 bytes); use kh_merge_across (DeviceCounter.merge_across), which splits and verifies")
 
 
 def exchange_pairs(keys, counts, part_counts, group=None, return_sizes=False):
@@ -120,6 +138,7 @@ def _all_to_all_async(out, inp, out_splits=None, in_splits=None, group=None):
     if out.is_cuda and _host_staged(group):
         _all_to_all(out, inp, out_splits, in_splits, group=group)
         return None
+    _refuse_huge_messages(out, inp, out_splits, in_splits, group)
     return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group, async_op=True)
 
 

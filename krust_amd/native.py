@@ -47,7 +47,9 @@ class KhMergeInfo(C.Structure):
     _fields_ = [("route", C.c_uint32), ("pieces", C.c_uint32), ("unit_bytes", C.c_uint32), ("nranks", C.c_uint32),
                 ("local_distinct", C.c_uint64), ("sent_units", C.c_uint64), ("recv_units", C.c_uint64),
                 ("owned_distinct", C.c_uint64), ("export_ms", C.c_double), ("wait_ms", C.c_double),
-                ("merge_ms", C.c_double), ("total_ms", C.c_double)]
+                ("merge_ms", C.c_double), ("total_ms", C.c_double),
+                ("nranks_seen", C.c_uint32), ("conserved", C.c_uint32), ("sent_count_sum", C.c_uint64),
+                ("merged_count_sum", C.c_uint64)]
 
 
 ROUTES = ("none", "dense", "regions-heads", "regions-packed", "regions", "pairs")  # KH_ROUTE_*

@@ -136,6 +136,29 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert len(line) <= 6144
     mg = d["config"]["merge"]
     assert mg["conserved"] and mg["path"].startswith("regions"), mg
     assert mg["merged_occurrences"] == 2 * d["config"]["kmers_per_step_per_gpu"] or mg["conserved"]
+    assert d["config"]["single_gpu_same_share"]["value"] > 0       # the N = 1 point of the SAME workload, measured in this run
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_group_mode_runs_the_multi_rank_accounting_through_the_c_abi(n):
+    """RCCL refuses two ranks on one device, so the bench's C-ABI merge branch cannot run under torchrun on
+    a 1-GPU box.  `bench.py --group N` drives N thread ranks through kh_group_create / kh_group_merge (the in-process hub) and
+    fills the same config.merge / per_rank / conserved / rccl_nranks fields: the accounting code of the 8-GPU line runs here."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--group", str(n), "--steps", "2", "--warmup", "1", "--reads", "1000000"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BENCH_FULL_PATH=f"/tmp/bench_group{n}.json"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 6144          # ONE line, and one the driver's 8 KB tail holds whole
+    d = json.loads(lines[0])
+    mg = d["config"]["merge"]
+    assert mg["rccl_nranks"] == n and mg["conserved"] is True and mg["lib_conserved"] is True, mg
+    assert mg["path"].startswith("regions") and mg["merged_occurrences"] == n * d["config"]["kmers_per_step_per_gpu"] or mg["conserved"]
+    assert len(d["config"]["per_rank"]) == n and d["config"]["per_rank_columns"][0] == "rank"
+    assert d["verify"]["ok"] is True and d["config"]["mode"] == f"group{n}"
+    full = json.load(open(f"/tmp/bench_group{n}.json"))
+    assert full["config"]["merge"]["sent_count_sum"] > 0 and len(full["config"]["per_rank"]) == n

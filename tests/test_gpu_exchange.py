@@ -418,3 +418,124 @@ def test_ranks_with_tables_of_different_sizes_agree_on_the_largest(K, world, k):
             keys, cnts = dc.result()
             sel = owners == r
             assert np.array_equal(keys, fk[sel]) and np.array_equal(cnts, fc[sel]), f"shard {r} differs from the oracle"
+
+
+# ---- conservation (round 5): the merge checks itself --------------------------------------------------------------
+@pytest.mark.parametrize("world,k,pieces,expect", [(2, 19, None, "regions-heads-x4"), (4, 21, "1", "regions-packed"), (2, 31, None, "regions"),
+                                                   (3, 21, None, "pairs")])
+def test_the_merge_reports_what_it_conserved(K, monkeypatch, world, k, pieces, expect):
+    """kh_merge_info (round 5): nranks_seen = what the transport itself reports, conserved = 1, and the counts that left the
+    ranks (sum of every exported unit's count, from the senders' digests) equal the counts the merge kernels put into the
+    shards, equal the oracle's k-mer total."""
+    if pieces is None:
+        monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    else:
+        monkeypatch.setenv("KMERHIP_MERGE_PIECES", pieces)
+    n_reads = 60_000
+    full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
+    fk, fc = oracle_arrays(full_b, k)
+    per = n_reads // world
+    with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
+        for r, dc in enumerate(g.counters):
+            lo, hi = r * per, (n_reads if r == world - 1 else (r + 1) * per)
+            dc.push(full_b[lo * 151: hi * 151])
+        locals_ = [dc.finish()["kmers"] for dc in g.counters]
+        infos = g.merge()
+        assert all(i["path"] == expect and i["nranks_seen"] == world and i["conserved"] == 1 for i in infos), infos
+        assert [i["sent_count_sum"] for i in infos] == locals_          # every rank exported exactly what its table held
+        assert sum(i["merged_count_sum"] for i in infos) == int(fc.sum()) == sum(locals_)
+        for dc, i in zip(g.counters, infos):
+            st = dc.finish()
+            assert st["kmers"] == i["merged_count_sum"] == int(dc.result()[1].sum())   # a shard's kmers = the occurrences it holds
+
+
+@pytest.mark.parametrize("world,k,pieces,bad", [(2, 19, None, 1), (4, 21, "1", 2), (2, 31, None, 0), (3, 21, None, 1)])
+def test_half_a_message_lost_fails_the_merge_on_every_rank(K, monkeypatch, world, k, pieces, bad):
+    """round 4's transport incident -- a message of >= 2^30 bytes arrived HALF, and the merged table was
+    quietly smaller.  KMERHIP_FAULT=rank:drop_half zeroes the upper half of what arrived on `rank` (pipelined heads, one-shot
+    packed, wide pairs, the generic route): that rank's digest of the arrival differs from what the senders announced, it
+    returns KH_ERR_RCCL naming the sender, every other rank returns KH_ERR_PEER from the same call -- nobody keeps a table that
+    lost keys.  Afterwards the same group merges correctly."""
+    if pieces is None:
+        monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    else:
+        monkeypatch.setenv("KMERHIP_MERGE_PIECES", pieces)
+    monkeypatch.setenv("KMERHIP_MERGE_TIMEOUT_S", "60")
+    n_reads = 40_000
+    full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
+    fk, fc = oracle_arrays(full_b, k)
+    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    per = n_reads // world
+
+    def count_all(g):
+        for r, dc in enumerate(g.counters):
+            dc.reset()
+            lo, hi = r * per, (n_reads if r == world - 1 else (r + 1) * per)
+            dc.push(full_b[lo * 151: hi * 151])
+
+    with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
+        count_all(g)
+        monkeypatch.setenv("KMERHIP_FAULT", f"{bad}:drop_half")
+        res = _merge_each_rank_on_its_own_thread(K, g)
+        for r, (rc, err, info) in enumerate(res):
+            if r == bad:
+                assert rc == K.native.KH_ERR_RCCL and "conservation" in err and "differs from what it sent" in err, (r, rc, err)
+            else:
+                assert rc == K.native.KH_ERR_PEER and f"rank {bad} failed" in err, (r, rc, err)
+            assert info["conserved"] == 0
+        monkeypatch.delenv("KMERHIP_FAULT")
+        count_all(g)
+        infos = g.merge()
+        assert all(i["conserved"] == 1 for i in infos)
+        for r, dc in enumerate(g.counters):
+            keys, cnts = dc.result()
+            assert np.array_equal(keys, fk[owners == r]) and np.array_equal(cnts, fc[owners == r]), f"shard {r} after the failed merge"
+
+
+def test_rccl_world1_detects_a_lost_half_too(K, reads, monkeypatch):
+    """The same through RCCL itself (a world of one: the send to self that lost half a message in round 4)."""
+    monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    ok, oc = oracle_arrays(reads, 19)
+    with K.DeviceCounter(19, capacity_hint=3_000_000) as dc:
+        dc.comm_init(1, 0, K.comm_unique_id())
+        dc.push(reads)
+        monkeypatch.setenv("KMERHIP_FAULT", "0:drop_half")
+        with pytest.raises(K.KmerHipError) as e:
+            dc.merge_across()
+        assert e.value.status == K.native.KH_ERR_RCCL and "conservation" in str(e.value)
+        monkeypatch.delenv("KMERHIP_FAULT")
+        dc.reset()
+        dc.push(reads)
+        info = dc.merge_across()
+        assert info["conserved"] == 1 and info["nranks_seen"] == 1 and info["owned_distinct"] == len(ok)
+        assert info["sent_count_sum"] == info["merged_count_sum"] == int(oc.sum())
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
+
+
+def test_small_count_then_merge_into_a_larger_geometry_then_a_large_partitioned_push(K, monkeypatch):
+    """the merge raised the context's region capacity after growing only the three per-region arrays it
+    uses itself; a later partitioned batch into the same context (little counted -> merged into the world's larger geometry ->
+    kh_reset -> much counted) then skipped the allocation of the region pass's other arrays.  One helper grows them all now
+    (kmerhip.hip ensure_region_scratch)."""
+    monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    k, world = 21, 2
+    big_b, _ = O.synth_reads(SEED + 9, 1 << 22, 150, 0, 400_000, with_qual=False)
+    small_b = big_b[: 151 * 2_000]
+    with K.DeviceGroup(k, [0] * world) as g:
+        g[0].push(big_b)                   # rank 0: a partitioned batch, a table of several thousand regions
+        g[1].push(small_b)                 # rank 1: the direct path, a small table, no region scratch of its own
+        slots = [dc.finish()["table_slots"] for dc in g.counters]
+        assert slots[0] > slots[1]
+        infos = g.merge()                  # rank 1 is re-laid-out to rank 0's geometry and merges into it
+        assert all(i["conserved"] == 1 for i in infos)
+        g[0].reset()
+        g[1].reset()
+        g[1].push(big_b)                   # ... and now counts a large partitioned batch itself
+        st = g[1].finish()
+        m = O.OracleMap()
+        m.scan_flat(big_b, k, nthreads=4)
+        ok, oc = m.arrays()
+        assert st["part_batches"] >= 1 and st["distinct"] == len(ok)
+        keys, cnts = g[1].result()
+        assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)

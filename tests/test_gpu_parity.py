@@ -1466,3 +1466,24 @@ def test_tables_of_1024_x_b2_regions(K, monkeypatch, b2, k, minq):
                 assert st["kmers"] == total2 and st["distinct"] == len(m2)
                 keys, cnts = dc.result()
                 assert np.array_equal(keys, w2k) and np.array_equal(cnts, w2c), path
+
+
+@pytest.mark.parametrize("pow2", ["0", "1"], ids=["b2-steps", "pow2-tables"])
+@pytest.mark.parametrize("room_mb", [1, 48])
+def test_sample_sized_table_that_does_not_fit_the_room(K, monkeypatch, pow2, room_mb):
+    """when the table the level-1 sample asks for exceeds a third of the free memory, the size is stepped
+    down -- `round_cap(0.8 x)` -- and for every power-of-two size (all tables up to 2^28 slots, and every table with
+    KMERHIP_POW2_TABLE=1) that rounds straight back up: the loop never ended.  KMERHIP_TABLE_ROOM_MB (test build) plays the nearly
+    full device: the batch must come back -- with a smaller table that then grows by rehash -- and with the oracle's map."""
+    monkeypatch.setenv("KMERHIP_TABLE_ROOM_MB", str(room_mb))
+    monkeypatch.setenv("KMERHIP_POW2_TABLE", pow2)
+    bases, _ = O.synth_reads(SEED + 77, 1 << 23, 150, 0, 250_000, with_qual=False)
+    m = O.OracleMap()
+    m.scan_flat(bases, 21, nthreads=NCPU)
+    ok, oc = m.arrays()
+    with K.DeviceCounter(21, path="partition") as dc:       # no hint: the sample decides -- ~25 M keys want a table of 2^26 slots = 1 GiB
+        dc.push(bases)
+        st = dc.finish()
+        assert st["kmers"] == m.total() and st["distinct"] == len(ok)
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
