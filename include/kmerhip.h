@@ -42,6 +42,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: these declarations -- and nothing else -- are what it exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define KMERHIP_ABI_VERSION 1
 
@@ -377,6 +381,9 @@ int kh_synth_reads_device(int device, void *stream, uint64_t seed, uint64_t geno
                           uint32_t read_len, uint64_t first_read, uint64_t n_reads,
                           uint8_t *d_bases, uint8_t *d_qual);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -403,7 +403,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
                 else KH_ARENA(64, 1024, false);
             } else if (g.b2 > 512) {  // 513 .. 768: three buckets per lane group
 #ifndef KH_ARENA_UNITB_768
-#define KH_ARENA_UNITB_768 64  // (128: whole lines while a bin holds >= 48 payloads, i.e. up to 682 buckets -- A/B builds)
+#define KH_ARENA_UNITB_768 128  // whole lines while a bin holds >= 52 payloads of the 768-bucket instance's 144 KiB, i.e. up to 682 buckets (64: A/B builds)
 #endif
                 if (KH_ARENA_UNITB_768 == 128 && sizeof(PT) == 4 && g.b2 <= 682) KH_ARENA(128, 768, false);
                 else KH_ARENA(64, 768, false);

@@ -8,7 +8,8 @@
 //   exchange.hip  kh_comm_* / kh_merge_across / kh_group_*: the exchange between contexts (RCCL over xGMI, or the local hub)
 //   level1_*.hip  the level-1 kernels, one instance per k
 //
-// Everything here lives in namespace khi with hidden visibility: the library exports the kh_* entry points only.
+// Everything here is hidden: the library is built with -fvisibility=hidden and linked with kmerhip.map, so it exports the kh_*
+// entry points of include/kmerhip.h only (tests/test_abi.py holds `nm -D` to that list).
 #pragma once
 #include "../../include/kmerhip.h"
 

@@ -20,16 +20,19 @@ void launch_cpp(const L1Launch &l) {
     if (l.use_qual) hipLaunchKernelGGL((part1_bins_kernel<true, MODE, FAST, 0>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
     else hipLaunchKernelGGL((part1_bins_kernel<false, MODE, FAST, 0>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
 }
+#if KH_TESTING  // round 1's tile-sorting kernel: reachable through a test-build switch only, compiled into the test build only
 template <int MODE, bool FAST>
 void launch_legacy(const L1Launch &l) {
     if (l.use_qual) hipLaunchKernelGGL((part1_scatter_chunked_kernel<true, MODE, FAST, uint32_t, 0>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
     else hipLaunchKernelGGL((part1_scatter_chunked_kernel<false, MODE, FAST, uint32_t, 0>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
 }
+#endif
 }  // namespace
 
 void launch_level1_32(const L1Launch &l, const char **kernel) {
     const bool m24 = kh_k_uses_mul24(l.k);  // the Feistel multiplier is a compile-time choice in the hot kernels
     const bool fast = p1_fast_ok(l.g);
+#if KH_TESTING
     if (l.legacy) {
         if (kernel) *kernel = "part1_scatter_chunked_kernel";
         if (m24 && fast) launch_legacy<KH_MUL_24, true>(l);
@@ -38,6 +41,7 @@ void launch_level1_32(const L1Launch &l, const char **kernel) {
         else launch_legacy<KH_MUL_32, false>(l);
         return;
     }
+#endif
     if (kernel) *kernel = "part1_bins_kernel";
     // the written-out window: 1024 partitions, no shard shift (what every table of more than 1024 regions gets)
     if (!l.generic_k && fast && l.g.p1_bits == 10 && l.k >= 11 && l.k <= 21) {

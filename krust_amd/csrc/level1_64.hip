@@ -15,21 +15,25 @@ void launch_bins(const L1Launch &l) {
     if (l.use_qual) hipLaunchKernelGGL((part1_bins64_kernel<true, MODE, KW, 4>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
     else hipLaunchKernelGGL((part1_bins64_kernel<false, MODE, KW, 2>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
 }
+#if KH_TESTING  // round 1's tile-sorting kernel: reachable through a test-build switch only, compiled into the test build only
 template <int MODE>
 void launch_legacy(const L1Launch &l) {
     if (l.use_qual) hipLaunchKernelGGL((part1_scatter_chunked_kernel<true, MODE, false, u64, 0>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
     else hipLaunchKernelGGL((part1_scatter_chunked_kernel<false, MODE, false, u64, 0>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
 }
+#endif
 }  // namespace
 
 void launch_level1_64(const L1Launch &l, const char **kernel) {
     const bool m24 = kh_k_uses_mul24(l.k);
+#if KH_TESTING
     if (l.legacy) {
         if (kernel) *kernel = "part1_scatter_chunked_kernel";
         if (m24) launch_legacy<KH_MUL_24>(l);
         else launch_legacy<KH_MUL_32>(l);
         return;
     }
+#endif
     if (kernel) *kernel = "part1_bins64_kernel";
     if (!l.generic_k && l.g.shard_shift == 0 && l.g.p1_bits == 10 && l.k >= 22) {
         switch (l.k) {

@@ -8,6 +8,10 @@
 
 #include "part_common.hip.h"
 
+#ifndef KH_TESTING
+#define KH_TESTING 0  // (ctx.hip.h: the test build compiles kernel variants, geometry switches and failure injection in)
+#endif
+
 namespace kh {
 
 struct L1Launch {

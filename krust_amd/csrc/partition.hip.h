@@ -757,7 +757,11 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     constexpr int UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
     constexpr int HALF = PER / 2;
     constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin at 512 buckets (256 bytes)
-    constexpr uint32_t TOTAL = P2L_NBK * CAP;                 // payloads all bins hold together (128 KiB)
+    // payloads all bins hold together: 128 KiB -- 144 KiB in the 768-bucket instance (round 5), which is what the CU's 160 KiB
+    // leave beside the counters, the chunk list and the positions: at 640 buckets a bin then holds 56 payloads instead of 48, and
+    // that is the room a whole-LINE unit (32 payloads) needs beside a half batch's arrivals (12.8 +- 3.6: with 48 the bins
+    // overflowed into the list 1.5 % of the time and ate what the 128-byte units had won -- profiles/README.md r04a, 2)
+    constexpr uint32_t TOTAL = NBK == 768 ? (144u << 10) / (uint32_t)sizeof(PT) : P2L_NBK * CAP;
     constexpr uint32_t UW = UNITB / 16;                       // 16-byte words per unit
     static_assert(NBK == 512 || NBK == 768 || (NBK == 1024 && UNITB == 64), "1024 buckets: 128-byte bins, 64-byte units");
     __shared__ __attribute__((aligned(16))) PT s_bin[TOTAL + UNIT];  // 128 KiB (+ a trash unit)

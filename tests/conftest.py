@@ -24,6 +24,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
 
 
+# The suite's long CPU-oracle computations run in a child process from the start of the session, beside the tests that use
+# the device (tests/bg_oracle.py says why): started here when a test that collects one of them is part of the run.
+_BG = {"proc": None, "dir": None}
+_BG_USERS = {"test_hg38_scale_fasta_histogram_through_the_cli": "hg", "test_full_map_digest_10M_reads[k21]": "digest_k21",
+             "test_full_map_digest_10M_reads[k31-q20]": "digest_k31q20"}
+
+
+def pytest_collection_finish(session):
+    import tempfile
+    names = [i.name for i in session.items]
+    if len(names) < 50:      # (a hand-picked run: its tests compute what they need themselves)
+        return
+    jobs = [job for test, job in _BG_USERS.items() if test in names]
+    if not jobs or os.environ.get("KMERHIP_BG_ORACLE", "1") == "0":
+        return
+    jobs.sort(key=["digest_k21", "digest_k31q20", "hg"].index)   # (in the order the suite comes to need them)
+    d = tempfile.mkdtemp(prefix="kmerhip_bg_oracle_")
+    threads = max(2, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)) // 2)
+    threads = min(threads, 8)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    _BG["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bg_oracle.py"), d, str(threads)] + jobs,
+                                   stdout=subprocess.DEVNULL, stderr=open(os.path.join(d, "stderr.log"), "w"))
+    _BG["dir"] = d
+    os.environ["KMERHIP_BG_ORACLE_DIR"] = d
+
+
+def pytest_sessionfinish(session, exitstatus):
+    p = _BG["proc"]
+    if p is not None and p.poll() is None:   # (the run ended early, -x: do not leave the child behind)
+        p.terminate()
+        try:
+            p.wait(10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _build_oracle():
     """The oracle is the checker; build it if the .so is not there yet."""

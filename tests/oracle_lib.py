@@ -281,3 +281,36 @@ def synth_reads(seed, genome_len, read_len, first_read, n_reads, with_qual=True)
     lib().ko_synth_reads(seed, genome_len, read_len, first_read, n_reads, bases.ctypes.data,
                          qual.ctypes.data if with_qual else None)
     return bases, qual
+
+
+# ---- which shard owns a key, for whole arrays (test infrastructure) -------------------------------------------------
+# kh_owner (include/kmerhip.h) answers one key per call; the exchange tests ask for a million: a Python loop around the C ABI
+# was most of their run time (round 5).  This is the same arithmetic in numpy -- the table hash of krust_amd/csrc/kmer_bits.h
+# (kh_hash_n) and the fast-range of its top bits -- and every call holds a sample of its answers to the C ABI's.
+_FC = (0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F)
+
+
+def table_hash_np(keys, k):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    mask = np.uint64((1 << k) - 1)
+    m32 = np.uint64(0xFFFFFFFF)
+    L = (keys >> np.uint64(k)) & mask
+    R = keys & mask
+    for c in _FC:
+        cc = np.uint64((c & 0xFFFFFF) | 1) if 16 <= k <= 24 else np.uint64(c)
+        t = (R * cc) & m32
+        if k < 32:
+            t = t >> np.uint64(32 - k)
+        L, R = R, (L ^ t) & mask
+    return (L << np.uint64(k)) | R
+
+
+def owners(K, keys, k, nparts):
+    """kh_owner(key, k, nparts) for every key of an array; K = the krust_amd module (its C ABI checks a sample)."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    H = table_hash_np(keys, k) << np.uint64(64 - 2 * k)     # left-aligned, as kh_table_hash
+    own = (((H >> np.uint64(32)) * np.uint64(nparts)) >> np.uint64(32)).astype(np.int64)
+    if keys.size:
+        probe = np.unique(np.linspace(0, keys.size - 1, num=min(keys.size, 97)).astype(np.int64))
+        assert [int(own[i]) for i in probe] == [K.owner(int(keys[i]), k, nparts) for i in probe], "numpy owner() differs from kh_owner"
+    return own

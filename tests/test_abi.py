@@ -105,3 +105,19 @@ def test_owner_is_a_partition(K):
         assert min(owners) >= 0 and max(owners) < nparts
         if nparts > 1:
             assert len(set(owners)) == nparts
+
+
+def test_the_libraries_export_the_c_abi_and_nothing_else():
+    """the comment in ctx.hip.h said "everything here is hidden, the library exports the kh_* entry points only",
+    `nm -D` said otherwise (khi:: functions and data, kernel handles).  Both builds -- tests hold libkmerhip_testing.so while
+    the host library pulls in libkmerhip.so: one process, two copies of every internal -- now export exactly the ABI
+    (-fvisibility=hidden + the version script krust_amd/csrc/kmerhip.map)."""
+    import subprocess
+    from krust_amd import native
+    for name in ("libkmerhip.so", "libkmerhip_testing.so"):
+        path = os.path.join(ROOT, "krust_amd", "lib", name)
+        if not os.path.exists(path):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        syms = {l.split()[-1] for l in out.splitlines() if l.strip()}
+        assert syms == set(native.SYMBOLS), (name, sorted(syms ^ set(native.SYMBOLS))[:10])

@@ -97,7 +97,7 @@ def test_group_of_ranks_sharing_the_device(K, monkeypatch, world, k, pieces, exp
     n_reads = 120_000
     full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
     fk, fc = oracle_arrays(full_b, k)
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     per = n_reads // world
     with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000, path=path) as g:
         assert len(g) == world
@@ -147,7 +147,7 @@ def test_group_with_large_counts_leaves_the_pipeline_together(K, monkeypatch):
     reps = 200                                   # every k-mer ~200 x 30 x 150 / 4096 ~ 200+ times: cb = 5 -> > 2 heads each
     bases = np.tile(rec, reps)
     fk, fc = oracle_arrays(bases, k)
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
         half = (reps // 2) * rec.size
         g[0].push(bases[:half])
@@ -195,7 +195,7 @@ def test_one_rank_needs_a_wider_unit_than_the_others(K, monkeypatch):
     v[:40, :150] = ord("A")                       # rank 0's half: A^19 5280 times; cb = 5 at 2^11 regions -> 64 << 5 = 2048 is the most heads carry
     fk, fc = oracle_arrays(full_b, k)
     assert int(fc.max()) > 2048
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     per = n_reads // world
     with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
         for r, dc in enumerate(g.counters):
@@ -228,7 +228,7 @@ def test_a_rank_that_fails_takes_every_rank_out_of_the_merge(K, monkeypatch, wor
     n_reads = 40_000
     full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
     fk, fc = oracle_arrays(full_b, k)
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     per = n_reads // world
 
     def count_all(g):
@@ -359,7 +359,7 @@ def test_group_merge_of_tables_with_1024_x_b2_regions(K, monkeypatch, world, k, 
     n_reads = 120_000
     full_b, _ = O.synth_reads(SEED + b2, 1 << 20, 150, 0, n_reads, with_qual=False)
     fk, fc = oracle_arrays(full_b, k)
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     per = n_reads // world
     with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000, path="partition" if b2 >= 40 else None) as g:
         for r, dc in enumerate(g.counters):
@@ -383,7 +383,7 @@ def test_a_world_that_does_not_divide_b2_takes_the_generic_route(K, monkeypatch)
     k, world, n_reads = 21, 4, 40_000
     full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
     fk, fc = oracle_arrays(full_b, k)
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     per = n_reads // world
     with K.DeviceGroup(k, [0] * world, capacity_hint=3_000_000) as g:
         for r, dc in enumerate(g.counters):
@@ -404,7 +404,7 @@ def test_ranks_with_tables_of_different_sizes_agree_on_the_largest(K, world, k):
     n_reads = 110_000
     full_b, _ = O.synth_reads(SEED + 5, 1 << 22, 150, 0, n_reads, with_qual=False)
     fk, fc = oracle_arrays(full_b, k)
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     small = 10_000
     cuts = [0, n_reads - small * (world - 1)] + [n_reads - small * (world - 1 - i) for i in range(1, world)]
     with K.DeviceGroup(k, [0] * world) as g:
@@ -464,7 +464,7 @@ def test_half_a_message_lost_fails_the_merge_on_every_rank(K, monkeypatch, world
     n_reads = 40_000
     full_b, _ = O.synth_reads(SEED, 1 << 20, 150, 0, n_reads, with_qual=False)
     fk, fc = oracle_arrays(full_b, k)
-    owners = np.array([K.owner(int(x), k, world) for x in fk])
+    owners = O.owners(K, fk, k, world)
     per = n_reads // world
 
     def count_all(g):
