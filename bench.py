@@ -509,7 +509,7 @@ def cli_leg(krust_amd, torch, dev, local_rank, reads=10_000_000, k=21):
         #  instead of 0.1-0.3 right after that -- `create_s` of the runs below says which it was: give the driver a moment)
         # (measured, tools/cli_s100m_probe.py: started 0-3 s after a process that held ~230 GB of HBM has exited, a new process's
         #  hipMalloc of its partition buffers takes 1-5 s -- the driver is still reclaiming; after 10 s it takes milliseconds)
-        pause = 10.0 if reads >= 40_000_000 else 3.0
+        pause = float(os.environ.get("BENCH_CLI_PAUSE_S") or (10.0 if reads >= 40_000_000 else 3.0))   # (BENCH_CLI_PAUSE_S: tests)
         subprocess.run(["cat", path], stdout=subprocess.DEVNULL)  # (the file was written slice by slice: read once, it streams at the page cache's rate)
         for rep in range(3):   # (the first run pages the binary and the ROCm libraries in)
             time.sleep(pause)

@@ -156,7 +156,7 @@ def test_bench_prints_one_small_line_and_a_full_report(tmp_path):
     key, and the full report lands in the side file."""
     path = str(tmp_path / "full.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2000000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BENCH_FULL_PATH=path))
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BENCH_FULL_PATH=path, BENCH_CLI_PAUSE_S="0.3"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines

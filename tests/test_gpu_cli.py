@@ -129,7 +129,7 @@ def test_save_and_query(tmp_path):
 
 def test_hg_like_fasta_histogram(tmp_path):
     """BASELINE.json configs[4] in miniature (hg38 itself is not on the box): a generated 'hg-like'
-    FASTA -- 12 records of very different lengths up to 16 Mbp, 60-column lines, ~50 % soft-masked
+    FASTA -- 10 records of very different lengths up to 9 Mbp, 60-column lines, ~50 % soft-masked
     (lowercase) blocks, runs of N, a poly-A tract and a tandem repeat -- counted by the CLI with
     `--format histogram` and compared line by line with the oracle's histogram, then `tsv` on a
     1/64 key sample.  Exercises long records (k-mers across tile / workgroup / staging-chunk
@@ -139,7 +139,7 @@ def test_hg_like_fasta_histogram(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     rng = np.random.default_rng(38)
-    lens = [16_000_000, 9_000_000, 5_000_000, 3_000_000, 2_000_000, 1_000_000, 500_000, 200_000, 50_000, 3_000, 40, 7]
+    lens = [9_000_000, 4_000_000, 2_000_000, 1_000_000, 500_000, 200_000, 50_000, 3_000, 40, 7]
     path = tmp_path / "hg_like.fa"
     seqs = []
     with open(path, "wb") as f:

@@ -1207,6 +1207,36 @@ def test_level2_arena_path_and_its_fallbacks(K, monkeypatch, mode, k, skewed):
         assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
 
 
+_WINDOW_READS = {}
+
+
+def _window_reads():
+    """24,000 reads with N, lower case and low qualities, lengths of every residue mod 16, both strands -- built once for the
+    46 cases of the test below (a Python loop per record: it was most of each case's run time)."""
+    if not _WINDOW_READS:
+        rng = np.random.default_rng(7700)
+        n_reads = 24_000
+        genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1 << 17)
+        recs, quals = [], []
+        for i in range(n_reads):
+            n = int(rng.integers(20, 240))
+            o = int(rng.integers(0, genome.size - n))
+            s = genome[o:o + n].copy()
+            u = rng.random()
+            if u > 0.9:
+                a = int(rng.integers(0, n))
+                s[a:a + int(rng.integers(1, 4))] = ord("N")
+            if u < 0.05:
+                s = np.frombuffer(s.tobytes().lower(), dtype=np.uint8).copy()
+            if i % 2:
+                s = np.frombuffer(s.tobytes().translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1], dtype=np.uint8).copy()  # both strands
+            recs.append(s.tobytes())
+            quals.append(rng.choice(np.frombuffer(b"#5IIIIII", dtype=np.uint8), size=n).astype(np.uint8).tobytes())
+        _WINDOW_READS["bases"] = np.frombuffer(b"\n".join(recs) + b"\n", dtype=np.uint8)
+        _WINDOW_READS["qual"] = np.frombuffer(b"\n".join(quals) + b"\n", dtype=np.uint8)
+    return _WINDOW_READS["bases"], _WINDOW_READS["qual"]
+
+
 @pytest.mark.parametrize("minq", [None, 20], ids=["noqual", "q20"])
 @pytest.mark.parametrize("k", list(range(10, 33)))
 def test_written_out_window_every_k(K, k, minq):
@@ -1215,26 +1245,7 @@ def test_written_out_window_every_k(K, k, minq):
     case and low qualities, lengths of every residue mod 16, three batches of different sizes through the partitioned
     path into a table of 2^12 regions (1024 level-1 partitions: the geometry the written-out window is for); the whole
     map against the oracle.  (The reference serves k = 1..32 uniformly, src/kmer.rs:100-110.)"""
-    rng = np.random.default_rng(7700 + k)
-    n_reads = 24_000
-    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=1 << 17)
-    recs, quals = [], []
-    for i in range(n_reads):
-        n = int(rng.integers(20, 240))
-        o = int(rng.integers(0, genome.size - n))
-        s = genome[o:o + n].copy()
-        u = rng.random()
-        if u > 0.9:
-            a = int(rng.integers(0, n))
-            s[a:a + int(rng.integers(1, 4))] = ord("N")
-        if u < 0.05:
-            s = np.frombuffer(s.tobytes().lower(), dtype=np.uint8).copy()
-        if i % 2:
-            s = np.frombuffer(s.tobytes().translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))[::-1], dtype=np.uint8).copy()  # both strands
-        recs.append(s.tobytes())
-        quals.append(rng.choice(np.frombuffer(b"#5IIIIII", dtype=np.uint8), size=n).astype(np.uint8).tobytes())
-    bases = np.frombuffer(b"\n".join(recs) + b"\n", dtype=np.uint8)
-    qual = np.frombuffer(b"\n".join(quals) + b"\n", dtype=np.uint8)
+    bases, qual = _window_reads()
     m = O.OracleMap()
     m.scan_flat(bases, k, qual=qual if minq is not None else None, min_quality=minq, nthreads=NCPU)
     want_k, want_c = m.arrays()
@@ -1483,7 +1494,7 @@ def test_tables_of_1024_x_b2_regions(K, monkeypatch, b2, k, minq):
     # and from the partitioned one (whose regions overflow first: the failed buckets' re-insert)
     # (both payload widths; the -Q twins of the same two would differ only in the mask, which every counting test above draws)
     if b2 == 640 and minq is None:
-        bases2, qual2 = O.synth_reads(SEED + 77, 1 << 24, 150, 0, 1_200_000)
+        bases2, qual2 = O.synth_reads(SEED + 77, 1 << 24, 150, 0, 400_000)
         m2 = O.OracleMap()
         total2 = m2.scan_flat(bases2, k, qual=qual2 if minq is not None else None, min_quality=minq, nthreads=NCPU)
         w2k, w2c = m2.arrays()

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #define CK(x)                                                                \
@@ -98,6 +99,70 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(d, p, M, hipMemcpyHostToDevice));
         const double t6 = now();
         printf("hipMemcpy of 1 GiB of pageable memory (the runtime's staging): %.1f ms (%.1f GB/s)\n", (t6 - t5) * 1e3, 1.0737 / (t6 - t5));
+        free(p);
+    }
+    // ---- the command line's loop in miniature: 128 MiB pinned chunks, pushed one after the other (each waited for), while
+    // helper threads fill the OTHER chunk buffer from ordinary memory (what the pread()s do) ----
+    {
+        const uint64_t CH = 128ull << 20;
+        const int NCH = 48;
+        uint8_t *pb[2], *src = (uint8_t *)aligned_alloc(4096, CH);
+        memset(src, 3, CH);
+        for (auto &p : pb) {
+            CK(hipHostMalloc((void **)&p, CH, hipHostMallocPortable));
+            memset(p, 7, CH);
+        }
+        for (int fillers : {0, 4, 12}) {
+            for (int split : {1, 2}) {
+                CK(hipDeviceSynchronize());
+                const double t0 = now();
+                for (int i = 0; i < NCH; ++i) {
+                    std::vector<std::thread> th;
+                    uint8_t *other = pb[(i + 1) & 1];
+                    for (int t = 0; t < fillers; ++t)
+                        th.emplace_back([=] { memcpy(other + (CH / fillers) * t, src + (CH / fillers) * t, CH / fillers); });
+                    uint8_t *cur = pb[i & 1];
+                    if (split == 1) {
+                        CK(hipMemcpyAsync(d, cur, CH, hipMemcpyHostToDevice, st[0]));
+                    } else {
+                        CK(hipMemcpyAsync(d, cur, CH / 2, hipMemcpyHostToDevice, st[0]));
+                        CK(hipMemcpyAsync(d + CH / 2, cur + CH / 2, CH / 2, hipMemcpyHostToDevice, st[1]));
+                        CK(hipStreamSynchronize(st[1]));
+                    }
+                    CK(hipStreamSynchronize(st[0]));
+                    for (auto &t : th) t.join();
+                }
+                const double dt = now() - t0;
+                printf("chunk loop: %d x 128 MiB, %d stream(s) per chunk, %2d filler threads on the other buffer: %6.1f GB/s\n", NCH, split, fillers,
+                       (double)CH * NCH / dt / 1e9);
+            }
+        }
+    }
+    // ---- pinning the caller's pageable memory in place, slices registered by several threads at once ----
+    {
+        const uint64_t M = 4ull << 30, SL = 64ull << 20;
+        uint8_t *p = (uint8_t *)aligned_alloc(1 << 21, M);
+        memset(p, 1, M);
+        for (int nt : {1, 2, 4, 8}) {
+            const double t0 = now();
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t)
+                th.emplace_back([=] {
+                    (void)hipSetDevice(0);
+                    for (uint64_t o = SL * t; o < M; o += SL * nt)
+                        if (hipHostRegister(p + o, SL, hipHostRegisterDefault) != hipSuccess) fprintf(stderr, "register failed\n");
+                });
+            for (auto &t : th) t.join();
+            const double t1 = now();
+            // one DMA out of the registered range, to see that it is usable
+            CK(hipMemcpyAsync(d, p, std::min<uint64_t>(N, M), hipMemcpyHostToDevice, st[0]));
+            CK(hipStreamSynchronize(st[0]));
+            const double t2 = now();
+            for (uint64_t o = 0; o < M; o += SL) CK(hipHostUnregister(p + o));
+            const double t3 = now();
+            printf("hipHostRegister of 4 GiB in 64 MiB slices by %d thread(s): %7.1f ms (%5.1f GB/s); DMA of the first GiB %5.1f GB/s; unregister %6.1f ms\n", nt,
+                   (t1 - t0) * 1e3, (double)M / (t1 - t0) / 1e9, (double)std::min<uint64_t>(N, M) / (t2 - t1) / 1e9, (t3 - t2) * 1e3);
+        }
         free(p);
     }
     return 0;
