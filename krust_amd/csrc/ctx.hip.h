@@ -148,7 +148,8 @@ struct kh_ctx {
 
     // ---- kh_push: pinned staging -> device accumulation buffers -> one count per filled buffer ----
     hipStream_t cstream = nullptr;             // copy stream (H2D overlaps counting on `stream`)
-    uint8_t *h_stage[2] = {nullptr, nullptr};  // pinned: bases then qual, each STAGE_BYTES
+    uint8_t *h_stage[2] = {nullptr, nullptr};  // pinned: bases then qual, each stage_bytes
+    u64 stage_bytes = 0;                       // 0 until pageable memory is pushed / fetched; then 1, 8 or 64 MiB (input.hip ensure_stage)
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
     int stage_next = 0;

@@ -51,16 +51,33 @@ void staged_memcpy(void *dst, const void *src, size_t n) {
     for (auto &t : th) t.join();
 }
 
-int ensure_stage(kh_ctx *c) {
+// The copy stream and its events; and, for `need` > 0, the two pinned staging buffers through which PAGEABLE caller memory
+// travels -- each 2 x stage_bytes (bases and qualities; or one text chunk), stage_bytes = the smallest of 1 / 8 / 64 MiB that
+// holds `need` (round 5: every context that saw a host push pinned 256 MiB for them, ~50 ms -- of a ten-byte test input, and
+// of every command-line run, whose chunks are pinned and never touch the staging at all: need = 0).
+int ensure_stage(kh_ctx *c, u64 need) {
     if (!c->cstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->cstream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
-        if (!c->h_stage[i]) {
-            hipError_t e = hipHostMalloc((void **)&c->h_stage[i], 2 * STAGE_BYTES, hipHostMallocDefault);
-            if (e != hipSuccess) return fail(c, KH_ERR_OOM, "hipHostMalloc(stage)", e);
-            HIP_TRY(c, hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->acc_free[i], hipEventDisableTiming));
-        }
+        if (!c->stage_done[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_done[i], hipEventDisableTiming));
+        if (!c->acc_free[i]) HIP_TRY(c, hipEventCreateWithFlags(&c->acc_free[i], hipEventDisableTiming));
     }
+    if (!need) return KH_OK;
+    u64 want = 1ull << 20;
+    while (want < need && want < STAGE_BYTES) want *= 8;
+    want = std::min(want, STAGE_BYTES);
+    if (c->stage_bytes >= want) return KH_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->cstream));  // (nothing in flight out of the buffers about to go)
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+        c->h_stage[i] = nullptr;
+        c->stage_used[i] = false;
+    }
+    c->stage_bytes = 0;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipHostMalloc((void **)&c->h_stage[i], 2 * want, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, KH_ERR_OOM, "hipHostMalloc(stage)", e);
+    }
+    c->stage_bytes = want;
     return KH_OK;
 }
 
@@ -68,9 +85,10 @@ int ensure_stage(kh_ctx *c) {
 // while chunk i is copied out (by several threads: first-touch page faults of a fresh destination
 // array cost more than the copy itself).
 int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes) {
-    int rc = ensure_stage(c);
+    const bool pinned_dst = is_pinned_host(dst);
+    int rc = ensure_stage(c, pinned_dst ? 0 : (bytes + 1) / 2);
     if (rc != KH_OK) return rc;
-    if (is_pinned_host(dst)) {  // a registered destination takes the DMA itself: no bounce, no first-touch faults
+    if (pinned_dst) {  // a registered destination takes the DMA itself: no bounce, no first-touch faults
         HIP_TRY(c, hipStreamSynchronize(c->stream));  // d_src was produced on the compute stream
         HIP_TRY(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->cstream));
         HIP_TRY(c, hipStreamSynchronize(c->cstream));
@@ -85,7 +103,7 @@ int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes) {
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // d_src was produced on the compute stream
     HIP_TRY(c, hipStreamSynchronize(c->cstream));  // the staging buffers are free
-    const u64 CH = 2 * STAGE_BYTES;
+    const u64 CH = 2 * c->stage_bytes;
     const u64 nch = (bytes + CH - 1) / CH;
     auto issue = [&](u64 i) -> hipError_t {
         const u64 off = i * CH, len = std::min(CH, bytes - off);
@@ -220,7 +238,10 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
     if (c->shard_shift) return fail(c, KH_ERR_STATE, "a shard table only accepts kh_merge_*; kh_reset makes it a full table again");
     if (n == 0) return KH_OK;
     const bool with_qual = (qual != nullptr) && (c->minq >= 0);
-    rc = ensure_stage(c);
+    // Pinned / registered source (kh_host_alloc, kh_host_register): the copy engine reads the caller's memory itself --
+    // no staging memcpy (which, not PCIe, bounded kh_push from pageable memory: ~20-30 against 57 GB/s), no staging buffers.
+    const bool direct = is_pinned_host(bases) && (!with_qual || is_pinned_host(qual));
+    rc = ensure_stage(c, direct ? 0 : n);
     if (rc != KH_OK) return rc;
     if (c->acc_len && c->acc_qual != with_qual) {  // a buffer is counted with or without qualities, not both
         rc = flush_acc(c, false);
@@ -237,9 +258,6 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
     }
     c->acc_qual = with_qual;
     const u64 stride = acc_stride(c->acc_cap);
-    // Pinned / registered source (kh_host_alloc, kh_host_register): the copy engine reads the caller's memory itself --
-    // no staging memcpy (which, not PCIe, bounded kh_push from pageable memory: ~20-30 against 57 GB/s).
-    const bool direct = is_pinned_host(bases) && (!with_qual || is_pinned_host(qual));
     if (direct) {
         hipEvent_t t0, t1;
         HIP_TRY(c, hipEventCreate(&t0));
@@ -269,7 +287,7 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
     for (u64 off = 0; off < n;) {
         // (an accumulation buffer may be SMALLER than a staging chunk -- KMERHIP_ACC_MAX_MB, or little free device memory:
         //  acc_limit() -- so a chunk is cut to the room that is left, +1 for the separator appended after the push)
-        const u64 want = std::min(STAGE_BYTES, n - off);
+        const u64 want = std::min(c->stage_bytes, n - off);
         if (c->acc_len && c->acc_len + want + 1 > c->acc_cap) {
             rc = flush_acc(c, off != 0);          // inside a push the seam needs the k-1 look-back
             if (rc != KH_OK) return rc;
@@ -279,14 +297,14 @@ extern "C" int kh_push(kh_ctx *c, const uint8_t *bases, const uint8_t *qual, uin
         c->stage_next ^= 1;
         if (c->stage_used[p]) HIP_TRY(c, hipEventSynchronize(c->stage_done[p]));
         staged_memcpy(c->h_stage[p], bases + off, len);
-        if (with_qual) staged_memcpy(c->h_stage[p] + STAGE_BYTES, qual + off, len);
+        if (with_qual) staged_memcpy(c->h_stage[p] + c->stage_bytes, qual + off, len);
         hipEvent_t t0, t1;
         HIP_TRY(c, hipEventCreate(&t0));
         HIP_TRY(c, hipEventCreate(&t1));
         HIP_TRY(c, hipEventRecord(t0, c->cstream));
         uint8_t *dst = c->acc[c->acc_cur] + HALO + c->acc_len;
         HIP_TRY(c, hipMemcpyAsync(dst, c->h_stage[p], len, hipMemcpyHostToDevice, c->cstream));
-        if (with_qual) HIP_TRY(c, hipMemcpyAsync(dst + stride, c->h_stage[p] + STAGE_BYTES, len, hipMemcpyHostToDevice, c->cstream));
+        if (with_qual) HIP_TRY(c, hipMemcpyAsync(dst + stride, c->h_stage[p] + c->stage_bytes, len, hipMemcpyHostToDevice, c->cstream));
         HIP_TRY(c, hipEventRecord(t1, c->cstream));
         HIP_TRY(c, hipEventRecord(c->stage_done[p], c->cstream));
         c->stage_used[p] = true;
@@ -589,7 +607,8 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
     if (rc != KH_OK) return rc;
     if ((rc = text_args(c, text, n, format)) != KH_OK) return rc;
     if (n == 0) return KH_OK;
-    if ((rc = ensure_stage(c)) != KH_OK) return rc;
+    const bool pinned_text = is_pinned_host(text);
+    if ((rc = ensure_stage(c, pinned_text ? 0 : (n + 1) / 2)) != KH_OK) return rc;
     if (c->acc_len && (rc = flush_acc(c, false)) != KH_OK) return rc;  // (kh_push's own accumulation: counted first, so that its buffers stay bounded)
     const bool defer = (c->flags & KH_FLAG_DEFER_TEXT_SCAN) != 0;
     if (defer && !c->sstream) HIP_TRY(c, hipStreamCreateWithFlags(&c->sstream, hipStreamNonBlocking));
@@ -617,7 +636,7 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
         c->txt_scanned_on[r] = false;
     }
     // the text -> the device, on the copy stream (behind the previous text's scan where that read the same buffer)
-    if (is_pinned_host(text)) {  // pinned / registered text: DMA straight from the caller's memory, no staging memcpy
+    if (pinned_text) {  // pinned / registered text: DMA straight from the caller's memory, no staging memcpy
         // (one DMA engine moves ~42 GB/s from pinned memory, the link takes 57: a large text travels as two halves on two
         //  streams; the copy stream then waits for the second half)
         const u64 half = n >= (64ull << 20) ? ((n / 2) & ~4095ull) : n;
@@ -644,8 +663,8 @@ extern "C" int kh_push_text(kh_ctx *c, const uint8_t *text, uint64_t n, int form
         HIP_TRY(c, hipEventRecord(t1, c->cstream));
         c->h2d_events.emplace_back(t0, t1);
     } else
-    for (u64 off = 0; off < n; off += 2 * STAGE_BYTES) {
-        const u64 len = std::min(2 * STAGE_BYTES, n - off);
+    for (u64 off = 0; off < n; off += 2 * c->stage_bytes) {
+        const u64 len = std::min(2 * c->stage_bytes, n - off);
         const int p = c->stage_next;
         c->stage_next ^= 1;
         if (c->stage_used[p]) HIP_TRY(c, hipEventSynchronize(c->stage_done[p]));

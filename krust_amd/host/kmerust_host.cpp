@@ -12,6 +12,7 @@
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -420,8 +421,7 @@ struct Session {
             }
             uint8_t *data() { return p; }
             size_t size() const { return cap; }
-        } buf, buf2;  // (buf2: the chunk being filled while `buf` is pushed -- plain files on one device)
-        buf.reserve(chunk, 0);
+        } buf, buf2;  // (buf2: the chunk being filled while `buf` is pushed -- plain files on one device, KMERUST_PIPELINED_READER=0)
         size_t have = 0;
         bool eof = false, pushed = false;
         // plain files: where the next byte comes from, and how many there are (pread needs no shared cursor)
@@ -473,6 +473,130 @@ struct Session {
             if (pushed) reset_all();
             return false;
         };
+        // ---- one device, a plain file: a READER THREAD runs ahead of the pushes through three chunk buffers (round 5) ----
+        // Round 4 read chunk i + 1 beside the push of chunk i and joined the two after every chunk: an iteration took the longer
+        // of the two plus the hand-over (thread start and join, the search for the record boundary, the tail's copy) -- 3.35 ms
+        // per 128 MiB where the transfer alone takes 2.3 (tools/ubench/h2d_probe.hip: 57 GB/s from such buffers, 50 with twelve
+        // threads writing the neighbouring buffer).  Now nothing but the queue sits between two kh_push_text calls; the reader
+        // cuts the chunks (the boundary search, the carry of the tail) and pins the second and third buffer itself.
+        if (ndev == 1 && can_pread && pipelined_reader()) {
+            constexpr int NB = 3;
+            ChunkBuf bufs[NB];
+            bufs[0].reserve(chunk, 0);
+            struct Item {
+                int idx;
+                size_t cut;
+                bool last;
+            };
+            std::mutex qm;
+            std::condition_variable qcv;
+            std::deque<Item> ready;
+            bool busy[NB] = {false, false, false};
+            bool stop = false, too_long = false;
+            std::exception_ptr rd_err;
+            std::thread reader([&] {
+                try {
+                    size_t fill = 0;
+                    int cur = 0;
+                    bool at_end = false;
+                    for (;;) {
+                        while (!at_end && fill < bufs[cur].size()) {
+                            const double t0 = wall_s();
+                            const size_t n = read_parallel(bufs[cur].data() + fill, bufs[cur].size() - fill);
+                            timing().read_s += wall_s() - t0;
+                            timing().bytes_read += n;
+                            if (n == 0) at_end = true;
+                            fill += n;
+                        }
+                        size_t cut = fill;
+                        if (!at_end) {
+                            cut = fastq ? fastq_cut(bufs[cur].data(), fill) : fasta_cut(bufs[cur].data(), fill);
+                            if (cut == 0) {  // no record boundary in a whole chunk: grow and read on
+                                if (bufs[cur].size() >= (size_t)8 << 30) {
+                                    std::lock_guard<std::mutex> lk(qm);
+                                    too_long = true;
+                                    qcv.notify_all();
+                                    return;
+                                }
+                                bufs[cur].reserve(bufs[cur].size() * 2, fill);
+                                continue;
+                            }
+                        }
+                        const int nxt = (cur + 1) % NB;
+                        if (!at_end) {  // the tail behind the last whole record opens the next chunk
+                            {
+                                std::unique_lock<std::mutex> lk(qm);
+                                qcv.wait(lk, [&] { return !busy[nxt] || stop; });
+                                if (stop) return;
+                            }
+                            bufs[nxt].reserve(chunk, 0);
+                            memcpy(bufs[nxt].data(), bufs[cur].data() + cut, fill - cut);
+                        }
+                        {
+                            std::lock_guard<std::mutex> lk(qm);
+                            busy[cur] = true;
+                            ready.push_back(Item{cur, cut, at_end});
+                            qcv.notify_all();
+                        }
+                        if (at_end) return;
+                        fill -= cut;
+                        cur = nxt;
+                    }
+                } catch (...) {
+                    std::lock_guard<std::mutex> lk(qm);
+                    rd_err = std::current_exception();
+                    qcv.notify_all();
+                }
+            });
+            auto end_reader = [&]() {
+                {
+                    std::lock_guard<std::mutex> lk(qm);
+                    stop = true;
+                    qcv.notify_all();
+                }
+                if (reader.joinable()) reader.join();
+            };
+            try {
+                for (;;) {
+                    Item it{0, 0, true};
+                    {
+                        std::unique_lock<std::mutex> lk(qm);
+                        qcv.wait(lk, [&] { return !ready.empty() || rd_err || too_long; });
+                        if (ready.empty()) break;  // (the reader gave up: its reason is looked at below)
+                        it = ready.front();
+                        ready.pop_front();
+                    }
+                    if (it.cut) {
+                        timing().chunks++;
+                        int rc;
+                        {
+                            Lap lap(timing().push_s);
+                            rc = kh_push_text(ctx, bufs[it.idx].data(), it.cut, text_fmt);
+                        }
+                        if (rc == KH_ERR_FORMAT) {
+                            end_reader();
+                            return refuse();
+                        }
+                        check(rc, "kh_push_text");
+                        pushed = true;
+                    }
+                    {
+                        std::lock_guard<std::mutex> lk(qm);
+                        busy[it.idx] = false;
+                        qcv.notify_all();
+                    }
+                    if (it.last) break;
+                }
+            } catch (...) {
+                end_reader();
+                throw;
+            }
+            end_reader();
+            if (rd_err) std::rethrow_exception(rd_err);
+            if (too_long) return refuse();
+            eof = true;  // (skips the loop below: on to kh_finish)
+        }
+        if (!eof) buf.reserve(chunk, 0);
         while (!eof) {
             while (have < buf.size()) {
                     size_t n;
@@ -594,6 +718,10 @@ struct Session {
         //  next one's copy: four pread()s side by side take as long, eight leave a margin -- measured, profiles/README.md r03b)
         const unsigned hw = std::thread::hardware_concurrency();
         return std::max(1u, std::min(12u, hw ? hw : 1u));
+    }
+    static bool pipelined_reader() {  // KMERUST_PIPELINED_READER=0: round 4's read-beside-push loop (A/B)
+        const char *e = getenv("KMERUST_PIPELINED_READER");
+        return !(e && e[0] == '0');
     }
     static size_t text_chunk_bytes() {
         const char *e = getenv("KMERUST_TEXT_CHUNK_KB");  // tests use small chunks to exercise the cuts

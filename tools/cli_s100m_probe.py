@@ -36,18 +36,22 @@ try:
     torch.cuda.empty_cache()
     print("file", os.path.getsize(path) / 1e9, "GB", flush=True)
     t0 = time.perf_counter(); subprocess.run(["cat", path], stdout=subprocess.DEVNULL); print("cat once:", round(time.perf_counter() - t0, 2), "s", flush=True)
-    env = dict(os.environ, KMERUST_TIMING="1", KMERHIP_TRACE="1")
-    for pause in [float(x) for x in os.environ.get("PROBE_PAUSES", "3,3,10,10,0,0").split(",")]:
-        time.sleep(pause)
-        t0 = time.perf_counter()
-        p = subprocess.run([exe, "21", path, "--format", "histogram", "-q"], capture_output=True, env=env, timeout=600)
-        wall = time.perf_counter() - t0
-        err = p.stderr.decode(errors="replace").splitlines()
-        tj = [json.loads(l)["kmerust_timing"] for l in err if l.startswith('{"kmerust_timing"')]
-        slow = [l for l in err if "took" in l or "host side" in l or "accumulation buffer" in l]
-        print(f"pause {pause}: wall {wall:.2f} rc {p.returncode} chunk_kb {os.environ.get('KMERUST_TEXT_CHUNK_KB', 'default')}", {k: round(v, 3) for k, v in (tj[0] if tj else {}).items() if k.endswith("_s")}, flush=True)
-        for l in slow[:12]:
-            print("     ", l[:200], flush=True)
+    # PROBE_VARIANTS="A=1,B=2;C=3": environment settings to run one after the other (each with every pause), "" = the default
+    variants = [dict(kv.split("=", 1) for kv in v.split(",") if kv) for v in os.environ.get("PROBE_VARIANTS", "").split(";")]
+    for var in variants:
+        env = dict(os.environ, KMERUST_TIMING="1", KMERHIP_TRACE="1", **var)
+        print("variant", var or "default", flush=True)
+        for pause in [float(x) for x in os.environ.get("PROBE_PAUSES", "3,3,10,10,0,0").split(",")]:
+          time.sleep(pause)
+          t0 = time.perf_counter()
+          p = subprocess.run([exe, "21", path, "--format", "histogram", "-q"], capture_output=True, env=env, timeout=600)
+          wall = time.perf_counter() - t0
+          err = p.stderr.decode(errors="replace").splitlines()
+          tj = [json.loads(l)["kmerust_timing"] for l in err if l.startswith('{"kmerust_timing"')]
+          slow = [l for l in err if "took" in l or "host side" in l or "accumulation buffer" in l]
+          print(f"pause {pause}: wall {wall:.2f} rc {p.returncode} chunk_kb {os.environ.get('KMERUST_TEXT_CHUNK_KB', 'default')}", {k: round(v, 3) for k, v in (tj[0] if tj else {}).items() if k.endswith("_s")}, flush=True)
+          for l in slow[:12]:
+              print("     ", l[:200], flush=True)
 finally:
     if os.path.exists(path):
         os.remove(path)
