@@ -529,7 +529,7 @@ struct Session {
                                 qcv.wait(lk, [&] { return !busy[nxt] || stop; });
                                 if (stop) return;
                             }
-                            bufs[nxt].reserve(chunk, 0);
+                            bufs[nxt].reserve(std::max(chunk, bufs[cur].size()), 0);  // (a buffer that had to grow for a long record: its tail can be as long)
                             memcpy(bufs[nxt].data(), bufs[cur].data() + cut, fill - cut);
                         }
                         {

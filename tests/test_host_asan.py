@@ -173,3 +173,26 @@ def test_text_chunks_are_whole_records_and_cover_the_file(tmp_path, text, chunk_
     kinds = [kind for kind, _, _ in entries]
     assert kinds.count("TEXT") == 1 and "RESET" in kinds                      # the accepted chunk was forgotten first
     assert kinds.index("RESET") < kinds.index("PUSH")
+
+
+def test_records_longer_than_the_chunk_then_short_ones(tmp_path):
+    """Round 5's reader thread (three chunk buffers): a buffer that had to GROW for a record longer than the chunk hands a tail
+    as long as itself to the next buffer -- which must grow with it (the first version copied it into a chunk-sized buffer:
+    a segfault on the GPU box, test_gpu_cli.py::test_records_larger_than_the_text_chunk).  Under ASan, with the stub."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    text = b""
+    for i, n in enumerate([9_000, 30, 2_500, 14_000, 5, 40_000, 12]):
+        s = np.frombuffer(b"ACGTacgtN", dtype=np.uint8)[rng.choice(9, size=n)].tobytes()
+        text += b">chr%d\n" % i + b"".join(s[o:o + 60] + b"\n" for o in range(0, n, 60))
+    p = tmp_path / "long.fa"
+    p.write_bytes(text)
+    log = tmp_path / "long.log"
+    for reader in ("1", "0"):
+        if log.exists():
+            log.unlink()
+        r = run("7", str(p), "--quiet", "-f", "histogram", env={"KMERUST_TEXT_CHUNK_KB": "1", "KH_STUB_LOG": str(log), "KH_STUB_TEXT": "1",
+                                                                 "KMERUST_PIPELINED_READER": reader})
+        assert r.returncode == 0, r.stderr
+        chunks = [b for kind, _, b in read_log(str(log)) if kind == "TEXT"]
+        assert all(c[:1] == b">" for c in chunks) and b"".join(chunks) == text and len(chunks) >= 3
