@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--group", type=int, default=0,
                     help="N thread ranks on ONE device through kh_group_create / kh_group_merge (the N > 1 accounting on a 1-GPU box)")
+    ap.add_argument("--force-merge", action="store_true",
+                    help="N = 1 only: run the N > 1 step -- count, then kh_merge_across over a REAL RCCL communicator of one rank -- and fill "
+                         "config.merge / per_rank / single_gpu_same_share as a torchrun launch would (pre-flight of the 8-GPU line on one GPU)")
     ap.add_argument("--no-hint", action="store_true", help="create the context with capacity_hint = 0 (KmerMap::new() takes none): the table is sized from the level-1 sample")
     ap.add_argument("--hg", action="store_true", help="run configs[4] alone (hg-shaped FASTA text -> histogram): for profiling that workload")
     ap.add_argument("--no-extras", action="store_true",
@@ -754,11 +757,19 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    merged = world > 1 or args.force_merge     # the step ends in kh_merge_across (and the line carries config.merge)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL
         else:
             dist.init_process_group(backend)
+    elif args.force_merge:   # a world of one, for the reductions below (the merge itself talks RCCL through the library)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        backend = "gloo"
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where small reduction operands live
 
     import krust_amd
@@ -778,7 +789,7 @@ def main():
         return
 
     k = args.k
-    reads = args.reads or (READS_N1 if world == 1 else READS_NX)
+    reads = args.reads or (READS_NX if merged else READS_N1)
     stride = READ_LEN + 1
     nbytes = reads * stride
     with_qual = args.min_quality is not None
@@ -799,9 +810,9 @@ def main():
     # only carries the 128-byte communicator id and the final timing reductions.  BENCH_MERGE=python (or the gloo
     # backend of the 1-GPU tests, where ranks share a device and RCCL cannot be used) selects the
     # torch.distributed harness krust_amd/distributed.py instead; both leave identical shard tables.
-    merge_impl = os.environ.get("BENCH_MERGE", "c" if backend == "nccl" else "python")
+    merge_impl = os.environ.get("BENCH_MERGE", "c" if (backend == "nccl" or args.force_merge) else "python")
     merge_note = None
-    if world > 1 and merge_impl == "c":
+    if merged and merge_impl == "c":
         ok = 1
         try:
             box = [krust_amd.comm_unique_id() if rank == 0 else None]
@@ -829,12 +840,12 @@ def main():
         dc.reset()
         dc.push_device(tb.data_ptr(), tq.data_ptr() if with_qual else None, nbytes)
         st = dc.finish()
-        mg = merge() if world > 1 else None  # (phase walls of rank 0 go into the JSON)
+        mg = merge() if merged else None  # (phase walls of rank 0 go into the JSON)
         return st, mg
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if merged:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -855,7 +866,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     per_rank = None
-    if world > 1:
+    if merged:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -903,11 +914,11 @@ def main():
         same_share = None
 
     verify = None
-    do_verify = (args.verify or (world == 1 and not args.no_verify))
+    do_verify = (args.verify or (not merged and not args.no_verify))
     if do_verify and rank == 0:
         host = tb.cpu().numpy()
         hq = tq.cpu().numpy() if with_qual else None
-        if world == 1:
+        if not merged:
             verify = verify_reads(dc, st, host, hq, k, args.min_quality)
         else:  # (the table is a shard by now: only the rank's k-mer total can be checked here)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -964,7 +975,7 @@ def main():
                        "table_load": st["distinct"] / st["table_slots"],
                        "capacity_hint": int(hint), "capacity_hint_source": "--capacity-hint" if args.capacity_hint else HINT_SOURCE,
                        "table_grows": int(st["grows"]),
-                       "parallelism": f"reads sharded x{world}" + ("; RCCL all-to-all table merge (kh_merge_across)" if world > 1 else "")},
+                       "parallelism": f"reads sharded x{world}" + ("; RCCL all-to-all table merge (kh_merge_across)" if merged else "")},
             "roofline": rf,
         }
         if mg is not None:
@@ -973,12 +984,12 @@ def main():
             out["config"]["single_gpu_same_share"] = same_share
         if verify is not None:
             out["verify"] = verify
-        if world == 1 and not args.no_cpu_baseline:
+        if not merged and not args.no_cpu_baseline:
             sample_reads = min(reads, 6_000_000)
             host = tb[: sample_reads * stride].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host, k, args.cpu_seconds)
             del host
-        if world == 1 and not args.no_extras:
+        if not merged and not args.no_extras:
             try:
                 out["end_to_end"] = end_to_end(dc, tb, torch, k)
             except Exception as e:  # (never lose the headline line over an extra)
@@ -1040,7 +1051,7 @@ def main():
         emit(out)
 
     dc.close()
-    if world > 1:
+    if merged:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -162,3 +162,21 @@ def test_bench_group_mode_runs_the_multi_rank_accounting_through_the_c_abi(n):
     assert d["verify"]["ok"] is True and d["config"]["mode"] == f"group{n}"
     full = json.load(open(f"/tmp/bench_group{n}.json"))
     assert full["config"]["merge"]["sent_count_sum"] > 0 and len(full["config"]["per_rank"]) == n
+
+
+def test_bench_force_merge_drives_the_rccl_merge_on_one_gpu():
+    """`bench.py --force-merge`: the N > 1 step -- count, then kh_merge_across over a REAL RCCL communicator (of one rank) inside
+    the timed region -- with every key of the N > 1 line (config.merge from the library, rccl_nranks from ncclCommCount,
+    conservation, per_rank, single_gpu_same_share): what a torchrun launch on 8 GPUs executes, on the box's one."""
+    import json
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-merge", "--steps", "2", "--warmup", "1", "--reads", "1500000", "--verify"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BENCH_FULL_PATH="/tmp/bench_force_merge.json"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 6144
+    d = json.loads(lines[0])
+    mg = d["config"]["merge"]
+    assert mg["impl"].startswith("kh_merge_across") and mg["rccl_nranks"] == 1 and mg["conserved"] is True and mg["lib_conserved"] is True, mg
+    assert mg["merged_occurrences"] == d["config"]["kmers_per_step_per_gpu"] and mg["path"].startswith("regions")
+    assert d["config"]["single_gpu_same_share"]["value"] > 0 and len(d["config"]["per_rank"]) == 1
+    assert d["verify"]["ok"] is True

@@ -1466,7 +1466,7 @@ def test_tables_of_1024_x_b2_regions(K, monkeypatch, b2, k, minq):
     then every consumer of the layout: results (through the 8-byte image where there is one), histogram, lookups, min-count,
     and growth by rehash into a larger table (a push through the direct path that doubles it)."""
     monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * b2))
-    n_reads = 60_000 if b2 < 500 else 400_000
+    n_reads = 60_000 if b2 < 500 else 200_000
     bases, qual = O.synth_reads(SEED + b2, 1 << 21, 150, 0, n_reads)
     m = O.OracleMap()
     total = m.scan_flat(bases, k, qual=qual if minq is not None else None, min_quality=minq, nthreads=NCPU)
@@ -1496,7 +1496,7 @@ def test_tables_of_1024_x_b2_regions(K, monkeypatch, b2, k, minq):
     # and from the partitioned one (whose regions overflow first: the failed buckets' re-insert)
     # (both payload widths; the -Q twins of the same two would differ only in the mask, which every counting test above draws)
     if b2 == 640 and minq is None:
-        bases2, qual2 = O.synth_reads(SEED + 77, 1 << 24, 150, 0, 400_000)
+        bases2, qual2 = O.synth_reads(SEED + 77, 1 << 24, 150, 0, 250_000)
         m2 = O.OracleMap()
         total2 = m2.scan_flat(bases2, k, qual=qual2 if minq is not None else None, min_quality=minq, nthreads=NCPU)
         w2k, w2c = m2.arrays()
