@@ -716,8 +716,12 @@ void ensure_part_budget(kh_ctx *c) {
     //  0.55 instead, and configs[3]'s share ran as two batches there.)
     u64 budget = 224ull << 30;
     const double share = 0.78;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess) budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * share));
-    else (void)hipGetLastError();
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+        budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * share));
+        // (buffers given back for a merge: the table image and the shard's table they left room for exist by now -- the same budget
+        //  again where it still fits, so that a rank that counted in one batch goes on counting in one)
+        if (c->prev_part_budget > budget && (u64)fr + c->key_cap + c->keyb_cap >= c->prev_part_budget + (3ull << 30)) budget = c->prev_part_budget;
+    } else (void)hipGetLastError();
     if (c->knobs.part_budget_gb > 0) budget = (u64)(c->knobs.part_budget_gb * (double)(1ull << 30));
     c->part_budget = std::max<u64>(budget, 64ull << 20);
 }
@@ -829,6 +833,10 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
 
     if (c->pending_bound) {  // exact counters before switching paths
         int rc = sync_counters(c);
+        if (rc != KH_OK) return rc;
+    }
+    if (c->borrow_on) {  // the partition buffers are about to be written: whatever a merge borrowed of them moves out
+        int rc = end_borrow(c);
         if (rc != KH_OK) return rc;
     }
     ensure_part_budget(c);

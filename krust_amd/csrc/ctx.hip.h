@@ -186,8 +186,18 @@ struct kh_ctx {
     u64 *merge_off = nullptr;  // scans of the senders' region counts (kh_merge_regions_device)
     u64 merge_off_cap = 0;
     u64 part_budget = 0;       // bytes for the two key buffers (0 = decide at first use)
+    u64 prev_part_budget = 0;  // ... as it was when release_part_buffers gave them back
     uint8_t *keysA = nullptr, *keysB = nullptr;  // partition ping-pong buffers
     u64 key_cap = 0, keyb_cap = 0;  // bytes of keysA / keysB
+    // Round 5: between the end of a count and the next kh_reset the two partition buffers are idle -- up to 0.78 of the device --
+    // while a merge needs tens of GB of scratch AND the shard's 16-byte table.  Round 4 gave the buffers back to the driver
+    // (release_part_buffers) and took them again at the next count: 370 ms of hipFree / hipMalloc per count-and-merge step
+    // at configs[3]'s size (bench.py --force-merge).  Now the merge BORROWS from them: a bump allocator over keysA / keysB
+    // (kmerhip.hip borrow()), for the exchange's send / receive buffers and for the table itself (table_borrowed).  The loan
+    // ends with kh_reset, or when anything is about to write the partition buffers (end_borrow: a borrowed table moves out).
+    bool borrow_on = false;
+    u64 borrow_off[2] = {0, 0};     // bytes lent out of keysA / keysB
+    bool table_borrowed = false;    // `table` points into keysA / keysB: never hipFree'd
     kh::Part2Block *blocks = nullptr;
     u64 blocks_cap = 0;
     u64 *moff = nullptr;
@@ -313,6 +323,10 @@ int ensure_room(kh_ctx *c, u64 bound, bool allow_shrink_hint, bool *want_smaller
 int drain_events(kh_ctx *c);
 int ensure_region_scratch(kh_ctx *c, u64 nregions);  // every [regions] scratch array of the context, grown together
 int release_part_buffers(kh_ctx *c);  // the two partition buffers back to the device (they come back with the next partitioned batch)
+void *borrow(kh_ctx *c, u64 bytes);   // `bytes` of the idle partition buffers (nullptr: not lent out, or no room); never freed
+u64 borrow_room(const kh_ctx *c);     // the largest single request borrow() could serve now
+int end_borrow(kh_ctx *c);            // the partition buffers are about to be written (or freed): a borrowed table moves to memory of its own
+void drop_table(kh_ctx *c);           // the 16-byte table is no longer needed: freed, unless it was borrowed
 int device_scan(kh_ctx *c, const uint32_t *in, u64 n, u64 *out);
 int zero_cursors(kh_ctx *c);
 int read_cursor(kh_ctx *c, u64 *cursor, u64 *big);

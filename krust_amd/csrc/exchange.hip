@@ -346,17 +346,26 @@ int xp_allreduce_sum_u64(kh_ctx *c, u64 *d_buf, u64 n) {
 
 struct DevBuf {  // scratch of one merge; freed when it goes out of scope
     void *p = nullptr;
+    bool owned = true;  // false: carved out of the context's idle partition buffers (borrow(): nothing to free, alive until kh_reset)
     void release() {
         if (!p) return;
-        if (tl_hub && tl_hub->is_poisoned()) tl_hub->keep(p);  // (a peer may still be reading it: LocalHub::keep)
-        else (void)hipFree(p);
+        if (owned) {
+            if (tl_hub && tl_hub->is_poisoned()) tl_hub->keep(p);  // (a peer may still be reading it: LocalHub::keep)
+            else (void)hipFree(p);
+        }
         p = nullptr;
+        owned = true;
     }
     ~DevBuf() { release(); }
     int alloc(kh_ctx *c, u64 bytes, const char *what) {
         release();
+        if ((p = borrow(c, bytes ? bytes : 16)) != nullptr) {
+            owned = false;
+            return KH_OK;
+        }
         hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-        if (e != hipSuccess && (c->keysA || c->keysB)) {  // the partition buffers of the counting that is over: room for this
+        // the partition buffers of the counting that is over: room for this -- unless parts of them are lent out to this very merge
+        if (e != hipSuccess && (c->keysA || c->keysB) && !(c->borrow_off[0] | c->borrow_off[1])) {
             (void)hipGetLastError();
             p = nullptr;
             if (release_part_buffers(c) == KH_OK) e = hipMalloc(&p, bytes ? bytes : 16);
@@ -394,6 +403,18 @@ int digest_units(kh_ctx *c, int fmt, const void *base, const u64 *counts, const 
     else hipLaunchKernelGGL((kh::unit_digest_kernel<0>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);
     HIP_TRY(c, hipGetLastError());
     return KH_OK;
+}
+
+// kh_reset in the middle of a merge (the table becomes the shard's): what the merge has borrowed of the partition buffers --
+// its send and receive buffers, in use right now -- stays lent out (a caller's kh_reset ends the loan: ctx.hip.h borrow_on)
+int merge_reset(kh_ctx *c) {
+    const bool on = c->borrow_on;
+    const u64 o0 = c->borrow_off[0], o1 = c->borrow_off[1];
+    const int rc = kh_reset(c);
+    c->borrow_on = on;
+    c->borrow_off[0] = o0;
+    c->borrow_off[1] = o1;
+    return rc;
 }
 
 uint32_t merge_pieces_default() {  // (a tunable of the exchange: how many shares the pipeline works in; any value gives the same shards)
@@ -589,15 +610,29 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     // The counting is over: its partition buffers (up to 0.78 of the device) are given back where the exchange would not fit
     // beside them -- send and receive buffers (<= 16 B per local key together) and the shard's 16-byte table.  (Not always: a
     // host that counts and merges in a loop would pay for 150 GB of hipMalloc per round.)
+    // Round 5: first the merge BORROWS from them (ctx.hip.h, borrow_on): its send / receive buffers and the shard's 16-byte table
+    // are carved out of the idle buffers, nothing is freed or allocated in a count-and-merge loop (bench.py --force-merge at
+    // configs[3]'s size: 514 ms per step with the buffers going back and forth, of which 146 were kernels).  Only where they
+    // cannot hold it all is the old way taken.
     if (lrc == KH_OK) {
         size_t fr = 0, tot = 0;
         const u64 keys_now = c->h_ctr->distinct;
-        const u64 want = 16ull * keys_now + 16ull * (c->cap / W + kh::REGION_SLOTS) + (8ull << 30);
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
-            (void)hipGetLastError();
-            fr = 0;
+        const u64 scratch = 16ull * keys_now + (4ull << 30);                        // send + receive buffers, counts
+        const u64 tab = c->table ? 0 : 16ull * std::max<u64>(c->cap, 2 * keys_now);   // the shard's table (it may have to hold every rank's keys of its range)
+        const bool lend = (c->keysA || c->keysB) && c->key_cap + c->keyb_cap >= scratch + tab + (1ull << 30) &&
+                          std::max(c->key_cap, c->keyb_cap) >= std::max(tab, 8ull * keys_now + (1ull << 20));
+        if (lend) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->borrow_on = true;
+            c->borrow_off[0] = c->borrow_off[1] = 0;
+        } else {
+            const u64 want = scratch + 16ull * (c->cap / W + kh::REGION_SLOTS) + (4ull << 30);
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+                (void)hipGetLastError();
+                fr = 0;
+            }
+            if ((u64)fr < want) lrc = release_part_buffers(c);
         }
-        if ((u64)fr < want) lrc = release_part_buffers(c);
     }
     if (lrc == KH_OK) lrc = inject("start");
     if (lrc == KH_OK) lrc = dig.alloc(c, (size_t)3 * W * (1 + 64) * sizeof(u64), "hipMalloc(digests)");
@@ -623,7 +658,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         transfers = false;
         t_wait += now_ms() - t0;
         t0 = now_ms();
-        lrc = kh_reset(c);
+        lrc = merge_reset(c);
         if (lrc == KH_OK) lrc = inject("dense_merge");
         if (lrc == KH_OK) lrc = kh_merge_dense_device(c, (const uint64_t *)dense.p, n, R, W);
         if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
@@ -876,7 +911,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
                 if (lrc != KH_OK && cm->nccl) return done(lrc);  // (an RCCL failure aborted the communicator: the peers' waits end)
             }
             if (lrc == KH_OK) lrc = kh_set_region_window(c, 0, 1);
-            if (lrc == KH_OK) lrc = kh_reset(c);
+            if (lrc == KH_OK) lrc = merge_reset(c);
             if (lrc == KH_OK) lrc = kh_set_shard(c, R, W);
             for (uint32_t i = 0; i < npieces && lrc == KH_OK; ++i) {
                 double t0 = now_ms();
@@ -1023,7 +1058,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
             lrc = digest_units(c, xfmt, rbuf.p, wide ? (const u64 *)rbuf2.p : nullptr, seg_ro.data(), seg_rl.data(), W, ub, head_cmask, d_rx(0));
             rx_slots = 1;
         }
-        if (lrc == KH_OK) lrc = kh_reset(c);
+        if (lrc == KH_OK) lrc = merge_reset(c);
         if (lrc == KH_OK) lrc = kh_set_shard(c, R, W);
         if (lrc == KH_OK) lrc = inject("oneshot_merge");
         if (lrc == KH_OK) {
@@ -1094,7 +1129,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
             lrc = digest_units(c, XF_WIDE, rk.p, (const u64 *)rcn.p, seg_ro.data(), seg_rl.data(), W, 8, 0u, d_rx(0));
             rx_slots = 1;
         }
-        if (lrc == KH_OK) lrc = kh_reset(c);
+        if (lrc == KH_OK) lrc = merge_reset(c);
         if (lrc == KH_OK) lrc = inject("generic_merge");
         if (lrc == KH_OK) lrc = kh_merge_pairs_device(c, (const uint64_t *)rk.p, (const uint64_t *)rcn.p, rtot);
         if (lrc == KH_OK) lrc = kh_finish(c, nullptr);  // (also: the kernels are done with rk / rcn before they are freed)

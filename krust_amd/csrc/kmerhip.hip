@@ -90,6 +90,12 @@ int alloc_table(kh_ctx *c, u64 cap, Slot **out) {
 // fresh region pass writes every slot anyway.
 int need_table(kh_ctx *c) {
     if (c->table) return KH_OK;
+    if (void *p = borrow(c, c->cap * sizeof(Slot))) {  // (a merge's shard table, inside the idle partition buffers: see ctx.hip.h)
+        c->table = (Slot *)p;
+        c->table_borrowed = true;
+        c->table_dirty = true;
+        return KH_OK;
+    }
     hipError_t e = hipMalloc((void **)&c->table, c->cap * sizeof(Slot));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -99,10 +105,54 @@ int need_table(kh_ctx *c) {
     c->table_dirty = true;
     return KH_OK;
 }
+void drop_table(kh_ctx *c) {
+    if (c->table && !c->table_borrowed) (void)hipFree(c->table);  // (synchronises the device)
+    c->table = nullptr;
+    c->table_borrowed = false;
+}
+// ---- the idle partition buffers as a merge's scratch (ctx.hip.h, borrow_on) ----
+u64 borrow_room(const kh_ctx *c) {
+    if (!c->borrow_on) return 0;
+    const u64 a = c->keysA && c->key_cap > c->borrow_off[0] ? c->key_cap - c->borrow_off[0] : 0;
+    const u64 b = c->keysB && c->keyb_cap > c->borrow_off[1] ? c->keyb_cap - c->borrow_off[1] : 0;
+    return std::max(a, b) & ~4095ull;
+}
+void *borrow(kh_ctx *c, u64 bytes) {
+    if (!c->borrow_on) return nullptr;
+    const u64 need = (std::max<u64>(bytes, 16) + 4095) & ~4095ull;
+    uint8_t *const base[2] = {c->keysA, c->keysB};
+    const u64 cap[2] = {c->key_cap, c->keyb_cap};
+    // the smaller fit first: the large buffer stays whole for the large request (the table)
+    int order[2] = {0, 1};
+    if (cap[0] - std::min(cap[0], c->borrow_off[0]) > cap[1] - std::min(cap[1], c->borrow_off[1])) std::swap(order[0], order[1]);
+    for (int i : order) {
+        if (!base[i] || c->borrow_off[i] + need > cap[i]) continue;
+        void *p = base[i] + c->borrow_off[i];
+        c->borrow_off[i] += need;
+        return p;
+    }
+    return nullptr;
+}
+int end_borrow(kh_ctx *c) {
+    if (c->table_borrowed && c->table) {  // (rare: a table built by a merge is still wanted while a new count starts, or the buffers go)
+        Slot *nt = nullptr;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (hipMalloc((void **)&nt, c->cap * sizeof(Slot)) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(c, KH_ERR_OOM, "hipMalloc(table leaving the partition buffers)");
+        }
+        HIP_TRY(c, hipMemcpyAsync(nt, c->table, c->cap * sizeof(Slot), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->table = nt;
+    }
+    c->table_borrowed = false;
+    c->borrow_on = false;
+    c->borrow_off[0] = c->borrow_off[1] = 0;
+    return KH_OK;
+}
 // an EMPTY table of another size: nothing to move, nothing to allocate yet
 void resize_empty_table(kh_ctx *c, u64 newcap) {
-    if (c->table) (void)hipFree(c->table);  // (synchronises the device)
-    c->table = nullptr;
+    drop_table(c);
     if (c->ntab) {
         (void)hipFree(c->ntab);
         c->ntab = nullptr;
@@ -238,7 +288,7 @@ int grow_to(kh_ctx *c, u64 newcap) {
         HIP_TRY(c, hipGetLastError());
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipFree(c->table));
+    drop_table(c);
     if (c->trace) fprintf(stderr, "[kmerhip] table grown %llu -> %llu slots\n", c->cap, newcap);
     c->rheads_valid = false;
     c->table = nt;
@@ -321,11 +371,14 @@ int drain_events(kh_ctx *c) {
 
 int release_part_buffers(kh_ctx *c) {
     if (!c->keysA && !c->keysB) return KH_OK;
+    int brc = end_borrow(c);
+    if (brc != KH_OK) return brc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->keysA) (void)hipFree(c->keysA);
     if (c->keysB) (void)hipFree(c->keysB);
     c->keysA = c->keysB = nullptr;
     c->key_cap = c->keyb_cap = 0;
+    c->prev_part_budget = c->part_budget;  // (what the context had: it gets it back if the memory is still there, batch.hip ensure_part_budget)
     c->part_budget = 0;  // (decided again at the next partitioned range)
     return KH_OK;
 }
@@ -478,7 +531,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)
         if (q) (void)hipFree(q);
-    if (c->table) (void)hipFree(c->table);
+    drop_table(c);
     if (c->ntab) (void)hipFree(c->ntab);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->h_ctr) (void)hipHostFree(c->h_ctr);
@@ -517,6 +570,9 @@ extern "C" int kh_reset(kh_ctx *c) {
     // Lazy: no table_init here (5.5 ms for a 34 GB table).  A partitioned batch into an empty table
     // rewrites every region; any other use clears first (clear_if_dirty).
     if (!c->table_empty) c->table_dirty = true;
+    if (c->table_borrowed) drop_table(c);  // (a merge's table inside the partition buffers: forgotten with its content)
+    c->borrow_on = false;
+    c->borrow_off[0] = c->borrow_off[1] = 0;
     c->narrow = false;         // (both images are stale now; the next fresh pass chooses again)
     c->narrow_banned = false;
     c->new_rate = -1.0;

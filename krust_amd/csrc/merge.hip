@@ -161,7 +161,7 @@ extern "C" int kh_set_shard(kh_ctx *c, uint32_t index, uint32_t count) {
             (void)hipGetLastError();
             fr = 0;
         }
-        if ((u64)fr < 16ull * (c->cap >> sh) + (8ull << 30)) {
+        if (borrow_room(c) < 16ull * c->cap && (u64)fr < 16ull * (c->cap >> sh) + (8ull << 30)) {  // (round 5: not where the table will be borrowed from the partition buffers)
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             (void)hipFree(c->ntab);
             c->ntab = nullptr;
