@@ -557,6 +557,18 @@ def _r(x, nd=4):
 
 
 LINE_LIMIT = 6144   # bytes: the whole line must fit the driver's 8 KB stdout tail
+_CONTRACT_OUT = None  # the process's real stdout, once own_stdout() has moved everybody else to stderr
+
+
+def own_stdout():
+    """stdout carries ONE line: ours.  RCCL prints a five-line banner (version, HIP / ROCm version, host name, library path) to
+    fd 1 from every process that creates a communicator -- after our line, at exit -- and gloo its own; a driver that reads
+    the last line of stdout would read that.  So fd 1 is pointed at stderr for everything but emit()."""
+    global _CONTRACT_OUT
+    if _CONTRACT_OUT is None:
+        sys.stdout.flush()
+        _CONTRACT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
 
 
 def contract_line(full):
@@ -647,7 +659,7 @@ def emit(full):
         full["full_report"] = f"not written: {e!r}"
     line = json.dumps(contract_line(full))
     assert len(line) <= LINE_LIMIT, len(line)
-    print(line, flush=True)
+    print(line, file=_CONTRACT_OUT or sys.stdout, flush=True)
 
 
 def main_group(args):
@@ -739,6 +751,7 @@ def main_group(args):
 
 def main():
     args = parse_args()
+    own_stdout()
     if args.group > 1:
         return main_group(args)
     rank = int(os.environ.get("RANK", "0"))

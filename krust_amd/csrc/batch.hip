@@ -708,14 +708,15 @@ int direct_range(kh_ctx *c, const RangeArgs &ra, u64 first_tile, u64 end_tile) {
 void ensure_part_budget(kh_ctx *c) {
     if (c->part_budget) return;
     size_t fr = 0, tot = 0;
-    // (up to 0.78 of what is free: the 8-byte table image -- 8 bytes per slot, allocated after level 2 -- and the small arrays
+    // (up to 0.80 of what is free: the 8-byte table image -- 8 bytes per slot, allocated after level 2 -- and the small arrays
     //  take the rest.  Round 3 stopped at 160 GiB / 0.75: configs[3]'s 125 M reads then ran as two batches, the second one a
     //  pass over a filled table that re-reads and re-writes all of it: 36 ms of region pass where one fresh pass takes 24)
     // (A rank of a multi-GPU merge gets the same: kh_merge_across gives the partition buffers back before it allocates its
     //  send / receive buffers and the shard's 16-byte table -- release_part_buffers.  For an hour of round 4 such a rank kept
     //  0.55 instead, and configs[3]'s share ran as two batches there.)
     u64 budget = 224ull << 30;
-    const double share = 0.78;
+    const double share = 0.80;  // (round 5: 0.78 -- two RCCL communicators' worth of device memory tipped configs[3]'s 125 M reads, which need 207.6 of
+                                //  the 288 GB by the 11-bytes-per-window rule, into two batches: 100 ms of kernels instead of 80, bench.py --force-merge)
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
         budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * share));
         // (buffers given back for a merge: the table image and the shard's table they left room for exist by now -- the same budget

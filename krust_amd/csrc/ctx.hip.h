@@ -189,7 +189,7 @@ struct kh_ctx {
     u64 prev_part_budget = 0;  // ... as it was when release_part_buffers gave them back
     uint8_t *keysA = nullptr, *keysB = nullptr;  // partition ping-pong buffers
     u64 key_cap = 0, keyb_cap = 0;  // bytes of keysA / keysB
-    // Round 5: between the end of a count and the next kh_reset the two partition buffers are idle -- up to 0.78 of the device --
+    // Round 5: between the end of a count and the next kh_reset the two partition buffers are idle -- up to 0.8 of the device --
     // while a merge needs tens of GB of scratch AND the shard's 16-byte table.  Round 4 gave the buffers back to the driver
     // (release_part_buffers) and took them again at the next count: 370 ms of hipFree / hipMalloc per count-and-merge step
     // at configs[3]'s size (bench.py --force-merge).  Now the merge BORROWS from them: a bump allocator over keysA / keysB

@@ -607,7 +607,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     }
     int lrc = pre;
     if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
-    // The counting is over: its partition buffers (up to 0.78 of the device) are given back where the exchange would not fit
+    // The counting is over: its partition buffers (up to 0.8 of the device) are given back where the exchange would not fit
     // beside them -- send and receive buffers (<= 16 B per local key together) and the shard's 16-byte table.  (Not always: a
     // host that counts and merges in a loop would pay for 150 GB of hipMalloc per round.)
     // Round 5: first the merge BORROWS from them (ctx.hip.h, borrow_on): its send / receive buffers and the shard's 16-byte table
