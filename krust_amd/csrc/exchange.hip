@@ -617,21 +617,22 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     if (lrc == KH_OK) {
         size_t fr = 0, tot = 0;
         const u64 keys_now = c->h_ctr->distinct;
-        const u64 scratch = 16ull * keys_now + (4ull << 30);                        // send + receive buffers, counts
-        const u64 tab = c->table ? 0 : 16ull * std::max<u64>(c->cap, 2 * keys_now);   // the shard's table (it may have to hold every rank's keys of its range)
-        const bool lend = (c->keysA || c->keysB) && c->key_cap + c->keyb_cap >= scratch + tab + (1ull << 30) &&
-                          std::max(c->key_cap, c->keyb_cap) >= std::max(tab, 8ull * keys_now + (1ull << 20));
-        if (lend) {
+        const u64 scratch = 16ull * keys_now + (64ull << 20);                        // send + receive buffers, counts
+        const u64 tab = c->table ? 0 : 16ull * std::max<u64>(c->cap, 2 * keys_now);  // the shard's table (it may have to hold every rank's keys of its range)
+        const u64 lendable = (c->keysA ? c->key_cap : 0) + (c->keysB ? c->keyb_cap : 0);
+        // (what does not fit the loan comes from hipMalloc -- borrow() just says no --, so lending is always safe; the buffers go
+        //  back to the driver only where that remainder would not fit the free memory either)
+        const u64 rest = scratch + tab > lendable ? scratch + tab - lendable : 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            fr = 0;
+        }
+        if (lendable && (u64)fr >= rest + (rest ? (2ull << 30) : 0)) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             c->borrow_on = true;
             c->borrow_off[0] = c->borrow_off[1] = 0;
-        } else {
-            const u64 want = scratch + 16ull * (c->cap / W + kh::REGION_SLOTS) + (4ull << 30);
-            if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
-                (void)hipGetLastError();
-                fr = 0;
-            }
-            if ((u64)fr < want) lrc = release_part_buffers(c);
+        } else if ((u64)fr < scratch + 16ull * (c->cap / W + kh::REGION_SLOTS) + (4ull << 30)) {
+            lrc = release_part_buffers(c);
         }
     }
     if (lrc == KH_OK) lrc = inject("start");

@@ -546,3 +546,43 @@ def test_small_count_then_merge_into_a_larger_geometry_then_a_large_partitioned_
         assert st["part_batches"] >= 1 and st["distinct"] == len(ok)
         keys, cnts = g[1].result()
         assert np.array_equal(keys, ok) and np.array_equal(cnts, oc)
+
+
+@pytest.mark.parametrize("world,k,expect", [(2, 21, "regions"), (3, 21, "pairs")])
+def test_merge_borrows_the_idle_partition_buffers_and_gives_them_back(K, monkeypatch, world, k, expect):
+    """Round 5: a merge takes its scratch -- and the shard's 16-byte table -- out of the partition buffers the count has just
+    finished with, instead of handing ~200 GB back to the driver and taking them again at the next count (bench.py
+    --force-merge at configs[3]'s size: 514 -> 120 ms per count-and-merge step).  Here, at test size: partitioned counts (so
+    the buffers exist), a merge (its table lives in them: KMERHIP_TRACE says so), the shards against the oracle, then
+    (a) reset + count + merge again on the same group -- the loan ends with the reset -- and (b) on the route that leaves a
+    table one can push into (pairs), a partitioned push AFTER the merge: the borrowed table has to move out of the buffers
+    the push is about to overwrite (end_borrow), with its counts."""
+    monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    n_reads = 240_000
+    full_b, _ = O.synth_reads(SEED + 11, 1 << 20, 150, 0, n_reads, with_qual=False)
+    fk, fc = oracle_arrays(full_b, k)
+    owners = O.owners(K, fk, k, world)
+    per = n_reads // world
+    extra = full_b[: 151 * 60_000]
+    ek, ec = oracle_arrays(extra, k)
+    with K.DeviceGroup(k, [0] * world, capacity_hint=600_000, path="partition") as g:   # (a small table beside large batches: it fits the buffers)
+        for rnd in range(2):
+            for r, dc in enumerate(g.counters):
+                dc.reset()
+                lo, hi = r * per, (n_reads if r == world - 1 else (r + 1) * per)
+                dc.push(full_b[lo * 151: hi * 151])
+            assert all(dc.finish()["part_batches"] >= 1 for dc in g.counters)
+            infos = g.merge()
+            assert all(i["path"].startswith(expect) and i["conserved"] == 1 for i in infos), infos
+            for r, dc in enumerate(g.counters):
+                keys, cnts = dc.result()
+                assert np.array_equal(keys, fk[owners == r]) and np.array_equal(cnts, fc[owners == r]), f"round {rnd}, shard {r}"
+        if expect == "pairs":    # (a hash-range shard refuses pushes until reset; the owner-partitioned route leaves an ordinary table)
+            dc = g[0]
+            dc.push(extra)
+            st = dc.finish()
+            want = dict(zip(fk[owners == 0].tolist(), fc[owners == 0].tolist()))
+            for a, b in zip(ek.tolist(), ec.tolist()):
+                want[a] = want.get(a, 0) + b
+            keys, cnts = dc.result()
+            assert st["distinct"] == len(want) and dict(zip(keys.tolist(), cnts.tolist())) == want
