@@ -700,12 +700,18 @@ extern "C" int kh_result_copy(kh_ctx *c, uint64_t *keys, uint64_t *counts, uint6
     // The compacted pairs need two device arrays on their way out.  The partition buffers are idle here (every batch is
     // counted: enter() flushed) and, after any sizeable count, far larger than the result: use them instead of two fresh
     // multi-gigabyte allocations (mapping and unmapping 17 GB cost more than the compaction itself).
+    // (Round 5: unless a merge has BORROWED parts of them -- its shard table may live there: then only what is not lent out,
+    //  through the same bump allocator, handed back below.)
     uint64_t *dk = nullptr, *dc = nullptr;
-    const bool scratch = c->keysA && c->keysB && c->key_cap >= need * sizeof(u64) && c->keyb_cap >= need * sizeof(u64);
+    const u64 loan0 = c->borrow_off[0], loan1 = c->borrow_off[1];
+    bool scratch = !c->borrow_on && c->keysA && c->keysB && c->key_cap >= need * sizeof(u64) && c->keyb_cap >= need * sizeof(u64);
     if (scratch) {
         dk = reinterpret_cast<uint64_t *>(c->keysA);
         dc = reinterpret_cast<uint64_t *>(c->keysB);
-    } else if (hipMalloc((void **)&dk, need * sizeof(u64)) != hipSuccess || hipMalloc((void **)&dc, need * sizeof(u64)) != hipSuccess) {
+    } else if (c->borrow_on && (dk = (uint64_t *)borrow(c, need * sizeof(u64))) != nullptr && (dc = (uint64_t *)borrow(c, need * sizeof(u64))) != nullptr) {
+        scratch = true;
+    } else if ((c->borrow_off[0] = loan0, c->borrow_off[1] = loan1, dk = dc = nullptr, false) ||
+               hipMalloc((void **)&dk, need * sizeof(u64)) != hipSuccess || hipMalloc((void **)&dc, need * sizeof(u64)) != hipSuccess) {
         (void)hipGetLastError();
         if (dk) (void)hipFree(dk);
         return fail(c, KH_ERR_OOM, "hipMalloc(result)");
@@ -719,6 +725,8 @@ extern "C" int kh_result_copy(kh_ctx *c, uint64_t *keys, uint64_t *counts, uint6
         (void)hipFree(dk);
         (void)hipFree(dc);
     }
+    c->borrow_off[0] = loan0;  // (a loan taken for this call alone goes back)
+    c->borrow_off[1] = loan1;
     return rc;
 }
 
