@@ -557,6 +557,12 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         }
     }
     HIP_TRY(c, hipGetLastError());
+    // a SHORT overflow list has just been inserted: the head counts of the regions it touched are made again, the others' stand
+    // (merge.hip recount_touched_heads; a failed region, a narrow overflow or a long list drop the counts as before)
+    bool heads_recounted = false;
+    if (was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->ovf_pending && c->ovf_pending <= (4ull << 20) && !heavy_exact) {
+        heads_recounted = recount_touched_heads(c, nregions, c->ovf_list, c->ovf, ovf_lim) == KH_OK;
+    }
     c->table_empty = false;
     c->table_dirty = false;  // the FRESH region pass wrote every region
     c->launches++;
@@ -567,7 +573,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     if (rc != KH_OK) return rc;
     // the per-region exchange-head counts of a FRESH 32-bit pass describe the whole table until
     // anything else touches it
-    c->rheads_valid = was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->h_ctr->part_failed == 0 && c->ovf_pending == 0;
+    c->rheads_valid = was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->h_ctr->part_failed == 0 && (c->ovf_pending == 0 || heads_recounted) &&
+                      !(nar && c->h_ctr->narrow_ovf);
     c->rheads_wide = c->h_ctr->heads_wide != 0;
     if (nar && c->h_ctr->narrow_ovf) {
         // overflow-list entries whose count would not fit the 8-byte image were left in the list: widen, insert them the

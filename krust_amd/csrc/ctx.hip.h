@@ -216,6 +216,7 @@ struct kh_ctx {
     uint32_t rheads_cb = 0;
     u64 *bend = nullptr;             // arena path: end of every region's data (the exact path uses bstart + 1)
     uint32_t *hot_list = nullptr;    // [regions] buckets left to hot_buckets_kernel (partition.hip.h)
+    uint8_t *rtouch = nullptr;       // [regions] all zero between uses: the regions an overflow list touched (merge.hip recount_touched_heads)
     u64 *radd = nullptr;             // [regions] shard_merge_kernel: sum of the counts it put into every target region (conservation)
     u64 *ptotal = nullptr;           // [MAX_P1] payloads per level-1 partition
     uint32_t *pcap = nullptr;        // [MAX_P1] arena capacity of that partition's buckets
@@ -343,6 +344,7 @@ bool is_pinned_host(const void *p);
 int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes);
 // ---- merge.hip
 enum { XF_WIDE = 0, XF_PACKED64 = 1, XF_HEADS32 = 2 };  // exchange unit formats (shard.hip.h)
+int recount_touched_heads(kh_ctx *c, u64 nregions, const void *ovf_list, const u64 *d_ovf, u64 ovf_lim);  // (batch.hip: after a short overflow list)
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap, uint32_t *d_region_counts,
                    uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions);
 int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions, const void *const *d_keys,

@@ -397,7 +397,7 @@ int digest_units(kh_ctx *c, int fmt, const void *base, const u64 *counts, const 
     }
     HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)3 * W * sizeof(u64), c->stream));
     if (!maxlen) return KH_OK;
-    const dim3 grid((unsigned)std::max<u64>(1, std::min<u64>(1024, (maxlen + kh::BLOCK * 16 - 1) / (kh::BLOCK * 16))), W), block(kh::BLOCK);
+    const dim3 grid((unsigned)std::max<u64>(1, std::min<u64>(2048, (maxlen + kh::BLOCK * 32 - 1) / (kh::BLOCK * 32))), W), block(kh::BLOCK);
     if (fmt == XF_HEADS32) hipLaunchKernelGGL((kh::unit_digest_kernel<2>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);
     else if (fmt == XF_PACKED64) hipLaunchKernelGGL((kh::unit_digest_kernel<1>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);
     else hipLaunchKernelGGL((kh::unit_digest_kernel<0>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);

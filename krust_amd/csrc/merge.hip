@@ -184,6 +184,22 @@ kh::SlotSrc slot_src(const kh_ctx *c) {
     return s;
 }
 
+// The region pass of a FRESH batch leaves every region's exchange-head count behind (rheads): a later heads export needs no
+// counting pass over the table (4 ms at configs[3]'s size).  The batch's overflow list -- a few entries on well-mixed input --
+// is inserted after that pass and changes the counts of the regions it touches: those, and only those, are counted again
+// (round 5; until then ANY entry dropped the counts of the whole table).  rtouch, a byte per region, is all zero between uses.
+int recount_touched_heads(kh_ctx *c, u64 nregions, const void *ovf_list, const u64 *d_ovf, u64 ovf_lim) {
+    const int cb = head_count_bits(c, nregions);
+    if (cb < 0 || (uint32_t)cb != c->rheads_cb) return KH_ERR_RANGE;  // (not the unit the counts were made for: the caller drops them)
+    hipLaunchKernelGGL(kh::ovf_touch_kernel, dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream, (const kh::OvfEntry *)ovf_list, d_ovf, ovf_lim,
+                       c->rtouch);
+    hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream, slot_src(c), (uint32_t)cb, c->rheads,
+                       &c->d_ctr->heads_wide, (const uint8_t *)c->rtouch);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemsetAsync(c->rtouch, 0, nregions, c->stream));
+    return KH_OK;
+}
+
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap,
                    uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions) {
     int rc = enter(c, true, true, false, fmt != XF_WIDE);  // (packed and heads come straight out of the 8-byte image)
@@ -214,7 +230,7 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
         rc = zero_cursors(c);
         if (rc != KH_OK) return rc;
         hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                           slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big);
+                           slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big, (const uint8_t *)nullptr);
         // (kept for the exports that follow -- the other pieces of a pipelined exchange, its unit counts: one pass over the table
         //  instead of one per call; valid once the "too wide" flag below has come back clear, until anything touches the table)
         if (c->rheads && c->region_cap >= nregions) {
@@ -311,7 +327,7 @@ extern "C" int kh_region_unit_counts_device(kh_ctx *c, uint32_t unit_bytes, uint
             rc = zero_cursors(c);
             if (rc != KH_OK) return rc;
             hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
-                               slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big);
+                               slot_src(c), (uint32_t)cb, d_region_counts, &c->d_ctr->big, (const uint8_t *)nullptr);
             HIP_TRY(c, hipGetLastError());
             const bool keep = c->rheads && c->region_cap >= nregions;
             if (keep) HIP_TRY(c, hipMemcpyAsync(c->rheads, d_region_counts, nregions * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));

@@ -1043,6 +1043,18 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
     for (u64 i = s_ovf_next + tid; i < s_ovf_end && i < ovf_cap; i += NT) ovf_list[i].region = 0xFFFFFFFFu;
 }
 
+// touched[region] = 1 for every (valid) entry of the overflow list: the regions whose exchange-head counts the list's insert
+// changes (batch.hip counts those regions again instead of dropping the region pass's counts for the whole table)
+KH_GLOBAL __launch_bounds__(BLOCK) void ovf_touch_kernel(const OvfEntry *__restrict__ list, const u64 *__restrict__ ovf, u64 ovf_cap,
+                                                          uint8_t *__restrict__ touched) {
+    const u64 n = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;
+    const u64 stride = (u64)gridDim.x * BLOCK;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint32_t r = list[i].region;
+        if (r != 0xFFFFFFFFu) touched[r] = 1;
+    }
+}
+
 // ---- the 8-byte table image (round 3): slot = count << 32 | 32-bit payload, 0 = free --------------------------------
 // Written by region_count_kernel32<.., NARROW = true>; region r = slots [4096 r, 4096 (r + 1)), in-region start as in the
 // 16-byte table (the same hash bits), linear probing inside the region.  The key of slot i:

@@ -142,10 +142,14 @@ KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_packed_kernel(SlotSrc src
 // 23 hash bits + 9 count bits, 4 bytes per pair instead of 16.
 __device__ __forceinline__ uint32_t heads_of(u64 count, uint32_t cb) { return (uint32_t)((count + (1ull << cb) - 1) >> cb); }
 
+// `only` (optional): a byte per region -- regions whose byte is zero keep the count they have (batch.hip: the few regions the
+// overflow list of a partitioned batch touched are counted again, the others' counts are the region pass's).
 KH_GLOBAL __launch_bounds__(BLOCK) void region_head_count_kernel(SlotSrc src, uint32_t cb,
-                                                                  uint32_t *__restrict__ rcount, u64 *__restrict__ wide) {
+                                                                  uint32_t *__restrict__ rcount, u64 *__restrict__ wide,
+                                                                  const uint8_t *__restrict__ only) {
     __shared__ uint32_t s_n;
     const u64 r = blockIdx.x;
+    if (only && !only[r]) return;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     uint32_t n = 0;
@@ -457,18 +461,46 @@ __global__ __launch_bounds__(BLOCK) void unit_digest_kernel(const void *__restri
                                                             uint32_t head_cmask, u64 *__restrict__ out) {
     const uint32_t seg = blockIdx.y;
     const u64 lo = segs.off[seg], n = segs.len[seg];
-    const u64 stride = (u64)gridDim.x * BLOCK;
+    const u64 stride = (u64)gridDim.x * BLOCK, t0 = (u64)blockIdx.x * BLOCK + threadIdx.x;
     u64 sum = 0, chk = 0;
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        if (FMT == 2) {
-            const uint32_t h = reinterpret_cast<const uint32_t *>(base)[lo + i];
+    if (FMT == 2) {
+        // 16-byte loads over the aligned middle of the segment (a first version read one head per lane: 2 TB/s, 5.8 ms of a
+        // 39 ms merge leg at configs[3]'s size), single heads in front of it and behind
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(base) + lo;
+        auto one = [&](uint32_t h) {
             sum += (u64)(h & head_cmask) + 1;
             chk += h;
-        } else if (FMT == 1) {
-            const u64 v = reinterpret_cast<const u64 *>(base)[lo + i];
+        };
+        const u64 pre = n < 4 ? n : (((16 - ((uintptr_t)p & 15)) & 15) >> 2);
+        const u64 nvec = (n - pre) >> 2, rest0 = pre + (nvec << 2);
+        if (t0 < pre) one(p[t0]);
+        const uint4 *v = reinterpret_cast<const uint4 *>(p + pre);
+        for (u64 i = t0; i < nvec; i += stride) {
+            const uint4 x = v[i];
+            one(x.x);
+            one(x.y);
+            one(x.z);
+            one(x.w);
+        }
+        if (t0 < n - rest0) one(p[rest0 + t0]);
+    } else if (FMT == 1) {
+        const u64 *p = reinterpret_cast<const u64 *>(base) + lo;
+        auto one = [&](u64 v) {
             sum += v >> 32;
             chk += v;
-        } else {
+        };
+        const u64 pre = n < 2 ? n : (((uintptr_t)p & 8) ? 1 : 0);
+        const u64 nvec = (n - pre) >> 1, rest0 = pre + (nvec << 1);
+        if (t0 < pre) one(p[t0]);
+        const uint4 *v = reinterpret_cast<const uint4 *>(p + pre);
+        for (u64 i = t0; i < nvec; i += stride) {
+            const uint4 x = v[i];
+            one(((u64)x.y << 32) | x.x);
+            one(((u64)x.w << 32) | x.z);
+        }
+        if (t0 < n - rest0) one(p[rest0 + t0]);
+    } else {
+        for (u64 i = t0; i < n; i += stride) {
             const u64 key = reinterpret_cast<const u64 *>(base)[lo + i], cn = counts[lo + i];
             sum += cn;
             chk += key + 0x9E3779B97F4A7C15ull * cn;

@@ -832,6 +832,42 @@ def test_heads_export_uses_region_pass_counts(K):
     assert int(got["partition"][0].sum()) > st["distinct"]
 
 
+@pytest.mark.parametrize("k", [19, 21])
+def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k):
+    """Round 5: the arena level 2 leaves what does not fit a bucket's arena or bin in an overflow list that is inserted AFTER the
+    region pass -- a few entries on nearly every real batch -- and until now any entry dropped the region pass's per-region head
+    counts for the whole table (a 4 ms counting pass at the next export, configs[3]'s size).  Now the regions the list touched
+    are counted again and the others' counts stand.  Here: reads with a moderate share of repeats (arenas that fill up: a list
+    of thousands of entries, new keys and added counts alike), a table large enough for the arena path; the heads export of the
+    partitioned table -- counts from the pass + the recount -- must equal, region by region and head by head, the export of the
+    same table built through the direct path (whose export counts every region)."""
+    import torch
+    monkeypatch.setenv("KMERHIP_TRACE", "0")
+    n_reads = 200_000
+    bases, _ = O.synth_reads(SEED + 5, 1 << 22, 150, 0, n_reads, with_qual=False)
+    v = bases.reshape(n_reads, 151)
+    rng = np.random.default_rng(55)
+    rep = np.resize(np.frombuffer(b"ACGGTCAGTTACGATCCAGT", dtype=np.uint8), 150)
+    for i in rng.choice(n_reads, size=n_reads // 12, replace=False):     # ~8 % of the reads are one repeat: its buckets' arenas fill
+        v[i, :150] = np.roll(rep, int(i) % 20)
+    got = {}
+    for path in ("partition", "direct"):
+        with K.DeviceCounter(k, capacity_hint=40_000_000, path=path) as dc:
+            dc.push(bases)
+            st = dc.finish()
+            R = st["table_slots"] // 4096
+            buf = torch.empty(4 * st["distinct"] + (1 << 20), dtype=torch.int32, device="cuda")
+            rc = torch.empty(R, dtype=torch.int32, device="cuda")
+            res = dc.export_regions_heads_device(4, buf.data_ptr(), buf.numel(), rc.data_ptr(), R)
+            assert res is not None
+            parts, _ = res
+            heads = buf[: int(parts.sum())].cpu().numpy().copy()
+            got[path] = (parts.copy(), rc.cpu().numpy().copy(), np.sort(heads), st["stage_ms"])
+    assert got["partition"][3]["level2"] > 0 and got["partition"][3]["level2_count"] == 0      # the arena path took the batch
+    assert np.array_equal(got["partition"][1], got["direct"][1]), "per-region head counts differ"
+    assert np.array_equal(got["partition"][0], got["direct"][0]) and np.array_equal(got["partition"][2], got["direct"][2])
+
+
 @pytest.mark.parametrize("k,nshards", [(5, 3), (11, 4), (13, 2)])
 def test_dense_export_and_merge_small_k(K, k, nshards):
     """k <= 13: the table as a dense array of 4^k counts (what an all-reduce(sum) merges), and back into
