@@ -837,7 +837,7 @@ def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k):
     """Round 5: the arena level 2 leaves what does not fit a bucket's arena or bin in an overflow list that is inserted AFTER the
     region pass -- a few entries on nearly every real batch -- and until now any entry dropped the region pass's per-region head
     counts for the whole table (a 4 ms counting pass at the next export, configs[3]'s size).  Now the regions the list touched
-    are counted again and the others' counts stand.  Here: reads with a moderate share of repeats (arenas that fill up: a list
+    are counted again and the others' counts stand.  Here: reads with bursts of one repeated read (bins that overflow between two flushes: a list
     of thousands of entries, new keys and added counts alike), a table large enough for the arena path; the heads export of the
     partitioned table -- counts from the pass + the recount -- must equal, region by region and head by head, the export of the
     same table built through the direct path (whose export counts every region)."""
@@ -847,9 +847,12 @@ def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k):
     bases, _ = O.synth_reads(SEED + 5, 1 << 22, 150, 0, n_reads, with_qual=False)
     v = bases.reshape(n_reads, 151)
     rng = np.random.default_rng(55)
-    rep = np.resize(np.frombuffer(b"ACGGTCAGTTACGATCCAGT", dtype=np.uint8), 150)
-    for i in rng.choice(n_reads, size=n_reads // 12, replace=False):     # ~8 % of the reads are one repeat: its buckets' arenas fill
-        v[i, :150] = np.roll(rep, int(i) % 20)
+    # bursts: 1200 consecutive copies of one read, eight times over -- a key's copies arrive together, more than its level-2 bin
+    # holds between two flushes, and go to the overflow list; counts stay far below what heads can carry (64 << 5)
+    for b in range(8):
+        rep = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=150)
+        i0 = int(rng.integers(0, n_reads - 1200))
+        v[i0:i0 + 1200, :150] = rep
     got = {}
     for path in ("partition", "direct"):
         with K.DeviceCounter(k, capacity_hint=40_000_000, path=path) as dc:
