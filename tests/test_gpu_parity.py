@@ -847,15 +847,16 @@ def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k):
     bases, _ = O.synth_reads(SEED + 5, 1 << 22, 150, 0, n_reads, with_qual=False)
     v = bases.reshape(n_reads, 151)
     rng = np.random.default_rng(55)
-    # bursts: 1200 consecutive copies of one read, eight times over -- a key's copies arrive together, more than its level-2 bin
-    # holds between two flushes, and go to the overflow list; counts stay far below what heads can carry (64 << 5)
-    for b in range(8):
+    # bursts: 150 consecutive copies of one read, sixty times over -- a key's copies arrive together, more than its level-2 bin
+    # holds between two flushes, and go to the overflow list; counts stay far below what heads can carry (64 << 9)
+    for b in range(60):
         rep = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=150)
-        i0 = int(rng.integers(0, n_reads - 1200))
-        v[i0:i0 + 1200, :150] = rep
+        i0 = int(rng.integers(0, n_reads - 150))
+        v[i0:i0 + 150, :150] = rep
+    monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * 512))   # 512 buckets per partition: bins of 64 payloads
     got = {}
     for path in ("partition", "direct"):
-        with K.DeviceCounter(k, capacity_hint=40_000_000, path=path) as dc:
+        with K.DeviceCounter(k, capacity_hint=40_000_000, path=path, trace=(path == "partition")) as dc:
             dc.push(bases)
             st = dc.finish()
             R = st["table_slots"] // 4096
