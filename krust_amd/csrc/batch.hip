@@ -560,7 +560,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     // a SHORT overflow list has just been inserted: the head counts of the regions it touched are made again, the others' stand
     // (merge.hip recount_touched_heads; a failed region, a narrow overflow or a long list drop the counts as before)
     bool heads_recounted = false;
-    if (was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->ovf_pending && c->ovf_pending <= (4ull << 20) && !heavy_exact) {
+    if (was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->ovf_pending && c->ovf_pending <= (64ull << 20) && !heavy_exact) {
         heads_recounted = recount_touched_heads(c, nregions, c->ovf_list, c->ovf, ovf_lim) == KH_OK;
     }
     c->table_empty = false;
