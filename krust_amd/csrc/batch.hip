@@ -528,6 +528,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         launch_region<PT>(c, g, nregions, 4 * (n_ub / nregions) + 4096, bend, nar, hot_cut, n_ub);
     }
     if (nar) c->narrow = true;
+    bool heads_marked = false;
     {
         StageTimer t(c, ST_MISC);
         // (three same-address atomics per WAVE at ~10 ns each: a block per 256 regions -- 2048 blocks -- took 0.2 ms for 7 MB)
@@ -536,6 +537,9 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         // (a long list is mostly copies -- bursts of a tandem repeat's payloads, a repeat family's: summed in LDS first; 4-byte
         //  payloads, and on the 8-byte image only where no count can leave 32 bits: the table's k-mers so far plus this batch's
         //  windows stay below 2^32.  KMERHIP_OVF_AGG=0: never; =1: for lists of any length -- tests)
+        // (the head counts of the regions the list touches are made again after its insert: merge.hip)
+        heads_marked = was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->ovf_pending && c->ovf_pending <= (64ull << 20) && !heavy_exact &&
+                       mark_touched_regions(c, c->ovf_list, c->ovf, ovf_lim) == KH_OK;
         const int agg_env = c->knobs.ovf_agg;
         const bool ovf_agg = sizeof(PT) == 4 && agg_env != 0 && (agg_env == 1 || c->ovf_pending >= (1u << 16)) &&
                              (!nar || c->h_ctr->kmers + n_all < 0xFFFFFFFFull);
@@ -560,9 +564,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     // a SHORT overflow list has just been inserted: the head counts of the regions it touched are made again, the others' stand
     // (merge.hip recount_touched_heads; a failed region, a narrow overflow or a long list drop the counts as before)
     bool heads_recounted = false;
-    if (was_empty && sizeof(PT) == 4 && c->rheads_cb != 0 && c->ovf_pending && c->ovf_pending <= (64ull << 20) && !heavy_exact) {
-        heads_recounted = recount_touched_heads(c, nregions, c->ovf_list, c->ovf, ovf_lim) == KH_OK;
-    }
+    if (heads_marked) heads_recounted = recount_touched_heads(c, nregions) == KH_OK;
     c->table_empty = false;
     c->table_dirty = false;  // the FRESH region pass wrote every region
     c->launches++;

@@ -344,7 +344,8 @@ bool is_pinned_host(const void *p);
 int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes);
 // ---- merge.hip
 enum { XF_WIDE = 0, XF_PACKED64 = 1, XF_HEADS32 = 2 };  // exchange unit formats (shard.hip.h)
-int recount_touched_heads(kh_ctx *c, u64 nregions, const void *ovf_list, const u64 *d_ovf, u64 ovf_lim);  // (batch.hip: after a short overflow list)
+int mark_touched_regions(kh_ctx *c, const void *ovf_list, const u64 *d_ovf, u64 ovf_lim);  // (batch.hip: before the overflow list's insert ...
+int recount_touched_heads(kh_ctx *c, u64 nregions);                                           //  ... and after it)
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap, uint32_t *d_region_counts,
                    uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions);
 int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions, const void *const *d_keys,

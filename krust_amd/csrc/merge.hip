@@ -188,16 +188,25 @@ kh::SlotSrc slot_src(const kh_ctx *c) {
 // counting pass over the table (4 ms at configs[3]'s size).  The batch's overflow list -- a few entries on well-mixed input --
 // is inserted after that pass and changes the counts of the regions it touches: those, and only those, are counted again
 // (round 5; until then ANY entry dropped the counts of the whole table).  rtouch, a byte per region, is all zero between uses.
-int recount_touched_heads(kh_ctx *c, u64 nregions, const void *ovf_list, const u64 *d_ovf, u64 ovf_lim) {
-    const int cb = head_count_bits(c, nregions);
-    if (cb < 0 || (uint32_t)cb != c->rheads_cb) return KH_ERR_RANGE;  // (not the unit the counts were made for: the caller drops them)
+// Two steps around the list's insert, which marks the entries it has applied as consumed (region = ~0): the touched regions are
+// noted BEFORE it, counted AFTER it.  (The first version looked at the list after the insert, found every entry consumed, counted
+// nothing again -- and kh_merge_across's conservation check refused the export that followed: 157,486 of 15.9 G counts short.)
+int mark_touched_regions(kh_ctx *c, const void *ovf_list, const u64 *d_ovf, u64 ovf_lim) {
     hipLaunchKernelGGL(kh::ovf_touch_kernel, dim3(grid_for(c->ovf_pending)), dim3(kh::BLOCK), 0, c->stream, (const kh::OvfEntry *)ovf_list, d_ovf, ovf_lim,
                        c->rtouch);
-    hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream, slot_src(c), (uint32_t)cb, c->rheads,
-                       &c->d_ctr->heads_wide, (const uint8_t *)c->rtouch);
+    HIP_TRY(c, hipGetLastError());
+    return KH_OK;
+}
+int recount_touched_heads(kh_ctx *c, u64 nregions) {
+    const int cb = head_count_bits(c, nregions);
+    int rc = KH_OK;
+    if (cb < 0 || (uint32_t)cb != c->rheads_cb) rc = KH_ERR_RANGE;  // (not the unit the counts were made for: the caller drops them)
+    else
+        hipLaunchKernelGGL(kh::region_head_count_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream, slot_src(c), (uint32_t)cb, c->rheads,
+                           &c->d_ctr->heads_wide, (const uint8_t *)c->rtouch);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemsetAsync(c->rtouch, 0, nregions, c->stream));
-    return KH_OK;
+    return rc;
 }
 
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap,

@@ -832,8 +832,8 @@ def test_heads_export_uses_region_pass_counts(K):
     assert int(got["partition"][0].sum()) > st["distinct"]
 
 
-@pytest.mark.parametrize("k", [19, 21])
-def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k):
+@pytest.mark.parametrize("k,agg", [(19, "1"), (21, "0")], ids=["k19-summed-in-lds", "k21-entry-by-entry"])
+def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k, agg):
     """Round 5: the arena level 2 leaves what does not fit a bucket's arena or bin in an overflow list that is inserted AFTER the
     region pass -- a few entries on nearly every real batch -- and until now any entry dropped the region pass's per-region head
     counts for the whole table (a 4 ms counting pass at the next export, configs[3]'s size).  Now the regions the list touched
@@ -842,7 +842,7 @@ def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k):
     partitioned table -- counts from the pass + the recount -- must equal, region by region and head by head, the export of the
     same table built through the direct path (whose export counts every region)."""
     import torch
-    monkeypatch.setenv("KMERHIP_TRACE", "0")
+    monkeypatch.setenv("KMERHIP_OVF_AGG", agg)   # both insert kernels: the entry-by-entry one marks what it has applied as consumed
     n_reads = 200_000
     bases, _ = O.synth_reads(SEED + 5, 1 << 22, 150, 0, n_reads, with_qual=False)
     v = bases.reshape(n_reads, 151)
