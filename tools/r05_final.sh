@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 5, final measurements: profiles of the headline command, a driver-style bench run, the count-and-merge pre-flight
+mkdir -p gpurun_out/r05z
+bash tools/profiles_run.sh r05b > gpurun_out/r05z/prof.log 2>&1
+bash tools/sq_probe.sh r05b > gpurun_out/r05z/sq.log 2>&1
+BENCH_ARGS="--reads 125000000" bash tools/profiles_run.sh r05b_s125 > gpurun_out/r05z/prof_s125.log 2>&1
+BENCH_FULL_PATH=gpurun_out/r05z/bench_full.json python bench.py > gpurun_out/r05z/bench.json 2> gpurun_out/r05z/bench.err
+echo "bench rc=$?"; wc -c gpurun_out/r05z/bench.json
+BENCH_FULL_PATH=gpurun_out/r05z/forcemerge_full.json python bench.py --force-merge --steps 5 --warmup 1 > gpurun_out/r05z/forcemerge.json 2> gpurun_out/r05z/forcemerge.err
+BENCH_FULL_PATH=gpurun_out/r05z/group4_full.json python bench.py --group 4 --reads 25000000 --steps 3 --warmup 1 > gpurun_out/r05z/group4.json 2> gpurun_out/r05z/group4.err
+head -c 900 gpurun_out/r05z/bench.json; echo; tail -c 600 gpurun_out/r05z/forcemerge.json; echo; tail -c 900 gpurun_out/r05z/group4.json
