@@ -799,10 +799,22 @@ KH_GLOBAL __launch_bounds__(BLOCK) void table_hist_kernel(const Slot *table, u64
     __shared__ uint32_t s_bins[HIST_LDS];
     for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) s_bins[i] = 0;
     __syncthreads();
+    // (counts 1, 2, 3 -- what nearly every key of a real table has -- by ballot and popcount in the wave's registers instead of
+    //  sixty-four lanes' atomics on one LDS word: partition.hip.h ntable_hist_kernel)
     const u64 stride = (u64)gridDim.x * BLOCK;
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < cap; i += stride) {
-        const Slot s = table[i];
-        if (s.key == KH_EMPTY_KEY || s.count < min_count) continue;
+    uint32_t w1 = 0, w2 = 0, w3 = 0;
+    const u64 rounds = (cap + stride - 1) / stride;
+    for (u64 r = 0; r < rounds; ++r) {  // (uniform trip count: every lane takes part in the ballots)
+        const u64 i = r * stride + (u64)blockIdx.x * BLOCK + threadIdx.x;
+        Slot s;
+        s.key = KH_EMPTY_KEY;
+        s.count = 0;
+        if (i < cap) s = table[i];
+        const bool live = s.key != KH_EMPTY_KEY && s.count >= min_count && s.count != 0;
+        w1 += (uint32_t)__builtin_popcountll(kh_ballot(live && s.count == 1));
+        w2 += (uint32_t)__builtin_popcountll(kh_ballot(live && s.count == 2));
+        w3 += (uint32_t)__builtin_popcountll(kh_ballot(live && s.count == 3));
+        if (!live || s.count <= 3) continue;
         if (s.count < HIST_LDS) {
             atomicAdd(&s_bins[(uint32_t)s.count], 1u);
         } else if (s.count < HIST_DENSE) {
@@ -811,6 +823,11 @@ KH_GLOBAL __launch_bounds__(BLOCK) void table_hist_kernel(const Slot *table, u64
             const u64 o = atomicAdd(&ctr->big, 1ull);
             if (o < big_cap) big[o] = s.count;
         }
+    }
+    if (lane_id() == 0) {
+        if (w1) atomicAdd(&s_bins[1], w1);
+        if (w2) atomicAdd(&s_bins[2], w2);
+        if (w3) atomicAdd(&s_bins[3], w3);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < HIST_LDS; i += BLOCK) {

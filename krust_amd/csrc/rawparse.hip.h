@@ -169,6 +169,9 @@ __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__r
                                                               uint32_t *__restrict__ tile_keep, const u64 *__restrict__ tile_out,
                                                               uint8_t *__restrict__ out, uint32_t *__restrict__ err) {
     __shared__ uint32_t s_w[4];
+    // PASS 1: the tile's kept bytes are gathered in LDS -- at the offset their destination has inside its 16-byte word -- and
+    // leave as whole aligned 16-byte stores (round 5; one byte per store instruction took 4.5 ms for a 3.1 GB text)
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[PASS == 1 ? RAW_TILE + 32 : 16];
     for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const u64 p0 = t * RAW_TILE + (u64)threadIdx.x * 16;
         const uint4 v = load16_guard(raw, p0, n);
@@ -207,10 +210,24 @@ __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__r
             if (threadIdx.x == 0) tile_keep[t] = ktotal;
             if (kh_any(bad) && lane_id() == 0) atomicOr(err, 2u);
         } else {
-            u64 o = tile_out[t] + kpre;
+            const u64 obase = tile_out[t];
+            const uint32_t a = (uint32_t)(reinterpret_cast<uintptr_t>(out + obase) & 15u);  // where the tile's first byte sits in its word
+            uint32_t o = a + kpre;
 #pragma unroll
             for (int j = 0; j < 16; ++j)
-                if (keep & (1u << j)) out[o++] = (uint8_t)byte_of(v, j);
+                if (keep & (1u << j)) s_out[o++] = (uint8_t)byte_of(v, j);
+            __syncthreads();
+            const uint32_t end = a + ktotal;          // the tile's bytes are s_out[a, end)
+            uint8_t *const gb = out + obase - a;      // 16-byte aligned
+            for (uint32_t lo = threadIdx.x * 16u; lo < end; lo += BLOCK * 16u) {
+                if (lo >= a && lo + 16u <= end) {
+                    *reinterpret_cast<uint4 *>(gb + lo) = *reinterpret_cast<const uint4 *>(s_out + lo);
+                } else {  // the first and the last word of the tile are shared with its neighbours: byte by byte
+                    const uint32_t b0 = lo < a ? a : lo, b1 = lo + 16u < end ? lo + 16u : end;
+                    for (uint32_t b = b0; b < b1; ++b) gb[b] = s_out[b];
+                }
+            }
+            __syncthreads();  // (the next tile writes s_out)
         }
     }
 }
