@@ -265,7 +265,7 @@ struct kh_ctx {
     u64 *txt_scan_partial = nullptr;  u64 txt_scan_cap = 0;  // scan scratch of the text stream
     u64 expect_bytes = 0;                  // kh_config::input_mib: what the caller expects to push in total (0 = unknown)
     u64 *txt_ls = nullptr;        u64 txt_ls_cap = 0;    // line starts
-    uint8_t *txt_hdr = nullptr;   u64 txt_hdr_cap = 0;   // FASTA: line is a header
+    uint8_t *txt_st = nullptr;    u64 txt_st_cap = 0;    // FASTA: line state behind each 1 KiB unit (rawparse.hip.h)
     uint32_t *txt_tnl = nullptr;  u64 txt_tnl_cap = 0;   // per-tile newline counts
     u64 *txt_tbase = nullptr;     u64 txt_tbase_cap = 0;
     uint32_t *txt_tkeep = nullptr; u64 txt_tkeep_cap = 0;

@@ -464,33 +464,33 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s
         *cap = want;
         return KH_OK;
     };
-    if ((rc = tbuf(&c->txt_tnl, &c->txt_tnl_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
-    if ((rc = tbuf(&c->txt_tbase, &c->txt_tbase_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
     if ((rc = tbuf(&c->txt_err, &c->txt_err_cap, (u64)4, "hipMalloc(text err)")) != KH_OK) return rc;
     const unsigned grid = (unsigned)std::min<u64>(ntiles, (u64)GRID_CAP);
     u64 out_len = 0;
     {
         StageTimer tm(c, ST_TEXT, s);
-        hipLaunchKernelGGL(kh::raw_nl_count_kernel, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles, c->txt_tnl);
-        if ((rc = text_device_scan(c, s, c->txt_tnl, ntiles, c->txt_tbase)) != KH_OK) return rc;
         HIP_TRY(c, hipMemsetAsync(c->txt_err, 0, sizeof(uint32_t), s));
-        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tbase + ntiles, sizeof(u64), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(&c->h_txt->first, d_text, 1, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(&c->h_txt->last, d_text + n - 1, 1, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        const bool open_end = c->h_txt->last != '\n';           // no final newline: the text end closes the line
-        const u64 nlines = c->h_txt->total + (open_end ? 1 : 0);
-        if (c->h_txt->first != (fastq ? '@' : '>')) return text_fail(c, fastq ? "text does not start with '@'" : "text does not start with '>'");
-        if (fastq && (nlines & 3)) return text_fail(c, "FASTQ line count is not a multiple of 4");
-        if ((rc = tbuf(&c->txt_ls, &c->txt_ls_cap, nlines + 2, "hipMalloc(line starts)")) != KH_OK) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->txt_ls, 0, sizeof(u64), s));
-        hipLaunchKernelGGL(kh::raw_line_starts_kernel, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
-                           (const u64 *)c->txt_tbase, c->txt_ls);
-        if (open_end) {
-            c->h_txt->end_mark = n + 1;
-            HIP_TRY(c, hipMemcpyAsync(c->txt_ls + nlines, &c->h_txt->end_mark, sizeof(u64), hipMemcpyHostToDevice, s));
-        }
         if (fastq) {
+            if ((rc = tbuf(&c->txt_tnl, &c->txt_tnl_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
+            if ((rc = tbuf(&c->txt_tbase, &c->txt_tbase_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
+            hipLaunchKernelGGL(kh::raw_nl_count_kernel, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles, c->txt_tnl);
+            if ((rc = text_device_scan(c, s, c->txt_tnl, ntiles, c->txt_tbase)) != KH_OK) return rc;
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tbase + ntiles, sizeof(u64), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(&c->h_txt->last, d_text + n - 1, 1, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            const bool open_end = c->h_txt->last != '\n';           // no final newline: the text end closes the line
+            const u64 nlines = c->h_txt->total + (open_end ? 1 : 0);
+            if (c->h_txt->first != '@') return text_fail(c, "text does not start with '@'");
+            if (nlines & 3) return text_fail(c, "FASTQ line count is not a multiple of 4");
+            if ((rc = tbuf(&c->txt_ls, &c->txt_ls_cap, nlines + 2, "hipMalloc(line starts)")) != KH_OK) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->txt_ls, 0, sizeof(u64), s));
+            hipLaunchKernelGGL(kh::raw_line_starts_kernel, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
+                               (const u64 *)c->txt_tbase, c->txt_ls);
+            if (open_end) {
+                c->h_txt->end_mark = n + 1;
+                HIP_TRY(c, hipMemcpyAsync(c->txt_ls + nlines, &c->h_txt->end_mark, sizeof(u64), hipMemcpyHostToDevice, s));
+            }
             const u64 nrec = nlines / 4;
             hipLaunchKernelGGL(kh::fastq_validate_kernel, dim3(grid_for(nrec)), dim3(kh::BLOCK), 0, s, d_text,
                                (const u64 *)c->txt_ls, nrec, c->txt_err);
@@ -506,23 +506,24 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s
                                    (const u64 *)c->txt_tbase, (const u64 *)c->txt_ls, out, (uint8_t *)nullptr);
             out_len = n;
         } else {
-            if ((rc = tbuf(&c->txt_hdr, &c->txt_hdr_cap, nlines + 2, "hipMalloc(header flags)")) != KH_OK) return rc;
+            // (no line starts: where header lines are is carried from one 1 KiB unit of the text to the next, rawparse.hip.h)
+            const u64 nunits = (n + kh::FASTA_UNIT - 1) / kh::FASTA_UNIT;
+            if ((rc = tbuf(&c->txt_st, &c->txt_st_cap, nunits + 1, "hipMalloc(line states)")) != KH_OK) return rc;
             if ((rc = tbuf(&c->txt_tkeep, &c->txt_tkeep_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
             if ((rc = tbuf(&c->txt_tout, &c->txt_tout_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
-            hipLaunchKernelGGL(kh::fasta_headers_kernel, dim3(grid_for(nlines + 1)), dim3(kh::BLOCK), 0, s, d_text, n,
-                               (const u64 *)c->txt_ls, nlines + 1, c->txt_hdr);
+            hipLaunchKernelGGL(kh::fasta_line_state_kernel, dim3((unsigned)std::min<u64>((nunits + 3) / 4, (u64)GRID_CAP)), dim3(kh::BLOCK),
+                               0, s, d_text, n, nunits, c->txt_st);
             hipLaunchKernelGGL(kh::fasta_compact_kernel<0>, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
-                               (const u64 *)c->txt_tbase, (const uint8_t *)c->txt_hdr, c->txt_tkeep, (const u64 *)nullptr,
-                               (uint8_t *)nullptr, c->txt_err);
+                               (const uint8_t *)c->txt_st, c->txt_tkeep, (const u64 *)nullptr, (uint8_t *)nullptr, c->txt_err);
             if ((rc = text_device_scan(c, s, c->txt_tkeep, ntiles, c->txt_tout)) != KH_OK) return rc;
             HIP_TRY(c, hipMemcpyAsync(&c->h_txt->total, c->txt_tout + ntiles, sizeof(u64), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipMemcpyAsync(&c->h_txt->err, c->txt_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
+            if (c->h_txt->first != '>') return text_fail(c, "text does not start with '>'");
             if (c->h_txt->err) return text_fail(c, "blank before a line end, or a CR not followed by LF, inside a FASTA record");
             out_len = c->h_txt->total;
             hipLaunchKernelGGL(kh::fasta_compact_kernel<1>, dim3(grid), dim3(kh::BLOCK), 0, s, d_text, n, ntiles,
-                               (const u64 *)c->txt_tbase, (const uint8_t *)c->txt_hdr, (uint32_t *)nullptr,
-                               (const u64 *)c->txt_tout, out, (uint32_t *)nullptr);
+                               (const uint8_t *)c->txt_st, (uint32_t *)nullptr, (const u64 *)c->txt_tout, out, (uint32_t *)nullptr);
         }
         HIP_TRY(c, hipGetLastError());
         if (out_len) {  // a separator behind the text, and on to the next multiple of 16

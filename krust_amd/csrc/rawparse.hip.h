@@ -143,66 +143,124 @@ __global__ __launch_bounds__(BLOCK) void fastq_mark_kernel(const uint8_t *__rest
 }
 
 // ---- FASTA ---------------------------------------------------------------------------------------
-// hdr[L] = line L starts with '>'
-KH_GLOBAL __launch_bounds__(BLOCK) void fasta_headers_kernel(const uint8_t *__restrict__ raw, u64 n, const u64 *__restrict__ LS,
-                                                              u64 nlines, uint8_t *__restrict__ hdr) {
-    const u64 stride = (u64)gridDim.x * BLOCK;
-    for (u64 L = (u64)blockIdx.x * BLOCK + threadIdx.x; L < nlines; L += stride) {
-        const u64 s = LS[L];
-        hdr[L] = (s < n && raw[s] == '>') ? 1 : 0;
+// Round 5: the FASTA passes no longer take line starts (newline counts, their scan, LS[], one header flag per line: 2.9 ms of
+// kernels for a 3.1 GB text) nor walk their sixteen bytes one at a time (5.0 + 3.6 ms: with 64 lanes on a 16-wide SIMD a
+// wave instruction is four cycles, and ~40 instructions per byte step made both passes ALU-bound at a tenth of the HBM rate).
+// Whether a byte lies in a header line is a property of the last line end in front of it, so
+//   1. fasta_line_state_kernel: st[u] per 1 KiB unit (one wave's 64 x 16 bytes): 0 = no line end in it, 1 = the line behind
+//      its last line end is a record line, 2 = a header line;
+//   2. both compaction passes: a wave's state at its first byte = the nearest non-zero st[] in front of it (one coalesced
+//      64-byte look-back in all but pathological texts; a 100 Mbp single-line record costs the waves inside it ~200 steps),
+//      the lanes' states from two ballots, the bytes' states from ONE ADD: with p = "state carries over to byte j" (no line
+//      start at j) and g = "a header line starts at j", the carry chain of (p|g) + g + state_in is the header state of every
+//      byte; kept bytes, blank-before-line-end and bare-CR errors are 16-bit mask expressions of the '\n', '\r', '>', ' ',
+//      TAB byte masks.
+
+// bit j: byte j of v equals c
+__device__ __forceinline__ uint32_t eq_mask16(const uint4 &v, uint32_t c) {
+    // swar_eq_bytes leaves 0x80 per matching byte; the multiply gathers bits 0, 8, 16, 24 of (m >> 7) into bits 21..24
+    auto nib = [c](uint32_t w) { return (((swar_eq_bytes(w, c) >> 7) * 0x00204081u) >> 21) & 15u; };
+    return nib(v.x) | nib(v.y) << 4 | nib(v.z) << 8 | nib(v.w) << 12;
+}
+
+constexpr int FASTA_UNIT = 64 * 16;  // bytes one wave takes per step: the granule of st[]
+
+// the byte behind this lane's sixteen ('\n' past the end of the text)
+__device__ __forceinline__ uint32_t byte_after16(const uint8_t *__restrict__ raw, u64 p0, u64 n, const uint4 &v) {
+    uint32_t nx = (uint32_t)__shfl_down((int)(v.x & 255u), 1, 64);
+    if ((threadIdx.x & 63u) == 63u) nx = (p0 + 16 < n) ? raw[p0 + 16] : 0u;
+    return (p0 + 16 < n) ? nx : (uint32_t)'\n';
+}
+
+// 0: no line end among this lane's bytes; else the state behind its last one (1 record line, 2 header)
+__device__ __forceinline__ uint32_t lane_exit_state(uint32_t NL, uint32_t GT, uint32_t after) {
+    if (!NL) return 0u;
+    const uint32_t k = 32u - (uint32_t)__builtin_clz(NL);  // index of the byte behind the last '\n': 1..16
+    const bool gt = k < 16 ? ((GT >> k) & 1u) != 0 : after == '>';  // (bytes past the text's end read as 0 / '\n': never '>')
+    return gt ? 2u : 1u;
+}
+
+KH_GLOBAL __launch_bounds__(BLOCK) void fasta_line_state_kernel(const uint8_t *__restrict__ raw, u64 n, u64 nunits,
+                                                                 uint8_t *__restrict__ st) {
+    const u64 nw = (u64)gridDim.x * (BLOCK / 64);
+    for (u64 u = (u64)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); u < nunits; u += nw) {
+        const u64 p0 = u * FASTA_UNIT + (u64)(threadIdx.x & 63u) * 16;
+        const uint4 v = load16_guard(raw, p0, n);
+        const uint32_t after = byte_after16(raw, p0, n, v);
+        const uint32_t my = lane_exit_state(eq_mask16(v, '\n'), eq_mask16(v, '>'), after);
+        const u64 md = __ballot(my != 0), mh = __ballot(my == 2u);
+        if ((threadIdx.x & 63u) == 0) st[u] = md ? (((mh >> (63 - __builtin_clzll(md))) & 1) ? 2u : 1u) : 0u;
     }
 }
 
-// keep(byte): inside a record every byte but CR / LF; of a header line only its '\n' (as the separator)
-__device__ __forceinline__ bool fasta_keep(uint32_t b, bool header) {
-    return header ? (b == '\n') : (b != '\n' && b != '\r');
+// the state at the first byte of unit u: that of the nearest unit in front of it that holds a line end.  x = st[u - 1 - lane]
+// (0 for lane >= u) is loaded by the caller, ahead of time; first_state = that of the text's first line.
+__device__ __forceinline__ uint32_t fasta_unit_entry_state(const uint8_t *__restrict__ st, u64 u, uint32_t x, uint32_t first_state) {
+    const uint32_t lane = threadIdx.x & 63u;
+    u64 hi = u;  // units [hi - 64, hi) are in x
+    for (;;) {
+        const u64 m = __ballot(x != 0);
+        if (m) return (uint32_t)__shfl((int)x, __builtin_ctzll(m), 64);
+        if (hi <= 64) return first_state;
+        hi -= 64;
+        x = lane < hi ? st[hi - 1 - lane] : 0u;
+    }
 }
 
 // PASS 0: tile_keep[t] = bytes kept in tile t.   PASS 1: write them at out[tile_out[t] + ...].
+// Kept: inside a record every byte but CR / LF; of a header line only its '\n' (as the separator).
 // PASS 0 also raises err for a blank (' ' / TAB) right before a line end inside a record: the line
 // parsers strip those before joining wrapped lines (rust-bio trims line ends), the byte-wise rule
 // here would keep them as a separator in the middle of the record; and for a CR that is not directly
-// followed by the line's '\n' (the parsers keep it as an invalid base, this rule would drop it).
+// followed by the line's '\n' (the parsers keep it as an invalid base, this rule would drop it:
+// a CR is a line-end byte only right before '\n' or at the very end of the text -- rust-bio's trim_end()
+// and the host line parser strip nothing else; dropping a bare CR here would join "AC\rGT" to ACGT).
 template <int PASS>
 __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__restrict__ raw, u64 n, u64 ntiles,
-                                                              const u64 *__restrict__ tile_base, const uint8_t *__restrict__ hdr,
-                                                              uint32_t *__restrict__ tile_keep, const u64 *__restrict__ tile_out,
-                                                              uint8_t *__restrict__ out, uint32_t *__restrict__ err) {
+                                                              const uint8_t *__restrict__ st, uint32_t *__restrict__ tile_keep,
+                                                              const u64 *__restrict__ tile_out, uint8_t *__restrict__ out,
+                                                              uint32_t *__restrict__ err) {
     __shared__ uint32_t s_w[4];
     // PASS 1: the tile's kept bytes are gathered in LDS -- at the offset their destination has inside its 16-byte word -- and
     // leave as whole aligned 16-byte stores (round 5; one byte per store instruction took 4.5 ms for a 3.1 GB text)
     __shared__ __attribute__((aligned(16))) uint8_t s_out[PASS == 1 ? RAW_TILE + 32 : 16];
-    for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    static_assert(RAW_TILE == 4 * FASTA_UNIT, "a workgroup's four waves take one unit each");
+    u64 t = blockIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t first_state = raw[0] == '>' ? 2u : 1u;
+    uint4 v = load16_guard(raw, t * RAW_TILE + (u64)threadIdx.x * 16, n);
+    uint32_t sx = lane < 4 * t + wave ? st[4 * t + wave - 1 - lane] : 0u;
+    for (;;) {
         const u64 p0 = t * RAW_TILE + (u64)threadIdx.x * 16;
-        const uint4 v = load16_guard(raw, p0, n);
-        uint32_t total;
-        const u64 line0 = tile_base[t] + block_exclusive_scan_256(count_nl16(v), s_w, &total);
-        bool header = p0 < n ? hdr[line0] != 0 : false;  // (the line this lane's first byte is in)
-        uint32_t keep = 0;  // bit j: byte j is kept
+        const u64 tn = t + gridDim.x;
+        uint4 vn = make_uint4(0, 0, 0, 0);
+        uint32_t sxn = 0;
+        if (tn < ntiles) {  // the next tile's loads are in flight while this one is worked on
+            vn = load16_guard(raw, tn * RAW_TILE + (u64)threadIdx.x * 16, n);
+            sxn = lane < 4 * tn + wave ? st[4 * tn + wave - 1 - lane] : 0u;
+        }
+        const uint32_t after = byte_after16(raw, p0, n, v);
+        const uint32_t NL = eq_mask16(v, '\n'), CR = eq_mask16(v, '\r'), GT = eq_mask16(v, '>');
+        // the state at this lane's first byte: behind the last line end of an earlier lane of the wave, else the wave's
+        const uint32_t my = lane_exit_state(NL, GT, after);
+        const u64 md = __ballot(my != 0), mh = __ballot(my == 2u);
+        const u64 below = md & ((1ull << lane) - 1);
+        const uint32_t wave_in = fasta_unit_entry_state(st, 4 * t + wave, sx, first_state);
+        const uint32_t in = below ? (uint32_t)((mh >> (63 - __builtin_clzll(below))) & 1) : (wave_in == 2u ? 1u : 0u);
+        // H bit j: byte j lies in a header line.  A line starts at j where byte j - 1 is '\n' (byte 0's line start belongs
+        // to `in`); it is a header iff byte j is '>'.  H[j] = g[j] | (p[j] & H[j-1]) is the carry out of bit j of the sum.
+        const uint32_t LS = (NL << 1) & 0xFFFFu, g = LS & GT, p = ~LS & 0xFFFFu;
+        const uint32_t H = ((((p | g) + g + in) ^ p) >> 1) & 0xFFFFu;
+        const u64 left = p0 < n ? n - p0 : 0;  // bytes of the text from p0 on
+        const uint32_t VAL = left >= 16 ? 0xFFFFu : (1u << (uint32_t)left) - 1u;
+        const uint32_t keep = VAL & ((H & NL) | (~H & ~(NL | CR)));  // bit j: byte j is kept
         bool bad = false;
-        const uint32_t after = (p0 + 16 < n) ? raw[p0 + 16] : '\n';  // the byte after this lane's 16
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t b = byte_of(v, j);
-            if (p0 + j < n && fasta_keep(b, header)) keep |= 1u << j;
-            if (PASS == 0 && !header && (b == ' ' || b == '\t')) {
-                const uint32_t nx = j < 15 ? byte_of(v, (j + 1) & 15) : after;
-                bad |= (nx == '\n' || nx == '\r' || p0 + j + 1 >= n);
-            }
-            // A CR is a line-end byte only right before '\n' (or at the very end of the text): rust-bio's
-            // trim_end() and the host line parser strip nothing else.  A bare CR in the middle of a line
-            // stays an invalid base there and breaks windows; dropping it here would join "AC\rGT" to ACGT.
-            if (PASS == 0 && !header && b == '\r' && p0 + j < n) {
-                const uint32_t nx = j < 15 ? byte_of(v, (j + 1) & 15) : after;
-                bad |= !(nx == '\n' || p0 + j + 1 >= n);
-            }
-            if (b == '\n') {
-                // the next line is a header iff it starts with '>': hdr[] says the same (fasta_headers_kernel), but a load
-                // from it HERE is a dependent global load in the middle of a sixteen-step loop -- and with 61-byte lines some
-                // lane of the wave is at a line end in nearly every step (round 4: 6.1 ms per pass over a 3.1 GB text)
-                const uint32_t nx = j < 15 ? byte_of(v, (j + 1) & 15) : after;
-                header = (p0 + j + 1 < n) && nx == '>';
-            }
+        if (PASS == 0) {
+            const uint32_t BL = eq_mask16(v, ' ') | eq_mask16(v, '\t');
+            const uint32_t nxNL = (NL >> 1) | (after == '\n' ? 0x8000u : 0u), nxCR = (CR >> 1) | (after == '\r' ? 0x8000u : 0u);
+            const uint32_t END = left > 16 ? 0u : ~(VAL >> 1) & 0xFFFFu;  // byte j is the text's last, or behind it
+            bad = ((BL & ~H & (nxNL | nxCR | END)) | (CR & ~H & VAL & ~(nxNL | END))) != 0;
         }
         uint32_t ktotal;
         const uint32_t kpre = block_exclusive_scan_256((uint32_t)__builtin_popcount(keep), s_w, &ktotal);
@@ -229,6 +287,10 @@ __global__ __launch_bounds__(BLOCK) void fasta_compact_kernel(const uint8_t *__r
             }
             __syncthreads();  // (the next tile writes s_out)
         }
+        if (tn >= ntiles) break;
+        t = tn;
+        v = vn;
+        sx = sxn;
     }
 }
 

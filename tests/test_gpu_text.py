@@ -146,6 +146,58 @@ def test_fasta_without_final_newline():
     assert device(text, "fasta", 11, None) == expect(text, "fasta", 11, None)
 
 
+def _fasta_unit_cases():
+    """Texts whose header / record lines lie across the 1 KiB units and 4 KiB tiles the scan carries line states over."""
+    rng = np.random.default_rng(77)
+    seq = lambda n: rand_seq(rng, n)
+    cases = {}
+    # a header of 5 KB, one of 70 KB (more than 64 units: the look-back takes a second step), records behind them
+    cases["long-headers"] = (b">" + b"h ACGT>" * 730 + b"\n" + seq(300) + b"\n>" + b"ACGT" * 17500 + b"\n" + seq(5000) + b"\n"
+                             + b">x\n" + seq(100) + b"\n")
+    # a single-line record of 200 KB (about 200 units without a line end), then a header
+    cases["long-line"] = b">a\n" + seq(200_000) + b"\n>b ACGTACGTACGTACGTACGTACGT\n" + seq(3000) + b"\n"
+    # line ends at the last byte of a unit / tile, and '>' as the first byte of the next
+    for edge in (1024, 4096, 8192):
+        for d in (-1, 0, 1):
+            head = b">r\n"
+            body = seq(edge + d - len(head) - 1)
+            cases[f"edge{edge}{d:+d}"] = head + body + b"\n>ACGTACGTACGTACGTACGTACGTACGT\n" + seq(700) + b"\n" + seq(50) + b"\n"
+            # the same with CR LF across the edge
+            cases[f"crlf{edge}{d:+d}"] = head + seq(edge + d - len(head) - 1) + b"\r\n>ACGTACGTACGTACGTACGTACGTACGT\r\n" + seq(700) + b"\r\n"
+    # nothing but headers; a header without a record at the very end, without a final newline
+    cases["headers-only"] = b"".join(b">ACGTACGTACGTACGTACGT%d\n" % i for i in range(600))
+    cases["open-header-end"] = b">r\n" + seq(2000) + b"\n>ACGTACGTACGTACGTACGTACGT"
+    return cases
+
+
+_FASTA_UNIT_CASES = _fasta_unit_cases()
+
+
+@pytest.mark.parametrize("name", sorted(_FASTA_UNIT_CASES))
+def test_fasta_line_states_across_units(name):
+    text = _FASTA_UNIT_CASES[name]
+    for k in (4, 21):
+        assert device(text, "fasta", k, None) == expect(text, "fasta", k, None)
+
+
+@pytest.mark.parametrize("edge", [1024, 4096])
+@pytest.mark.parametrize("what", ["space-lf", "tab-crlf", "bare-cr", "cr-at-end-of-text"])
+def test_fasta_line_end_rules_across_units(edge, what):
+    """The blank-before-a-line-end and bare-CR rules look one byte ahead: across a lane, a wave and a tile."""
+    rng = np.random.default_rng(edge)
+    head = b">r\n"
+    body = rand_seq(rng, edge - len(head) - 1, alphabet=b"ACGT")
+    if what == "cr-at-end-of-text":  # a CR as the text's last byte is a line-end byte: accepted, and not a base
+        text = head + body + b"\r"
+        assert len(text) == edge
+        assert device(text, "fasta", 5, None) == expect(text, "fasta", 5, None)
+        return
+    tail = {"space-lf": b" \n", "tab-crlf": b"\t\r\n", "bare-cr": b"\rA"}[what]
+    text = head + body + tail + rand_seq(rng, 100, alphabet=b"ACGT") + b"\n"
+    assert text[edge - 1] == tail[0]
+    _format_error(text, "fasta")
+
+
 @pytest.mark.parametrize("name", ["simple.fa", "soft_masked.fa", "with_n.fa", "simple.fq", "with_n.fq", "low_quality.fq"])
 def test_reference_fixtures_as_text(name):
     with open(os.path.join(ROOT, "tests", "fixtures", name), "rb") as f:
