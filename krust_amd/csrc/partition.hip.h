@@ -886,6 +886,9 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
             }
         };
         // the lane group writes the whole units of its buckets' bins to their arenas (or, an arena full, its first lane to the overflow list)
+        // (A/B, round 5, hg-shaped input through the 1024-bucket instance: interleaving two buckets' flushes, or skipping the
+        //  bins that hold less than a unit, changed nothing -- 10.2-10.3 ms either way; the instance is bound by the chain of its
+        //  phases between barriers with ONE workgroup per CU, like the 512-bucket one, at half the payloads per flush)
         auto flush = [&]() {
 #pragma unroll POS_LDS ? 1 : NB
             for (uint32_t it = 0; it < NB; ++it) {
@@ -917,11 +920,20 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                             for (uint32_t q = 0; q < UW / LP; ++q) d[oi + LP * q] = x[q];
                         }
                         apos += UNIT;
-                    } else if (oi == 0) {
-                        u64 at;
-                        if (ovf_take(UNIT, at)) {
+                    } else {
+                        // The arena is full (a heavy hitter's bucket: every later unit of it comes this way): the group's first
+                        // lane takes the room, ALL its lanes write entries -- consecutive lanes consecutive entries.  (One lane
+                        // writing the unit's 16 or 32 entries one after the other was a chain of as many stores on the way to
+                        // the barrier, in some wave at nearly every flush of an hg-shaped batch: 4 % of its payloads come here.)
+                        u64 at = 0;
+                        bool room = false;
+                        if (oi == 0) room = ovf_take(UNIT, at);
+                        const int src = (int)((uint32_t)tid & 63u & ~(LP - 1u));
+                        at = (u64)__shfl((unsigned long long)at, src, 64);
+                        room = __shfl((int)room, src, 64) != 0;
+                        if (room) {
                             const PT *e = s_bin + ob * capr + u * UNIT;
-                            for (uint32_t q = 0; q < (uint32_t)UNIT; ++q) {
+                            for (uint32_t q = oi; q < (uint32_t)UNIT; q += LP) {
                                 OvfEntry oe;
                                 oe.region = p * P2 + ob;
                                 oe.pad = 0;

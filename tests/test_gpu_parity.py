@@ -1495,6 +1495,34 @@ def test_count_beyond_32_bits(K, monkeypatch, hot):
 # ---------------------------------------------------------------------------
 # round 4: tables of any multiple of 1024 regions (kernels.hip.h TableGeom)
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("k", [21, 31])
+@pytest.mark.parametrize("b2", [800, 1024])
+def test_more_than_768_buckets_per_partition_with_heavy_buckets(K, monkeypatch, b2, k):
+    """Level 2's 1024-bucket instance (128-byte bins, 64-byte units, write positions in LDS): a power of two and not, both
+    payload widths, with a burst of one read's copies whose buckets outgrow their bins and arenas (overflow list)."""
+    monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1024 * b2))
+    n_reads = 200_000
+    bases, _ = O.synth_reads(SEED + b2 + k, 1 << 21, 150, 0, n_reads, with_qual=False)
+    burst = np.tile(bases[: 151], 3000)  # 3000 copies of one read: its buckets outgrow their arenas
+    bases = np.concatenate([bases, burst])
+    m = O.OracleMap()
+    total = m.scan_flat(bases, k, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    import torch
+    tb = torch.from_numpy(bases).cuda()
+    torch.cuda.synchronize()
+    with K.DeviceCounter(k, capacity_hint=len(m), path="partition") as dc:
+        half = (n_reads // 2) * 151
+        dc.push_device(tb.data_ptr(), None, half)
+        dc.push_device(tb.data_ptr() + half, None, len(bases) - half)
+        st = dc.finish()
+        assert st["table_slots"] == 1024 * b2 * 4096, st
+        assert st["kmers"] == total and st["distinct"] == len(m)
+        keys, cnts = dc.result()
+        assert np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
+        assert dc.histogram() == m.histogram()
+
+
 @pytest.mark.parametrize("k,minq", [(21, None), (19, 20), (31, None), (25, 20)], ids=["k21", "k19q20", "k31", "k25q20"])
 @pytest.mark.parametrize("b2", [3, 40, 96, 520, 640, 1000])
 def test_tables_of_1024_x_b2_regions(K, monkeypatch, b2, k, minq):
