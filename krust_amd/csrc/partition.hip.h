@@ -961,18 +961,26 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 }
             }
         };
-        auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
+        // FULL: every lane of the wave holds all its payloads of the batch -- nineteen chunks in twenty are full -- and the
+        // ranks are taken without the per-payload test (and-compare-saveexec-restore around every LDS atomic: from the ISA)
+        auto batch_as = [&](auto full_tag, uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
+            constexpr bool FULL = decltype(full_tag)::value;
             load_batch(base + TILE, nxt, have_nxt);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint32_t rk[HALF], dg[HALF];
+                // (a partition of the arena path has >= 32 buckets: the POW2 digit is a plain shift, no "no digit at all" case)
+                auto digit = [&](PT w) -> uint32_t {
+                    if constexpr (sizeof(PT) == 4 && POW2) return (uint32_t)w >> (32u - g.p2_bits);
+                    else if constexpr (sizeof(PT) == 4) return part_bucket32<POW2>((uint32_t)w, g);
+                    else return Pay<PT>::p2(w, g);
+                };
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
-                    const bool ok = (have >> (h * HALF + j)) & 1u;
                     pay[h * HALF + j] = l2_finish(pay[h * HALF + j], p, g);  // (level 1 left the last Feistel round to us)
-                    if constexpr (sizeof(PT) == 4) dg[j] = part_bucket32<POW2>((uint32_t)pay[h * HALF + j], g);
-                    else dg[j] = Pay<PT>::p2(pay[h * HALF + j], g);
-                    rk[j] = ok ? atomicAdd(&s_cnt[dg[j]], 1u) : 0xFFFFFFFFu;
+                    dg[j] = digit(pay[h * HALF + j]);
+                    if constexpr (FULL) rk[j] = atomicAdd(&s_cnt[dg[j]], 1u);
+                    else rk[j] = ((have >> (h * HALF + j)) & 1u) ? atomicAdd(&s_cnt[dg[j]], 1u) : 0xFFFFFFFFu;
                 }
                 uint32_t omask = 0;
 #pragma unroll
@@ -1010,6 +1018,11 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #endif
                 if (s_ovf_want || s_ovf_end) ovf_refill();  // (uniform; skipped entirely while nothing has overflowed)
             }
+        };
+        auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
+            // (decided per wave: both forms pass the same barriers)
+            if (!kh_any(have != (1u << PER) - 1u)) batch_as(std::true_type{}, base, pay, have, nxt, have_nxt);
+            else batch_as(std::false_type{}, base, pay, have, nxt, have_nxt);
         };
         PT payA[PER], payB[PER];
         uint32_t haveA = 0, haveB = 0;
