@@ -2084,7 +2084,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
     const uint32_t rw = (uint32_t)wave_sum((u64)nreal);
     if ((tid & 63) == 0 && rw) atomicAdd(&s_real, rw);
     __syncthreads();
-    if (s_special && tid == 0 && !s_fail) {
+    if (s_special) {  // (uniform: read behind the barrier; almost never -- and then the region pays two more barriers)
+    if (tid == 0 && !s_fail) {
         // The payload equal to the free marker was only counted.  One lane places it now by plain
         // linear probing over the combined image (old keys from HBM, new claims from s_pay).
         const u64 key = Pay<uint32_t>::key(R32_FREE, p1, g);
@@ -2119,8 +2120,15 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
         }
     }
     __syncthreads();
+    }
     const uint32_t sp_off = s_special ? s_sp_off : 0xFFFFFFFFu;
-    if (NARROW && !s_fail) {  // would a count leave 32 bits?  Then nothing of the region is written (uniform decision: two barriers)
+    // (Round 5, same-box A/B x 3: without those two barriers and the check below in a fresh pass 16.92 -> 16.65 ms at the
+    //  headline, 17.62 -> 17.07 for the hg-shaped input's million regions of 2.9 K payloads.  Setting the image up and reading it
+    //  back two slots at a time -- 8-byte LDS accesses, 16-byte stores -- on top of that: 16.69 / 17.26, nothing; four at a
+    //  time, each store instruction writing every other 16 bytes of its lines: slower than one slot at a time.)
+    // would a count leave 32 bits?  Then nothing of the region is written (uniform decision: two barriers).  Not in a FRESH
+    // pass: its counts are the batch's deltas, and a bucket of 2^32 - 1 payloads or more was refused at the top.
+    if (NARROW && !FRESH && !s_fail) {
         bool wide_cnt = false;
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
