@@ -507,7 +507,7 @@ int scan_text(kh_ctx *c, const uint8_t *d_text, u64 n, int format, hipStream_t s
             out_len = n;
         } else {
             // (no line starts: where header lines are is carried from one 1 KiB unit of the text to the next, rawparse.hip.h)
-            const u64 nunits = (n + kh::FASTA_UNIT - 1) / kh::FASTA_UNIT;
+            const u64 nunits = ntiles * (kh::RAW_TILE / kh::FASTA_UNIT);  // (every unit of every tile has a state: those behind the text's end hold no line end)
             if ((rc = tbuf(&c->txt_st, &c->txt_st_cap, nunits + 1, "hipMalloc(line states)")) != KH_OK) return rc;
             if ((rc = tbuf(&c->txt_tkeep, &c->txt_tkeep_cap, ntiles, "hipMalloc(text tiles)")) != KH_OK) return rc;
             if ((rc = tbuf(&c->txt_tout, &c->txt_tout_cap, ntiles + 1, "hipMalloc(text tiles)")) != KH_OK) return rc;
