@@ -255,6 +255,23 @@ def verify_reads(dc, st, host, hq, k, min_quality):
             "cpu_seconds": time.perf_counter() - t0}
 
 
+def measured_traffic(rf, reads, k, min_quality):
+    """roofline.traffic / traffic_frac of a sub-result from profiles/hbm_traffic.json "configs" (separate rocprofv3 --pmc
+    passes of the same workload, committed -- tools/hbm_traffic.py --also; reads = 0: the hg-shaped text)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            tj = json.load(f)
+        for name, c in (tj.get("configs") or {}).items():
+            if c.get("reads") == reads and c.get("k") == k and c.get("min_quality") == min_quality:
+                ms = rf.get("kernel_ms_per_step")
+                rf["traffic"] = c["bytes_per_step"]
+                rf["traffic_source"] = f"profiles/{c.get('tag')}_summary.json (rocprofv3 --pmc passes of this workload, committed; not re-measured in this run)"
+                rf["traffic_frac"] = (c["bytes_per_step"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None
+                return
+    except Exception:
+        pass
+
+
 def sub_config(krust_amd, torch, dev, local_rank, name, reads, k, min_quality, first=0, hint=None, verify=False, steps=1):
     """One BASELINE.json configuration as a sub-result: its own reads, its own context, one warm-up and `steps`
     timed steps (reset + push_device + finish), with its own roofline.  hint = 0: no capacity hint (KmerMap::new() takes
@@ -283,6 +300,7 @@ def sub_config(krust_amd, torch, dev, local_rank, name, reads, k, min_quality, f
             if rep:
                 dt += (time.perf_counter() - t0) / steps
         rf = roofline_of(st, nbytes * (2 if with_qual else 1), st["count_kernel_ms"], st["stage_ms"], k)
+        measured_traffic(rf, reads, k, min_quality)
         out = {"workload": name, "k": k, "reads": reads, "first_read": first, "min_quality": min_quality, "capacity_hint": hint,
                "capacity_hint_source": hint_source, "value": st["kmers"] / dt, "unit": "k-mers/s",
                "ms_per_step": dt * 1e3, "steps": steps, "kmers_per_step": int(st["kmers"]), "distinct": int(st["distinct"]),
@@ -362,6 +380,7 @@ def sub_config_hg(krust_amd, torch, dev, local_rank, k=21, verify=True):
             torch.cuda.synchronize()
             t2 = time.perf_counter()
         rf = roofline_of(st, text.numel(), st["count_kernel_ms"], st["stage_ms"], k)
+        measured_traffic(rf, 0, k, None)  # (the counting kernels' share of the profiled step: scan and histogram kernels apart)
         out = {"workload": name, "k": k, "text_bytes": int(text.numel()), "records": len(HG38_LENGTHS), "largest_record": max(HG38_LENGTHS),
                "value": st["kmers"] / (t2 - t0), "unit": "k-mers/s", "ms_per_step": (t2 - t0) * 1e3, "steps": 1,
                "count_ms": (t1 - t0) * 1e3, "histogram_ms": (t2 - t1) * 1e3, "text_scan_ms": st["text_scan_ms"],
@@ -626,6 +645,8 @@ def contract_line(full):
         else:
             row.update({"value": _r(x.get("value"), 5), "ms_per_step": _r(x.get("ms_per_step"), 4), "frac": _r((x.get("roofline") or {}).get("frac")),
                         "verify_ok": (x.get("verify") or {}).get("ok")})
+            if (x.get("roofline") or {}).get("traffic_frac") is not None:  # (measured HBM bytes of this workload / its kernel time / peak)
+                row["traffic_frac"] = _r(x["roofline"]["traffic_frac"])
         rows.append(row)
     if rows:
         line["configs"] = rows

@@ -165,6 +165,16 @@ def _fasta_unit_cases():
             # the same with CR LF across the edge
             cases[f"crlf{edge}{d:+d}"] = head + seq(edge + d - len(head) - 1) + b"\r\n>ACGTACGTACGTACGTACGTACGTACGT\r\n" + seq(700) + b"\r\n"
     # nothing but headers; a header without a record at the very end, without a final newline
+    # '>' that does not start a line is an invalid base inside a record and plain text inside a header; a header of '>' alone
+    cases["gt-inside"] = (b">r1 >ACGTACGTACGTACGTACGTACGT> >\n" + seq(500) + b">" + seq(500) + b"\n" + seq(30) + b">>" + seq(30) + b"\n>\n"
+                          + seq(1500) + b"\n>>ACGTACGTACGTACGTACGTACGTACGTACGT\n" + seq(2000) + b">\n" + seq(100) + b"\n")
+    # short records, headers and lines of every length around the 16 bytes a lane takes
+    parts = []
+    for i in range(400):
+        parts.append(b">" + b"h" * (i % 37) + b"\n")
+        for _ in range(i % 4):
+            parts.append(seq(1 + (i * 7) % 45) + b"\n")
+    cases["ragged"] = b"".join(parts)
     cases["headers-only"] = b"".join(b">ACGTACGTACGTACGTACGT%d\n" % i for i in range(600))
     cases["open-header-end"] = b">r\n" + seq(2000) + b"\n>ACGTACGTACGTACGTACGTACGT"
     return cases
