@@ -991,8 +991,23 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 }
                 if (kh_any(omask != 0)) {  // ranks that did not fit their bins (a heavy bucket): straight to the overflow list
                     const uint32_t k = (uint32_t)__builtin_popcount(omask);
-                    u64 at = 0;
-                    if (k && ovf_take(k, at)) {
+                    // ONE request per wave (round 5): the lanes' counts are scanned in the wave and its last lane asks for the
+                    // sum -- with repeats in the input (4 % of an hg-shaped batch's payloads come here) some twenty lanes of
+                    // every wave would otherwise queue up at the same LDS word in every half batch.
+                    uint32_t incl = k;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+                        if ((int)lane_id() >= o) incl += up;
+                    }
+                    const uint32_t wtotal = (uint32_t)__shfl((int)incl, 63, 64);
+                    u64 wat = 0;
+                    bool wok = false;
+                    if (lane_id() == 63u) wok = ovf_take(wtotal, wat);
+                    wat = (u64)__shfl((unsigned long long)wat, 63, 64);
+                    wok = __shfl((int)wok, 63, 64) != 0;
+                    u64 at = wat + (incl - k);
+                    if (k && wok) {
                         uint32_t q = 0;
 #pragma unroll
                         for (int j = 0; j < HALF; ++j)
