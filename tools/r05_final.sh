@@ -11,3 +11,4 @@ echo "bench rc=$?"; wc -c gpurun_out/r05z/bench.json
 BENCH_FULL_PATH=gpurun_out/r05z/forcemerge_full.json python bench.py --force-merge --steps 5 --warmup 1 > gpurun_out/r05z/forcemerge.json 2> gpurun_out/r05z/forcemerge.err
 BENCH_FULL_PATH=gpurun_out/r05z/group4_full.json python bench.py --group 4 --reads 25000000 --steps 3 --warmup 1 > gpurun_out/r05z/group4.json 2> gpurun_out/r05z/group4.err
 head -c 900 gpurun_out/r05z/bench.json; echo; tail -c 600 gpurun_out/r05z/forcemerge.json; echo; tail -c 900 gpurun_out/r05z/group4.json
+python tools/skew_probe.py > gpurun_out/r05z/skew_probe.txt 2>&1; tail -7 gpurun_out/r05z/skew_probe.txt
