@@ -62,6 +62,12 @@ bool region_small_groups(const kh_ctx *c, u64 expect, u64 nregions) {
     const double keys = c->est_keys ? (double)(c->distinct_known + c->est_keys) : c->hinted ? (double)c->hint_keys : (double)(c->distinct_known + expect);
     return !(keys > 0.6 * (double)c->cap && expect / nregions > 16384);
 }
+// The fresh region pass can leave every region's exchange-head count behind (a multi-GPU export right after it then skips its
+// counting pass): worth its instructions -- a shift, an add and a compare per slot, a wave sum and a barrier per region --
+// only where an export will come: a context with a communicator (kh_comm_init / kh_group_create come before the pushes), or
+// one whose last table was exported (kh_export_regions_*: the Python harness, the tests).  Round 5, same-box A/B of a context without one: region pass 16.55 -> 16.37 ms at
+// the headline, 16.94 -> 16.52 for the hg-shaped input.
+static bool want_heads(const kh_ctx *c) { return c->comm != nullptr || c->exports_seen || c->knobs.heads_always; }
 template <>
 void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool, u64 skip, u64 expect) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
@@ -76,7 +82,7 @@ void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot,
 template <>
 void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool narrow, u64 skip, u64 expect) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
-    const int cb = (c->table_empty && !c->shard_shift) ? head_count_bits(c, nregions) : -1;
+    const int cb = (c->table_empty && !c->shard_shift && want_heads(c)) ? head_count_bits(c, nregions) : -1;
     c->rheads_cb = cb > 0 ? (uint32_t)cb : 0u;
     // (a narrow FRESH pass must write every region of the image whatever the table held: dirty = 1)
     const bool pow2 = g.p2_bits != 0xFFFFFFFFu;  // (the power-of-two instances take digit and start by shifts: rounds 1-3's code)

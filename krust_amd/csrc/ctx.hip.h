@@ -101,6 +101,7 @@ struct Knobs {
     u64 hot_cut = 0;                 // KMERHIP_HOT_CUT (0: default; ~0: no bucket is hot)
     int ovf_agg = -1;                // KMERHIP_OVF_AGG
     double survival = 0;             // KMERHIP_SURVIVAL
+    bool heads_always = false;       // KMERHIP_HEADS_ALWAYS=1: every fresh pass leaves the exchange-head counts behind, communicator or not
     u64 table_room_mb = 0;           // KMERHIP_TABLE_ROOM_MB: what the sample-sized table may take, as if the device had no more
     bool stop_after_p1 = false, stop_after_p2 = false;  // ablation builds (KH_ABL*)
 };
@@ -195,6 +196,7 @@ struct kh_ctx {
     // at configs[3]'s size (bench.py --force-merge).  Now the merge BORROWS from them: a bump allocator over keysA / keysB
     // (kmerhip.hip borrow()), for the exchange's send / receive buffers and for the table itself (table_borrowed).  The loan
     // ends with kh_reset, or when anything is about to write the partition buffers (end_borrow: a borrowed table moves out).
+    bool exports_seen = false;       // a heads export was asked of this context: its fresh passes leave the head counts behind (batch.hip want_heads)
     bool borrow_on = false;
     u64 borrow_off[2] = {0, 0};     // bytes lent out of keysA / keysB
     bool table_borrowed = false;    // `table` points into keysA / keysB: never hipFree'd

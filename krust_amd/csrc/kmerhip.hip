@@ -34,6 +34,7 @@ void read_knobs(Knobs &k) {
     if (const char *e = env_of("KMERHIP_OVF_AGG")) k.ovf_agg = atoi(e);
     if (const char *e = env_of("KMERHIP_SURVIVAL")) k.survival = atof(e);
     if (const char *e = env_of("KMERHIP_TABLE_ROOM_MB")) k.table_room_mb = strtoull(e, nullptr, 10);
+    k.heads_always = env_of("KMERHIP_HEADS_ALWAYS") != nullptr;
     k.stop_after_p1 = env_of("KMERHIP_STOP_AFTER_P1") != nullptr;
     k.stop_after_p2 = env_of("KMERHIP_STOP_AFTER_P2") != nullptr;
 #endif

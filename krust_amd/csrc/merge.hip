@@ -383,6 +383,7 @@ extern "C" int kh_export_regions_packed_device(kh_ctx *c, uint32_t nparts, uint6
 extern "C" int kh_export_regions_heads_device(kh_ctx *c, uint32_t nparts, uint32_t *d_heads, uint64_t cap,
                                               uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts,
                                               uint64_t *table_regions) {
+    if (c) c->exports_seen = true;  // (from now on this context's fresh passes leave the head counts behind: batch.hip want_heads)
     return export_regions(c, XF_HEADS32, nparts, d_heads, nullptr, cap, d_region_counts, region_cap, part_counts, table_regions);
 }
 

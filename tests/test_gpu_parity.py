@@ -843,6 +843,7 @@ def test_heads_counts_survive_a_short_overflow_list(K, monkeypatch, k, agg):
     same table built through the direct path (whose export counts every region)."""
     import torch
     monkeypatch.setenv("KMERHIP_OVF_AGG", agg)   # both insert kernels: the entry-by-entry one marks what it has applied as consumed
+    monkeypatch.setenv("KMERHIP_HEADS_ALWAYS", "1")  # (a context without a communicator leaves no head counts behind since round 5)
     n_reads = 200_000
     bases, _ = O.synth_reads(SEED + 5, 1 << 22, 150, 0, n_reads, with_qual=False)
     v = bases.reshape(n_reads, 151)
