@@ -2009,7 +2009,16 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
         // go on to the queue and the loop anyway), so the round skips it and goes through the lanes' own queues -- which are
         // balanced there, eight items each.
         const bool first_round = KH_REGION_R1_LOOP && FRESH && base == 0;
-        if (hot || may_special || !FRESH || first_round) {
+        // ... unless the payloads are plain (no hot bucket, no free-marker payload): then the first round CLAIMS in straight-line
+        // code -- a compare-and-swap on the first slot of every payload's home group, eight in flight -- and only what finds that
+        // slot taken by another key goes through the loop (round 5, below)
+#ifndef KH_REGION_R1_CLAIM
+#define KH_REGION_R1_CLAIM 1  // (0: A/B builds -- the first round of a fresh pass goes through the lanes' queues and the loop)
+#endif
+        // (a FULL round only: with 2.9 K payloads in a region's one round -- the hg-shaped input -- three of a lane's eight places
+        //  are empty and still swap at a dummy word, and the pass was 1.0 ms slower than through the queues: 16.5 -> 17.5 ms)
+        const bool claim_round = KH_REGION_R1_CLAIM && first_round && !hot && !may_special && rem >= (u64)REGION_RK * NT;
+        if (hot || may_special || !FRESH || (first_round && !claim_round)) {
             // (the pass over a filled table keeps the old slots in registers; the straight-line first probe below
             // would push it over the 64 registers that two workgroups per CU allow)
             uint32_t rq = 0;  // real payloads, compacted into the lane's queue (sentinels dropped)
@@ -2046,29 +2055,51 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             // CHECK = false: a FULL round of a bucket that holds no sentinels (the arena level 2 writes none) -- every lane has
             // REGION_RK payloads and all of them are the region's: no validity test per payload (3 of the ~18 vector
             // instructions a payload costs here)
-            auto first_probe = [&](auto chk) -> uint32_t {
-                constexpr bool CHECK = decltype(chk)::value;
+            // CLAIM (round 5): the first round of a fresh pass.  The image is empty, a read-only probe cannot hit: the payload is
+            // compared-and-swapped into the FIRST slot of its home group instead (FREE -> payload: a new key; already this
+            // payload: a copy that came a moment earlier), FP of them in flight.  What finds another key there goes to the loop,
+            // which looks at the whole group and on.  Measured with probing taken out (KH_ABLR-style builds, round 5): of the
+            // 16.6 ms of an hg-shaped input's pass -- a million regions of 2.9 K payloads, nine in ten of them new keys, ALL of them
+            // first-round payloads -- 11 were the loop, 27 vector + 30 scalar instructions per iteration and payload.  (That input
+            // keeps the loop all the same -- see claim_round; the full first rounds of denser regions gain: 16.4 -> 16.0 ms at the headline.)
+            auto first_probe = [&](auto chk, auto clm) -> uint32_t {
+                constexpr bool CHECK = decltype(chk)::value, CLAIM = decltype(clm)::value;
                 uint32_t wrun = 0;  // items queued by the wave so far (wave-uniform)
 #pragma unroll
                 for (int h = 0; h < REGION_RK; h += FP) {
                     uint32_t oj[FP];
                     R32Group cj[FP];
+                    bool vj[FP];
 #pragma unroll
                     for (int j = 0; j < FP; ++j) oj[j] = rg.start_b(pj[h + j]);  // (byte offsets)
 #pragma unroll
-                    for (int j = 0; j < FP; ++j) cj[j] = r32_group_load_b(s_pay, oj[j]);
+                    for (int j = 0; j < FP; ++j) {
+                        vj[j] = true;
+                        if constexpr (CHECK) vj[j] = (uint32_t)(h + j) < nk && rg.mine(pj[h + j]);
+                        if constexpr (CLAIM) {  // (a payload that is not the region's swaps at the lane's dummy word)
+                            char *const at = vj[j] ? reinterpret_cast<char *>(s_pay) + oj[j] : reinterpret_cast<char *>(s_add) + dummy_b;
+                            cj[j].v[0] = atomicCAS(reinterpret_cast<uint32_t *>(at), R32_FREE, pj[h + j]);
+                        } else {
+                            cj[j] = r32_group_load_b(s_pay, oj[j]);
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < FP; ++j) {
                         // (predicated, not branched: the exec-mask bookkeeping of sixteen small branches per round cost
                         //  as many scalar instructions as the kernel has vector ones)
                         const uint32_t pay = pj[h + j];
-                        bool valid = true;
-                        if constexpr (CHECK) {
-                            valid = (uint32_t)(h + j) < nk && rg.mine(pay);
-                            nreal += valid;
-                        }
+                        const bool valid = vj[j];
+                        if constexpr (CHECK) nreal += valid;
                         uint32_t o4;
-                        const bool hit = r32_group_find_b(cj[j], pay, o4) && valid;
+                        bool hit;
+                        if constexpr (CLAIM) {
+                            const uint32_t was = cj[j].v[0];
+                            nd += (valid && was == R32_FREE) ? 1u : 0u;
+                            hit = valid && (was == R32_FREE || was == pay);
+                            o4 = 0;
+                        } else {
+                            hit = r32_group_find_b(cj[j], pay, o4) && valid;
+                        }
 #if !(KH_ABLR & 2)  /* timing experiment otherwise: no count updates in the first probe */
                         // no-return ds_add_u32; misses add to a private dummy word
                         atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s_add) + (hit ? (oj[j] | o4) : dummy_b)), 1u);
@@ -2087,7 +2118,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
 #define KH_REGION_NOCHECK 1  // (0: A/B builds -- every round tests every payload)
 #endif
             const bool plain = KH_REGION_NOCHECK && no_sentinels && rem >= (u64)REGION_RK * NT;  // uniform
-            const uint32_t wrun = plain ? first_probe(std::false_type{}) : first_probe(std::true_type{});
+            uint32_t wrun;
+            if (claim_round) wrun = plain ? first_probe(std::false_type{}, std::true_type{}) : first_probe(std::true_type{}, std::true_type{});
+            else wrun = plain ? first_probe(std::false_type{}, std::false_type{}) : first_probe(std::true_type{}, std::false_type{});
             const uint32_t r = wrun > lane ? (wrun - lane + 63u) >> 6 : 0u;  // this lane's share: rows 0 .. r-1 of its column
 #if !(KH_ABLR & 1)  /* timing experiment otherwise: no probing loop behind the straight-line first probe */
             region32_probe_lean<POW2>(r, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
