@@ -552,10 +552,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         if (c->ovf_pending && ovf_agg) {
             const unsigned grid = (unsigned)std::min<u64>(2048, (c->ovf_pending + 8191) / 8192);
             if (nar)
-                hipLaunchKernelGGL((kh::ovf_agg_insert_kernel<true>), dim3(grid), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
+                hipLaunchKernelGGL((kh::ovf_agg_insert_kernel<true>), dim3(grid), dim3(kh::OVF_AGG_NT), 0, c->stream, table_geom(c, c->table, c->cap), g,
                                    (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, c->ntab);
             else
-                hipLaunchKernelGGL((kh::ovf_agg_insert_kernel<false>), dim3(grid), dim3(kh::BLOCK), 0, c->stream, table_geom(c, c->table, c->cap), g,
+                hipLaunchKernelGGL((kh::ovf_agg_insert_kernel<false>), dim3(grid), dim3(kh::OVF_AGG_NT), 0, c->stream, table_geom(c, c->table, c->cap), g,
                                    (const kh::OvfEntry *)c->ovf_list, (const u64 *)c->ovf, ovf_lim, c->d_ctr, (u64 *)nullptr);
         } else if (c->ovf_pending) {  // what did not fit its arena / its bin: through the direct path, now that the table holds the rest
             if (nar)

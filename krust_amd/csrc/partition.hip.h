@@ -1137,18 +1137,22 @@ __device__ __forceinline__ bool narrow_upsert(u64 *nreg, const PartGeom &g, uint
 // workgroup sums slices of 8192 entries in an LDS table keyed by (region, payload) and applies the sums -- an atomic per key and
 // table flush instead of one per entry.  4-byte payloads only (region and payload are one 64-bit key).  NARROW: only where no
 // count can leave 32 bits in the 8-byte image (the host checks the table's k-mer total), so that nothing has to stay in the list.
+// 512 lanes per workgroup (round 5): the 48 KiB table allows three workgroups per CU either way, and with 256 lanes that was
+// twelve waves per CU for a kernel made of LDS round trips: 2.4 -> 1.5 ms for the hg-shaped batch's 1.3e8 entries (1024 lanes,
+// two workgroups per CU: 2.2).
+constexpr int OVF_AGG_NT = 512;
 template <bool NARROW>
-__global__ __launch_bounds__(BLOCK) void ovf_agg_insert_kernel(TableGeom tg, PartGeom g, const OvfEntry *__restrict__ list,
+__global__ __launch_bounds__(OVF_AGG_NT) void ovf_agg_insert_kernel(TableGeom tg, PartGeom g, const OvfEntry *__restrict__ list,
                                                                const u64 *__restrict__ ovf, u64 ovf_cap, Counters *ctr, u64 *__restrict__ ntab) {
     constexpr u64 SLICE = 8192;
-    constexpr int TAB = 4096;
+    constexpr int TAB = 4096, NT = OVF_AGG_NT, PER = 1024 / NT;
     constexpr u64 FREE = ~0ull;  // (a valid entry's region is never 0xFFFFFFFF: that marks the unused entries of a segment)
     __shared__ u64 s_key[TAB];
     __shared__ uint32_t s_cnt[TAB];
     __shared__ uint32_t s_fill;
     const int tid = threadIdx.x;
     const u64 n = ovf[0] < ovf_cap ? ovf[0] : ovf_cap;  // (the cursor moves in whole segments: see ovf_insert_kernel)
-    for (int i = tid; i < TAB; i += BLOCK) {
+    for (int i = tid; i < TAB; i += NT) {
         s_key[i] = FREE;
         s_cnt[i] = 0;
     }
@@ -1158,7 +1162,7 @@ __global__ __launch_bounds__(BLOCK) void ovf_agg_insert_kernel(TableGeom tg, Par
     u64 km = 0;
     auto apply = [&]() {  // the LDS table -> the table in HBM; leaves it empty (all threads)
         __syncthreads();
-        for (int i = tid; i < TAB; i += BLOCK) {
+        for (int i = tid; i < TAB; i += NT) {
             const uint32_t cnt = s_cnt[i];
             if (cnt) {
                 const u64 key = s_key[i];
@@ -1174,10 +1178,10 @@ __global__ __launch_bounds__(BLOCK) void ovf_agg_insert_kernel(TableGeom tg, Par
     };
     for (u64 s0 = (u64)blockIdx.x * SLICE; s0 < n; s0 += (u64)gridDim.x * SLICE) {  // (uniform per workgroup: barriers inside)
         const u64 s1 = s0 + SLICE < n ? s0 + SLICE : n;
-        for (u64 c0 = s0; c0 < s1; c0 += 4 * BLOCK) {  // 1024 entries between two looks at the fill
+        for (u64 c0 = s0; c0 < s1; c0 += PER * NT) {  // 1024 entries between two looks at the fill
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u64 i = c0 + (u64)j * BLOCK + tid;
+            for (int j = 0; j < PER; ++j) {
+                const u64 i = c0 + (u64)j * NT + tid;
                 if (i >= s1) continue;
                 const OvfEntry e = list[i];
                 if (e.region == 0xFFFFFFFFu) continue;
@@ -1201,7 +1205,7 @@ __global__ __launch_bounds__(BLOCK) void ovf_agg_insert_kernel(TableGeom tg, Par
                 }
             }
             __syncthreads();
-            const bool full = s_fill > TAB / 2;  // (uniform: read between two barriers; at most 4 * BLOCK more before the next look)
+            const bool full = s_fill > TAB / 2;  // (uniform: read between two barriers; at most 1024 more before the next look)
             __syncthreads();
             if (full) apply();
         }
