@@ -35,6 +35,26 @@ def test_hbm_traffic_json_is_what_the_pmc_summary_says():
     assert tj["reads_per_gpu"] == 100_000_000 and tj["k"] == 21
 
 
+def test_hbm_traffic_of_the_other_configurations_is_what_their_summaries_say():
+    """hbm_traffic.json "configs" (round 5: configs[2], configs[3]'s share, configs[4]) -- what bench.py reports as the
+    sub-results' roofline.traffic -- recomputed from the committed PMC summaries of their tags."""
+    tj = json.loads(_read("profiles", "hbm_traffic.json"))
+    assert {"k31q20", "s125", "hg"} <= set(tj.get("configs", {}))
+    for name, c in tj["configs"].items():
+        s = json.loads(_read("profiles", f"{c['tag']}_summary.json"))
+        steps = max(k["calls"] for k in s["kernels"] if "region_count" in k["name"])
+        fetch = write = 0.0
+        for kn, ctrs in s["pmc"].items():
+            if "kh::" not in kn or "synth_reads" in kn or "table_init" in kn:
+                continue
+            if any(x in kn for x in ("fasta_", "fastq_", "raw_", "scan_", "hist", "lookup")):
+                continue
+            fetch += ctrs.get("FETCH_SIZE", {}).get("sum", 0.0) * 1024 / steps
+            write += ctrs.get("WRITE_SIZE", {}).get("sum", 0.0) * 1024 / steps
+        assert c["bytes_per_step"] == int(2 * fetch + write), name
+        assert (c["reads"], c["k"]) in ((100_000_000, 31), (125_000_000, 21), (0, 21))
+
+
 def test_headline_numbers_of_the_documents_are_the_committed_bench_line():
     tag = json.loads(_read("profiles", "hbm_traffic.json"))["tag"]
     b = _bench(tag)
