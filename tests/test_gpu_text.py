@@ -190,6 +190,30 @@ def test_fasta_line_states_across_units(name):
         assert device(text, "fasta", k, None) == expect(text, "fasta", k, None)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_fasta_random_layouts_across_units(seed):
+    """Random FASTA layouts of 20-120 KB: line and header lengths from 0 to several units, LF or CR LF, '>' inside lines,
+    empty records, with or without the final line end -- the line states carried across 1 KiB units, waves and 4 KiB tiles
+    against the Python line parser + oracle."""
+    rng = np.random.default_rng(4200 + seed)
+    eol = b"\r\n" if seed % 3 == 0 else b"\n"
+    out = []
+    for r in range(int(rng.integers(3, 60))):
+        hl = int(rng.choice([0, 1, 7, 15, 16, 17, 60, 300, 1023, 1024, 5000])) if rng.random() < 0.5 else int(rng.integers(0, 200))
+        out.append(b">" + rand_seq(rng, hl, alphabet=b"ACGT >xyz|0123") + eol)
+        for _ in range(int(rng.integers(0, 12))):
+            ll = int(rng.choice([0, 1, 15, 16, 17, 60, 61, 70, 1023, 1024, 1025, 4095, 4096, 9000])) if rng.random() < 0.4 else int(rng.integers(1, 120))
+            line = bytearray(rand_seq(rng, ll))
+            if ll > 3 and rng.random() < 0.1:
+                line[int(rng.integers(1, ll))] = ord(">")  # not at the line's start: an invalid base, not a header
+            out.append(bytes(line) + eol)
+    text = b"".join(out)
+    if seed % 2 and text.endswith(eol):
+        text = text[: -len(eol)]
+    k = [4, 21, 11, 31][seed % 4]
+    assert device(text, "fasta", k, None) == expect(text, "fasta", k, None)
+
+
 @pytest.mark.parametrize("edge", [1024, 4096])
 @pytest.mark.parametrize("what", ["space-lf", "tab-crlf", "bare-cr", "cr-at-end-of-text"])
 def test_fasta_line_end_rules_across_units(edge, what):
