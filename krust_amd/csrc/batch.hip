@@ -379,13 +379,6 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         if ((rc = ensure_buf(c, &c->ovf_list, &z, ovf_need, "hipMalloc(ovf_list)")) != KH_OK) return rc;
         c->ovf_cap = ovf_need;
     }
-    {
-        StageTimer t(c, ST_MISC);
-        if (size_from_sample)  // (b2 is final now: the plan's matrix offsets again)
-            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
-                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)nullptr);
-        HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
-    }
     const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
     bool arena_done = false, heavy_exact = false;
     const u64 ovf_test_cap = c->knobs.l2_ovf_cap;
@@ -444,10 +437,15 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     // buckets then go behind the arenas, and their (small) counting pass is booked under "misc": stage_ms[P2_COUNT] == 0
     // still says "this batch's level 2 was the arena kernel"
     PT *const outB = heavy_exact ? bufB + heavy_base : bufB;
-    if (heavy_exact) {
+    {
+        // (the exact path's plan and its cleared histogram matrix are made HERE since round 5: a batch the arenas took whole --
+        //  every batch of the bench -- never reads them.  The plan runs again because b2 is final only now -- the matrix offsets
+        //  depend on it -- or for the heavy partitions alone.)
         StageTimer t(c, ST_MISC);
-        hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
-                           c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)c->heavy);
+        if (heavy_exact || size_from_sample)
+            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
+                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, heavy_exact ? (const uint8_t *)c->heavy : (const uint8_t *)nullptr);
+        HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
     }
     {
         StageTimer t(c, heavy_exact ? ST_MISC : ST_P2_COUNT);
