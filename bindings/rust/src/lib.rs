@@ -41,6 +41,7 @@ pub mod sys {
         pub part_batches: u64,
         pub stage_ms: [f64; 8],
         pub text_scan_ms: f64,
+        pub slot_bytes: u64,
     }
 
     #[repr(C)]
@@ -266,7 +267,7 @@ impl HipKmerMap {
             b.push(b'\n');
             match qual {
                 Some(qs) => q.extend_from_slice(&qs),
-                None => q.resize(q.len() + seq.len(), b'~'),
+                None => q.resize(q.len() + seq.len(), 0xFF), // 0xFF >= any threshold (<= 255): never masked
             }
             q.push(b'\n');
             if b.len() >= BATCH {

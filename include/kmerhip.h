@@ -47,7 +47,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define KMERHIP_ABI_VERSION 1
+#define KMERHIP_ABI_VERSION 2
 
 typedef enum kh_status {
     KH_OK = 0,
@@ -122,6 +122,9 @@ typedef struct kh_stats {
     uint64_t part_batches;   /* batches that went through the partitioned path */
     double   stage_ms[KH_NUM_STAGES]; /* per-stage kernel time, see KH_STAGE_* */
     double   text_scan_ms;   /* kh_push_text*: record-scanning kernels (not part of count_kernel_ms) */
+    uint64_t slot_bytes;     /* ABI 2: bytes per slot of the form the counts live in right now -- 16: {u64 key, u64 count};
+                              * 8: the image a partitioned count, or a fresh merge of packed / heads units, leaves (count << 32 |
+                              * 32 hash bits); what reads results takes either, everything else converts first */
 } kh_stats;
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -134,8 +137,13 @@ int  kh_reset(kh_ctx *ctx);
 /* Host buffers.  `bases` is a flat byte buffer of n bytes holding any number
  * of records separated by >=1 non-ACGTacgt byte; `qual` is NULL or a parallel
  * buffer of n bytes (same offsets).  With qual==NULL or min_quality==-1 no
- * quality masking happens (run.rs:543: both must be Some).  Returns after the
- * buffers have been consumed (caller may reuse them). */
+ * quality masking happens (run.rs:543: both must be Some).  A quality byte of
+ * 0xFF can never mask (the threshold is min_quality.saturating_add(33) <= 255
+ * and a base is masked iff its byte is BELOW it): it is the filler for records
+ * without qualities (FASTA) pushed beside FASTQ ones in one flat buffer --
+ * any smaller filler ('~' = 126) would drop those records' windows once
+ * min_quality >= 94.  Returns after the buffers have been consumed (caller may
+ * reuse them). */
 int kh_push(kh_ctx *ctx, const uint8_t *bases, const uint8_t *qual, uint64_t n);
 /* Same, for buffers already resident in this device's HBM (no copy). */
 int kh_push_device(kh_ctx *ctx, const uint8_t *d_bases, const uint8_t *d_qual, uint64_t n);

@@ -734,7 +734,10 @@ void ensure_part_budget(kh_ctx *c) {
         budget = std::min<u64>(budget, (u64)((double)(fr + c->key_cap + c->keyb_cap) * share));
         // (buffers given back for a merge: the table image and the shard's table they left room for exist by now -- the same budget
         //  again where it still fits, so that a rank that counted in one batch goes on counting in one)
-        if (c->prev_part_budget > budget && (u64)fr + c->key_cap + c->keyb_cap >= c->prev_part_budget + (3ull << 30)) budget = c->prev_part_budget;
+        // (... unless kh_set_shard's low-memory path freed the image: its 8 bytes per slot must still fit beside the budget,
+        //  or the next count falls back to the 16-byte table and a second batch)
+        const u64 image = c->ntab ? 0 : 8ull * c->cap;
+        if (c->prev_part_budget > budget && (u64)fr + c->key_cap + c->keyb_cap >= c->prev_part_budget + image + (3ull << 30)) budget = c->prev_part_budget;
     } else (void)hipGetLastError();
     if (c->knobs.part_budget_gb > 0) budget = (u64)(c->knobs.part_budget_gb * (double)(1ull << 30));
     c->part_budget = std::max<u64>(budget, 64ull << 20);

@@ -628,15 +628,17 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
             fr = 0;
         }
         if (lendable && (u64)fr >= rest + (rest ? (2ull << 30) : 0)) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            c->borrow_on = true;
-            c->borrow_off[0] = c->borrow_off[1] = 0;
+            // (a failure here is carried into the next gather like every other one: the peers must not be left in it -- ADVICE r5)
+            if (hipStreamSynchronize(c->stream) != hipSuccess) lrc = fail(c, KH_ERR_HIP, "hipStreamSynchronize(before the merge borrows the partition buffers)");
+            else {
+                c->borrow_on = true;
+                c->borrow_off[0] = c->borrow_off[1] = 0;
+            }
         } else if ((u64)fr < scratch + 16ull * (c->cap / W + kh::REGION_SLOTS) + (4ull << 30)) {
             lrc = release_part_buffers(c);
         }
     }
     if (lrc == KH_OK) lrc = inject("start");
-    if (lrc == KH_OK) lrc = dig.alloc(c, (size_t)3 * W * (1 + 64) * sizeof(u64), "hipMalloc(digests)");
     const u64 n_local = lrc == KH_OK ? c->h_ctr->distinct : 0;
     local_total = lrc == KH_OK ? c->h_ctr->kmers : 0;  // the sum of all counts of this rank's table
     u64 nreg = c->cap / kh::REGION_SLOTS;
@@ -683,7 +685,19 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         for (uint32_t r = 0; r < W; ++r) target = std::max(target, all[r]);
         if (nreg < target && kh::kh_regions_valid(target)) {
             const double t0 = now_ms();
-            lrc = grow_to(c, target * kh::REGION_SLOTS);
+            // (the borrow-or-release decision above was taken for THIS rank's table; the re-laid-out one -- 16 B per slot
+            //  of the world's largest, from hipMalloc, beside the widened 8-byte image -- may not fit beside the partition buffers.
+            //  Nothing has been carved out of them yet -- the digests come below --, so they can still go back to the driver.)
+            {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+                    (void)hipGetLastError();
+                    fr = 0;
+                }
+                const u64 need = 16ull * target * kh::REGION_SLOTS + (c->table ? 0 : 16ull * c->cap) + (2ull << 30);
+                if ((u64)fr < need && (c->keysA || c->keysB)) lrc = release_part_buffers(c);  // (ends the loan too)
+            }
+            if (lrc == KH_OK) lrc = grow_to(c, target * kh::REGION_SLOTS);
             if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
             if (lrc == KH_OK) nreg = c->cap / kh::REGION_SLOTS;
             t_export += now_ms() - t0;
@@ -692,6 +706,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         }
     }
 
+    if (lrc == KH_OK) lrc = dig.alloc(c, (size_t)3 * W * (1 + 64) * sizeof(u64), "hipMalloc(digests)");
     const bool pow2 = (W & (W - 1)) == 0;
     const int head_cb = head_count_bits(c, nreg);  // (< 0: heads do not apply to this table -- the vote then never agrees on them)
     const uint32_t head_cmask = head_cb > 0 ? (1u << head_cb) - 1u : 0u;
@@ -1164,6 +1179,9 @@ void comm_release(kh_ctx *c) {
 int comm_setup(kh_ctx *c, uint32_t nranks, uint32_t rank, const ncclUniqueId *id, LocalHub *hub) {
     if (c->comm) return fail(c, KH_ERR_STATE, "the context already has a communicator");
     if (nranks < 1 || rank >= nranks) return fail(c, KH_ERR_BAD_ARG, "kh_comm_init: rank must be < nranks");
+    // (every route keeps per-sender state in arrays of MAX_SENDERS -- the merge kernels' segment tables, the digests, the small
+    //  gathers' 3 words per rank: a larger world is refused here, by every rank alike, before any collective -- ADVICE r5)
+    if (nranks > (uint32_t)kh::MAX_SENDERS) return fail(c, KH_ERR_BAD_ARG, "kh_comm_init: at most 64 ranks per communicator");
     HIP_TRY(c, hipSetDevice(c->device));
     Comm *cm = new (std::nothrow) Comm();
     if (!cm) return fail(c, KH_ERR_OOM, "Comm");

@@ -183,8 +183,11 @@ int close_fresh_window(kh_ctx *c) {
     const u64 per_piece = c->cap / c->win_open_n;  // slots; a piece is a contiguous range of target regions
     for (uint32_t p = 0; p < c->win_open_n; ++p) {
         if (c->win_mask & (1ull << p)) continue;
-        hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(per_piece)), dim3(kh::BLOCK), 0, c->stream,
-                           c->table + (u64)p * per_piece, per_piece);
+        if (c->narrow)  // (a shard built as the 8-byte image, merge.hip: 0 = a free slot)
+            HIP_TRY(c, hipMemsetAsync(c->ntab + (u64)p * per_piece, 0, per_piece * sizeof(u64), c->stream));
+        else
+            hipLaunchKernelGGL(kh::table_init_kernel, dim3(grid_for(per_piece)), dim3(kh::BLOCK), 0, c->stream,
+                               c->table + (u64)p * per_piece, per_piece);
     }
     HIP_TRY(c, hipGetLastError());
     return KH_OK;
@@ -613,6 +616,7 @@ extern "C" int kh_finish(kh_ctx *c, kh_stats *st) {
         st->part_batches = c->part_batches;
         for (int i = 0; i < KH_NUM_STAGES; ++i) st->stage_ms[i] = i < ST_N ? c->stage_ms[i] : 0.0;
         st->text_scan_ms = c->text_ms;
+        st->slot_bytes = c->narrow ? 8 : 16;
     }
     if (c->trace)
         fprintf(stderr, "[kmerhip] bases=%llu kmers=%llu distinct=%llu slots=%llu load=%.3f launches=%llu kernel=%.3f ms h2d=%.3f ms | direct=%.2f p1c=%.2f p1s=%.2f p2c=%.2f p2s=%.2f region=%.2f misc=%.2f grow=%.2f\n",

@@ -393,7 +393,8 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     // a FRESH merge rewrites every region of a lazily reset table; in pieces (kh_set_region_window), the
     // pieces still to come stay unwritten until then (win_open)
     const bool windowed = c && c->win_n > 1;
-    int rc = enter(c, true, false, windowed && c->win_open && c->win_open_n == c->win_n && !(c->win_mask & (1ull << c->win_piece)));
+    // (narrow_ok: a fresh merge of packed pairs / heads builds the shard as the 8-byte image, piece by piece -- decided below)
+    int rc = enter(c, true, false, windowed && c->win_open && c->win_open_n == c->win_n && !(c->win_mask & (1ull << c->win_piece)), true);
     if (rc != KH_OK) return rc;
     const bool packed = fmt != XF_WIDE;
     if (nsenders < 1 || nsenders > (uint32_t)kh::MAX_SENDERS || !d_keys || (!packed && !d_counts) || !d_region_counts)
@@ -456,7 +457,33 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
             if (rc != KH_OK) return rc;
         }
     }
-    if ((rc = need_table(c)) != KH_OK) return rc;  // (uninitialised if new: a fresh merge writes every region -- `dirty` below)
+    // ---- the shard as the 8-byte image (round 6; shard.hip.h shard_merge_narrow_kernel) ----
+    // A FRESH merge of packed pairs or heads -- all of it, or the pieces of a window one after the other -- into a table whose
+    // 32-bit payload (the hash bits behind its level-1 digit) holds everything the region index does not: count << 32 | payload
+    // per slot, what a partitioned count leaves behind too; the readers take it as it is, everything else widens it (enter()).
+    // The count's own image is the room: every export of this merge has been made by now.
+    const bool fresh_now = windowed ? (c->table_empty || (c->win_open && !(c->win_mask & (1ull << c->win_piece)))) : c->table_empty;
+    const int xbits = 2 * (int)c->k - (int)c->shard_shift - (int)geom_of_cap(c->cap).p1_bits;
+    bool nar = packed && fresh_now && c->knobs.narrow && !c->narrow_banned && xbits >= 1 && xbits <= 32 && (c->table_empty || c->narrow);
+    if (nar && c->ntab_cap != c->cap) {
+        if (c->ntab) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->ntab);
+            c->ntab = nullptr;
+            c->ntab_cap = 0;
+        }
+        if (hipMalloc((void **)&c->ntab, c->cap * sizeof(u64)) != hipSuccess) {  // (no room for the image: the 16-byte table it is)
+            (void)hipGetLastError();
+            c->ntab = nullptr;
+            nar = false;
+        } else {
+            c->ntab_cap = c->cap;
+        }
+    }
+    if (!nar && c->narrow) {  // (a merge into a shard that IS an image: units it cannot take that way -- wide pairs, a second merge)
+        if ((rc = close_fresh_window(c)) != KH_OK || (rc = ensure_wide(c)) != KH_OK) return rc;
+    }
+    if (!nar && (rc = need_table(c)) != KH_OK) return rc;  // (uninitialised if new: a fresh merge writes every region -- `dirty` below)
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
     const u64 nregions = c->cap / kh::REGION_SLOTS;
     if ((rc = ensure_region_scratch(c, nregions)) != KH_OK) return rc;
@@ -492,7 +519,7 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
             c->win_open = true;
             c->win_open_n = c->win_n;
             c->win_mask = 0;
-            c->win_dirty = c->table_dirty;
+            c->win_dirty = nar ? true : c->table_dirty;  // (the image holds the slots of the count that was exported: always stale)
         }
         fresh = c->win_open && !(c->win_mask & (1ull << c->win_piece));  // (enter() closed a window this piece does not fit)
     }
@@ -504,7 +531,25 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
 #define KH_MERGE_LAUNCH(FRESH, FMT) \
     hipLaunchKernelGGL((kh::shard_merge_kernel<FRESH, false, FMT>), mg, mb, 0, c->stream, tg, a, c->rfail, c->rnew, c->radd, none, kh::RegionGeom{0u, 1u}, c->d_ctr, \
                        FRESH ? dirty : 0u, (uint32_t)region0)
-        if (fresh) {
+        if (nar) {
+            kh::PartGeom ng;
+            memset(&ng, 0, sizeof(ng));
+            ng.p1_bits = tg.p1_bits;
+            ng.b2 = tg.b2;
+            ng.b2_magic = kh::part_magic_of(tg.b2);
+            ng.p2_bits = kh::part_p2_bits_of(tg.b2);
+            ng.k = c->k;
+            ng.shard_shift = c->shard_shift;
+            ng.shard_index = c->shard_index;
+            // the siblings that read the same sender segments take consecutive turns on one XCD (shard.hip.h)
+            const uint32_t swz = (a.dshift > 0 && a.dshift <= 8 && nwin % (8ull << a.dshift) == 0) ? (uint32_t)a.dshift : 0u;
+            if (fmt == XF_PACKED64)
+                hipLaunchKernelGGL((kh::shard_merge_narrow_kernel<1>), mg, dim3(kh::SHARD_NT), 0, c->stream, tg, a, c->ntab, c->rfail, c->rnew, c->radd, (uint32_t)region0, swz);
+            else
+                hipLaunchKernelGGL((kh::shard_merge_narrow_kernel<2>), mg, dim3(kh::SHARD_NT), 0, c->stream, tg, a, c->ntab, c->rfail, c->rnew, c->radd, (uint32_t)region0, swz);
+            c->narrow = true;
+            c->narrow_g = ng;
+        } else if (fresh) {
             if (fmt == XF_WIDE) KH_MERGE_LAUNCH(true, 0);
             else if (fmt == XF_PACKED64) KH_MERGE_LAUNCH(true, 1);
             else KH_MERGE_LAUNCH(true, 2);

@@ -1304,6 +1304,11 @@ KH_GLOBAL __launch_bounds__(BLOCK) void ntable_lookup_kernel(const u64 *__restri
             out[i] = 0;
             continue;
         }
+        // (a shard's image identifies a key by the hash bits BELOW the owner's: a key of another shard must not alias one of this)
+        if (g.shard_shift && (kh_table_hash(key, g.k) >> (64 - g.shard_shift)) != g.shard_index) {
+            out[i] = 0;
+            continue;
+        }
         const u64 H = part_hash(g, key);
         const uint32_t pay = Pay<uint32_t>::make(key, H, g);
         const u64 region = (u64)kh_p1_of(H, g.p1_bits) * g.b2 + kh_bucket_of_x(pay, g.b2);

@@ -425,6 +425,196 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
     }
 }
 
+// ---- the shard as an 8-byte image (round 6) ------------------------------------------------------------
+// A FRESH merge of packed pairs or heads can leave the shard in the form a partitioned count leaves its table in: one
+// u64 per slot, count << 32 | x, x = the 32 hash bits behind the shard table's level-1 digit (partition.hip.h: the 8-byte
+// image; kh_finish / kh_result_* / kh_histogram / kh_lookup read it as it is, ensure_wide() converts) -- whenever those 32 bits
+// hold everything the region index does not: 2k - shard_shift - p1_bits <= 32.  Round 5's kernel above rebuilt 16-byte slots:
+// 43 GB of writes at configs[3]'s size behind a 64 KiB LDS image with 64-bit compare-and-swaps and an inverse hash per unit,
+// 4.7 ms per piece of a four-piece merge.  Here: a 32 KiB LDS image (payload and count words, 32-bit claims), 512 lanes per
+// workgroup, no inverse hash -- a unit's x is a few shifts of its own bits --, 8 bytes per slot written.
+//   * a unit whose x equals the free marker (0xFFFFFFFF: possible only when all 32 bits are significant) is summed apart and
+//     placed by one lane at the end (as region_count_kernel32 does);
+//   * counts are 32-bit in this image: a target region that took in 2^32 occurrences or more fails with code 2 (a region that is
+//     full: code 1); the host widens, grows and re-inserts those regions' units through the direct path, as for the wide form.
+// swz: log2 of the target regions that read the same sender segments (MergeArgs::dshift, when the grid divides evenly; 0 =
+// identity).  Workgroups go to the XCDs round robin by blockIdx: the 2^swz siblings are given consecutive turns on ONE XCD, so
+// that a sender segment is fetched from HBM once and found in that XCD's L2 by the other siblings (at W = 8 every segment feeds
+// eight target regions).
+constexpr int SHARD_NT = 512;
+template <int FMT>
+__global__ __launch_bounds__(SHARD_NT, 8) void shard_merge_narrow_kernel(TableGeom tg, MergeArgs a, u64 *__restrict__ ntab, uint8_t *__restrict__ rfail,
+                                                                          uint32_t *__restrict__ rnew, u64 *__restrict__ radd, uint32_t region0,
+                                                                          uint32_t swz) {
+    static_assert(FMT == 1 || FMT == 2, "packed pairs or heads");
+    constexpr int NT = SHARD_NT;
+    constexpr uint32_t FREE = 0xFFFFFFFFu;
+    __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_add[REGION_SLOTS];
+    __shared__ uint32_t s_fail, s_new, s_special, s_sp_off;
+    __shared__ u64 s_sum;
+    __shared__ u64 s_seg_lo[MAX_SENDERS];
+    __shared__ uint32_t s_seg_len[MAX_SENDERS];
+    const int tid = threadIdx.x;
+    u64 tl = blockIdx.x;
+    if (swz) {  // (see above: blockIdx -> XCD b & 7, turn b >> 3 there; siblings = consecutive turns)
+        const u64 xcd = tl & 7u, j = tl >> 3;
+        tl = ((((j >> swz) << 3) | xcd) << swz) | (j & ((1u << swz) - 1u));
+    }
+    const u64 t = tl + region0;
+    {
+        uint4 *p4 = reinterpret_cast<uint4 *>(s_pay), *a4 = reinterpret_cast<uint4 *>(s_add);
+        for (uint32_t i = tid; i < REGION_SLOTS / 4; i += NT) {
+            p4[i] = make_uint4(FREE, FREE, FREE, FREE);
+            a4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    if (tid == 0) {
+        s_fail = 0;
+        s_new = 0;
+        s_special = 0;
+        s_sp_off = FREE;
+        s_sum = 0;
+    }
+    const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
+    const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
+    if (nrl == 1 && tid < (int)a.nsenders) {
+        const u64 lo = a.src[tid].off[rl0];
+        s_seg_lo[tid] = lo;
+        s_seg_len[tid] = (uint32_t)(a.src[tid].off[rl0 + 1] - lo);
+    }
+    __syncthreads();
+    const uint32_t sw = kh_below_w(a.sgeo.b2);
+    const uint32_t tp1 = (uint32_t)(t / tg.b2), tb = (uint32_t)(t - (u64)tp1 * tg.b2);  // the target's own (level-1 digit, bucket)
+    struct SegBase {
+        u64 htop;
+        uint32_t xlo;
+    };
+    auto seg_base = [&](u64 rs) -> SegBase {  // rs: the senders' (global) region index
+        SegBase sb;
+        const uint32_t p1 = (uint32_t)(rs / a.sgeo.b2), b = (uint32_t)(rs % a.sgeo.b2);
+        sb.htop = a.sgeo.p1_bits ? (u64)p1 << (64 - a.sgeo.p1_bits) : 0ull;
+        sb.xlo = kh_xlo_k(b, a.sgeo.b2, kh_x_zero_bits(tg.k, a.sgeo.p1_bits));
+        return sb;
+    };
+    uint32_t nd = 0;
+    u64 nadd = 0;
+    auto take = [&](u64 raw0, const SegBase &sb) {
+        const uint32_t low = FMT == 1 ? (uint32_t)raw0 : ((uint32_t)raw0 & ~a.head_cmask);
+        const uint32_t addend = FMT == 1 ? (uint32_t)(raw0 >> 32) : ((uint32_t)raw0 & a.head_cmask) + 1u;
+        const uint32_t xs = sb.xlo + (sw < 32 ? low >> (32 - sw) : low);
+        const u64 below = ((u64)xs << 32) | (sw < 32 ? (u64)(uint32_t)(low << sw) : 0ull);
+        const u64 H = (sb.htop | (below >> a.sgeo.p1_bits)) << tg.shard_shift;  // the unit's placement hash in this shard
+        const uint32_t x = kh_x_of(H, tg.p1_bits);
+        if (kh_p1_of(H, tg.p1_bits) != tp1 || kh_bucket_of_x(x, tg.b2) != tb) return;  // the segment also feeds the sibling targets
+        if (addend == 0) return;  // (a packed pair without a count carries nothing; 0 would read as a free slot)
+        nadd += addend;
+        if (x == FREE) {
+            atomicAdd(&s_special, addend);
+            return;
+        }
+        uint32_t off = kh_start_of_x(x, tg.b2), probes = 0;
+        for (; probes < REGION_SLOTS; ++probes) {
+            uint32_t cur = s_pay[off];
+            if (cur == FREE) {
+                cur = atomicCAS(&s_pay[off], FREE, x);
+                if (cur == FREE) {
+                    ++nd;
+                    cur = x;
+                }
+            }
+            if (cur == x) {
+                atomicAdd(&s_add[off], addend);  // (wraps only where the region's total reaches 2^32: caught below)
+                break;
+            }
+            off = (off + 1) & REGION_MASK;
+        }
+        if (probes == REGION_SLOTS) s_fail = 1;
+    };
+    auto load0 = [&](const MergeSrc &src, u64 i) -> u64 {
+        return FMT == 2 ? (u64)reinterpret_cast<const uint32_t *>(src.keys)[i] : src.keys[i];
+    };
+    if (nrl == 1) {  // one segment per sender: four senders' unit loads in flight (as in shard_merge_kernel)
+        const SegBase sb = seg_base(a.src_region0 + rl0);
+        for (uint32_t s0 = 0; s0 < a.nsenders; s0 += 4) {
+            uint32_t len[4], maxlen = 0;
+            u64 lo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool on = s0 + q < a.nsenders;
+                len[q] = on ? s_seg_len[s0 + q] : 0u;
+                lo[q] = on ? s_seg_lo[s0 + q] : 0ull;
+                maxlen = len[q] > maxlen ? len[q] : maxlen;
+            }
+            for (uint32_t base = 0; base < maxlen; base += NT) {
+                u64 r0[4];
+                const uint32_t idx = base + tid;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    r0[q] = 0;
+                    if (len[q]) {  // uniform
+                        const MergeSrc &src = a.src[(s0 + q) < a.nsenders ? (s0 + q) : 0];
+                        r0[q] = load0(src, lo[q] + (idx < len[q] ? idx : len[q] - 1));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (idx < len[q]) take(r0[q], sb);
+            }
+        }
+    } else {  // a receiver coarser than the senders: 2^-dshift sender regions per target, segment by segment
+        for (uint32_t s = 0; s < a.nsenders; ++s)
+            for (u64 rl = rl0; rl < rl0 + nrl; ++rl) {
+                const MergeSrc src = a.src[s];
+                const u64 lo = src.off[rl], hi = src.off[rl + 1];
+                const SegBase sb = seg_base(a.src_region0 + rl);
+                for (u64 i = lo + tid; i < hi; i += NT) take(load0(src, i), sb);
+            }
+    }
+    const uint32_t dw = (uint32_t)wave_sum((u64)nd);
+    const u64 aw = wave_sum(nadd);
+    if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
+    if ((tid & 63) == 0 && aw) atomicAdd(&s_sum, aw);
+    __syncthreads();
+    if (s_special) {  // (uniform; almost never)
+        if (tid == 0 && !s_fail) {
+            uint32_t off = kh_start_of_x(FREE, tg.b2), probes = 0;
+            for (; probes < REGION_SLOTS && s_pay[off] != FREE; ++probes) off = (off + 1) & REGION_MASK;
+            if (probes == REGION_SLOTS) s_fail = 1;
+            else {
+                s_sp_off = off;
+                s_new += 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && !s_fail && s_sum >= 0xFFFFFFFFull) s_fail = 2;  // a 32-bit count may have wrapped
+    __syncthreads();
+    uint4 *o4 = reinterpret_cast<uint4 *>(ntab + t * REGION_SLOTS);
+    if (s_fail) {  // an EMPTY region of the image (it held another table's slots), the units again through the direct path
+        for (uint32_t i = tid; i < REGION_SLOTS / 2; i += NT) o4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) {
+            rfail[t] = (uint8_t)s_fail;
+            rnew[t] = 0;
+            radd[t] = 0;
+        }
+        return;
+    }
+    const uint32_t sp_off = s_sp_off, sp_cnt = s_special;
+    for (uint32_t i = tid; i < REGION_SLOTS / 2; i += NT) {  // two slots per lane: 8-byte LDS reads, one 16-byte store
+        const uint2 pp = reinterpret_cast<const uint2 *>(s_pay)[i], cc = reinterpret_cast<const uint2 *>(s_add)[i];
+        uint32_t p0 = pp.x, c0 = cc.x, p1 = pp.y, c1 = cc.y;
+        if (2 * i == sp_off) c0 = sp_cnt;      // (its payload word is the free marker already: that IS its payload)
+        if (2 * i + 1 == sp_off) c1 = sp_cnt;
+        o4[i] = make_uint4(c0 ? p0 : 0u, c0, c1 ? p1 : 0u, c1);
+    }
+    if (tid == 0) {
+        rfail[t] = 0;
+        rnew[t] = s_new;
+        radd[t] = s_sum;
+    }
+}
+
 // distinct += sum(rnew), kmers += sum(radd), part_failed += number of failed target regions
 KH_GLOBAL __launch_bounds__(BLOCK) void shard_reduce_kernel(const uint8_t *__restrict__ rfail, const uint32_t *__restrict__ rnew,
                                                              const u64 *__restrict__ radd, u64 nregions, Counters *ctr) {

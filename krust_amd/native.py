@@ -37,7 +37,8 @@ class KhStats(C.Structure):
     _fields_ = [("bases", C.c_uint64), ("kmers", C.c_uint64), ("distinct", C.c_uint64),
                 ("table_slots", C.c_uint64), ("grows", C.c_uint64), ("launches", C.c_uint64),
                 ("count_kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("part_batches", C.c_uint64),
-                ("stage_ms", C.c_double * 8), ("text_scan_ms", C.c_double)]
+                ("stage_ms", C.c_double * 8), ("text_scan_ms", C.c_double),
+                ("slot_bytes", C.c_uint64)]
 
 class KhUniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]

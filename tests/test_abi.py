@@ -35,13 +35,13 @@ def test_library_exports_every_declared_symbol(K):
         for name in declared:
             assert hasattr(raw, name), f"{name} declared in kmerhip.h but not exported by {so}"
     assert sorted(native.SYMBOLS) == declared, "native.py binding list out of sync with kmerhip.h"
-    assert K.lib().kh_abi_version() == 1
+    assert K.lib().kh_abi_version() == 2
 
 
 def test_struct_layouts(K):
     from krust_amd import native
     assert C.sizeof(native.KhConfig) == 40
-    assert C.sizeof(native.KhStats) == 64 + 8 + 64 + 8
+    assert C.sizeof(native.KhStats) == 64 + 8 + 64 + 8 + 8
 
 
 def test_strerror_and_bad_k(K):

@@ -80,6 +80,15 @@ def test_rccl_world1_through_the_c_abi(K, reads, monkeypatch, k, pieces, expect)
         assert info["owned_distinct"] == 0 and dc.result_size() == 0
 
 
+def test_more_than_64_ranks_are_refused_before_any_collective(K):
+    """every route keeps per-sender state in arrays of 64 entries; a larger world used to reach them."""
+    with K.DeviceCounter(21) as dc:
+        with pytest.raises(K.KmerHipError) as e:
+            dc.comm_init(65, 0, K.comm_unique_id())
+        assert e.value.status == K.native.KH_ERR_BAD_ARG and "64 ranks" in str(e.value)
+        dc.comm_init(1, 0, K.comm_unique_id())   # (the context is still good for a communicator)
+
+
 def test_merge_without_a_communicator_is_a_no_op(K, reads):
     ok, oc = oracle_arrays(reads, 21)
     with K.DeviceCounter(21) as dc:
@@ -122,6 +131,12 @@ def test_group_of_ranks_sharing_the_device(K, monkeypatch, world, k, pieces, exp
             assert np.array_equal(keys, fk[sel]) and np.array_equal(cnts, fc[sel]), f"shard {r} differs from the oracle"
             assert info["owned_distinct"] == int(sel.sum())
             assert np.array_equal(dc.lookup(keys[:1000]), cnts[:1000])      # lookups use the sharded placement
+            # (round 6) heads / packed pairs build the shard as the 8-byte image; its lookups must not take another shard's key
+            # for one of this shard's (the image names a key by the hash bits below the owner's)
+            if expect.startswith("regions"):
+                assert dc.finish()["slot_bytes"] == (16 if expect == "regions" else 8)
+            foreign = fk[~sel][:2000]
+            assert not dc.lookup(foreign).any()
             if expect.startswith("regions"):      # (the pairs route leaves an ordinary table that holds the rank's keys)
                 with pytest.raises(K.KmerHipError) as e:                     # a hash-range shard refuses reads until reset,
                     dc.push(b"ACGTACGTACGTACGTACGTACGTACGTACGT\n")

@@ -362,6 +362,81 @@ def test_payload_equal_to_the_lds_free_marker(K):
             assert st["distinct"] == len(want4) and dc.as_dict() == want4
 
 
+@pytest.mark.parametrize("narrow", ["1", "0"], ids=["image", "wide-only"])
+def test_shard_image_takes_the_free_marker_payload(K, monkeypatch, narrow):
+    """Round 6: kh_merge_across builds the shard as the 8-byte image (shard.hip.h shard_merge_narrow_kernel), whose LDS form
+    marks free slots with the payload 0xFFFFFFFF.  In a world of one rank at k = 21 the payload is ALL 32 hash bits behind the
+    level-1 digit, so a key can carry that very value: summed apart, placed by one lane at the end.  The keys built by
+    inverting the hash (as above), with the neighbours that probe over their slots, through RCCL's world of one."""
+    monkeypatch.setenv("KMERHIP_NARROW", narrow)
+    k = 21
+    rng = np.random.default_rng(12)
+    recs, n_special = [], 0
+    for p1 in range(1024):
+        for low, reps in ((0xFFFFFFFF, 1 + p1 % 5), (0xFFFFFFFE, 2), (0xFFFFFFFD, 1), (0xFFFFFFFC, 1)):
+            key = _table_unhash((p1 << 32) | low, k)
+            if K.canonical(key, k)[0] != key:
+                continue
+            n_special += low == 0xFFFFFFFF
+            recs += [K.unpack(key, k).encode()] * reps
+    assert n_special > 300
+    genome = _dirty(rng, 1 << 16, p_bad=0.0, lower=False)
+    recs += [genome[o:o + 150] for o in rng.integers(0, (1 << 16) - 150, size=20_000)]
+    recs = [recs[i] for i in rng.permutation(len(recs))]
+    want = oracle_dict(recs, k)
+    b, _ = flat(recs)
+    for pieces in ("1", "4"):
+        monkeypatch.setenv("KMERHIP_MERGE_PIECES", pieces)
+        with K.DeviceCounter(k, capacity_hint=3_000_000) as dc:   # 2^11 regions: packed pairs (31 bits below the region index)
+            dc.comm_init(1, 0, K.comm_unique_id())
+            dc.push(b)
+            info = dc.merge_across()
+            assert info["path"].startswith("regions-packed") and info["conserved"] == 1, info
+            st = dc.finish()
+            assert st["slot_bytes"] == (8 if narrow == "1" else 16)
+            assert st["distinct"] == len(want) and dc.as_dict() == want
+            probe = np.array(list(want)[:3000], dtype=np.uint64)
+            assert dc.lookup(probe).tolist() == [want[int(x)] for x in probe]
+
+
+def test_shard_image_counts_beyond_32_bits_fall_back(K):
+    """The image's counts are 32-bit: a target region that takes in 2^32 occurrences or more fails with code 2, the host widens the
+    shard, and that region's units go in again through the direct path -- u64 counts are the reference's range (src/run.rs:569).
+    One rank's packed export (a homopolymer with 1.66 G copies among ordinary reads) merged as THREE senders."""
+    import torch
+    k = 21
+    n_a = 1_600_000
+    poly = np.full((n_a, 151), ord("A"), dtype=np.uint8)
+    poly[:, 150] = 10
+    other, _ = O.synth_reads(SEED, 1 << 18, 150, 0, 50_000, with_qual=False)
+    m = O.OracleMap()
+    m.scan_flat(other, k, nthreads=NCPU)
+    ta = torch.from_numpy(poly.reshape(-1)).cuda()
+    to = torch.from_numpy(other.copy()).cuda()
+    torch.cuda.synchronize()
+    pushes = 8
+    with K.DeviceCounter(k, capacity_hint=6_000_000, path="partition") as dc:
+        dc.push_device(to.data_ptr(), None, to.numel())
+        for _ in range(pushes):
+            dc.push_device(ta.data_ptr(), None, ta.numel())
+        st = dc.finish()
+        R = st["table_slots"] // 4096
+        dk = torch.empty(st["distinct"], dtype=torch.int64, device="cuda")
+        rc = torch.empty(R, dtype=torch.int32, device="cuda")
+        parts, R2 = dc.export_regions_packed_device(1, dk.data_ptr(), st["distinct"], rc.data_ptr(), R)
+        assert R2 == R and int(parts.sum()) == st["distinct"]
+    one = dict(m.as_dict())
+    one[0] = one.get(0, 0) + pushes * n_a * 130
+    assert 3 * one[0] > 1 << 32 > one[0]
+    with K.DeviceCounter(k, capacity_hint=6_000_000) as dc:
+        dc.set_shard(0, 1)
+        dc.merge_regions_packed_device(R, [dk.data_ptr()] * 3, [rc.data_ptr()] * 3)
+        st = dc.finish()
+        assert st["slot_bytes"] == 16 and st["distinct"] == len(one) and st["kmers"] == 3 * sum(one.values())
+        assert dc.as_dict() == {key: 3 * c for key, c in one.items()}
+        assert int(dc.lookup(np.array([0], dtype=np.uint64))[0]) == 3 * one[0]
+
+
 def test_lazy_reset_never_leaks_old_entries(K, path):
     """kh_reset does not clear the table (the next FRESH partitioned pass rewrites every region, any
     other use clears first).  Fill the table, reset, then go through each way of using a reset table:
@@ -619,6 +694,18 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, pac
             assert st["distinct"] == len(d)
             probe = np.array(list(d)[:500] + [12345], dtype=np.uint64)  # lookups use the sharded placement
             assert dc.lookup(probe).tolist() == [d.get(int(x), 0) for x in probe]
+            # Round 6: a fresh merge of packed pairs / heads leaves the shard as the 8-byte image (count << 32 | the 32 hash bits
+            # behind the shard table's level-1 digit) wherever those 32 bits hold what the region index does not -- unless the table
+            # had to grow (overflowing regions go through the 16-byte table).  The image names a key by the hash bits BELOW the
+            # owner's: the keys of the OTHER shards must not alias one of this shard's in a lookup.
+            regions = st["table_slots"] // 4096
+            p1_bits = 10 if regions > 1024 else regions.bit_length() - 1
+            xbits = 2 * k - (nshards.bit_length() - 1) - p1_bits
+            if st["grows"] == 0:
+                assert st["slot_bytes"] == (8 if packed in (1, 2) and 1 <= xbits <= 32 else 16), (st, xbits)
+            everyone = np.array(list(want)[:: max(1, len(want) // 20_000)], dtype=np.uint64)
+            assert dc.lookup(everyone).tolist() == [d.get(int(x), 0) for x in everyone]
+            assert dict(dc.histogram()) == dict(zip(*[a.tolist() for a in np.unique(np.array(list(d.values()), dtype=np.uint64), return_counts=True)]))
         assert not (set(d) & set(merged))
         assert all(K.owner(key, k, nshards) == o for key in list(d)[:300])
         merged.update(d)

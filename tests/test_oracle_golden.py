@@ -218,6 +218,41 @@ def test_flat_buffer_equals_per_record():
         assert a == b
 
 
+@given(st.lists(st.tuples(st.text(alphabet="ACGTNacgt", min_size=0, max_size=40).map(str.encode), st.booleans()), min_size=1, max_size=8),
+       st.integers(1, 12), st.integers(0, 255), st.data())
+@settings(max_examples=300, deadline=None)
+def test_prop_flat_quality_filler_never_masks(recs, k, minq, data):
+    """`build_with_quality` (src/run.rs:505-520,538,543) over records of which some carry no qualities (`qual: None`: a FASTA
+    record is never masked), laid out as ONE flat buffer the way bindings/rust/src/lib.rs and INTEGRATION.md do it: records
+    without qualities get the filler 0xFF.  Must equal per-record processing for every threshold a u8 can hold -- with the old
+    filler '~' (126) it does not from min_quality = 94 on (94 + 33 = 127 > 126)."""
+    per, flat_b, flat_q, flat_q_old = O.OracleMap(), b"", b"", b""
+    for seq, has_q in recs:
+        q = bytes(data.draw(st.lists(st.integers(33, 126), min_size=len(seq), max_size=len(seq)))) if has_q else None
+        per.process(seq, k, qual=q, min_quality=minq if has_q else None)
+        flat_b += seq + b"\n"
+        flat_q += (q if has_q else b"\xff" * len(seq)) + b"\n"
+        flat_q_old += (q if has_q else b"~" * len(seq)) + b"\n"
+    got = O.OracleMap()
+    got.process(flat_b, k, qual=flat_q, min_quality=minq)
+    assert got.as_dict() == per.as_dict()
+    if minq < 94:  # (below that the old filler was right too: the slip needed a threshold no Phred+33 byte reaches)
+        old = O.OracleMap()
+        old.process(flat_b, k, qual=flat_q_old, min_quality=minq)
+        assert old.as_dict() == per.as_dict()
+
+
+def test_flat_quality_filler_regression_q94():
+    # one FASTA record beside -Q 94: '~' drops its windows, 0xFF keeps them (src/run.rs:543: no qualities -> no mask)
+    seq = b"ACGTACGTAC"
+    want = O.OracleMap()
+    want.process(seq, 4)
+    for filler, same in ((b"\xff", True), (b"~", False)):
+        m = O.OracleMap()
+        m.process(seq + b"\n", 4, qual=filler * len(seq) + b"\n", min_quality=94)
+        assert (m.as_dict() == want.as_dict()) is same
+
+
 def test_threaded_baseline_equals_serial():
     bases, qual = O.synth_reads(20260130, 1 << 16, 150, 0, 2000)
     offs = np.arange(2000, dtype=np.uint64) * 151
