@@ -220,6 +220,8 @@ struct kh_ctx {
     uint32_t *hot_list = nullptr;    // [regions] buckets left to hot_buckets_kernel (partition.hip.h)
     uint8_t *rtouch = nullptr;       // [regions] all zero between uses: the regions an overflow list touched (merge.hip recount_touched_heads)
     u64 *radd = nullptr;             // [regions] shard_merge_kernel: sum of the counts it put into every target region (conservation)
+    u64 *rdig = nullptr;             // shard_merge_narrow_kernel: [target][sender][3] arrival-digest partials; region_compact_*: [region][2]
+    u64 rdig_cap = 0;
     u64 *ptotal = nullptr;           // [MAX_P1] payloads per level-1 partition
     uint32_t *pcap = nullptr;        // [MAX_P1] arena capacity of that partition's buckets
     uint8_t *heavy = nullptr;        // [MAX_P1] the partition is too heavy for one workgroup: the exact kernels take it
@@ -348,10 +350,14 @@ int d2h_staged(kh_ctx *c, void *dst, const void *d_src, u64 bytes);
 enum { XF_WIDE = 0, XF_PACKED64 = 1, XF_HEADS32 = 2 };  // exchange unit formats (shard.hip.h)
 int mark_touched_regions(kh_ctx *c, const void *ovf_list, const u64 *d_ovf, u64 ovf_lim);  // (batch.hip: before the overflow list's insert ...
 int recount_touched_heads(kh_ctx *c, u64 nregions);                                           //  ... and after it)
+// d_digest (optional; 3 x nparts u64 on the device): where the compaction can digest what it writes on the way (packed pairs / heads out
+// of the 8-byte image), the sender's digests of exchange.hip are left there and *digest_done is set; otherwise the caller digests.
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap, uint32_t *d_region_counts,
-                   uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions);
+                   uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions, u64 *d_digest = nullptr, bool *digest_done = nullptr);
+// d_digest (optional; 3 x nsenders u64 on the device): where the merge kernel can digest what it reads on the way (the shard built as
+// the 8-byte image), the arrival digests of exchange.hip are written there and *digest_done is set; otherwise the caller digests.
 int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions, const void *const *d_keys,
-                  const uint64_t *const *d_counts, const uint32_t *const *d_region_counts);
+                  const uint64_t *const *d_counts, const uint32_t *const *d_region_counts, u64 *d_digest = nullptr, bool *digest_done = nullptr);
 // ---- exchange.hip
 void comm_release(kh_ctx *c);
 

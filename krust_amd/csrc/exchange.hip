@@ -281,7 +281,8 @@ int xp_gather(kh_ctx *c, int lrc, const u64 *mine, uint32_t n, u64 *all, const c
 // `send` must be complete in device memory (the export calls block until it is) and stay untouched until
 // the completion event has been waited for -- with the hub also until the closing barrier of the merge.
 // Only called right after a clean xp_gather: every rank is known to arrive.
-int xp_alltoallv(kh_ctx *c, const void *send, const u64 *soff, const u64 *slen, void *recv, const u64 *roff, const u64 *rlen) {
+// skip_self: this rank's own segment does not travel (the caller reads it where it lies: merge_across_impl, `self_direct`).
+int xp_alltoallv(kh_ctx *c, const void *send, const u64 *soff, const u64 *slen, void *recv, const u64 *roff, const u64 *rlen, bool skip_self = false) {
     Comm *cm = c->comm;
     if (cm->hub) {
         LocalHub *h = cm->hub;
@@ -292,6 +293,7 @@ int xp_alltoallv(kh_ctx *c, const void *send, const u64 *soff, const u64 *slen, 
         int rc = KH_OK;  // (no return between the two barriers: the other threads would wait for the time-out)
         for (uint32_t p = 0; p < cm->nranks && rc == KH_OK; ++p) {
             const u64 n = h->len[p][cm->rank];
+            if (skip_self && p == cm->rank) continue;
             if (n != rlen[p]) rc = fail(c, KH_ERR_STATE, "local exchange: announced and posted segment sizes differ");
             else if (n && hipMemcpyAsync((char *)recv + roff[p], (const char *)h->base[p] + h->off[p][cm->rank], n, hipMemcpyDefault,
                                          cm->xs) != hipSuccess)
@@ -312,6 +314,7 @@ int xp_alltoallv(kh_ctx *c, const void *send, const u64 *soff, const u64 *slen, 
     // transport, no message of this library comes near it now.
     constexpr u64 XP_MSG = 256ull << 20;
     for (uint32_t p = 0; p < cm->nranks && r == ncclSuccess; ++p) {
+        if (skip_self && p == cm->rank) continue;
         for (u64 o = 0; o < slen[p] && r == ncclSuccess; o += XP_MSG) {
             NCCL_CALL(cm, r, ncclSend((const char *)send + soff[p] + o, (size_t)std::min(XP_MSG, slen[p] - o), ncclUint8, (int)p, cm->nccl, cm->xs));
             what = "ncclSend";
@@ -386,7 +389,7 @@ struct DevBuf {  // scratch of one merge; freed when it goes out of scope
 // (units, sum of counts, checksum) of W unit segments of one buffer, into d_out[3 * W] (device), on the context's stream.
 // off / len in BYTES of the unit array; ub = bytes per unit (4 heads, 8 packed or the key array of wide pairs).
 int digest_units(kh_ctx *c, int fmt, const void *base, const u64 *counts, const u64 *off_bytes, const u64 *len_bytes, uint32_t W, u64 ub,
-                 uint32_t head_cmask, u64 *d_out) {
+                 uint32_t head_cmask, u64 *d_out, bool accumulate = false) {
     kh::DigestSegs segs;
     memset(&segs, 0, sizeof(segs));
     u64 maxlen = 0;
@@ -395,7 +398,7 @@ int digest_units(kh_ctx *c, int fmt, const void *base, const u64 *counts, const 
         segs.len[p] = len_bytes[p] / ub;
         maxlen = std::max(maxlen, segs.len[p]);
     }
-    HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)3 * W * sizeof(u64), c->stream));
+    if (!accumulate) HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)3 * W * sizeof(u64), c->stream));
     if (!maxlen) return KH_OK;
     const dim3 grid((unsigned)std::max<u64>(1, std::min<u64>(2048, (maxlen + kh::BLOCK * 32 - 1) / (kh::BLOCK * 32))), W), block(kh::BLOCK);
     if (fmt == XF_HEADS32) hipLaunchKernelGGL((kh::unit_digest_kernel<2>), grid, block, 0, c->stream, base, counts, segs, head_cmask, d_out);
@@ -476,6 +479,16 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         }
         return KH_OK;
     };
+    // Round 6: A RANK'S OWN SHARE DOES NOT TRAVEL.  The region routes used to send it like any other segment -- ncclSend / ncclRecv to
+    // self, a device-local copy at 0.8 TB/s that every small gather of the pipeline then queued behind (7.6 ms of the exchange
+    // stream per step at configs[3]'s size in a world of one) -- although the merge can read it where the export put it: the send
+    // buffer stays untouched until the merge is over anyway.  The merge kernels get that pointer for sender `rank`, the arrival
+    // digest of that segment is taken from there too.  (Test build: KMERHIP_SELF_SEND=1 sends it through the transport as before --
+    // what keeps RCCL's send / receive to self under test on the one-GPU box.)
+    bool self_direct = true;
+#if KH_TESTING
+    if (const char *e = getenv("KMERHIP_SELF_SEND")) self_direct = e[0] != '1';
+#endif
     bool transfers = false;  // something may be in flight on the exchange stream (into / out of this merge's buffers)
     auto done = [&](int rc) {
         if (transfers) {
@@ -518,12 +531,18 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     u64 tx_sum_total = 0, local_total = 0;
     uint32_t rx_slots = 0;  // pieces whose arrival has been digested
     auto d_tx = [&]() { return (u64 *)dig.p; };
+    bool *tx_done_ptr = nullptr;  // (set below: whether the export that has just run took its own digests -- merge.hip)
+    auto tx_done_flag = [&]() {
+        const bool v = tx_done_ptr && *tx_done_ptr;
+        if (tx_done_ptr) *tx_done_ptr = false;  // (one export, one digest)
+        return v;
+    };
     auto d_rx = [&](uint32_t i) { return (u64 *)dig.p + (size_t)3 * W * (1 + i); };
     // digests of one export's W segments (bytes so / sl inside `base`), read back: m[3 p + {units, counts, checksum}]
     auto tx_digest = [&](int fmt, const void *base, const u64 *counts, const std::vector<u64> &so, const std::vector<u64> &sl, u64 ub, uint32_t cmask,
                          std::vector<u64> &m) -> int {
         m.assign((size_t)3 * W, 0);
-        int r = digest_units(c, fmt, base, counts, so.data(), sl.data(), W, ub, cmask, d_tx());
+        int r = tx_done_flag() ? KH_OK : digest_units(c, fmt, base, counts, so.data(), sl.data(), W, ub, cmask, d_tx());
         if (r != KH_OK) return r;
         HIP_TRY(c, hipMemcpyAsync(m.data(), d_tx(), m.size() * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -536,8 +555,14 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
             for (int j = 0; j < 3; ++j) want_rx[3 * s2 + j] += all[(size_t)s2 * 3 * W + 3 * R + j];
     };
     // (test build) KMERHIP_FAULT=rank:drop_half -- the upper half of what arrived is lost, as in round 4's transport incident
-    auto sabotage = [&](void *buf, u64 bytes) {
-        if ((int)R == flt.rank && flt.point == "drop_half" && bytes) (void)hipMemsetAsync((char *)buf + bytes / 2, 0, bytes - bytes / 2, c->stream);
+    // (of every segment that travelled: byte offsets / lengths per sender inside `buf`)
+    auto sabotage = [&](void *buf, const u64 *roff, const u64 *rlen) {
+        if ((int)R != flt.rank || flt.point != "drop_half") return;
+        for (uint32_t s2 = 0; s2 < W; ++s2)
+            if (rlen[s2] && !(self_direct && s2 == R)) {
+                hipError_t e = hipMemsetAsync((char *)buf + roff[s2] + rlen[s2] / 2, 0, rlen[s2] - rlen[s2] / 2, c->stream);
+                if (c->trace) fprintf(stderr, "[kmerhip] sabotage rank %u sender %u buf %p off %llu len %llu -> %d\n", R, s2, buf, (unsigned long long)roff[s2], (unsigned long long)rlen[s2], (int)e);
+            }
     };
     // everything has been merged (kh_finish has run: the stream is idle, h_ctr current): arrived == announced == merged?
     auto verify_rx = [&]() -> int {
@@ -726,9 +751,11 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
     std::vector<uint64_t> parts(W, 0);
     uint64_t treg = 0;
     // fmt: 2 heads, 1 packed, 0 = neither fits
+    bool tx_done = false;  // the last export left its digests in d_tx() (merge.hip: taken by the compaction on the way)
+    tx_done_ptr = &tx_done;
     auto export_fmt = [&](int fmt, void *dst, u64 cap) -> int {
         const double t0 = now_ms();
-        int r = export_regions(c, fmt == 2 ? XF_HEADS32 : XF_PACKED64, W, dst, nullptr, cap, (uint32_t *)rcnt.p, nreg, parts.data(), &treg);
+        int r = export_regions(c, fmt == 2 ? XF_HEADS32 : XF_PACKED64, W, dst, nullptr, cap, (uint32_t *)rcnt.p, nreg, parts.data(), &treg, d_tx(), &tx_done);
         t_export += now_ms() - t0;
         return r;
     };
@@ -894,6 +921,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
                 t_wait += now_ms() - t0;
             }
             u64 used = 0;  // units of the send buffer in use
+            std::vector<const char *> self_ptr(npieces, nullptr);  // this rank's own segment of every piece, where the export put it
             for (uint32_t i = 0; i < npieces; ++i) {
                 void *dst = (char *)sendbuf.p + used * ub;
                 std::vector<u64> so(W), sl(W), rl(W);
@@ -921,7 +949,8 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
                 mi.sent_units += o - parts[R];
                 used += o;
                 const double t0 = now_ms();
-                lrc = xp_alltoallv(c, dst, so.data(), sl.data(), flights[i].buf.p, flights[i].roff.data(), rl.data());
+                self_ptr[i] = (const char *)dst + so[R];
+                lrc = xp_alltoallv(c, dst, so.data(), sl.data(), flights[i].buf.p, flights[i].roff.data(), rl.data(), self_direct);
                 if (lrc == KH_OK && hipEventRecord(flights[i].ev, cm->xs) != hipSuccess) lrc = fail(c, KH_ERR_HIP, "hipEventRecord(exchange)");
                 t_wait += now_ms() - t0;
                 if (lrc != KH_OK && cm->nccl) return done(lrc);  // (an RCCL failure aborted the communicator: the peers' waits end)
@@ -942,23 +971,31 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
                 t_wait += now_ms() - t0;
                 if (lrc != KH_OK) break;
                 t0 = now_ms();
-                {   // what arrived, per source (on the context's stream, in front of the merge that reads the same bytes)
+                {
                     std::vector<u64> rl(W);
                     for (uint32_t s2 = 0; s2 < W; ++s2) rl[s2] = recv_mat[(size_t)s2 * npieces + i] * ub;
-                    sabotage(flights[i].buf.p, flights[i].units * ub);
-                    lrc = digest_units(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, flights[i].buf.p, nullptr, flights[i].roff.data(), rl.data(), W, ub, head_cmask, d_rx(i));
-                    rx_slots = i + 1;
-                    if (lrc != KH_OK) break;
+                    sabotage(flights[i].buf.p, flights[i].roff.data(), rl.data());
                 }
                 std::vector<const void *> kp(W);
                 std::vector<const uint32_t *> rp(W);
                 for (uint32_t s = 0; s < W; ++s) {
-                    kp[s] = (const char *)flights[i].buf.p + flights[i].roff[s];
+                    kp[s] = (self_direct && s == R) ? self_ptr[i] : (const char *)flights[i].buf.p + flights[i].roff[s];
                     rp[s] = (const uint32_t *)rrc.p + (u64)s * per;
                 }
                 lrc = kh_set_region_window(c, i, npieces);
                 if (lrc == KH_OK) lrc = inject("merge_piece");
-                if (lrc == KH_OK) lrc = merge_regions(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, W, nreg, kp.data(), nullptr, rp.data());
+                // what arrived, per source: digested by the merge kernel on the way where it can (merge.hip), else by a pass of its own over
+                // the same bytes -- either way on the context's stream, from the very buffer the merge reads
+                bool digested = false;
+                if (lrc == KH_OK) lrc = merge_regions(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, W, nreg, kp.data(), nullptr, rp.data(), d_rx(i), &digested);
+                if (lrc == KH_OK && !digested) {
+                    std::vector<u64> rl(W), zo(W, 0), own(W, 0);
+                    for (uint32_t s2 = 0; s2 < W; ++s2) rl[s2] = recv_mat[(size_t)s2 * npieces + i] * ub;
+                    if (self_direct) std::swap(own[R], rl[R]);  // (its own segment: digested where it lies)
+                    lrc = digest_units(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, flights[i].buf.p, nullptr, flights[i].roff.data(), rl.data(), W, ub, head_cmask, d_rx(i));
+                    if (lrc == KH_OK && self_direct) lrc = digest_units(c, agreed == 2 ? XF_HEADS32 : XF_PACKED64, self_ptr[i], nullptr, zo.data(), own.data(), W, ub, head_cmask, d_rx(i), true);
+                }
+                rx_slots = i + 1;
                 mi.recv_units += flights[i].units;
                 t_merge += now_ms() - t0;
             }
@@ -1005,7 +1042,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         t_wait += now_ms() - t0;
         return KH_OK;
     };
-    auto a2a_units = [&](const void *send, const std::vector<uint64_t> &su, const std::vector<u64> &ru, u64 ub, void *recv) -> int {
+    auto a2a_units = [&](const void *send, const std::vector<uint64_t> &su, const std::vector<u64> &ru, u64 ub, void *recv, bool skip_self = false) -> int {
         std::vector<u64> so(W), sl(W), ro(W), rl(W);
         u64 a = 0, b = 0;
         for (uint32_t p = 0; p < W; ++p) {
@@ -1016,13 +1053,14 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
             rl[p] = ru[p] * ub;
             b += ru[p];
         }
-        return xp_alltoallv(c, send, so.data(), sl.data(), recv, ro.data(), rl.data());
+        return xp_alltoallv(c, send, so.data(), sl.data(), recv, ro.data(), rl.data(), skip_self);
     };
 
     if (agreed || (regions_ok && same_size)) {
         const bool wide = !agreed;
         const u64 ub = agreed == 2 ? 4 : 8;
         const u64 per = nreg / W;
+        if (wide) tx_done = false;  // (a speculative narrow export's digests say nothing about the wide one)
         if (wide && lrc == KH_OK) {  // (u64 key, u64 count): two arrays
             lrc = sendcnt.alloc(c, cap_units64 * 8, "hipMalloc(exchange send counts)");
             const double t0 = now_ms();
@@ -1058,8 +1096,8 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         note_announced();
         double t0 = now_ms();
         transfers = true;
-        lrc = a2a_units(sendbuf.p, parts, recv_units, ub, rbuf.p);
-        if (lrc == KH_OK && wide) lrc = a2a_units(sendcnt.p, parts, recv_units, 8, rbuf2.p);
+        lrc = a2a_units(sendbuf.p, parts, recv_units, ub, rbuf.p, self_direct);
+        if (lrc == KH_OK && wide) lrc = a2a_units(sendcnt.p, parts, recv_units, 8, rbuf2.p, self_direct);
         if (lrc == KH_OK) {
             std::vector<u64> so(W), sl(W, per * 4);
             for (uint32_t p = 0; p < W; ++p) so[p] = (u64)p * per * 4;
@@ -1069,11 +1107,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         if (lrc == KH_OK) lrc = xp_wait(c, nullptr, "exchange");  // the merge kernels run on the context's stream
         t_wait += now_ms() - t0;
         t0 = now_ms();
-        if (lrc == KH_OK) {
-            sabotage(rbuf.p, rtot * ub);
-            lrc = digest_units(c, xfmt, rbuf.p, wide ? (const u64 *)rbuf2.p : nullptr, seg_ro.data(), seg_rl.data(), W, ub, head_cmask, d_rx(0));
-            rx_slots = 1;
-        }
+        if (lrc == KH_OK) sabotage(rbuf.p, seg_ro.data(), seg_rl.data());
         if (lrc == KH_OK) lrc = merge_reset(c);
         if (lrc == KH_OK) lrc = kh_set_shard(c, R, W);
         if (lrc == KH_OK) lrc = inject("oneshot_merge");
@@ -1083,12 +1117,22 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
             std::vector<const uint32_t *> rp(W);
             u64 o = 0;
             for (uint32_t s = 0; s < W; ++s) {
-                kp[s] = (const char *)rbuf.p + o * ub;
-                cp[s] = wide ? (const uint64_t *)rbuf2.p + o : nullptr;
+                const bool own = self_direct && s == R;  // (this rank's own segment: read where the export put it)
+                kp[s] = own ? (const char *)sendbuf.p + seg_so[R] : (const char *)rbuf.p + o * ub;
+                cp[s] = !wide ? nullptr : own ? (const uint64_t *)sendcnt.p + seg_so[R] / ub : (const uint64_t *)rbuf2.p + o;
                 rp[s] = (const uint32_t *)rrc.p + (u64)s * per;
                 o += recv_units[s];
             }
-            lrc = merge_regions(c, wide ? XF_WIDE : (agreed == 2 ? XF_HEADS32 : XF_PACKED64), W, nreg, kp.data(), wide ? cp.data() : nullptr, rp.data());
+            bool digested = false;
+            lrc = merge_regions(c, wide ? XF_WIDE : (agreed == 2 ? XF_HEADS32 : XF_PACKED64), W, nreg, kp.data(), wide ? cp.data() : nullptr, rp.data(), d_rx(0), &digested);
+            if (lrc == KH_OK && !digested) {
+                std::vector<u64> rl(seg_rl), zo(W, 0), own(W, 0);
+                if (self_direct) std::swap(own[R], rl[R]);
+                lrc = digest_units(c, xfmt, rbuf.p, wide ? (const u64 *)rbuf2.p : nullptr, seg_ro.data(), rl.data(), W, ub, head_cmask, d_rx(0));
+                if (lrc == KH_OK && self_direct)
+                    lrc = digest_units(c, xfmt, (const char *)sendbuf.p + seg_so[R], wide ? (const u64 *)sendcnt.p + seg_so[R] / ub : nullptr, zo.data(), own.data(), W, ub, head_cmask, d_rx(0), true);
+            }
+            rx_slots = 1;
         }
         if (lrc == KH_OK) lrc = kh_finish(c, nullptr);
         if (lrc == KH_OK) lrc = verify_rx();
@@ -1103,6 +1147,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
 
     // ---- generic route: any world size, tables of any size; device-atomic re-insert ----
     {
+        tx_done = false;  // (as above)
         if (lrc == KH_OK) lrc = sendcnt.alloc(c, cap_units64 * 8, "hipMalloc(exchange send counts)");
         double t0 = now_ms();
         if (lrc == KH_OK) lrc = inject("generic_export");
@@ -1141,7 +1186,7 @@ int merge_across_impl(kh_ctx *c, kh_merge_info *info, int pre) {
         t_wait += now_ms() - t0;
         t0 = now_ms();
         if (lrc == KH_OK) {
-            sabotage(rk.p, rtot * 8);
+            sabotage(rk.p, seg_ro.data(), seg_rl.data());
             lrc = digest_units(c, XF_WIDE, rk.p, (const u64 *)rcn.p, seg_ro.data(), seg_rl.data(), W, 8, 0u, d_rx(0));
             rx_slots = 1;
         }

@@ -532,7 +532,7 @@ extern "C" void kh_destroy(kh_ctx *c) {
     }
     if (c->cstream) (void)hipStreamDestroy(c->cstream);
     void *scratch[] = {c->keysA, c->keysB, c->blocks, c->moff, c->nch, c->info, c->H2, c->O2,
-                       c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->radd, c->rtouch, c->scan_partial, c->est_set, c->merge_off, c->chunk_part, c->fill8, c->plist,
+                       c->bstart, c->bend, c->hot_list, c->ptotal, c->pcap, c->heavy, c->ovf, c->ovf_list, c->rfail, c->rnew, c->rreal, c->rheads, c->radd, c->rdig, c->rtouch, c->scan_partial, c->est_set, c->merge_off, c->chunk_part, c->fill8, c->plist,
                        c->pcount, c->pstart, c->pool_next, c->txt_raw2[0], c->txt_raw2[1], c->txt_acc[0], c->txt_acc[1], c->txt_accq[0], c->txt_accq[1], c->txt_scan_partial, c->txt_ls, c->txt_st,
                        c->txt_tnl, c->txt_tbase, c->txt_tkeep, c->txt_tout, c->txt_err};
     for (void *q : scratch)

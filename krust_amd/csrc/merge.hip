@@ -210,7 +210,8 @@ int recount_touched_heads(kh_ctx *c, u64 nregions) {
 }
 
 int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *d_counts, uint64_t cap,
-                   uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions) {
+                   uint32_t *d_region_counts, uint64_t region_cap, uint64_t *part_counts, uint64_t *table_regions, u64 *d_digest, bool *digest_done) {
+    if (digest_done) *digest_done = false;
     int rc = enter(c, true, true, false, fmt != XF_WIDE);  // (packed and heads come straight out of the 8-byte image)
     if (rc != KH_OK) return rc;
     const bool packed = fmt != XF_WIDE;
@@ -285,7 +286,28 @@ int export_regions(kh_ctx *c, int fmt, uint32_t nparts, void *d_keys, uint64_t *
     const u64 total = bounds[nparts];
     if (total > cap) return fail(c, KH_ERR_RANGE, "export arrays too small");
     if (total && (!d_keys || (!packed && !d_counts))) return fail(c, KH_ERR_BAD_ARG, "NULL output");
-    if (total && fmt == XF_HEADS32) {
+    if (total && packed && c->narrow) {
+        // out of the 8-byte image (what a rank exports right after its count): shard.hip.h region_compact_image_kernel, which also
+        // takes the sender's digest of what it writes where the caller wants one
+        const kh::SlotSrc ss = slot_src(c);
+        u64 *rdig = nullptr;
+        if (d_digest && digest_done && ensure_buf(c, &c->rdig, &c->rdig_cap, 2 * nregions, "hipMalloc(digest partials)") == KH_OK) rdig = c->rdig;
+        if (fmt == XF_HEADS32)
+            hipLaunchKernelGGL((kh::region_compact_image_kernel<true>), dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream, ss.ntab, ss.geo, (const u64 *)c->merge_off, c->k,
+                               (uint32_t)cb, d_keys, rdig);
+        else
+            hipLaunchKernelGGL((kh::region_compact_image_kernel<false>), dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream, ss.ntab, ss.geo, (const u64 *)c->merge_off, c->k,
+                               0u, d_keys, rdig);
+        HIP_TRY(c, hipGetLastError());
+        if (rdig) {
+            HIP_TRY(c, hipMemsetAsync(d_digest, 0, (size_t)3 * nparts * sizeof(u64), c->stream));
+            hipLaunchKernelGGL(kh::export_digest_reduce_kernel, dim3((unsigned)std::min<u64>(256, (per + kh::BLOCK - 1) / kh::BLOCK), nparts), dim3(kh::BLOCK), 0, c->stream,
+                               (const u64 *)rdig, (const u64 *)c->merge_off, per, d_digest);
+            HIP_TRY(c, hipGetLastError());
+            *digest_done = true;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if (total && fmt == XF_HEADS32) {
         hipLaunchKernelGGL(kh::region_compact_heads_kernel, dim3((unsigned)nregions), dim3(kh::BLOCK), 0, c->stream,
                            slot_src(c), (const u64 *)c->merge_off, c->k, (uint32_t)cb,
                            (uint32_t *)d_keys);
@@ -389,7 +411,8 @@ extern "C" int kh_export_regions_heads_device(kh_ctx *c, uint32_t nparts, uint32
 
 namespace khi {
 int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions, const void *const *d_keys,
-                  const uint64_t *const *d_counts, const uint32_t *const *d_region_counts) {
+                  const uint64_t *const *d_counts, const uint32_t *const *d_region_counts, u64 *d_digest, bool *digest_done) {
+    if (digest_done) *digest_done = false;
     // a FRESH merge rewrites every region of a lazily reset table; in pieces (kh_set_region_window), the
     // pieces still to come stay unwritten until then (win_open)
     const bool windowed = c && c->win_n > 1;
@@ -463,8 +486,15 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
     // per slot, what a partitioned count leaves behind too; the readers take it as it is, everything else widens it (enter()).
     // The count's own image is the room: every export of this merge has been made by now.
     const bool fresh_now = windowed ? (c->table_empty || (c->win_open && !(c->win_mask & (1ull << c->win_piece)))) : c->table_empty;
-    const int xbits = 2 * (int)c->k - (int)c->shard_shift - (int)geom_of_cap(c->cap).p1_bits;
-    bool nar = packed && fresh_now && c->knobs.narrow && !c->narrow_banned && xbits >= 1 && xbits <= 32 && (c->table_empty || c->narrow);
+    const kh::RegionGeom rgc = geom_of_cap(c->cap);
+    const int xbits = 2 * (int)c->k - (int)c->shard_shift - (int)rgc.p1_bits;
+    // ... and the geometry the kernel's 32-bit arithmetic covers (shard.hip.h NarrowK): targets no coarser than the senders' regions, the
+    // shard's level-1 digit ending inside or at the senders' x, no hash bits behind that x -- every table of a real exchange; the rest
+    // (receivers far smaller than the senders, tiny tables) goes through the 16-byte form as before
+    const int o_bits = (int)c->shard_shift + (int)rgc.p1_bits - (int)sgeo.p1_bits;
+    const bool geo_fast = c->cap / kh::REGION_SLOTS >= nr && o_bits >= 0 && o_bits < 32 && 2 * (int)c->k - (int)sgeo.p1_bits <= 32 && sgeo.b2 <= 1024 &&
+                          sender_regions < (1ull << 22) && c->cap / kh::REGION_SLOTS < (1ull << 22) && nsenders <= kh::SHARD_SEGS;
+    bool nar = packed && fresh_now && c->knobs.narrow && !c->narrow_banned && xbits >= 1 && xbits <= 32 && geo_fast && (c->table_empty || c->narrow);
     if (nar && c->ntab_cap != c->cap) {
         if (c->ntab) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -541,12 +571,47 @@ int merge_regions(kh_ctx *c, int fmt, uint32_t nsenders, uint64_t sender_regions
             ng.k = c->k;
             ng.shard_shift = c->shard_shift;
             ng.shard_index = c->shard_index;
-            // the siblings that read the same sender segments take consecutive turns on one XCD (shard.hip.h)
-            const uint32_t swz = (a.dshift > 0 && a.dshift <= 8 && nwin % (8ull << a.dshift) == 0) ? (uint32_t)a.dshift : 0u;
+            // a workgroup walks 2^gshift consecutive targets (shard.hip.h): up to eight, as long as their segment bounds fit the kernel's
+            // table and the grid keeps every CU busy
+            kh::NarrowK K;
+            memset(&K, 0, sizeof(K));
+            while (K.gshift < 3 && nwin % (2ull << K.gshift) == 0 && (2u << K.gshift) * nsenders <= kh::SHARD_SEGS && nwin >> (K.gshift + 1) >= 2048) ++K.gshift;
+            K.nsenders = nsenders;
+            if ((nsenders & (nsenders - 1)) == 0)
+                while ((nsenders << (K.pshift + 1)) <= (uint32_t)kh::SHARD_NT / 64) ++K.pshift;
+            K.dshift = (uint32_t)a.dshift;
+            K.b2r = tg.b2;
+            K.b2s = sgeo.b2;
+            K.magic_r = kh::part_magic_of(tg.b2);
+            K.magic_s = kh::part_magic_of(sgeo.b2);
+            K.sw_shr = (32u - kh::kh_below_w(sgeo.b2)) & 31u;
+            K.o = (uint32_t)o_bits;
+            K.o_shr = (32u - K.o) & 31u;
+            K.omask = (1u << K.o) - 1u;
+            K.rmask = tg.p1_bits ? (1u << tg.p1_bits) - 1u : 0u;
+            K.cmask = a.head_cmask;
+            K.zs_mask = (1u << kh::kh_x_zero_bits(c->k, sgeo.p1_bits)) - 1u;
+            K.stepQ = (1ull << 32) / sgeo.b2;
+            K.stepR = (uint32_t)((1ull << 32) - K.stepQ * sgeo.b2);
+            K.src_region0 = a.src_region0;
+            K.region0 = (uint32_t)region0;
+            const dim3 mgn((unsigned)(nwin >> K.gshift));
+            // the arrival digests on the way (exchange.hip): per-workgroup partial sums, folded by a small kernel
+            u64 *rdig = nullptr;
+            const uint32_t cols = 3 * nsenders;
+            if (d_digest && digest_done && ensure_buf(c, &c->rdig, &c->rdig_cap, (nwin >> K.gshift) * cols, "hipMalloc(digest partials)") == KH_OK) rdig = c->rdig;
             if (fmt == XF_PACKED64)
-                hipLaunchKernelGGL((kh::shard_merge_narrow_kernel<1>), mg, dim3(kh::SHARD_NT), 0, c->stream, tg, a, c->ntab, c->rfail, c->rnew, c->radd, (uint32_t)region0, swz);
+                hipLaunchKernelGGL((kh::shard_merge_narrow_kernel<1>), mgn, dim3(kh::SHARD_NT), 0, c->stream, K, a, c->ntab, c->rfail, c->rnew, c->radd, rdig);
             else
-                hipLaunchKernelGGL((kh::shard_merge_narrow_kernel<2>), mg, dim3(kh::SHARD_NT), 0, c->stream, tg, a, c->ntab, c->rfail, c->rnew, c->radd, (uint32_t)region0, swz);
+                hipLaunchKernelGGL((kh::shard_merge_narrow_kernel<2>), mgn, dim3(kh::SHARD_NT), 0, c->stream, K, a, c->ntab, c->rfail, c->rnew, c->radd, rdig);
+            const uint32_t gshift = K.gshift;
+            if (rdig) {
+                HIP_TRY(c, hipMemsetAsync(d_digest, 0, cols * sizeof(u64), c->stream));
+                const unsigned bs = cols * std::max(1u, 256u / cols);
+                hipLaunchKernelGGL(kh::digest_reduce_kernel, dim3((unsigned)std::min<u64>(1024, ((nwin >> gshift) * cols + bs - 1) / bs)), dim3(bs), 0, c->stream, (const u64 *)rdig,
+                                   (u64)(nwin >> gshift), cols, d_digest);
+                *digest_done = true;
+            }
             c->narrow = true;
             c->narrow_g = ng;
         } else if (fresh) {

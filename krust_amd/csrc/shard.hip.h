@@ -9,6 +9,8 @@
 #pragma once
 #include "kernels.hip.h"
 
+#include <type_traits>
+
 namespace kh {
 
 // What an export reads: the 16-byte table, or (ntab != nullptr) its 8-byte image -- count << 32 | the 32-bit payload
@@ -205,6 +207,111 @@ KH_GLOBAL __launch_bounds__(BLOCK) void region_compact_heads_kernel(SlotSrc src,
                 left -= take;
             }
         }
+    }
+}
+
+// ---- the same two compactions out of the 8-byte IMAGE (round 6) -----------------------------------------------------------
+// What a rank exports right after its count is the image, and the loop above walks a region sixteen slots deep with a scan, an
+// LDS atomic and a shuffle per step, one load in flight per lane: 1.9 ms per piece at configs[3]'s size, 3.6 TB/s.  Here a
+// lane asks for its sixteen slots at once, ONE scan over the lanes' totals places them, the units are put together in LDS and
+// leave in order as whole wave-wide stores; and the sender's digest of what it exports (exchange.hip: units, sum of counts,
+// checksum per destination) is taken on the way -- rdig[2 r] = sum of the counts region r's units carry, rdig[2 r + 1] = the wrapping
+// sum of its unit words -- instead of by a pass over the send buffer (export_digest_reduce_kernel folds them per owner).
+template <bool HEADS>
+__global__ __launch_bounds__(BLOCK) void region_compact_image_kernel(const u64 *__restrict__ ntab, RegionGeom geo, const u64 *__restrict__ roff, uint32_t k,
+                                                                      uint32_t cb, void *__restrict__ out, u64 *__restrict__ rdig) {
+    constexpr int SPL = REGION_SLOTS / BLOCK;
+    typedef typename std::conditional<HEADS, uint32_t, u64>::type UT;
+    __shared__ UT s_units[REGION_SLOTS];
+    __shared__ uint32_t s_wsum[BLOCK / 64];
+    __shared__ u64 s_dsum, s_dchk;
+    const int tid = threadIdx.x;
+    const u64 r = blockIdx.x;
+    const u64 base = roff[r];
+    const uint32_t total = (uint32_t)(roff[r + 1] - base);  // (<= 4096 x 64 units)
+    if (total == 0) {  // (an empty region, or one outside the export's window)
+        if (rdig && tid == 0) rdig[2 * r] = rdig[2 * r + 1] = 0;
+        return;
+    }
+    u64 sl[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) sl[j] = ntab[r * REGION_SLOTS + (uint32_t)j * BLOCK + tid];
+    if (tid == 0) s_dsum = s_dchk = 0;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const u64 cnt = sl[j] >> 32;
+        mine += cnt ? (HEADS ? heads_of(cnt, cb) : 1u) : 0u;
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)lane_id() >= off) incl += v;
+    }
+    if (lane_id() == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t pos = incl - mine;
+    for (int w = 0; w < (tid >> 6); ++w) pos += s_wsum[w];
+    const uint32_t xlo = kh_xlo_k((uint32_t)(r % geo.b2), geo.b2, kh_x_zero_bits(k, geo.p1_bits)), w = kh_below_w(geo.b2);
+    const uint32_t cmask = HEADS ? (1u << cb) - 1u : 0u;
+    UT *const gout = reinterpret_cast<UT *>(out) + base;
+    u64 dsum = 0, dchk = 0;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        u64 left = sl[j] >> 32;
+        if (!left) continue;
+        const uint32_t xoff = (uint32_t)sl[j] - xlo;
+        const uint32_t below = w < 32 ? xoff << (32 - w) : xoff;  // (the payload IS x: no hash bits follow it)
+        if (HEADS) {
+            const uint32_t hw = below & ~cmask;
+            while (left) {
+                const u64 take = left < (1ull << cb) ? left : (1ull << cb);
+                const uint32_t h = hw | (uint32_t)(take - 1);
+                if (pos < REGION_SLOTS) s_units[pos] = (UT)h;
+                else gout[pos] = (UT)h;  // (more units than the staging holds: a region of many large counts)
+                ++pos;
+                dsum += take;
+                dchk += h;
+                left -= take;
+            }
+        } else {
+            const u64 u = (left << 32) | below;
+            s_units[pos++] = (UT)u;  // (one unit per live slot: always fits)
+            dsum += left;
+            dchk += u;
+        }
+    }
+    if (rdig) {
+        dsum = wave_sum(dsum);
+        dchk = wave_sum(dchk);
+        if (lane_id() == 0) {
+            atomicAdd(&s_dsum, dsum);
+            atomicAdd(&s_dchk, dchk);
+        }
+    }
+    __syncthreads();
+    const uint32_t staged = total < REGION_SLOTS ? total : REGION_SLOTS;
+    for (uint32_t i = tid; i < staged; i += BLOCK) gout[i] = s_units[i];
+    if (rdig && tid == 0) {
+        rdig[2 * r] = s_dsum;
+        rdig[2 * r + 1] = s_dchk;
+    }
+}
+// out[3 p + {0, 1, 2}] += (units, sum of counts, checksum) of owner p's regions [p per, (p + 1) per); blockIdx.y = owner
+KH_GLOBAL __launch_bounds__(BLOCK) void export_digest_reduce_kernel(const u64 *__restrict__ rdig, const u64 *__restrict__ roff, u64 per, u64 *__restrict__ out) {
+    const u64 p = blockIdx.y, r0 = p * per;
+    u64 sm = 0, ck = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < per; i += (u64)gridDim.x * BLOCK) {
+        sm += rdig[2 * (r0 + i)];
+        ck += rdig[2 * (r0 + i) + 1];
+    }
+    sm = wave_sum(sm);
+    ck = wave_sum(ck);
+    if (lane_id() == 0) {
+        if (sm) atomicAdd(&out[3 * p + 1], sm);
+        if (ck) atomicAdd(&out[3 * p + 2], ck);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&out[3 * p], roff[r0 + per] - roff[r0]);
     }
 }
 
@@ -437,182 +544,275 @@ __global__ __launch_bounds__(1024, 8) void shard_merge_kernel(TableGeom tg, Merg
 //     placed by one lane at the end (as region_count_kernel32 does);
 //   * counts are 32-bit in this image: a target region that took in 2^32 occurrences or more fails with code 2 (a region that is
 //     full: code 1); the host widens, grows and re-inserts those regions' units through the direct path, as for the wide form.
-// swz: log2 of the target regions that read the same sender segments (MergeArgs::dshift, when the grid divides evenly; 0 =
-// identity).  Workgroups go to the XCDs round robin by blockIdx: the 2^swz siblings are given consecutive turns on ONE XCD, so
-// that a sender segment is fetched from HBM once and found in that XCD's L2 by the other siblings (at W = 8 every segment feeds
-// eight target regions).
+// WHAT A REGION COSTS IS INSTRUCTIONS.  The first version (one workgroup per region, the general arithmetic of the kernel above)
+// took 3.1 ms per piece at configs[3]'s size against 1.4 ms for its bytes: SQ counters, 800 vector + 1000 scalar instructions
+// per wave and region -- uniform 64-bit divisions (seg_base, kh_xlo, t / b2) done over by every wave for every region, 64-bit
+// shifts per unit -- on SIMDs that issue one instruction per four cycles whatever its kind.  So:
+//   * the geometry is the host's: NarrowK holds every shift, mask and magic number; no division on the device;
+//   * ONE WORKGROUP WALKS 2^gshift CONSECUTIVE TARGETS: their (digit, bucket) and the sender region's (digit, bucket, first x) move on
+//     by increments, all their segment bounds are fetched at once, and the units of target g + 1 are asked for before target g's
+//     write-back.  At W ranks with equal tables the W siblings that read the same sender segments are consecutive targets: one
+//     workgroup's, which finds the segments in the L1 / L2 from the second sibling on;
+//   * a unit's place in this shard is 32-bit work: xs = the sender bucket's first x + the unit's offset, x = xs << o, its level-1
+//     digit = (sender digit : xs) bits, o = shard_shift + p1_bits - the senders' p1_bits.  That needs the receiver's digit to end
+//     inside or at the senders' x (0 <= o < 32), no hash bits behind the senders' x (2k - their p1_bits <= 32: what an image
+//     exports), targets no coarser than the senders' regions -- every table of a real exchange; merge.hip sends the other
+//     geometries to the kernel above.
+// rdig (optional): [workgroup][sender][3] -- units this workgroup's targets took from that sender, the sum of their counts, the wrapping
+// sum of their raw words: the arrival digest of exchange.hip (what unit_digest_kernel computes in a pass of its own), as partial
+// sums per workgroup; every unit is taken by exactly one target, so their sum over the grid is the digest of what arrived.
 constexpr int SHARD_NT = 512;
+constexpr uint32_t SHARD_SEGS = 64;  // (targets per workgroup) x senders <= this: the bounds kept in LDS
+struct NarrowK {
+    uint32_t nsenders, pshift, gshift, dshift;  // P = 2^pshift waves per sender; 2^gshift targets per workgroup; target t reads sender-local region t >> dshift
+    uint32_t b2r, b2s;                          // buckets per level-1 partition: the shard table's, the senders' tables'
+    u64 magic_r, magic_s;                       // ceil(2^40 / b2): r / b2 == (r * magic) >> 40 for r < 2^22
+    uint32_t sw_shr;                            // a unit's x offset = its window >> this ((32 - kh_below_w(b2s)) & 31)
+    uint32_t o, o_shr, omask, rmask;            // see above; o_shr = (32 - o) & 31, omask = 2^o - 1, rmask = 2^p1_bits - 1
+    uint32_t cmask;                             // heads: 2^cb - 1 (the count field); packed pairs: 0
+    uint32_t zs_mask;                           // 2^zs - 1: the low bits of every x a k-mer's hash leaves zero (kh_xlo_k)
+    uint32_t stepR;                             // 2^32 mod b2s ...
+    u64 stepQ;                                  // ... and 2^32 / b2s: one step of the senders' bucket -> first x
+    u64 src_region0;                            // the senders' region index of this shard's first region
+    uint32_t region0;                           // first target of this launch (kh_set_region_window)
+};
 template <int FMT>
-__global__ __launch_bounds__(SHARD_NT, 8) void shard_merge_narrow_kernel(TableGeom tg, MergeArgs a, u64 *__restrict__ ntab, uint8_t *__restrict__ rfail,
-                                                                          uint32_t *__restrict__ rnew, u64 *__restrict__ radd, uint32_t region0,
-                                                                          uint32_t swz) {
+__global__ __launch_bounds__(SHARD_NT, 6) void shard_merge_narrow_kernel(NarrowK K, MergeArgs a, u64 *__restrict__ ntab, uint8_t *__restrict__ rfail,
+                                                                          uint32_t *__restrict__ rnew, u64 *__restrict__ radd, u64 *__restrict__ rdig) {
     static_assert(FMT == 1 || FMT == 2, "packed pairs or heads");
     constexpr int NT = SHARD_NT;
-    constexpr uint32_t FREE = 0xFFFFFFFFu;
+    constexpr uint32_t FREE = 0xFFFFFFFFu, NW = NT / 64, DEPTH = 4;
+    typedef typename std::conditional<FMT == 2, uint32_t, u64>::type UT;  // one exchange unit
     __shared__ __attribute__((aligned(16))) uint32_t s_pay[REGION_SLOTS];
     __shared__ __attribute__((aligned(16))) uint32_t s_add[REGION_SLOTS];
     __shared__ uint32_t s_fail, s_new, s_special, s_sp_off;
     __shared__ u64 s_sum;
-    __shared__ u64 s_seg_lo[MAX_SENDERS];
-    __shared__ uint32_t s_seg_len[MAX_SENDERS];
+    __shared__ u64 s_seg_lo[SHARD_SEGS];
+    __shared__ uint32_t s_seg_len[SHARD_SEGS];
+    __shared__ u64 s_dig[MAX_SENDERS * 3];
     const int tid = threadIdx.x;
-    u64 tl = blockIdx.x;
-    if (swz) {  // (see above: blockIdx -> XCD b & 7, turn b >> 3 there; siblings = consecutive turns)
-        const u64 xcd = tl & 7u, j = tl >> 3;
-        tl = ((((j >> swz) << 3) | xcd) << swz) | (j & ((1u << swz) - 1u));
-    }
-    const u64 t = tl + region0;
-    {
-        uint4 *p4 = reinterpret_cast<uint4 *>(s_pay), *a4 = reinterpret_cast<uint4 *>(s_add);
-        for (uint32_t i = tid; i < REGION_SLOTS / 4; i += NT) {
-            p4[i] = make_uint4(FREE, FREE, FREE, FREE);
-            a4[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
-    if (tid == 0) {
-        s_fail = 0;
-        s_new = 0;
-        s_special = 0;
-        s_sp_off = FREE;
-        s_sum = 0;
-    }
-    const u64 rl0 = a.dshift >= 0 ? (t >> a.dshift) : (t << -a.dshift);
-    const u64 nrl = a.dshift >= 0 ? 1 : (1ull << -a.dshift);
-    if (nrl == 1 && tid < (int)a.nsenders) {
-        const u64 lo = a.src[tid].off[rl0];
+    const uint32_t wave = (uint32_t)tid >> 6, lane = (uint32_t)tid & 63u;
+    const uint32_t G = 1u << K.gshift, P = 1u << K.pshift, nitems = K.nsenders << K.pshift;
+    u64 t = ((u64)blockIdx.x << K.gshift) + K.region0;  // the workgroup's first target
+    if ((uint32_t)tid < G * K.nsenders) {  // all the bounds at once (host: G x senders <= SHARD_SEGS)
+        const uint32_t g = (uint32_t)tid / K.nsenders, s = (uint32_t)tid - g * K.nsenders;
+        const u64 rl = (t + g) >> K.dshift;
+        const u64 lo = a.src[s].off[rl];
         s_seg_lo[tid] = lo;
-        s_seg_len[tid] = (uint32_t)(a.src[tid].off[rl0 + 1] - lo);
+        s_seg_len[tid] = (uint32_t)(a.src[s].off[rl + 1] - lo);  // a region holds <= 4096 keys x <= 64 heads
     }
-    __syncthreads();
-    const uint32_t sw = kh_below_w(a.sgeo.b2);
-    const uint32_t tp1 = (uint32_t)(t / tg.b2), tb = (uint32_t)(t - (u64)tp1 * tg.b2);  // the target's own (level-1 digit, bucket)
-    struct SegBase {
-        u64 htop;
-        uint32_t xlo;
-    };
-    auto seg_base = [&](u64 rs) -> SegBase {  // rs: the senders' (global) region index
-        SegBase sb;
-        const uint32_t p1 = (uint32_t)(rs / a.sgeo.b2), b = (uint32_t)(rs % a.sgeo.b2);
-        sb.htop = a.sgeo.p1_bits ? (u64)p1 << (64 - a.sgeo.p1_bits) : 0ull;
-        sb.xlo = kh_xlo_k(b, a.sgeo.b2, kh_x_zero_bits(tg.k, a.sgeo.p1_bits));
-        return sb;
-    };
-    uint32_t nd = 0;
-    u64 nadd = 0;
-    auto take = [&](u64 raw0, const SegBase &sb) {
-        const uint32_t low = FMT == 1 ? (uint32_t)raw0 : ((uint32_t)raw0 & ~a.head_cmask);
-        const uint32_t addend = FMT == 1 ? (uint32_t)(raw0 >> 32) : ((uint32_t)raw0 & a.head_cmask) + 1u;
-        const uint32_t xs = sb.xlo + (sw < 32 ? low >> (32 - sw) : low);
-        const u64 below = ((u64)xs << 32) | (sw < 32 ? (u64)(uint32_t)(low << sw) : 0ull);
-        const u64 H = (sb.htop | (below >> a.sgeo.p1_bits)) << tg.shard_shift;  // the unit's placement hash in this shard
-        const uint32_t x = kh_x_of(H, tg.p1_bits);
-        if (kh_p1_of(H, tg.p1_bits) != tp1 || kh_bucket_of_x(x, tg.b2) != tb) return;  // the segment also feeds the sibling targets
-        if (addend == 0) return;  // (a packed pair without a count carries nothing; 0 would read as a free slot)
-        nadd += addend;
-        if (x == FREE) {
-            atomicAdd(&s_special, addend);
-            return;
+    if (rdig && tid < 3 * (int)K.nsenders) s_dig[tid] = 0;
+    // the first target's (digit, bucket); the sender region it reads: (digit, bucket) and floor / remainder of (bucket << 32) / b2s
+    uint32_t tp1 = (uint32_t)((t * K.magic_r) >> 40), tb = (uint32_t)t - tp1 * K.b2r;
+    u64 rl_have = t >> K.dshift;
+    uint32_t sp1, sbk, sr;
+    u64 sq;
+    {
+        const u64 rs = K.src_region0 + rl_have;
+        sp1 = (uint32_t)((rs * K.magic_s) >> 40);
+        sbk = (uint32_t)rs - sp1 * K.b2s;
+        const uint32_t v = sbk * K.stepR, vq = (uint32_t)(((u64)v * K.magic_s) >> 40);  // (host: b2s <= 1024, so v < 2^20)
+        sq = (u64)sbk * K.stepQ + vq;
+        sr = v - vq * K.b2s;
+    }
+    // this wave's item: sender s (of P waves), every P-th group of 64 units.  The first DEPTH units of a target are asked for a
+    // target ahead (branch-free: clamped index; a wave without an item, or an empty segment, reads unit 0 of sender 0 and ignores it)
+    const bool has_item = wave < nitems;
+    const uint32_t s0 = has_item ? wave >> K.pshift : 0u, part0 = has_item ? wave - (s0 << K.pshift) : 0u;
+    UT pre[DEPTH];
+    auto prefetch = [&](uint32_t g) {
+        const uint32_t len = has_item ? s_seg_len[g * K.nsenders + s0] : 0u;
+        const u64 lo = has_item ? s_seg_lo[g * K.nsenders + s0] : 0ull;
+        const UT *const keys = reinterpret_cast<const UT *>(a.src[s0].keys);
+#pragma unroll
+        for (uint32_t q = 0; q < DEPTH; ++q) {
+            const uint32_t idx = ((part0 + q * P) << 6) + lane;
+            pre[q] = keys[len ? lo + (idx < len ? idx : len - 1) : 0ull];
         }
-        uint32_t off = kh_start_of_x(x, tg.b2), probes = 0;
-        for (; probes < REGION_SLOTS; ++probes) {
-            uint32_t cur = s_pay[off];
-            if (cur == FREE) {
-                cur = atomicCAS(&s_pay[off], FREE, x);
-                if (cur == FREE) {
-                    ++nd;
-                    cur = x;
+    };
+    __syncthreads();  // (the bounds)
+    prefetch(0);
+    uint32_t dg_n = 0, dg_s = s0;  // digest of the units this lane took from sender dg_s, over all of the workgroup's targets
+    u64 dg_sum = 0, dg_chk = 0;
+    auto flush_digest = [&]() {  // -> that sender's digest words (LDS; three wave sums)
+        const u64 n = wave_sum((u64)dg_n), sm = wave_sum(dg_sum), ck = wave_sum(dg_chk);
+        if (lane == 0) {
+            if (n) atomicAdd(&s_dig[3 * dg_s], n);
+            if (sm) atomicAdd(&s_dig[3 * dg_s + 1], sm);
+            if (ck) atomicAdd(&s_dig[3 * dg_s + 2], ck);
+        }
+        dg_n = 0;
+        dg_sum = dg_chk = 0;
+    };
+    for (uint32_t g = 0; g < G; ++g, ++t) {
+        {
+            uint4 *p4 = reinterpret_cast<uint4 *>(s_pay), *a4 = reinterpret_cast<uint4 *>(s_add);
+#pragma unroll
+            for (uint32_t i = 0; i < REGION_SLOTS / 4 / NT; ++i) {
+                p4[i * NT + tid] = make_uint4(FREE, FREE, FREE, FREE);
+                a4[i * NT + tid] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        if (tid == 0) {
+            s_fail = 0;
+            s_new = 0;
+            s_special = 0;
+            s_sp_off = FREE;
+            s_sum = 0;
+        }
+        if ((t >> K.dshift) != rl_have) {  // the next sender region (consecutive targets: its successor)
+            ++rl_have;
+            if (++sbk == K.b2s) {
+                sbk = 0;
+                ++sp1;
+                sq = 0;
+                sr = 0;
+            } else {
+                sq += K.stepQ;
+                sr += K.stepR;
+                if (sr >= K.b2s) {
+                    sr -= K.b2s;
+                    ++sq;
                 }
             }
-            if (cur == x) {
-                atomicAdd(&s_add[off], addend);  // (wraps only where the region's total reaches 2^32: caught below)
-                break;
-            }
-            off = (off + 1) & REGION_MASK;
         }
-        if (probes == REGION_SLOTS) s_fail = 1;
-    };
-    auto load0 = [&](const MergeSrc &src, u64 i) -> u64 {
-        return FMT == 2 ? (u64)reinterpret_cast<const uint32_t *>(src.keys)[i] : src.keys[i];
-    };
-    if (nrl == 1) {  // one segment per sender: four senders' unit loads in flight (as in shard_merge_kernel)
-        const SegBase sb = seg_base(a.src_region0 + rl0);
-        for (uint32_t s0 = 0; s0 < a.nsenders; s0 += 4) {
-            uint32_t len[4], maxlen = 0;
-            u64 lo[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool on = s0 + q < a.nsenders;
-                len[q] = on ? s_seg_len[s0 + q] : 0u;
-                lo[q] = on ? s_seg_lo[s0 + q] : 0ull;
-                maxlen = len[q] > maxlen ? len[q] : maxlen;
+        const uint32_t sxlo = ((uint32_t)sq + (sr != 0 ? 1u : 0u) + K.zs_mask) & ~K.zs_mask;  // kh_xlo_k of the sender region's bucket
+        const uint32_t sp1o = (sp1 << K.o) & K.rmask;  // the sender digit's share of a unit's digit in this shard
+        __syncthreads();
+        uint32_t nd = 0, nadd_lo = 0, nadd_hi = 0;
+        auto take = [&](UT raw) {
+            const uint32_t low = FMT == 1 ? (uint32_t)raw : ((uint32_t)raw & ~K.cmask);
+            const uint32_t addend = FMT == 1 ? (uint32_t)((u64)raw >> 32) : ((uint32_t)raw & K.cmask) + 1u;
+            const uint32_t xs = sxlo + (low >> K.sw_shr);
+            const uint32_t x = xs << K.o;
+            const uint32_t dgt = sp1o | ((xs >> K.o_shr) & K.omask);
+            const u64 prod = (u64)x * K.b2r;  // high word: the bucket; low word: the in-region start (kernels.hip.h)
+            if (dgt != tp1 || (uint32_t)(prod >> 32) != tb) return;  // the segment also feeds the sibling targets
+            ++dg_n;
+            dg_sum += addend;
+            dg_chk += (u64)raw;
+            if (addend == 0) return;  // (a packed pair without a count carries nothing; 0 would read as a free slot)
+            const uint32_t before = nadd_lo;
+            nadd_lo += addend;
+            nadd_hi += nadd_lo < before ? 1u : 0u;
+            if (x == FREE) {
+                atomicAdd(&s_special, addend);
+                return;
             }
-            for (uint32_t base = 0; base < maxlen; base += NT) {
-                u64 r0[4];
-                const uint32_t idx = base + tid;
+            uint32_t off = ((uint32_t)prod >> (32 - REGION_BITS)) & REGION_START_MASK;
+            const uint32_t off0 = off;
+            for (;;) {
+                uint32_t cur = s_pay[off];
+                if (cur == FREE) {
+                    cur = atomicCAS(&s_pay[off], FREE, x);
+                    if (cur == FREE) {
+                        ++nd;
+                        cur = x;
+                    }
+                }
+                if (cur == x) {
+                    atomicAdd(&s_add[off], addend);  // (wraps only where the region's total reaches 2^32: caught below)
+                    break;
+                }
+                off = (off + 1) & REGION_MASK;
+                if (off == off0) {  // every slot seen: region full
+                    s_fail = 1;
+                    break;
+                }
+            }
+        };
+        for (uint32_t it = wave; it < nitems; it += NW) {
+            const uint32_t s = it >> K.pshift, part = it - (s << K.pshift);
+            if (rdig && s != dg_s) {  // (uniform: a wave with several senders hands the last one's digest in before it goes on)
+                flush_digest();
+                dg_s = s;
+            }
+            const uint32_t len = s_seg_len[g * K.nsenders + s];
+            const u64 lo = s_seg_lo[g * K.nsenders + s];
+            const UT *const keys = reinterpret_cast<const UT *>(a.src[s].keys);
+            for (uint32_t base = part << 6; base < len; base += (DEPTH << 6) << K.pshift) {
+                if (it != wave || base != (part << 6)) {  // (uniform) every round but the one asked for a target ago
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    r0[q] = 0;
-                    if (len[q]) {  // uniform
-                        const MergeSrc &src = a.src[(s0 + q) < a.nsenders ? (s0 + q) : 0];
-                        r0[q] = load0(src, lo[q] + (idx < len[q] ? idx : len[q] - 1));
+                    for (uint32_t q = 0; q < DEPTH; ++q) {
+                        const uint32_t idx = base + ((q * P) << 6) + lane;
+                        pre[q] = keys[lo + (idx < len ? idx : len - 1)];
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (idx < len[q]) take(r0[q], sb);
+                for (uint32_t q = 0; q < DEPTH; ++q)
+                    if (base + ((q * P) << 6) + lane < len) take(pre[q]);
             }
         }
-    } else {  // a receiver coarser than the senders: 2^-dshift sender regions per target, segment by segment
-        for (uint32_t s = 0; s < a.nsenders; ++s)
-            for (u64 rl = rl0; rl < rl0 + nrl; ++rl) {
-                const MergeSrc src = a.src[s];
-                const u64 lo = src.off[rl], hi = src.off[rl + 1];
-                const SegBase sb = seg_base(a.src_region0 + rl);
-                for (u64 i = lo + tid; i < hi; i += NT) take(load0(src, i), sb);
-            }
-    }
-    const uint32_t dw = (uint32_t)wave_sum((u64)nd);
-    const u64 aw = wave_sum(nadd);
-    if ((tid & 63) == 0 && dw) atomicAdd(&s_new, dw);
-    if ((tid & 63) == 0 && aw) atomicAdd(&s_sum, aw);
-    __syncthreads();
-    if (s_special) {  // (uniform; almost never)
-        if (tid == 0 && !s_fail) {
-            uint32_t off = kh_start_of_x(FREE, tg.b2), probes = 0;
-            for (; probes < REGION_SLOTS && s_pay[off] != FREE; ++probes) off = (off + 1) & REGION_MASK;
-            if (probes == REGION_SLOTS) s_fail = 1;
-            else {
-                s_sp_off = off;
-                s_new += 1;
-            }
-        }
+        if (g + 1 < G) prefetch(g + 1);  // (in flight during the barriers, the write-back and the next target's set-up)
+        const uint32_t dw = (uint32_t)wave_sum((u64)nd);
+        const u64 aw = wave_sum(((u64)nadd_hi << 32) | nadd_lo);
+        if (lane == 0 && dw) atomicAdd(&s_new, dw);
+        if (lane == 0 && aw) atomicAdd(&s_sum, aw);
         __syncthreads();
-    }
-    if (tid == 0 && !s_fail && s_sum >= 0xFFFFFFFFull) s_fail = 2;  // a 32-bit count may have wrapped
-    __syncthreads();
-    uint4 *o4 = reinterpret_cast<uint4 *>(ntab + t * REGION_SLOTS);
-    if (s_fail) {  // an EMPTY region of the image (it held another table's slots), the units again through the direct path
-        for (uint32_t i = tid; i < REGION_SLOTS / 2; i += NT) o4[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid == 0) {
-            rfail[t] = (uint8_t)s_fail;
-            rnew[t] = 0;
-            radd[t] = 0;
+        if (s_special) {  // (uniform; almost never)
+            if (tid == 0 && !s_fail) {
+                uint32_t off = kh_start_of_x(FREE, K.b2r), probes = 0;
+                for (; probes < REGION_SLOTS && s_pay[off] != FREE; ++probes) off = (off + 1) & REGION_MASK;
+                if (probes == REGION_SLOTS) s_fail = 1;
+                else {
+                    s_sp_off = off;
+                    s_new += 1;
+                }
+            }
+            __syncthreads();
         }
-        return;
+        if (tid == 0 && !s_fail && s_sum >= 0xFFFFFFFFull) s_fail = 2;  // a 32-bit count may have wrapped
+        __syncthreads();
+        uint4 *o4 = reinterpret_cast<uint4 *>(ntab + t * REGION_SLOTS);
+        if (s_fail) {  // an EMPTY region of the image (it held another table's slots), the units again through the direct path
+            for (uint32_t i = tid; i < REGION_SLOTS / 2; i += NT) o4[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid == 0) {
+                rfail[t] = (uint8_t)s_fail;
+                rnew[t] = 0;
+                radd[t] = 0;
+            }
+        } else {
+            const uint32_t sp_off = s_sp_off, sp_cnt = s_special;
+#pragma unroll
+            for (uint32_t j = 0; j < REGION_SLOTS / 2 / NT; ++j) {  // two slots per lane: 8-byte LDS reads, one 16-byte store
+                const uint32_t i = j * NT + tid;
+                const uint2 pp = reinterpret_cast<const uint2 *>(s_pay)[i], cc = reinterpret_cast<const uint2 *>(s_add)[i];
+                uint32_t c0 = cc.x, c1 = cc.y;
+                if (2 * i == sp_off) c0 = sp_cnt;      // (its payload word is the free marker already: that IS its payload)
+                if (2 * i + 1 == sp_off) c1 = sp_cnt;
+                o4[i] = make_uint4(c0 ? pp.x : 0u, c0, c1 ? pp.y : 0u, c1);
+            }
+            if (tid == 0) {
+                rfail[t] = 0;
+                rnew[t] = s_new;
+                radd[t] = s_sum;
+            }
+        }
+        if (++tb == K.b2r) {  // the next target's (level-1 digit, bucket)
+            tb = 0;
+            ++tp1;
+        }
+        __syncthreads();  // (the image and the flags are set up again from here)
     }
-    const uint32_t sp_off = s_sp_off, sp_cnt = s_special;
-    for (uint32_t i = tid; i < REGION_SLOTS / 2; i += NT) {  // two slots per lane: 8-byte LDS reads, one 16-byte store
-        const uint2 pp = reinterpret_cast<const uint2 *>(s_pay)[i], cc = reinterpret_cast<const uint2 *>(s_add)[i];
-        uint32_t p0 = pp.x, c0 = cc.x, p1 = pp.y, c1 = cc.y;
-        if (2 * i == sp_off) c0 = sp_cnt;      // (its payload word is the free marker already: that IS its payload)
-        if (2 * i + 1 == sp_off) c1 = sp_cnt;
-        o4[i] = make_uint4(c0 ? p0 : 0u, c0, c1 ? p1 : 0u, c1);
+    if (rdig) {  // (a failed region's units too: they did arrive)
+        flush_digest();
+        __syncthreads();
+        if (tid < 3 * (int)K.nsenders) rdig[(u64)blockIdx.x * 3 * K.nsenders + tid] = s_dig[tid];
     }
-    if (tid == 0) {
-        rfail[t] = 0;
-        rnew[t] = s_new;
-        radd[t] = s_sum;
-    }
+}
+
+// out[c] += sum over the targets of rdig[target][c], c < cols = 3 x senders.  blockDim.x is a multiple of cols, so a lane stays in one
+// column however far it strides.
+KH_GLOBAL void digest_reduce_kernel(const u64 *__restrict__ rdig, u64 ntargets, uint32_t cols, u64 *__restrict__ out) {
+    __shared__ u64 s_col[3 * MAX_SENDERS];
+    const u64 total = ntargets * cols, stride = (u64)gridDim.x * blockDim.x;
+    if (threadIdx.x < cols) s_col[threadIdx.x] = 0;
+    __syncthreads();
+    u64 acc = 0;
+    for (u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) acc += rdig[e];
+    if (acc) atomicAdd(&s_col[threadIdx.x % cols], acc);
+    __syncthreads();
+    if (threadIdx.x < cols && s_col[threadIdx.x]) atomicAdd(&out[threadIdx.x], s_col[threadIdx.x]);
 }
 
 // distinct += sum(rnew), kmers += sum(radd), part_failed += number of failed target regions

@@ -49,10 +49,14 @@ def oracle_arrays(bases, k):
 
 # capacity_hint 3 M -> 2^11 regions.  k = 19: 27 hash bits below the region index -> u32 heads; k = 21: 31 bits ->
 # packed u64; k = 31: neither -> key + count; k = 11: dense counts + all-reduce
+@pytest.mark.parametrize("self_send", ["1", "0"], ids=["own-share-through-rccl", "own-share-read-in-place"])
 @pytest.mark.parametrize("k,pieces,expect", [(19, "1", "regions-heads"), (19, None, "regions-heads-x4"), (19, "8", "regions-heads-x8"),
                                              (21, "1", "regions-packed"), (21, "2", "regions-packed-x2"), (31, None, "regions"),
                                              (11, None, "dense")])
-def test_rccl_world1_through_the_c_abi(K, reads, monkeypatch, k, pieces, expect):
+def test_rccl_world1_through_the_c_abi(K, reads, monkeypatch, k, pieces, expect, self_send):
+    # (round 6: a rank's own share of the region routes is read where the export put it; KMERHIP_SELF_SEND=1 sends it through the
+    #  transport as rounds 2-5 did -- ncclSend / ncclRecv to self: the only data RCCL can carry on a one-GPU box)
+    monkeypatch.setenv("KMERHIP_SELF_SEND", self_send)
     if pieces is None:
         monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
     else:
@@ -517,6 +521,7 @@ def test_half_a_message_lost_fails_the_merge_on_every_rank(K, monkeypatch, world
 def test_rccl_world1_detects_a_lost_half_too(K, reads, monkeypatch):
     """The same through RCCL itself (a world of one: the send to self that lost half a message in round 4)."""
     monkeypatch.delenv("KMERHIP_MERGE_PIECES", raising=False)
+    monkeypatch.setenv("KMERHIP_SELF_SEND", "1")   # (round 6: by default a rank's own share does not travel -- here it must, there is nothing else)
     ok, oc = oracle_arrays(reads, 19)
     with K.DeviceCounter(19, capacity_hint=3_000_000) as dc:
         dc.comm_init(1, 0, K.comm_unique_id())

@@ -700,9 +700,14 @@ def test_region_ordered_merge_logical_shards(K, nshards, k, minq, recv_hint, pac
             # owner's: the keys of the OTHER shards must not alias one of this shard's in a lookup.
             regions = st["table_slots"] // 4096
             p1_bits = 10 if regions > 1024 else regions.bit_length() - 1
-            xbits = 2 * k - (nshards.bit_length() - 1) - p1_bits
+            sh = nshards.bit_length() - 1
+            xbits = 2 * k - sh - p1_bits
+            # (... and the geometry the image kernel's 32-bit arithmetic covers, merge.hip geo_fast: targets no coarser than the senders'
+            #  regions, the shard's level-1 digit ending inside or at the senders' x, no hash bits behind that x)
+            s_p1 = 10 if nreg > 1024 else nreg.bit_length() - 1
+            fast = regions >= nreg // nshards and 0 <= sh + p1_bits - s_p1 < 32 and 2 * k - s_p1 <= 32
             if st["grows"] == 0:
-                assert st["slot_bytes"] == (8 if packed in (1, 2) and 1 <= xbits <= 32 else 16), (st, xbits)
+                assert st["slot_bytes"] == (8 if packed in (1, 2) and 1 <= xbits <= 32 and fast else 16), (st, xbits, fast)
             everyone = np.array(list(want)[:: max(1, len(want) // 20_000)], dtype=np.uint64)
             assert dc.lookup(everyone).tolist() == [d.get(int(x), 0) for x in everyone]
             assert dict(dc.histogram()) == dict(zip(*[a.tolist() for a in np.unique(np.array(list(d.values()), dtype=np.uint64), return_counts=True)]))

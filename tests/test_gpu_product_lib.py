@@ -82,7 +82,17 @@ for kat in KATS["histogram_kats"]:                                   # tests/int
     assert tuple(kat["contains_line"]) in h, kat
     n_kat += 1
 for kat in KATS["pack_kats"]:                                        # src/kmer.rs:299-302,836-841
-    assert krust_amd.pack(kat["seq"].encode()) == kat["packed"] and krust_amd.unpack(kat["packed"], len(kat["seq"])) == kat["seq"]
+    if "seq" in kat:
+        assert krust_amd.pack(kat["seq"].encode()) == kat["packed"]
+    else:
+        assert krust_amd.unpack(kat["packed"], kat["k"]) == kat["unpacked"]
+    n_kat += 1
+for kat in KATS["from_sub_error_kats"]:                              # src/kmer.rs:646-660: the position of the first failing byte
+    try:
+        krust_amd.pack(kat["seq"].encode())
+        raise AssertionError(kat)
+    except ValueError as e:
+        assert f"invalid base '{kat['base']}'" in str(e) and str(e).endswith(f"at position {kat['position']}"), (kat, str(e))
     n_kat += 1
 for kat in KATS["canonical_kats"]:                                   # src/kmer.rs:712-728
     s = kat["seq"].encode()
@@ -144,4 +154,4 @@ def test_product_library_counts_like_the_oracle_and_has_no_test_switches():
     assert all(pth.startswith("regions") for pth in res["merge_paths"]), res
     # (round 6) every count / quality / equal-map / histogram / pack / canonical / k-range vector of tests/golden/krust_kats.json (both
     # insert paths), every derived fixture table incl. BASELINE configs[0]'s k = 5 rows, and the eight fixtures as text
-    assert res["kats"] >= 2 * (15 + 4) + 1 + 1 + 2 + 4 + 2 and res["derived_rows"] >= 9 and res["text_cases"] == 8 * 3, res
+    assert res["kats"] >= 2 * (15 + 4) + 1 + 1 + 2 + 5 + 4 + 2 and res["derived_rows"] >= 9 and res["text_cases"] == 8 * 3, res
