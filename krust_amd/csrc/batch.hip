@@ -72,7 +72,7 @@ template <>
 void launch_region<u64>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64 hot, const u64 *bend, bool, u64 skip, u64 expect) {
     const kh::TableGeom tg = table_geom(c, c->table, c->cap);
 #define KH_REGION64(FRESH, NT) \
-    hipLaunchKernelGGL((kh::region_count_kernel64<FRESH, NT>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, \
+    hipLaunchKernelGGL((kh::region_count_kernel64<FRESH, NT>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, g, \
                        (const u64 *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, (uint32_t)c->table_dirty, c->rreal, skip)
     if (c->table_empty && region_small_groups(c, expect, nregions)) KH_REGION64(true, 512);
     else if (c->table_empty) KH_REGION64(true, kh::REGION_NT);

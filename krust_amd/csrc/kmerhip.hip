@@ -412,6 +412,12 @@ GeomChoice make_geom(const kh_ctx *c, u64 cap) {
             p1 = kh::MAX_P1_BITS;
             p2 = rbits - p1;
         }
+        // (an 8-byte payload is the hash below the level-1 digit, shifted up by it -- part_common.hip.h Pay<u64> -- and all ones marks
+        //  the padding of its segments: with at least one level-1 bit a payload's low bit is zero and cannot be taken for it)
+        if (p1 == 0 && rbits >= 1 && (hbits > 32 || c->pay_mode == 64)) {
+            p1 = 1;
+            p2 = rbits - 1;
+        }
         gc.ok = p1 <= kh::MAX_P1_BITS && p2 <= kh::MAX_P2_BITS;
         b2 = p2 <= 20 ? 1u << p2 : 0u;
     } else {  // 1024 x b2 regions, b2 not a power of two: the partition passes use the table's own geometry

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(PART_NT) void part1_scatter_chunked_kernel(
                 // there the branch pays.
                 if (!QUAL || ok) {
                     if (sizeof(PT) == 8) {
-                        pay[j] = (PT)key;
                         const u64 H = kh_table_hash<MODE>(key, k) << g.shard_shift;
+                        pay[j] = (PT)(H << g.p1_bits);  // (Pay<u64>::make: the hash below the level-1 digit)
                         p1 = p1_of_hash(H, g);
                     } else if (FAST) {
                         uint32_t pw;
@@ -608,6 +608,17 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
     __shared__ uint16_t s_val[2][PART_NT + 2];
     __shared__ uint32_t s_flag;              // some rank of this flush interval did not fit its bin
     __shared__ u64 s_priv_next, s_priv_end;  // the workgroup's private range of chunk ids
+    // ---- -Q: ONLY THE LIVE CHUNKS ARE WORKED ON (round 6) ----
+    // The reference skips ahead past a masked base (src/run.rs:543-548); here a window is a lane's fixed place, and with -Q 20 on
+    // configs[2]'s reads 56 % of the windows are dead and still ran the whole window: 31.2 ms for 5.25 G k-mers where k = 21
+    // without masks spends 25.4 on 12.7 G.  Skipping a window when it is dead in EVERY lane of its wave (what round 5's review asked
+    // for) meets no such window (0.0 % of them: a wave spans seven reads; the A/B build, KH_L1_WAVE_SKIP, is 3.5 ms SLOWER) --
+    // but masked bases kill 31 windows in a row, and 47 % of the CHUNKS (a lane's sixteen windows) are dead from end to end.  So the
+    // lanes whose chunk has a countable window publish it -- (chunk index, its 16-bit window mask): one word in a list, a ballot and an
+    // LDS add per wave, one more barrier per tile --, lane i takes list entry i (a chunk's code words are in LDS already), and the
+    // waves behind the list's end sit the window phases out: they only keep the barriers and flush their partitions' bins.
+    __shared__ uint32_t s_live[QUAL ? PART_NT : 1];
+    __shared__ uint32_t s_nlive;
     uint32_t *const s_cnt = s_mem;
     u64 *const s_bin = reinterpret_cast<u64 *>(s_mem + K64_BIN_OFF / 4);
     __attribute__((address_space(3))) char *const lds = (__attribute__((address_space(3))) char *)s_mem;
@@ -617,6 +628,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
     s_cnt[MAX_P1 + tid] = K21_WASTE0;  // the lane's own waste counter
     if (tid == 0) {
         s_flag = 0;
+        s_nlive = 0;
         s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
         s_priv_end = s_priv_next + POOL_GRAB;
     }
@@ -698,7 +710,12 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
         }
         s_cnt[MAX_P1 + tid] = K21_WASTE0;
     };
-    auto p1_of = [&](u64 key) -> uint32_t { return p1_of_hash(kh_table_hash<MODE>(key, k) << g.shard_shift, g); };
+    // level-1 digit and payload (Pay<u64>::make: the hash below the digit, left-aligned) of a key
+    auto p1_pay_of = [&](u64 key, u64 &pay) -> uint32_t {
+        const u64 H = kh_table_hash<MODE>(key, k) << g.shard_shift;
+        pay = H << g.p1_bits;
+        return p1_of_hash(H, g);
+    };
     {
         const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
         stage_encode<QUAL, PART_NT>(s_code, s_val, 0, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
@@ -707,31 +724,74 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
         __syncthreads();  // B0: tile t's codes are in s_code[buf], the previous flush is over
         // (the next tile's bases: requested here, encoded before this tile's first store -- see part1_bins_kernel)
         const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
-        const WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
-        const uint32_t good = window_good(w, k, wlo);
+        WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
+        uint32_t good = window_good(w, k, wlo);
+        bool wave_busy = true;  // (uniform per wave)
+        if constexpr (QUAL) {   // the live chunks, compacted: see the banner at s_live
+            const bool live = good != 0u;
+            const u64 m = kh_ballot(live);
+            uint32_t lbase = 0;
+            if (m) {
+                if ((int)lane_id() == __builtin_ctzll(m)) lbase = atomicAdd(&s_nlive, (uint32_t)__builtin_popcountll(m));
+                lbase = (uint32_t)__shfl((int)lbase, __builtin_ctzll(m), 64);
+            }
+            if (live) s_live[lbase + mbcnt(m)] = (uint32_t)tid | (good << 16);
+            __syncthreads();  // B0': the list is whole
+            const uint32_t nlive = s_nlive;
+#ifndef KH_L1_WAVE_ORDER
+#define KH_L1_WAVE_ORDER 0  // (1: A/B builds -- the list fills the waves in the order 0, 4, 8, 12, 1, 5, ...)
+#endif
+            // Which 64 entries a wave takes: wave w the w-th.  A workgroup's sixteen waves are dealt to the CU's four SIMDs round
+            // robin, so nine busy waves are 3 + 2 + 2 + 2 of them -- and what the list buys is the busiest SIMD's three instead of
+            // four (measured, configs[2]: level 1 31.2 -> 30.4 ms; with the order 0, 4, 8, 12, 1, ... -- the nine on two SIMDs --
+            // 33.9 ms: that is also what the list itself costs, a barrier and ~40 instructions per lane and tile).
+            const uint32_t wv = (uint32_t)tid >> 6, seg = KH_L1_WAVE_ORDER ? ((wv & 3u) << 2) | (wv >> 2) : wv;
+            const uint32_t li = (seg << 6) | ((uint32_t)tid & 63u);
+            wave_busy = (seg << 6) < nlive;
+            const uint32_t item = li < nlive ? s_live[li] : 0u;  // (a lane behind the list's end: no countable window)
+            const uint32_t c = item & 0xFFFFu;
+            good = item >> 16;
+            w.hi = s_code[buf][c];
+            w.lo64 = ((u64)s_code[buf][c + 1] << 32) | s_code[buf][c + 2];
+            w.V = ((u64)s_val[buf][c] << 32) | ((u64)s_val[buf][c + 1] << 16) | (u64)s_val[buf][c + 2];
+            w.p0 = (u64)chunk_pos<PART_NT>(t, (int)c);
+        }
         const uint32_t w0 = (uint32_t)w.lo64, w1 = (uint32_t)(w.lo64 >> 32), w2 = w.hi;
         const uint32_t c0 = ASM ? rev2_complement(w2) : 0u, c1 = ASM ? rev2_complement(w1) : 0u, c2 = ASM ? rev2_complement(w0) : 0u;
         Roller roll;  // (the C++ window rolls through the lane's 16 windows in order, across the flushes)
-        if (!ASM) roll.init(w, k, wlo);
+        if (!ASM) {
+            roll.init(w, k, wlo);
+            if constexpr (QUAL) roll.good = good;  // (a lane behind the list's end holds chunk 0's words and no window)
+        }
         static_for<NFLUSH>([&](auto hc) {
             constexpr int h = decltype(hc)::value;
             uint32_t omask = 0;  // bit j: window h * FW + j has a key and its rank did not fit the bin
-            {
+            if (wave_busy) {
                 uint32_t klo[FW], khi[FW], binb[FW], rk[FW];
                 static_for<FW>([&](auto jc) {
                     constexpr int j = decltype(jc)::value, J = h * FW + j;
                     uint32_t cnta;
+#ifndef KH_L1_WAVE_SKIP
+#define KH_L1_WAVE_SKIP 0  // (1: A/B builds -- VERDICT r5 next-3: a window that is dead in EVERY lane of the wave branches around its
+                           //  hash.  Measured, round 6: profiles/README.md r06 -- such windows are 0.0 % of configs[2]'s; level 1 unchanged)
+#endif
                     if constexpr (ASM) {
-                        uint32_t flo, fhi, rlo, rhi;
-                        win_fields<KW ? KW : 31, J>(w0, w1, w2, c0, c1, c2, flo, fhi, rlo, rhi);
-                        win_hash64<KW ? KW : 31, J>(flo, fhi, rlo, rhi, good, waste, L1_ROT_MASK, klo[j], khi[j], cnta, binb[j]);
+                        if (KH_L1_WAVE_SKIP && QUAL && !kh_any(((good >> (15 - J)) & 1u) != 0u)) {
+                            klo[j] = khi[j] = 0u;
+                            cnta = waste;
+                            binb[j] = 0u;
+                        } else {
+                            uint32_t flo, fhi, rlo, rhi;
+                            win_fields<KW ? KW : 31, J>(w0, w1, w2, c0, c1, c2, flo, fhi, rlo, rhi);
+                            win_hash64<KW ? KW : 31, J>(flo, fhi, rlo, rhi, good, waste, L1_ROT_MASK, klo[j], khi[j], cnta, binb[j]);
+                        }
                     } else {
-                        u64 key;
+                        u64 key, pv = 0;
                         const bool ok = roll.next(J, key);
                         uint32_t p = 0;
-                        if (!QUAL || ok) p = p1_of(key);  // (without -Q nearly every window has a key: hashing unconditionally is cheaper than a branch per window)
-                        klo[j] = (uint32_t)key;
-                        khi[j] = (uint32_t)(key >> 32);
+                        if (!QUAL || ok) p = p1_pay_of(key, pv);  // (without -Q nearly every window has a key: hashing unconditionally is cheaper than a branch per window)
+                        klo[j] = (uint32_t)pv;
+                        khi[j] = (uint32_t)(pv >> 32);
                         cnta = ok ? 4u * p : waste;
                         binb[j] = l1_bin_offset(p);
                     }
@@ -757,6 +817,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
             }
             __syncthreads();  // B1
             const bool slow = s_flag != 0u;  // uniform
+            if (QUAL && h == 0 && tid == 0) s_nlive = 0;  // (everybody read it behind B0'; the next tile adds to it behind its B0)
             if (h == 0)  // tile t + 1's codes -> the other buffer (its bases were requested at B0)
                 stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
             flush(s_cnt[tid] >> 3);
@@ -770,17 +831,18 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
                         u64 key;
                         again.next(j, key);
                         if (j / FW == h && ((omask >> (j % FW)) & 1u)) {
-                            const uint32_t p = p1_of(key);
+                            u64 pv;
+                            const uint32_t p = p1_pay_of(key, pv);
                             u64 *const pbin = s_bin + p * CAP;
                             const int32_t r2 = (int32_t)atomicAdd(&s_cnt[p], 8u) >> 3;
                             if (r2 >= 0) {
-                                pbin[l1_word64(p, (uint32_t)r2)] = key;
+                                pbin[l1_word64(p, (uint32_t)r2)] = pv;
                             } else {
                                 const u64 ra = pbin[l1_word64(p, 8)], rb = pbin[l1_word64(p, 9)];
                                 const u64 d10 = pbin[l1_word64(p, 10)];
                                 const uint32_t split = (uint32_t)d10, lim = (uint32_t)(d10 >> 32);
                                 const uint32_t e = (uint32_t)pbin[l1_word64(p, 11)] + (uint32_t)r2;
-                                if (e < lim) pool[(e < split ? ra : rb) + e] = key;
+                                if (e < lim) pool[(e < split ? ra : rb) + e] = pv;
                             }
                         }
                     }

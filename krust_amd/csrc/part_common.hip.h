@@ -83,13 +83,23 @@ __device__ __forceinline__ u64 part_unhash(const PartGeom &g, u64 Hs) {
 template <typename PT>
 struct Pay;
 
+// Round 6: the 8-byte payload is the HASH below the level-1 digit, left-aligned (H << p1_bits) -- what the 4-byte payload has
+// always been, 32 bits wider -- not the key.  Rounds 1-5 carried the canonical key through the partition buffers and hashed it
+// three times: level 1 (the digit), level 2 (the bucket: Pay<u64>::p2), the region pass (the in-region start), each a four-round
+// Feistel per OCCURRENCE -- configs[2]'s region pass spent a quarter of its vector instructions there.  The hash is a
+// bijection: level 2's bucket is a fast-range of the payload's top word, the region pass probes on the payload and inverts the
+// hash once per NEW key at the write-back.  Costs level 1 three instructions per window (window.hip.h win_hash64: the
+// payload is put together from the two halves instead of falling out of the canonical choice).
+// KH_EMPTY_KEY (all ones) still pads 8-byte segments: a payload's low bit is zero -- make_geom gives 8-byte payloads at least
+// one level-1 bit.
 template <>
-struct Pay<u64> {  // the key itself
-    __device__ static __forceinline__ u64 make(u64 key, u64 H, const PartGeom &g) { return key; }
-    __device__ static __forceinline__ uint32_t p2(u64 pay, const PartGeom &g) {
-        return kh_bucket_of_x(kh_x_of(part_hash(g, pay), g.p1_bits), g.b2);
+struct Pay<u64> {
+    __device__ static __forceinline__ u64 make(u64 key, u64 H, const PartGeom &g) { return H << g.p1_bits; }
+    __device__ static __forceinline__ uint32_t p2(u64 pay, const PartGeom &g) { return kh_bucket_of_x((uint32_t)(pay >> 32), g.b2); }
+    __device__ static __forceinline__ u64 hash(u64 pay, uint32_t p1, const PartGeom &g) {
+        return g.p1_bits ? (((u64)p1 << (64 - g.p1_bits)) | (pay >> g.p1_bits)) : pay;
     }
-    __device__ static __forceinline__ u64 key(u64 pay, uint32_t p1, const PartGeom &g) { return pay; }
+    __device__ static __forceinline__ u64 key(u64 pay, uint32_t p1, const PartGeom &g) { return part_unhash(g, hash(pay, p1, g)); }
 };
 
 template <>

@@ -115,12 +115,14 @@ __global__ __launch_bounds__(BLOCK) void distinct_sample_kernel(ChunkSrc cs, con
         if (threadIdx.x >= fill) continue;
         const PT pay = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + threadIdx.x];
         if (sizeof(PT) == 8 && (u64)pay == KH_EMPTY_KEY) continue;
-        if (sub_bits) {  // (a 32-bit payload IS hash bits; an 8-byte one is the key: any fixed function of it will do)
+        if (sub_bits) {  // (a 32-bit payload IS hash bits; for an 8-byte one any fixed function of it will do)
             const uint32_t sel = sizeof(PT) == 4 ? (uint32_t)pay >> (32 - sub_bits) : (uint32_t)(kh_mix64((u64)pay) >> 40) >> (24 - sub_bits);
             if (sel) continue;
         }
         ++seen;
-        const u64 v = sizeof(PT) == 4 ? ((u64)(p - p_first) << 32) | (u64)pay : (u64)pay;
+        // (a payload names a key inside its partition: the sampled partition's number rides in the 8-byte payload's low bits, which are
+        //  zero -- ten of them: the sample is taken with 1024 level-1 partitions -- and beside the 4-byte one)
+        const u64 v = sizeof(PT) == 4 ? ((u64)(p - p_first) << 32) | (u64)pay : ((u64)pay | (u64)(p - p_first));
         u64 h = kh_mix64(v) & set_mask;
         uint32_t probes = 0;
         for (; probes < 128; ++probes, h = (h + 1) & set_mask) {
@@ -1435,8 +1437,11 @@ KH_GLOBAL __launch_bounds__(256) void bucket_bounds_heavy_kernel(const u64 *__re
 // side (measured: ~6 ns per same-address atomic, >100 ms per pass).  Per-region results go to
 // rnew[]/rfail[] and region_reduce_kernel folds them afterwards.
 //
-// u64 payloads (= keys): LDS image is structure-of-arrays {key[], count[]}, 64 KiB, so that 8-byte
-// key probes spread over all 64 banks.
+// u64 payloads: LDS image is structure-of-arrays {payload[], count[]}, 64 KiB, so that 8-byte
+// probes spread over all 64 banks.  Round 6: the payload is the hash below the level-1 digit (part_common.hip.h Pay<u64>), the
+// image holds payloads, a slot's place comes from the payload's top word (no hash per occurrence: rounds 1-5 hashed every key
+// a third time here), and the table's 16-byte slots get their KEYS at the write-back -- one inverse hash per slot the batch
+// claimed; a pass over a filled table turns the old keys into payloads when it loads them.
 // `dirty`: kh_reset no longer clears the table (5.5 ms for 34 GB); the first FRESH pass after it
 // overwrites every region instead, so the regions it would otherwise skip (empty bucket, overflow)
 // must be written as empty images.
@@ -1448,7 +1453,7 @@ __device__ __forceinline__ void write_empty_region(Slot *reg, int tid, int nt = 
 // NT: as for region_count_kernel32 -- a FRESH pass keeps 32-bit count deltas (48 KiB of LDS with the keys: three 512-lane
 // workgroups per CU); a pass over a filled table has the old 64-bit counts in LDS too (64 KiB, two workgroups per CU).
 template <bool FRESH, int NT = REGION_NT>
-__global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(TableGeom tg, const u64 *__restrict__ keys, const u64 *__restrict__ bend,
+__global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(TableGeom tg, PartGeom g, const u64 *__restrict__ keys, const u64 *__restrict__ bend,
                                                                    const u64 *__restrict__ bstart, uint8_t *__restrict__ rfail,
                                                                    uint32_t *__restrict__ rnew, u64 hot_threshold, uint32_t dirty,
                                                                    u64 *__restrict__ rreal, u64 skip_threshold) {
@@ -1493,6 +1498,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(T
         nreal += kbuf[j] != KH_EMPTY_KEY;
     }
     const uint4 *g4 = reinterpret_cast<const uint4 *>(reg);
+    const uint32_t p1 = part_div_b2(g, r);
 #pragma unroll
     for (uint32_t i = tid; i < REGION_SLOTS; i += NT) {
         if (FRESH) {
@@ -1500,7 +1506,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(T
             s_add[i] = 0;
         } else {
             const uint4 v = g4[i];
-            s_key[i] = ((u64)v.y << 32) | v.x;
+            const u64 ok_ = ((u64)v.y << 32) | v.x;
+            s_key[i] = ok_ == KH_EMPTY_KEY ? (u64)KH_EMPTY_KEY : Pay<u64>::make(ok_, table_hash(tg, ok_), g);  // an old key, as the payload it is probed for
             s_cnt[i] = ((u64)v.w << 32) | v.z;
         }
     }
@@ -1539,7 +1546,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(T
             if (key == KH_EMPTY_KEY) continue;
             // a probe sequence starts at a multiple of REGION_GROUP slots (start_of): the group's keys come with one LDS read;
             // a value that is not EMPTY is final, a stale EMPTY is corrected by what the compare-and-swap returns
-            uint32_t off = start_of(tg, table_hash(tg, key));
+            uint32_t off = kh_start_of_x((uint32_t)(key >> 32), g.b2);  // (`key` is the payload: its top word is x)
             uint32_t probes = 0;
             bool placed = false;
             for (; probes < REGION_SLOTS && !placed; probes += REGION_GROUP) {
@@ -1592,7 +1599,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel64(T
     uint4 *o4 = reinterpret_cast<uint4 *>(reg);
 #pragma unroll
     for (uint32_t i = tid; i < REGION_SLOTS; i += NT) {
-        const u64 kk = s_key[i], cc = FRESH ? (u64)s_add[i] : s_cnt[i];
+        const u64 pv = s_key[i], cc = FRESH ? (u64)s_add[i] : s_cnt[i];
+        const u64 kk = pv == KH_EMPTY_KEY ? (u64)KH_EMPTY_KEY : Pay<u64>::key(pv, p1, g);  // the slot's key back from its payload
         o4[i] = make_uint4((uint32_t)kk, (uint32_t)(kk >> 32), (uint32_t)cc, (uint32_t)(cc >> 32));
     }
     if (tid == 0) {

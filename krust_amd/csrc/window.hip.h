@@ -206,8 +206,10 @@ __device__ __forceinline__ void win_hash32(uint32_t flo, uint32_t fhi, uint32_t 
 #undef KH_W32_OPERANDS
 }
 
-// 64-bit payloads (the canonical key itself), K = 22..32.  Out: the key, the counter's byte address (or the waste
-// counter's), the bin's byte offset (16 payloads of 8 bytes = 128 bytes per bin: the same (L >> (K - 17)) & 0x1ff80).
+// 64-bit payloads, K = 22..32.  Out: the payload (klo, khi) -- round 6: the 2k - 10 hash bits below the level-1 digit,
+// left-aligned in 64 bits (part_common.hip.h Pay<u64>; rounds 1-5: the canonical key) --, the counter's byte address (or the
+// waste counter's), the bin's byte offset (16 payloads of 8 bytes = 128 bytes per bin: the same (L >> (K - 17)) & 0x1ff80).
+// With h = L << K | R the payload is h << (74 - 2K): low word R << S, high word L << (42 - K) | R >> (32 - S), S = 74 - 2K.
 template <int K, int J>
 __device__ __forceinline__ void win_hash64(uint32_t flo, uint32_t fhi, uint32_t rlo, uint32_t rhi, uint32_t good, uint32_t waste,
                                            uint32_t rot, uint32_t &klo, uint32_t &khi, uint32_t &cnta, uint32_t &binb) {
@@ -215,14 +217,18 @@ __device__ __forceinline__ void win_hash64(uint32_t flo, uint32_t fhi, uint32_t 
     constexpr uint32_t KM = K < 32 ? (1u << (K & 31)) - 1u : 0xFFFFFFFFu;
     constexpr int RS = 32 - K;
     constexpr int CS = K - 12, BS = K - 17;
+    constexpr int PS = 74 - 2 * K, PSR = 32 - PS, PLS = 42 - K;   // the payload's shifts (above)
     const uint32_t f0 = KH_FC0, f1 = KH_FC1, f2 = KH_FC2, f3 = KH_FC3;
     const uint64_t f64 = ((uint64_t)fhi << 32) | flo, r64 = ((uint64_t)rhi << 32) | rlo;
 #define KH_W64_OPERANDS                                                                                                   \
     : [klo] "=&v"(klo), [khi] "=&v"(khi), [cnta] "=&v"(cnta), [binb] "=&v"(binb)                                          \
     : [flo] "v"(flo), [fhi] "v"(fhi), [rlo] "v"(rlo), [rhi] "v"(rhi), [f] "v"(f64), [r] "v"(r64), [good] "v"(good),      \
       [waste] "v"(waste), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3), [rot] "s"(rot),                        \
-      [k] "n"(K & 31), [km] "n"(KM), [rs] "n"(RS), [cs] "n"(CS), [bs] "n"(BS), [gb] "n"(15 - J)                          \
+      [k] "n"(K & 31), [km] "n"(KM), [rs] "n"(RS), [cs] "n"(CS), [bs] "n"(BS), [gb] "n"(15 - J),                         \
+      [ps] "n"(PS), [psr] "n"(PSR), [pls] "n"(PLS)                                                                       \
     : "v120", "v122", "v123", "v124", "s98", "s99"
+    // the payload from the hashed halves (L = v122, R = v123): three instructions
+#define KH_W64_PAY "v_lshrrev_b32 v124, %[psr], v123\n v_lshl_or_b32 %[khi], v122, %[pls], v124\n v_lshlrev_b32 %[klo], %[ps], v123\n"
 #define KH_W64_CANON                                                \
     "v_cmp_lt_u64_e64 s[98:99], %[f], %[r]\n"                       \
     "v_cndmask_b32_e64 %[klo], %[rlo], %[flo], s[98:99]\n"          \
@@ -231,16 +237,17 @@ __device__ __forceinline__ void win_hash64(uint32_t flo, uint32_t fhi, uint32_t 
 #define KH_W64_SPLIT_K32 "v_mov_b32 v122, %[khi]\n v_mov_b32 v123, %[klo]\n"
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (K <= 24) {
-        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS24 KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
+        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS24 KH_W64_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
     } else if constexpr (K < 32) {
-        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS32 KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
+        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS32 KH_W64_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
     } else {
-        asm(KH_W64_CANON KH_W64_SPLIT_K32 KH_WIN_ROUNDS32_K32 KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
+        asm(KH_W64_CANON KH_W64_SPLIT_K32 KH_WIN_ROUNDS32_K32 KH_W64_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
     }
 #else
-    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)CS; (void)BS;
+    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)CS; (void)BS; (void)PS; (void)PSR; (void)PLS;
     klo = khi = cnta = binb = 0;
 #endif
+#undef KH_W64_PAY
 #undef KH_W64_SPLIT_K32
 #undef KH_W64_SPLIT
 #undef KH_W64_CANON
