@@ -34,6 +34,9 @@ struct RangeArgs {
 // Internal result of partition_batch: the level-1 pool, sized from RangeArgs::survive, ran out -- nothing but the pool
 // was written; the caller runs the same tiles again sized for every window.
 constexpr int KH_RETRY_FULL_SIZE = 1000;
+// ... and: the batch was sized on the assumption that level 2 narrows its 8-byte payloads (15 instead of 20 bytes per window), it
+// cannot after all, and the 8-byte level-2 output does not fit beside the pool: the caller runs the same tiles again in smaller batches.
+constexpr int KH_RETRY_WIDE = 1001;
 
 // payloads to make room for when at most n windows exist and a share `survive` of them is expected to be countable:
 // an eighth over the estimate plus a 64th of the windows (the sample is a 64th of the tiles)
@@ -89,7 +92,7 @@ void launch_region<uint32_t>(kh_ctx *c, const kh::PartGeom &g, u64 nregions, u64
 #define KH_REGION32_P(FRESH, NARROW, NT, DIRTY, CB, RH, P2) \
     hipLaunchKernelGGL((kh::region_count_kernel32<FRESH, NARROW, NT, P2>), dim3((unsigned)nregions), dim3(NT), 0, c->stream, tg, g, \
                        (const uint32_t *)c->keysB, bend, (const u64 *)c->bstart, c->rfail, c->rnew, hot, DIRTY, CB, RH, c->d_ctr, c->rreal, c->ntab, skip, \
-                       bend == (const u64 *)c->bend ? (const uint8_t *)c->heavy : (const uint8_t *)nullptr)  /* (arena level 2: which partitions the exact kernels took) */
+                       (bend == (const u64 *)c->bend && g.p1_bits <= kh::MAX_P1_BITS) ? (const uint8_t *)c->heavy : (const uint8_t *)nullptr)  /* (arena level 2: which partitions the exact kernels took; a narrowed batch's "partitions" are regions: no flags) */
 #define KH_REGION32(FRESH, NARROW, NT, DIRTY, CB, RH)                     \
     do {                                                                  \
         if (pow2) KH_REGION32_P(FRESH, NARROW, NT, DIRTY, CB, RH, true);  \
@@ -127,368 +130,13 @@ u64 policy_cap(double keys) {
     return round_cap(std::max(want, (double)(2048ull * kh::REGION_SLOTS)));
 }
 
+// What follows level 2 -- the region pass, the overflow list, failed and hot buckets, growth -- for payloads of type PT in `bufB`,
+// bucket r's in [bstart[r], bend[r]).  A function of its own since round 6: a batch whose level 2 NARROWED its 8-byte payloads to
+// the 4 bytes below the region index (partition_batch) goes on here as a 32-bit batch over the virtual geometry g = (p1_bits =
+// log2 regions, b2 = 1).
 template <typename PT>
-int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u64 ntiles, bool size_from_sample, double range_scale) {
-    constexpr bool CHUNKED = true;  // level 1 always goes into the chunk pool (partition.hip.h)
-    kh::PartGeom &g = gc.g;
-    const u64 P1 = 1ull << g.p1_bits;
-    const u64 n_all = ntiles * kh::PART_TILE;  // every window of these tiles
-    const bool estimated = ra.survive < 1.0;
-    const u64 n_ub = sized_for(n_all, ra.survive);  // upper bound on keys (an estimate when `estimated`: checked after level 1)
-    // chunk pool: every payload + one partial chunk per (workgroup, partition) + the unused tail of
-    // every workgroup's private ranges
-    const u64 pool_chunks = (n_ub / kh::CHUNK_PAY) + (n_ub / kh::CHUNK_PAY) / 24 + (u64)PART_G1 * (P1 + kh::POOL_GRAB) + 1024;
-    const u64 max_blocks = pool_chunks / kh::CPB + P1 + 1;
+int finish_batch(kh_ctx *c, const kh::PartGeom &g, PT *bufB, const u64 *bend, u64 nregions, u64 n_all, u64 n_ub, u64 ovf_lim, bool heavy_exact) {
     int rc;
-    // ---- what level 1 needs: the pool and its metadata (independent of the table's size) ----
-    if (!c->moff) {  // fixed-size scratch, allocated once
-        u64 z = 0;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->moff, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(moff)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->nch, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(nch)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->info, &z, 8, "hipMalloc(info)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->pcount, &z, (u64)kh::MAX_P1, "hipMalloc(pcount)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->pstart, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(pstart)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->pool_next, &z, 1, "hipMalloc(pool_next)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->ptotal, &z, (u64)kh::MAX_P1, "hipMalloc(ptotal)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->pcap, &z, (u64)kh::MAX_P1, "hipMalloc(pcap)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->ovf, &z, 4, "hipMalloc(ovf)")) != KH_OK) return rc;
-        z = 0;
-        if ((rc = ensure_buf(c, &c->heavy, &z, (u64)kh::MAX_P1, "hipMalloc(heavy)")) != KH_OK) return rc;
-    }
-    if ((rc = ensure_buf(c, &c->blocks, &c->blocks_cap, max_blocks, "hipMalloc(blocks)")) != KH_OK) return rc;
-    if (c->pool_cap < pool_chunks) {
-        u64 z = c->chunk_part ? c->pool_cap : 0;
-        if ((rc = ensure_buf(c, &c->chunk_part, &z, pool_chunks, "hipMalloc(chunk_part)")) != KH_OK) return rc;
-        z = c->fill8 ? c->pool_cap : 0;
-        if ((rc = ensure_buf(c, &c->fill8, &z, pool_chunks, "hipMalloc(fill8)")) != KH_OK) return rc;
-        z = c->plist ? c->pool_cap : 0;
-        if ((rc = ensure_buf(c, &c->plist, &z, pool_chunks, "hipMalloc(plist)")) != KH_OK) return rc;
-        c->pool_cap = pool_chunks;
-    }
-    const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);  // A: the level-1 pool
-    if (c->key_cap < a_bytes) {  // (capacities in BYTES)
-        u64 z = c->keysA ? c->key_cap : 0;
-        if ((rc = ensure_buf(c, &c->keysA, &z, a_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
-        c->key_cap = a_bytes;
-    }
-    // the sample: enough partitions for ~2 M payloads (one partition of a large batch), a set with room for all of them
-    const uint32_t est_np = size_from_sample ? (uint32_t)std::min<u64>(16, std::max<u64>(1, (2ull << 20) / std::max<u64>(1, n_ub / P1))) : 0u;
-    constexpr uint32_t EST_P0 = 517;  // (not partition 0: the hash of A^k is 0 -- its partition is the one a homopolymer makes heavy)
-    u64 est_slots = 0;
-    uint32_t est_sub = 0;  // ... and of a large batch's partition only the keys with est_sub zero bits behind the level-1 digit
-    if (size_from_sample) {
-        while (est_sub < 6 && (n_ub / P1) >> (est_sub + 1) >= (1ull << 19)) ++est_sub;
-        est_slots = 1ull << 16;
-        while (est_slots < 3 * (u64)est_np * ((n_ub / P1 >> est_sub) + 1)) est_slots *= 2;
-        if ((rc = ensure_buf(c, &c->est_set, &c->est_set_cap, est_slots, "hipMalloc(distinct sample)")) != KH_OK) return rc;
-    }
-
-    const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
-    const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
-    const dim3 b1(kh::PART_NT);
-    kh::ChunkSrc cs;
-    cs.pay = c->keysA;
-    cs.plist = c->plist;
-    cs.fill8 = c->fill8;
-    const uint32_t force_wide = c->knobs.p2_force_wide ? 1u : 0u;
-    bool have_total = false;  // the host knows how many payloads level 1 produced (it synchronised to read them)
-    u64 batch_total = 0;
-
-    {
-        {
-            StageTimer t(c, ST_MISC);
-            HIP_TRY(c, hipMemsetAsync(c->chunk_part, 0xFF, pool_chunks * sizeof(uint16_t), c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->fill8, 0xFF, pool_chunks, c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->pcount, 0, kh::MAX_P1 * sizeof(uint32_t), c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->pool_next, 0, sizeof(u64), c->stream));
-        }
-        {
-            StageTimer t(c, ST_P1_SCATTER);
-            // level 1 lives in translation units of its own (level1_api.h): one kernel per k for the written-out window
-            kh::L1Launch l1;
-            l1.stream = c->stream;
-            l1.grid = (unsigned)PART_G1;
-            l1.abase = ra.abase;
-            l1.qbase = ra.qbase;
-            l1.qaligned = ra.qaligned;
-            l1.use_qual = ra.use_qual;
-            l1.vbeg = ra.vbeg;
-            l1.vend = ra.vend;
-            l1.wlo = ra.wlo;
-            l1.tile0 = tile0;
-            l1.ntiles = ntiles;
-            l1.tiles_per_block = tpb;
-            l1.k = c->k;
-            l1.thr = thr;
-            l1.g = g;  // (level 1 reads p1_bits, k and the shard fields: not b2)
-            l1.pool = c->keysA;
-            l1.chunk_part = c->chunk_part;
-            l1.fill8 = c->fill8;
-            l1.pool_next = c->pool_next;
-            l1.pool_chunks = pool_chunks;
-            l1.ctr = c->d_ctr;
-            // KMERHIP_GENERIC_K=1: the C++ window where a written-out one exists; KMERHIP_P1_BINS=0: round 1's tile-sorting kernel (both for A/B)
-            l1.generic_k = c->knobs.generic_k;
-            l1.legacy = c->knobs.p1_legacy;
-            if (sizeof(PT) == 4) kh::launch_level1_32(l1, nullptr);
-            else kh::launch_level1_64(l1, nullptr);
-        }
-#if KH_ABL
-        if (c->knobs.stop_after_p1) {  // ablation builds only: time level 1 alone (its output is garbage)
-            HIP_TRY(c, hipGetLastError());
-            return sync_counters(c);
-        }
-#endif
-        {
-            StageTimer t(c, ST_MISC);
-            HIP_TRY(c, hipMemsetAsync(c->ptotal, 0, kh::MAX_P1 * sizeof(u64), c->stream));
-            hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
-                               (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, c->ptotal);
-            if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
-            // (the plan's moff / mbase depend on b2: it runs again below once that is final; this run sets the chunk list's cursors)
-            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
-                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)nullptr);
-            hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
-                               (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
-            if (size_from_sample) {
-                u64 *est_out = c->info + 4;  // [distinct, payloads seen, no room]
-                HIP_TRY(c, hipMemsetAsync(est_out, 0, 3 * sizeof(u64), c->stream));
-                HIP_TRY(c, hipMemsetAsync(c->est_set, 0xFF, est_slots * sizeof(u64), c->stream));
-                hipLaunchKernelGGL(kh::distinct_sample_kernel<PT>, dim3(1024), dim3(kh::BLOCK), 0, c->stream, cs, (const u64 *)c->pstart,
-                                   EST_P0 % (uint32_t)(P1 - est_np + 1), est_np, est_sub, c->est_set, est_slots - 1, est_out);
-            }
-        }
-        if (estimated || size_from_sample) {
-            // Everything behind the pool is sized for n_ub payloads, an estimate: are there more?  (The pool itself has
-            // slack -- a partial chunk per workgroup and partition -- so level 1 may well have found room for them: what
-            // counts is the total, from chunk_hist_kernel; and payloads level 1 found no room for are in ctr->failed,
-            // which is 0 on entry.)  Nothing but the pool and its chunk lists has been written yet.
-            std::vector<u64> pt(kh::MAX_P1);
-            u64 lost = 0, total = 0, est[3] = {0, 0, 0};
-            HIP_TRY(c, hipMemcpyAsync(pt.data(), c->ptotal, kh::MAX_P1 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(&lost, &c->d_ctr->failed, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-            if (size_from_sample) HIP_TRY(c, hipMemcpyAsync(est, c->info + 4, sizeof(est), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            for (u64 p = 0; p < P1; ++p) total += pt[p];
-            have_total = true;
-            batch_total = total;
-            if (estimated && (lost || total > n_ub)) {
-                HIP_TRY(c, hipMemsetAsync(&c->d_ctr->failed, 0, sizeof(u64), c->stream));
-                if (c->trace)
-                    fprintf(stderr, "[kmerhip] sized for %.3f of the windows (%llu payloads), found %llu%s: again at full size\n", ra.survive, n_ub,
-                            total, lost ? " and more that did not fit the pool" : "");
-                return KH_RETRY_FULL_SIZE;
-            }
-            if (size_from_sample) {
-                // distinct keys of the batch: the sample's, scaled by payloads (its partitions hold est[1] of `total`) -- and of the
-                // range, scaled by windows: an upper bound (later batches repeat keys of this one)
-                double keys = (double)total;  // no usable sample: as if every payload were a new key (round 3's sizing)
-                // (scaled by KEY SPACE -- the sample is every occurrence of an exact 1 / (1024 / np x 2^sub) of it -- not by payloads: a
-                //  sampled partition that holds a repeat family's heavy keys has more payloads, not more keys; an hg-shaped input
-                //  came out 21 % low that way)
-                if (est[2] == 0 && est[1] > 0) keys = std::min((double)total, (double)est[0] * ((double)P1 / (double)est_np) * (double)(1u << est_sub));
-                c->est_keys = (u64)(keys * range_scale) + 1;
-                const double load_now = (double)c->est_keys / (double)c->cap;
-                u64 newcap = c->cap;
-                // (a capacity hint is the caller's word on ALL the keys to come, this range being perhaps the first of many: a hinted
-                //  table is never made smaller, only larger when the sample says the hint cannot be right)
-                if (load_now > LOAD_KEEP_MAX || (!c->hinted && (load_now < LOAD_KEEP_MIN || c->cap < 2048ull * kh::REGION_SLOTS))) newcap = policy_cap((double)c->est_keys);
-                if (c->hinted && newcap < c->cap) newcap = c->cap;
-                // two levels of partitioning reach 1024 x 1024 regions: beyond that (more than ~3 G keys in one range) the table
-                // grows by rehash after the batch and later batches take the direct path, as before
-                newcap = std::min<u64>(newcap, (u64)kh::MAX_P1 * kh::MAX_B2 * kh::REGION_SLOTS);
-                size_t fr = 0, tot = 0;
-                if (hipMemGetInfo(&fr, &tot) == hipSuccess) {  // never beyond a third of what is free (the partition buffers of this batch come next)
-                    u64 room = ((u64)fr + (c->table ? c->cap * sizeof(Slot) : 0) + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
-                    if (c->knobs.table_room_mb) room = c->knobs.table_room_mb << 20;  // (test build: as if that were all the room)
-                    // (strictly smaller at every turn: round_cap() rounds UP, and 0.8 x a power of two -- every size up to 2^28 slots,
-                    //  every size with KMERHIP_POW2_TABLE=1 -- rounds back to where it came from: ADVICE r4, a loop without an end)
-                    while (newcap > c->cap && newcap * sizeof(Slot) > room) {
-                        u64 next = round_cap((double)newcap * 0.8);
-                        if (next >= newcap) next = round_cap((double)newcap * 0.5);
-                        if (next >= newcap) break;
-                        newcap = std::max(next, c->cap);
-                    }
-                }
-                if (c->trace)
-                    fprintf(stderr, "[kmerhip] %llu payloads, ~%llu distinct (sample: %llu of %llu in %u partition(s)%s): table %llu -> %llu slots, load %.3f\n", total,
-                            c->est_keys, est[0], est[1], est_np, est[2] ? ", VOID" : "", c->cap, newcap, (double)c->est_keys / (double)newcap);
-                if (newcap != c->cap) {
-                    // the table is empty (a lazily reset one may hold stale slots: the same to us): it just has another size now
-                    resize_empty_table(c, newcap);
-                    c->sized_by_sample = true;
-                    const GeomChoice g2 = make_geom(c, c->cap);
-                    if (!g2.ok || g2.g.p1_bits != g.p1_bits || g2.use32 != gc.use32) return fail(c, KH_ERR_STATE, "table geometry changed under a running batch");
-                    gc = g2;
-                }
-            }
-        }
-    }
-    // ---- what depends on the table's size ----
-    // (level 2's output is sized from the payloads level 1 really produced where the host has just read that number)
-    const u64 n_pay = have_total ? std::min(n_ub, batch_total) : n_ub;
-    const u64 nregions = kh::part_regions(g);
-    const u64 n2 = max_blocks * g.b2;
-    if (c->h2_cap < n2) {  // H2 and O2 grow together
-        u64 z = c->h2_cap;
-        if ((rc = ensure_buf(c, &c->H2, &z, n2, "hipMalloc(H2)")) != KH_OK) return rc;
-        z = c->O2 ? c->h2_cap + 1 : 0;
-        if ((rc = ensure_buf(c, &c->O2, &z, n2 + 1, "hipMalloc(O2)")) != KH_OK) return rc;
-        c->h2_cap = n2;
-    }
-    if ((rc = ensure_region_scratch(c, nregions)) != KH_OK) return rc;
-    // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
-    // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
-    const bool lines_on = c->knobs.p2_lines;
-    const bool lines = lines_on && g.b2 >= 2 && g.b2 <= 512;
-    // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
-    // each), 32..1024 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
-    const bool arena_on = c->knobs.l2_arena;
-    const bool arena = arena_on && g.p1_bits >= 8 && g.b2 >= 32 && g.b2 <= kh::MAX_B2;
-    const u64 arena_pay = arena ? (n_pay + nregions) + ((n_pay + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
-    // the overflow list: a sixteenth of the batch, plus what the workgroups RESERVE without using -- every workgroup that
-    // overflows at all takes private 8192-entry segments (part2_arena_kernel, OVF_SEG), so a batch in which most of the
-    // P1 partitions hold one moderately heavy bucket needs P1 segments before the first entry beyond them is "list full"
-    const u64 ovf_need = arena ? n_pay / 16 + 2 * P1 * 8192ull + (1ull << 20) : 0;
-    const u64 pad_ub = lines ? (max_blocks * g.b2) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
-    // Heavy level-1 partitions (a homopolymer's, a satellite's: arena_plan_kernel) go through the exact kernels while the
-    // others take the arenas; their buckets follow the arenas in the same buffer: room for an eighth of the batch there
-    // (more than that in heavy partitions: the batch takes the exact path as a whole).
-    const u64 heavy_room = arena ? n_pay / 8 : 0;
-    const u64 heavy_base = (arena_pay + 31) & ~31ull;   // payload index behind the arenas (an upper bound of their total)
-    const u64 heavy_pad = (arena && lines) ? ((heavy_room / (kh::CPB * kh::CHUNK_PAY) + 2 * P1) * g.b2) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;
-    // B: the level-2 output -- exact path: every payload + sentinel padding; arenas: a quarter more
-    const u64 b_bytes = std::max((n_pay + pad_ub) * (u64)sizeof(PT), arena ? (heavy_base + heavy_room + heavy_pad + 64) * (u64)sizeof(PT) : 0);
-    if (c->keyb_cap < b_bytes) {
-        u64 z = c->keysB ? c->keyb_cap : 0;
-        if ((rc = ensure_buf(c, &c->keysB, &z, b_bytes, "hipMalloc(keysB)")) != KH_OK) return rc;
-        c->keyb_cap = b_bytes;
-    }
-    PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);
-    if (arena && c->ovf_cap < ovf_need) {
-        u64 z = c->ovf_list ? c->ovf_cap : 0;
-        if ((rc = ensure_buf(c, &c->ovf_list, &z, ovf_need, "hipMalloc(ovf_list)")) != KH_OK) return rc;
-        c->ovf_cap = ovf_need;
-    }
-    const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
-    bool arena_done = false, heavy_exact = false;
-    const u64 ovf_test_cap = c->knobs.l2_ovf_cap;
-    const u64 ovf_lim = std::min(c->ovf_cap, ovf_test_cap);
-    if (arena) {
-        {
-            StageTimer t(c, ST_P2_SCATTER);
-            // (test knobs: KMERHIP_L2_SKEW_X = how many times the mean a partition may hold before it counts as heavy, 0 = no
-            //  limit; KMERHIP_L2_OVF_CAP = entries the overflow list may take; KMERHIP_L2_HEAVY_ROOM = payloads of room for heavy partitions)
-            const uint32_t skew_x = c->knobs.l2_skew_x >= 0 ? (uint32_t)c->knobs.l2_skew_x : 2u;
-            const u64 room = std::min<u64>(heavy_room, c->knobs.l2_heavy_room);
-            hipLaunchKernelGGL(kh::arena_plan_kernel, dim3((unsigned)std::min<u64>(64, (nregions + 1023) / 1024)), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
-                               c->ovf, skew_x, c->heavy, room);
-#define KH_ARENA(UB, NBK, P2)                                                                                                              \
-    hipLaunchKernelGGL((kh::part2_arena_kernel<PT, UB, NBK, P2>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g, \
-                       (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy)
-            const bool pow2 = g.p2_bits != 0xFFFFFFFFu;
-            constexpr int UB512 = sizeof(PT) == 4 ? KH_ARENA_UNITB : 64;
-            if (g.b2 > 768) {  // 769 .. 1024 buckets per partition: the 128 KiB of bins shared out among them, 64-byte units, four buckets per lane group
-                if (pow2) KH_ARENA(64, 1024, true);
-                else KH_ARENA(64, 1024, false);
-            } else if (g.b2 > 512) {  // 513 .. 768: three buckets per lane group
-#ifndef KH_ARENA_UNITB_768
-#define KH_ARENA_UNITB_768 128  // whole lines while a bin holds >= 52 payloads of the 768-bucket instance's 144 KiB, i.e. up to 682 buckets (64: A/B builds)
-#endif
-                if (KH_ARENA_UNITB_768 == 128 && sizeof(PT) == 4 && g.b2 <= 682) KH_ARENA(128, 768, false);
-                else KH_ARENA(64, 768, false);
-            } else if (pow2) {
-                KH_ARENA(UB512, 512, true);
-            } else {
-                KH_ARENA(UB512, 512, false);
-            }
-#undef KH_ARENA
-        }
-        u64 hov[4] = {0, 0, 0, 0};
-        HIP_TRY(c, hipMemcpyAsync(hov, c->ovf, sizeof(hov), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (hov[1] == 0) {
-            arena_done = true;
-            heavy_exact = hov[2] != 0;
-            bend = c->bend;
-            c->ovf_pending = std::min<u64>(hov[0], ovf_lim);  // (the cursor moves in whole segments: it may end beyond the list)
-            HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
-            if (c->trace && c->ovf_pending)
-                fprintf(stderr, "[kmerhip] level 2: %llu entries handed out to the overflow list (%.2f %% of the batch's payload room)\n", (u64)c->ovf_pending,
-                        100.0 * (double)c->ovf_pending / (double)n_ub);
-            if (heavy_exact && c->trace)
-                fprintf(stderr, "[kmerhip] %llu heavy level-1 partition(s) (%llu payloads) take the exact level-2 kernels, the others the arenas\n", hov[2], hov[3]);
-        } else if (c->trace) {
-            fprintf(stderr, hov[1] == 2 ? "[kmerhip] heavy level-1 partitions hold %llu payloads, more than the room behind the arenas: this batch takes the exact level-2 path\n"
-                                        : "[kmerhip] level-2 overflow list full (%llu entries): this batch takes the exact path\n", (u64)(hov[1] == 2 ? hov[3] : hov[0]));
-        }
-    }
-    if (!arena_done || heavy_exact) {
-    // the exact kernels: over every partition (the plan above), or over the heavy ones of an arena batch alone -- their
-    // buckets then go behind the arenas, and their (small) counting pass is booked under "misc": stage_ms[P2_COUNT] == 0
-    // still says "this batch's level 2 was the arena kernel"
-    PT *const outB = heavy_exact ? bufB + heavy_base : bufB;
-    {
-        // (the exact path's plan and its cleared histogram matrix are made HERE since round 5: a batch the arenas took whole --
-        //  every batch of the bench -- never reads them.  The plan runs again because b2 is final only now -- the matrix offsets
-        //  depend on it -- or for the heavy partitions alone.)
-        StageTimer t(c, ST_MISC);
-        if (heavy_exact || size_from_sample)
-            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
-                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, heavy_exact ? (const uint8_t *)c->heavy : (const uint8_t *)nullptr);
-        HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
-    }
-    {
-        StageTimer t(c, heavy_exact ? ST_MISC : ST_P2_COUNT);
-        hipLaunchKernelGGL((kh::part2_count_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA, cs,
-                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2, lines ? (uint32_t)kh::P2L<PT>::UNIT : 1u);
-    }
-    {
-        StageTimer t(c, ST_MISC);
-        if ((rc = device_scan(c, c->H2, n2, c->O2)) != KH_OK) return rc;
-    }
-    {
-        StageTimer t(c, ST_P2_SCATTER);
-        const uint32_t fallback = lines ? 1u : 0u;  // behind the unit kernel the unaligned one runs only where that stood down
-        if (lines)  // whole aligned 64-byte units only (32-bit payloads, 2..512 buckets per partition)
-            hipLaunchKernelGGL((kh::part2_scatter_lines_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::P2L_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB);
-        if (g.b2 <= 512)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
-            hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 512>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
-        else
-            hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 1024>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
-                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
-    }
-#if KH_ABL2 || KH_ABL3
-    if (c->knobs.stop_after_p2) {  // ablation builds only: time level 2 alone (its output is garbage)
-        HIP_TRY(c, hipGetLastError());
-        return sync_counters(c);
-    }
-#endif
-    {
-        StageTimer t(c, ST_MISC);
-        if (heavy_exact) {
-            hipLaunchKernelGGL(kh::bucket_bounds_heavy_kernel, dim3((unsigned)((nregions + 255) / 256)), dim3(256), 0, c->stream,
-                               (const u64 *)c->O2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, (const uint8_t *)c->heavy, heavy_base,
-                               c->bstart, c->bend);
-        } else {
-            hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((nregions + 256) / 256)), dim3(256), 0, c->stream,
-                               (const u64 *)c->O2, (u64)n2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, c->bstart);
-            HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
-        }
-    }
-    if (!heavy_exact) c->ovf_pending = 0;
-    }  // exact kernels
     const bool was_empty = c->table_empty;
     // The 8-byte table image (see kh_ctx::ntab): a fresh pass with 32-bit payloads writes it, a pass over a table that is
     // in that form updates it.  KMERHIP_NARROW=0: always the 16-byte table (A/B).
@@ -685,6 +333,445 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     return KH_OK;
 }
 
+template <typename PT>
+int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u64 ntiles, bool size_from_sample, double range_scale, bool sized_narrow) {
+    constexpr bool CHUNKED = true;  // level 1 always goes into the chunk pool (partition.hip.h)
+    kh::PartGeom &g = gc.g;
+    const u64 P1 = 1ull << g.p1_bits;
+    const u64 n_all = ntiles * kh::PART_TILE;  // every window of these tiles
+    const bool estimated = ra.survive < 1.0;
+    const u64 n_ub = sized_for(n_all, ra.survive);  // upper bound on keys (an estimate when `estimated`: checked after level 1)
+    // chunk pool: every payload + one partial chunk per (workgroup, partition) + the unused tail of
+    // every workgroup's private ranges
+    const u64 pool_chunks = (n_ub / kh::CHUNK_PAY) + (n_ub / kh::CHUNK_PAY) / 24 + (u64)PART_G1 * (P1 + kh::POOL_GRAB) + 1024;
+    const u64 max_blocks = pool_chunks / kh::CPB + P1 + 1;
+    int rc;
+    // ---- what level 1 needs: the pool and its metadata (independent of the table's size) ----
+    if (!c->moff) {  // fixed-size scratch, allocated once
+        u64 z = 0;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->moff, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(moff)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->nch, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(nch)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->info, &z, 8, "hipMalloc(info)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pcount, &z, (u64)kh::MAX_P1, "hipMalloc(pcount)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pstart, &z, (u64)kh::MAX_P1 + 1, "hipMalloc(pstart)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pool_next, &z, 1, "hipMalloc(pool_next)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->ptotal, &z, (u64)kh::MAX_P1, "hipMalloc(ptotal)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->pcap, &z, (u64)kh::MAX_P1, "hipMalloc(pcap)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->ovf, &z, 4, "hipMalloc(ovf)")) != KH_OK) return rc;
+        z = 0;
+        if ((rc = ensure_buf(c, &c->heavy, &z, (u64)kh::MAX_P1, "hipMalloc(heavy)")) != KH_OK) return rc;
+    }
+    if ((rc = ensure_buf(c, &c->blocks, &c->blocks_cap, max_blocks, "hipMalloc(blocks)")) != KH_OK) return rc;
+    if (c->pool_cap < pool_chunks) {
+        u64 z = c->chunk_part ? c->pool_cap : 0;
+        if ((rc = ensure_buf(c, &c->chunk_part, &z, pool_chunks, "hipMalloc(chunk_part)")) != KH_OK) return rc;
+        z = c->fill8 ? c->pool_cap : 0;
+        if ((rc = ensure_buf(c, &c->fill8, &z, pool_chunks, "hipMalloc(fill8)")) != KH_OK) return rc;
+        z = c->plist ? c->pool_cap : 0;
+        if ((rc = ensure_buf(c, &c->plist, &z, pool_chunks, "hipMalloc(plist)")) != KH_OK) return rc;
+        c->pool_cap = pool_chunks;
+    }
+    const u64 a_bytes = pool_chunks * kh::CHUNK_PAY * sizeof(PT);  // A: the level-1 pool
+    if (c->key_cap < a_bytes) {  // (capacities in BYTES)
+        u64 z = c->keysA ? c->key_cap : 0;
+        if ((rc = ensure_buf(c, &c->keysA, &z, a_bytes, "hipMalloc(keysA)")) != KH_OK) return rc;
+        c->key_cap = a_bytes;
+    }
+    // the sample: enough partitions for ~2 M payloads (one partition of a large batch), a set with room for all of them
+    const uint32_t est_np = size_from_sample ? (uint32_t)std::min<u64>(16, std::max<u64>(1, (2ull << 20) / std::max<u64>(1, n_ub / P1))) : 0u;
+    constexpr uint32_t EST_P0 = 517;  // (not partition 0: the hash of A^k is 0 -- its partition is the one a homopolymer makes heavy)
+    u64 est_slots = 0;
+    uint32_t est_sub = 0;  // ... and of a large batch's partition only the keys with est_sub zero bits behind the level-1 digit
+    if (size_from_sample) {
+        while (est_sub < 6 && (n_ub / P1) >> (est_sub + 1) >= (1ull << 19)) ++est_sub;
+        est_slots = 1ull << 16;
+        while (est_slots < 3 * (u64)est_np * ((n_ub / P1 >> est_sub) + 1)) est_slots *= 2;
+        if ((rc = ensure_buf(c, &c->est_set, &c->est_set_cap, est_slots, "hipMalloc(distinct sample)")) != KH_OK) return rc;
+    }
+
+    const uint32_t tpb = (uint32_t)((ntiles + PART_G1 - 1) / PART_G1);
+    const uint32_t thr = ra.use_qual ? qual_thr(c) : 0;
+    const dim3 b1(kh::PART_NT);
+    kh::ChunkSrc cs;
+    cs.pay = c->keysA;
+    cs.plist = c->plist;
+    cs.fill8 = c->fill8;
+    const uint32_t force_wide = c->knobs.p2_force_wide ? 1u : 0u;
+    bool have_total = false;  // the host knows how many payloads level 1 produced (it synchronised to read them)
+    u64 batch_total = 0;
+
+    {
+        {
+            StageTimer t(c, ST_MISC);
+            HIP_TRY(c, hipMemsetAsync(c->chunk_part, 0xFF, pool_chunks * sizeof(uint16_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->fill8, 0xFF, pool_chunks, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->pcount, 0, kh::MAX_P1 * sizeof(uint32_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->pool_next, 0, sizeof(u64), c->stream));
+        }
+        {
+            StageTimer t(c, ST_P1_SCATTER);
+            // level 1 lives in translation units of its own (level1_api.h): one kernel per k for the written-out window
+            kh::L1Launch l1;
+            l1.stream = c->stream;
+            l1.grid = (unsigned)PART_G1;
+            l1.abase = ra.abase;
+            l1.qbase = ra.qbase;
+            l1.qaligned = ra.qaligned;
+            l1.use_qual = ra.use_qual;
+            l1.vbeg = ra.vbeg;
+            l1.vend = ra.vend;
+            l1.wlo = ra.wlo;
+            l1.tile0 = tile0;
+            l1.ntiles = ntiles;
+            l1.tiles_per_block = tpb;
+            l1.k = c->k;
+            l1.thr = thr;
+            l1.g = g;  // (level 1 reads p1_bits, k and the shard fields: not b2)
+            l1.pool = c->keysA;
+            l1.chunk_part = c->chunk_part;
+            l1.fill8 = c->fill8;
+            l1.pool_next = c->pool_next;
+            l1.pool_chunks = pool_chunks;
+            l1.ctr = c->d_ctr;
+            // KMERHIP_GENERIC_K=1: the C++ window where a written-out one exists; KMERHIP_P1_BINS=0: round 1's tile-sorting kernel (both for A/B)
+            l1.generic_k = c->knobs.generic_k;
+            l1.legacy = c->knobs.p1_legacy;
+            if (sizeof(PT) == 4) kh::launch_level1_32(l1, nullptr);
+            else kh::launch_level1_64(l1, nullptr);
+        }
+#if KH_ABL
+        if (c->knobs.stop_after_p1) {  // ablation builds only: time level 1 alone (its output is garbage)
+            HIP_TRY(c, hipGetLastError());
+            return sync_counters(c);
+        }
+#endif
+        {
+            StageTimer t(c, ST_MISC);
+            HIP_TRY(c, hipMemsetAsync(c->ptotal, 0, kh::MAX_P1 * sizeof(u64), c->stream));
+            hipLaunchKernelGGL(kh::chunk_hist_kernel, dim3(1024), dim3(1024), 0, c->stream, (const uint16_t *)c->chunk_part,
+                               (const u64 *)c->pool_next, pool_chunks, c->pcount, (const uint8_t *)c->fill8, c->ptotal);
+            if ((rc = device_scan(c, c->pcount, P1, c->pstart)) != KH_OK) return rc;
+            // (the plan's moff / mbase depend on b2: it runs again below once that is final; this run sets the chunk list's cursors)
+            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
+                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, (const uint8_t *)nullptr);
+            hipLaunchKernelGGL(kh::chunk_list_kernel, dim3((unsigned)((pool_chunks + 16383) / 16384)), dim3(1024), 0, c->stream,
+                               (const uint16_t *)c->chunk_part, (const u64 *)c->pool_next, pool_chunks, c->pcount, c->plist);
+            if (size_from_sample) {
+                u64 *est_out = c->info + 4;  // [distinct, payloads seen, no room]
+                HIP_TRY(c, hipMemsetAsync(est_out, 0, 3 * sizeof(u64), c->stream));
+                HIP_TRY(c, hipMemsetAsync(c->est_set, 0xFF, est_slots * sizeof(u64), c->stream));
+                hipLaunchKernelGGL(kh::distinct_sample_kernel<PT>, dim3(1024), dim3(kh::BLOCK), 0, c->stream, cs, (const u64 *)c->pstart,
+                                   EST_P0 % (uint32_t)(P1 - est_np + 1), est_np, est_sub, c->est_set, est_slots - 1, est_out);
+            }
+        }
+        if (estimated || size_from_sample) {
+            // Everything behind the pool is sized for n_ub payloads, an estimate: are there more?  (The pool itself has
+            // slack -- a partial chunk per workgroup and partition -- so level 1 may well have found room for them: what
+            // counts is the total, from chunk_hist_kernel; and payloads level 1 found no room for are in ctr->failed,
+            // which is 0 on entry.)  Nothing but the pool and its chunk lists has been written yet.
+            std::vector<u64> pt(kh::MAX_P1);
+            u64 lost = 0, total = 0, est[3] = {0, 0, 0};
+            HIP_TRY(c, hipMemcpyAsync(pt.data(), c->ptotal, kh::MAX_P1 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&lost, &c->d_ctr->failed, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            if (size_from_sample) HIP_TRY(c, hipMemcpyAsync(est, c->info + 4, sizeof(est), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (u64 p = 0; p < P1; ++p) total += pt[p];
+            have_total = true;
+            batch_total = total;
+            if (estimated && (lost || total > n_ub)) {
+                HIP_TRY(c, hipMemsetAsync(&c->d_ctr->failed, 0, sizeof(u64), c->stream));
+                if (c->trace)
+                    fprintf(stderr, "[kmerhip] sized for %.3f of the windows (%llu payloads), found %llu%s: again at full size\n", ra.survive, n_ub,
+                            total, lost ? " and more that did not fit the pool" : "");
+                return KH_RETRY_FULL_SIZE;
+            }
+            if (size_from_sample) {
+                // distinct keys of the batch: the sample's, scaled by payloads (its partitions hold est[1] of `total`) -- and of the
+                // range, scaled by windows: an upper bound (later batches repeat keys of this one)
+                double keys = (double)total;  // no usable sample: as if every payload were a new key (round 3's sizing)
+                // (scaled by KEY SPACE -- the sample is every occurrence of an exact 1 / (1024 / np x 2^sub) of it -- not by payloads: a
+                //  sampled partition that holds a repeat family's heavy keys has more payloads, not more keys; an hg-shaped input
+                //  came out 21 % low that way)
+                if (est[2] == 0 && est[1] > 0) keys = std::min((double)total, (double)est[0] * ((double)P1 / (double)est_np) * (double)(1u << est_sub));
+                c->est_keys = (u64)(keys * range_scale) + 1;
+                const double load_now = (double)c->est_keys / (double)c->cap;
+                u64 newcap = c->cap;
+                // (a capacity hint is the caller's word on ALL the keys to come, this range being perhaps the first of many: a hinted
+                //  table is never made smaller, only larger when the sample says the hint cannot be right)
+                if (load_now > LOAD_KEEP_MAX || (!c->hinted && (load_now < LOAD_KEEP_MIN || c->cap < 2048ull * kh::REGION_SLOTS))) newcap = policy_cap((double)c->est_keys);
+                if (c->hinted && newcap < c->cap) newcap = c->cap;
+                // two levels of partitioning reach 1024 x 1024 regions: beyond that (more than ~3 G keys in one range) the table
+                // grows by rehash after the batch and later batches take the direct path, as before
+                newcap = std::min<u64>(newcap, (u64)kh::MAX_P1 * kh::MAX_B2 * kh::REGION_SLOTS);
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess) {  // never beyond a third of what is free (the partition buffers of this batch come next)
+                    u64 room = ((u64)fr + (c->table ? c->cap * sizeof(Slot) : 0) + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
+                    if (c->knobs.table_room_mb) room = c->knobs.table_room_mb << 20;  // (test build: as if that were all the room)
+                    // (strictly smaller at every turn: round_cap() rounds UP, and 0.8 x a power of two -- every size up to 2^28 slots,
+                    //  every size with KMERHIP_POW2_TABLE=1 -- rounds back to where it came from: ADVICE r4, a loop without an end)
+                    while (newcap > c->cap && newcap * sizeof(Slot) > room) {
+                        u64 next = round_cap((double)newcap * 0.8);
+                        if (next >= newcap) next = round_cap((double)newcap * 0.5);
+                        if (next >= newcap) break;
+                        newcap = std::max(next, c->cap);
+                    }
+                }
+                // 8-byte payloads (k >= 22): where a POWER-OF-TWO table of the next size up lets level 2 narrow them to the 4 bytes below
+                // the region index (2k - log2 regions <= 32: see `can_narrow` below), take it -- a table at load 0.25-0.5 whose batches
+                // then move half the bytes through level 2 and the region pass, and whose region pass is the 32-bit kernel (k = 25 on
+                // S100M: 146 ms per step with 1024 x 640 regions, 8 bytes a payload)
+                if (sizeof(PT) == 8 && c->knobs.l2_narrow && c->shard_shift == 0 && (newcap & (newcap - 1)) && !c->knobs.table_regions) {  // (a forced geometry stays)
+                    u64 p2cap = 2048ull * kh::REGION_SLOTS;
+                    uint32_t rb = 11;
+                    while (p2cap < newcap) {
+                        p2cap <<= 1;
+                        ++rb;
+                    }
+                    const int below = 2 * (int)c->k - (int)rb;
+                    size_t fr2 = 0, tot2 = 0;
+                    const bool fits = hipMemGetInfo(&fr2, &tot2) == hipSuccess && p2cap * sizeof(u64) <= ((u64)fr2 + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
+                    if (below >= 1 && below <= 32 && rb <= kh::MAX_P1_BITS + kh::MAX_P2_BITS && fits && (!c->hinted || p2cap >= c->cap)) newcap = p2cap;
+                }
+                if (c->trace)
+                    fprintf(stderr, "[kmerhip] %llu payloads, ~%llu distinct (sample: %llu of %llu in %u partition(s)%s): table %llu -> %llu slots, load %.3f\n", total,
+                            c->est_keys, est[0], est[1], est_np, est[2] ? ", VOID" : "", c->cap, newcap, (double)c->est_keys / (double)newcap);
+                if (newcap != c->cap) {
+                    // the table is empty (a lazily reset one may hold stale slots: the same to us): it just has another size now
+                    resize_empty_table(c, newcap);
+                    c->sized_by_sample = true;
+                    const GeomChoice g2 = make_geom(c, c->cap);
+                    if (!g2.ok || g2.g.p1_bits != g.p1_bits || g2.use32 != gc.use32) return fail(c, KH_ERR_STATE, "table geometry changed under a running batch");
+                    gc = g2;
+                }
+            }
+        }
+    }
+    // ---- what depends on the table's size ----
+    // (level 2's output is sized from the payloads level 1 really produced where the host has just read that number)
+    const u64 n_pay = have_total ? std::min(n_ub, batch_total) : n_ub;
+    const u64 nregions = kh::part_regions(g);
+    const u64 n2 = max_blocks * g.b2;
+    if (c->h2_cap < n2) {  // H2 and O2 grow together
+        u64 z = c->h2_cap;
+        if ((rc = ensure_buf(c, &c->H2, &z, n2, "hipMalloc(H2)")) != KH_OK) return rc;
+        z = c->O2 ? c->h2_cap + 1 : 0;
+        if ((rc = ensure_buf(c, &c->O2, &z, n2 + 1, "hipMalloc(O2)")) != KH_OK) return rc;
+        c->h2_cap = n2;
+    }
+    if ((rc = ensure_region_scratch(c, nregions)) != KH_OK) return rc;
+    // 32-bit payloads with 2..512 buckets per partition: level 2 writes whole aligned lines, every (bucket,
+    // workgroup) segment padded to a line with sentinels (KMERHIP_P2_LINES=0: the unpadded kernel, for A/B)
+    const bool lines_on = c->knobs.p2_lines;
+    const bool lines = lines_on && g.b2 >= 2 && g.b2 <= 512;
+    // Level 2 without a counting pass (partition.hip.h, part2_arena_kernel): >= 256 level-1 partitions (one workgroup
+    // each), 32..1024 buckets per partition.  KMERHIP_L2_ARENA=0: always the exact count -> scan -> scatter path.
+    const bool arena_on = c->knobs.l2_arena;
+    const bool arena = arena_on && g.p1_bits >= 8 && g.b2 >= 32 && g.b2 <= kh::MAX_B2;
+    const u64 arena_pay = arena ? (n_pay + nregions) + ((n_pay + nregions) >> 2) + 1056ull * nregions : 0;  // upper bound of arena_plan_kernel's total
+    // the overflow list: a sixteenth of the batch, plus what the workgroups RESERVE without using -- every workgroup that
+    // overflows at all takes private 8192-entry segments (part2_arena_kernel, OVF_SEG), so a batch in which most of the
+    // P1 partitions hold one moderately heavy bucket needs P1 segments before the first entry beyond them is "list full"
+    const u64 ovf_need = arena ? n_pay / 16 + 2 * P1 * 8192ull + (1ull << 20) : 0;
+    const u64 pad_ub = lines ? (max_blocks * g.b2) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;  // sentinels at the segment ends
+    // Heavy level-1 partitions (a homopolymer's, a satellite's: arena_plan_kernel) go through the exact kernels while the
+    // others take the arenas; their buckets follow the arenas in the same buffer: room for an eighth of the batch there
+    // (more than that in heavy partitions: the batch takes the exact path as a whole).
+    const u64 heavy_room = arena ? n_pay / 8 : 0;
+    const u64 heavy_base = (arena_pay + 31) & ~31ull;   // payload index behind the arenas (an upper bound of their total)
+    const u64 heavy_pad = (arena && lines) ? ((heavy_room / (kh::CPB * kh::CHUNK_PAY) + 2 * P1) * g.b2) * (u64)(kh::P2L<PT>::UNIT - 1) : 0;
+    // B: the level-2 output -- exact path: every payload + sentinel padding; arenas: a quarter more
+    // LEVEL 2 NARROWS (round 6; partition.hip.h part2_arena_kernel, IT): 8-byte payloads whose hash bits below the REGION index fit 32
+    // bits -- 2k - log2(regions) <= 32: k <= 25 in the headline's 2^19 regions -- leave level 2 as that 4-byte word, where the table's
+    // regions are a power of two (the bits below the region index are then a bit field of the payload).  What follows is a 32-bit
+    // batch over the virtual geometry (p1_bits = log2 regions, b2 = 1): the same table layout -- for powers of two any split of
+    // the region index describes it --, half the bytes, the 32-bit region kernel and the 8-byte table image.  A batch that turns
+    // out to have heavy partitions, or whose overflow list fills up, runs level 2 again un-narrowed (the pool is still whole).
+    const int below_region_bits = 2 * (int)c->k - (int)g.shard_shift - (int)g.p1_bits - (g.p2_bits != 0xFFFFFFFFu ? (int)g.p2_bits : 64);
+    const bool can_narrow = sizeof(PT) == 8 && arena && c->knobs.l2_narrow && g.p2_bits != 0xFFFFFFFFu && g.p2_bits >= 5 && g.b2 <= kh::MAX_B2 &&
+                            below_region_bits >= 1 && below_region_bits <= 32 && g.shard_shift == 0;
+    const u64 b_bytes_wide = std::max((n_pay + pad_ub) * (u64)sizeof(PT), arena ? (heavy_base + heavy_room + heavy_pad + 64) * (u64)sizeof(PT) : 0);
+    const u64 b_bytes = can_narrow ? (arena_pay + 64) * (u64)sizeof(uint32_t) : b_bytes_wide;  // (a narrowed batch: arenas of 4-byte payloads, nothing behind them)
+    // room for the 8-byte output after all (the batch cannot narrow, or its narrowed level 2 has to be run again wide): what is there, what can
+    // be allocated -- or the caller makes smaller batches
+    auto room_for_wide = [&]() -> int {
+        if (c->keyb_cap >= b_bytes_wide) return KH_OK;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) {
+            (void)hipGetLastError();
+            fr = 0;
+        }
+        if (sized_narrow && (u64)fr + c->keyb_cap < b_bytes_wide + (c->ntab ? 0 : c->cap * sizeof(u64)) + (2ull << 30)) return KH_RETRY_WIDE;
+        u64 z = c->keysB ? c->keyb_cap : 0;
+        const int r = ensure_buf(c, &c->keysB, &z, b_bytes_wide, "hipMalloc(keysB)");
+        if (r == KH_OK) c->keyb_cap = b_bytes_wide;
+        return r;
+    };
+    if (!can_narrow) {
+        if ((rc = room_for_wide()) != KH_OK) return rc;
+    } else if (c->keyb_cap < b_bytes) {
+        u64 z = c->keysB ? c->keyb_cap : 0;
+        if ((rc = ensure_buf(c, &c->keysB, &z, b_bytes, "hipMalloc(keysB)")) != KH_OK) return rc;
+        c->keyb_cap = b_bytes;
+    }
+    PT *bufA = reinterpret_cast<PT *>(c->keysA), *bufB = reinterpret_cast<PT *>(c->keysB);  // (bufB: again after a re-allocation)
+    if (arena && c->ovf_cap < ovf_need) {
+        u64 z = c->ovf_list ? c->ovf_cap : 0;
+        if ((rc = ensure_buf(c, &c->ovf_list, &z, ovf_need, "hipMalloc(ovf_list)")) != KH_OK) return rc;
+        c->ovf_cap = ovf_need;
+    }
+    const u64 *bend = c->bstart + 1;  // end of region r's data: the next region's start (exact path) or c->bend[r] (arenas)
+    bool arena_done = false, heavy_exact = false;
+    const u64 ovf_test_cap = c->knobs.l2_ovf_cap;
+    const u64 ovf_lim = std::min(c->ovf_cap, ovf_test_cap);
+    bool narrowed = false;
+    if (arena) {
+        u64 hov[4] = {0, 0, 0, 0};
+        for (int attempt = can_narrow ? 0 : 1; attempt < 2; ++attempt) {
+            const bool nw = attempt == 0;
+            StageTimer t(c, ST_P2_SCATTER);
+            // (test knobs: KMERHIP_L2_SKEW_X = how many times the mean a partition may hold before it counts as heavy, 0 = no
+            //  limit; KMERHIP_L2_OVF_CAP = entries the overflow list may take; KMERHIP_L2_HEAVY_ROOM = payloads of room for heavy partitions)
+            const uint32_t skew_x = c->knobs.l2_skew_x >= 0 ? (uint32_t)c->knobs.l2_skew_x : 2u;
+            const u64 room = std::min<u64>(heavy_room, c->knobs.l2_heavy_room);
+            hipLaunchKernelGGL(kh::arena_plan_kernel, dim3((unsigned)std::min<u64>(64, (nregions + 1023) / 1024)), dim3(1024), 0, c->stream, (const u64 *)c->ptotal, g, c->bstart, c->pcap,
+                               c->ovf, skew_x, c->heavy, room);
+#define KH_ARENA(UB, NBK, P2)                                                                                                              \
+    hipLaunchKernelGGL((kh::part2_arena_kernel<PT, UB, NBK, P2>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g, \
+                       (const u64 *)c->bstart, (const uint32_t *)c->pcap, bufB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy)
+            const bool pow2 = g.p2_bits != 0xFFFFFFFFu;
+            constexpr int UB512 = sizeof(PT) == 4 ? KH_ARENA_UNITB : 64;
+#define KH_ARENA_NARROW(UB, NBK)                                                                                                           \
+    hipLaunchKernelGGL((kh::part2_arena_kernel<uint32_t, UB, NBK, true, u64>), dim3((unsigned)P1), dim3(kh::P2L_NT), 0, c->stream, cs, (const u64 *)c->pstart, g, \
+                       (const u64 *)c->bstart, (const uint32_t *)c->pcap, (uint32_t *)c->keysB, c->bend, c->ovf_list, c->ovf, ovf_lim, (const uint8_t *)c->heavy)
+            if (nw) {
+                if constexpr (sizeof(PT) == 8) {
+                    if (g.b2 > 512) KH_ARENA_NARROW(64, 1024);
+                    else KH_ARENA_NARROW(KH_ARENA_UNITB, 512);
+                }
+            } else
+            if (g.b2 > 768) {  // 769 .. 1024 buckets per partition: the 128 KiB of bins shared out among them, 64-byte units, four buckets per lane group
+                if (pow2) KH_ARENA(64, 1024, true);
+                else KH_ARENA(64, 1024, false);
+            } else if (g.b2 > 512) {  // 513 .. 768: three buckets per lane group
+#ifndef KH_ARENA_UNITB_768
+#define KH_ARENA_UNITB_768 128  // whole lines while a bin holds >= 52 payloads of the 768-bucket instance's 144 KiB, i.e. up to 682 buckets (64: A/B builds)
+#endif
+                if (KH_ARENA_UNITB_768 == 128 && sizeof(PT) == 4 && g.b2 <= 682) KH_ARENA(128, 768, false);
+                else KH_ARENA(64, 768, false);
+            } else if (pow2) {
+                KH_ARENA(UB512, 512, true);
+            } else {
+                KH_ARENA(UB512, 512, false);
+            }
+#undef KH_ARENA
+#undef KH_ARENA_NARROW
+            t.stop();
+            HIP_TRY(c, hipMemcpyAsync(hov, c->ovf, sizeof(hov), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (nw && (hov[1] != 0 || hov[2] != 0)) {  // (heavy partitions' buckets come from the exact kernels, 8 bytes a payload: the batch stays wide)
+                if (c->trace) fprintf(stderr, "[kmerhip] level 2 narrowed to 4-byte payloads met %s: again with 8-byte payloads\n", hov[1] ? "a full overflow list" : "heavy partitions");
+                if ((rc = room_for_wide()) != KH_OK) return rc;
+                bufB = reinterpret_cast<PT *>(c->keysB);
+                continue;
+            }
+            narrowed = nw;
+            break;
+        }
+        if (hov[1] == 0) {
+            arena_done = true;
+            heavy_exact = hov[2] != 0;
+            bend = c->bend;
+            c->ovf_pending = std::min<u64>(hov[0], ovf_lim);  // (the cursor moves in whole segments: it may end beyond the list)
+            HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
+            if (c->trace && c->ovf_pending)
+                fprintf(stderr, "[kmerhip] level 2: %llu entries handed out to the overflow list (%.2f %% of the batch's payload room)\n", (u64)c->ovf_pending,
+                        100.0 * (double)c->ovf_pending / (double)n_ub);
+            if (heavy_exact && c->trace)
+                fprintf(stderr, "[kmerhip] %llu heavy level-1 partition(s) (%llu payloads) take the exact level-2 kernels, the others the arenas\n", hov[2], hov[3]);
+        } else if (c->trace) {
+            fprintf(stderr, hov[1] == 2 ? "[kmerhip] heavy level-1 partitions hold %llu payloads, more than the room behind the arenas: this batch takes the exact level-2 path\n"
+                                        : "[kmerhip] level-2 overflow list full (%llu entries): this batch takes the exact path\n", (u64)(hov[1] == 2 ? hov[3] : hov[0]));
+        }
+    }
+    if (!arena_done || heavy_exact) {
+    // the exact kernels: over every partition (the plan above), or over the heavy ones of an arena batch alone -- their
+    // buckets then go behind the arenas, and their (small) counting pass is booked under "misc": stage_ms[P2_COUNT] == 0
+    // still says "this batch's level 2 was the arena kernel"
+    PT *const outB = heavy_exact ? bufB + heavy_base : bufB;
+    {
+        // (the exact path's plan and its cleared histogram matrix are made HERE since round 5: a batch the arenas took whole --
+        //  every batch of the bench -- never reads them.  The plan runs again because b2 is final only now -- the matrix offsets
+        //  depend on it -- or for the heavy partitions alone.)
+        StageTimer t(c, ST_MISC);
+        if (heavy_exact || size_from_sample)
+            hipLaunchKernelGGL(kh::part2_plan_chunked_kernel, dim3(1), dim3(1024), 0, c->stream, (const u64 *)c->pstart, g,
+                               c->blocks, max_blocks, c->moff, c->nch, c->info, c->pcount, force_wide, heavy_exact ? (const uint8_t *)c->heavy : (const uint8_t *)nullptr);
+        HIP_TRY(c, hipMemsetAsync(c->H2, 0, n2 * sizeof(uint32_t), c->stream));
+    }
+    {
+        StageTimer t(c, heavy_exact ? ST_MISC : ST_P2_COUNT);
+        hipLaunchKernelGGL((kh::part2_count_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), b1, 0, c->stream, (const PT *)bufA, cs,
+                           (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, c->H2, lines ? (uint32_t)kh::P2L<PT>::UNIT : 1u);
+    }
+    {
+        StageTimer t(c, ST_MISC);
+        if ((rc = device_scan(c, c->H2, n2, c->O2)) != KH_OK) return rc;
+    }
+    {
+        StageTimer t(c, ST_P2_SCATTER);
+        const uint32_t fallback = lines ? 1u : 0u;  // behind the unit kernel the unaligned one runs only where that stood down
+        if (lines)  // whole aligned 64-byte units only (32-bit payloads, 2..512 buckets per partition)
+            hipLaunchKernelGGL((kh::part2_scatter_lines_kernel<PT, CHUNKED>), dim3((unsigned)max_blocks), dim3(kh::P2L_NT), 0, c->stream,
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB);
+        if (g.b2 <= 512)  // <= 512 buckets per partition: the small-LDS variant, two workgroups per CU
+            hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 512>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
+        else
+            hipLaunchKernelGGL((kh::part2_scatter_kernel<PT, CHUNKED, 1024>), dim3((unsigned)max_blocks), dim3(kh::PART2_NT), 0, c->stream,
+                               (const PT *)bufA, cs, (const kh::Part2Block *)c->blocks, (const u64 *)c->info, g, (const u64 *)c->O2, outB, fallback);
+    }
+#if KH_ABL2 || KH_ABL3
+    if (c->knobs.stop_after_p2) {  // ablation builds only: time level 2 alone (its output is garbage)
+        HIP_TRY(c, hipGetLastError());
+        return sync_counters(c);
+    }
+#endif
+    {
+        StageTimer t(c, ST_MISC);
+        if (heavy_exact) {
+            hipLaunchKernelGGL(kh::bucket_bounds_heavy_kernel, dim3((unsigned)((nregions + 255) / 256)), dim3(256), 0, c->stream,
+                               (const u64 *)c->O2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, (const uint8_t *)c->heavy, heavy_base,
+                               c->bstart, c->bend);
+        } else {
+            hipLaunchKernelGGL(kh::bucket_bounds_kernel, dim3((unsigned)((nregions + 256) / 256)), dim3(256), 0, c->stream,
+                               (const u64 *)c->O2, (u64)n2, (const u64 *)c->moff, (const uint32_t *)c->nch, g, c->bstart);
+            HIP_TRY(c, hipMemsetAsync(c->rfail, 0, nregions, c->stream));
+        }
+    }
+    if (!heavy_exact) c->ovf_pending = 0;
+    }  // exact kernels
+    if (narrowed) {  // a 32-bit batch from here on: regions as "partitions" of one bucket each, the payload = the 32 hash bits behind the region index
+        kh::PartGeom g2 = g;
+        g2.p1_bits = g.p1_bits + g.p2_bits;
+        g2.b2 = 1;
+        g2.b2_magic = kh::part_magic_of(1);
+        g2.p2_bits = 0;
+        g2.defer = 0;
+        if (c->trace) fprintf(stderr, "[kmerhip] level 2 narrowed the batch's payloads to the %d bits below the region index\n", below_region_bits);
+        return finish_batch<uint32_t>(c, g2, reinterpret_cast<uint32_t *>(c->keysB), bend, nregions, n_all, n_ub, ovf_lim, false);
+    }
+    return finish_batch<PT>(c, g, bufB, bend, nregions, n_all, n_ub, ovf_lim, heavy_exact);
+}
+
 int direct_range(kh_ctx *c, const RangeArgs &ra, u64 first_tile, u64 end_tile) {
     {
         int rc = ensure_wide(c);  // (device atomics work on the 16-byte slots)
@@ -860,11 +947,17 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
     const u64 first_tile = ra.wlo / kh::PART_TILE;
     const u64 end_tile = (ra.vend + kh::PART_TILE - 1) / kh::PART_TILE;
     const u64 distinct_before = c->distinct_known;
+    bool no_narrow = false;  // (KH_RETRY_WIDE: this range's batches are sized for 8-byte level-2 output from here on)
     for (u64 t = first_tile; t < end_tile;) {
         const GeomChoice gc = make_geom(c, c->cap);  // re-evaluated per batch: the table may have grown
         if (!gc.ok) return direct_range(c, ra, t * (kh::PART_TILE / kh::TILE), (ra.vend + kh::TILE - 1) / kh::TILE);
-        // bytes per key over the two buffers and the overflow list: pool (1.04 x payload) + arenas (1.25 x + 1) + 1
-        const u64 per_key = gc.use32 ? 11 : 20;
+        // bytes per key over the two buffers and the overflow list: pool (1.04 x payload) + arenas (1.25 x + 1) + 1.  8-byte payloads
+        // that level 2 will narrow (partition_batch: a fresh table takes a power-of-two size for them; an existing one must be one):
+        // 8-byte pool, 4-byte arenas.  A batch sized that way that cannot narrow after all comes back with KH_RETRY_WIDE.
+        const int rb_now = (int)kh::kh_floor_log2((uint32_t)std::min<u64>(c->cap / kh::REGION_SLOTS, 1u << 20));
+        const bool expect_narrow = !gc.use32 && !no_narrow && c->knobs.l2_narrow && c->shard_shift == 0 && c->knobs.l2_arena &&
+                                   (c->table_empty ? (sample && 2 * (int)c->k - 20 <= 32) : (cap_is_pow2(c->cap) && rb_now >= 15 && 2 * (int)c->k - rb_now <= 32 && 2 * (int)c->k - rb_now >= 1));
+        const u64 per_key = gc.use32 ? 11 : (expect_narrow ? 15 : 20);
         const u64 left = end_tile - t;
         // (a range sized from its survival rate: so many windows per batch that the expected payloads fit the budget)
         const double share = (double)sized_for(left * kh::PART_TILE, ra.survive) / (double)(left * kh::PART_TILE);
@@ -875,9 +968,15 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         GeomChoice gcb = gc;
         const bool from_sample = sample && t == first_tile && gcb.g.p1_bits == kh::MAX_P1_BITS;
         const double range_scale = (double)(end_tile - first_tile) / (double)nt;
-        int rc = gcb.use32 ? partition_batch<uint32_t>(c, ra, gcb, t, nt, from_sample, range_scale) : partition_batch<u64>(c, ra, gcb, t, nt, from_sample, range_scale);
+        int rc = gcb.use32 ? partition_batch<uint32_t>(c, ra, gcb, t, nt, from_sample, range_scale, false)
+                           : partition_batch<u64>(c, ra, gcb, t, nt, from_sample, range_scale, expect_narrow);
         if (rc == KH_RETRY_FULL_SIZE) {  // the sample misjudged these tiles: the rest of the range is sized for every window
             ra.survive = 1.0;
+            continue;
+        }
+        if (rc == KH_RETRY_WIDE) {  // sized for a narrowing level 2 that is not to be: the same tiles again, 20 bytes per window
+            no_narrow = true;
+            if (c->trace) fprintf(stderr, "[kmerhip] the batch was sized for 4-byte level-2 payloads and cannot have them: again in smaller batches\n");
             continue;
         }
         if (rc != KH_OK) return rc;

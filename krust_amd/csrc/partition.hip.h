@@ -750,13 +750,26 @@ struct OvfEntry {
 // unhinted 2-billion-key input gets; round 2 sent those to the exact path with the unaligned scatter).  The 128 KiB of
 // bins are shared out among the partition's buckets either way: 32 4-byte (16 8-byte) payloads per bin at 1024, units of
 // 64 bytes there, and the ranks that do not fit such a small bin (Poisson tail of ~8 arrivals per flush) take the overflow list.
-template <typename PT, int UNITB, int NBK, bool POW2>
+// IT (round 6): the type of the payloads the pool holds, where that is not PT -- u64 with PT = uint32_t: LEVEL 2 NARROWS.  An 8-byte
+// payload is the hash below the level-1 digit (part_common.hip.h Pay<u64>); once level 2 has put it into its bucket, the region is
+// known, and in a table of 2^R regions only 2k - R hash bits are left -- 31 at k = 25 in the headline's 2^19 regions.  Where they
+// fit 32 bits (and b2 is a power of two: the bits below the region index are then a bit field), the bins, the arenas and
+// everything behind them hold THAT word: half the bytes written here and read by the region pass, which is then the 32-bit
+// kernel -- over the virtual geometry (p1_bits = R, b2 = 1), for which such a word is exactly the payload it expects (batch.hip).
+template <typename PT, int UNITB, int NBK, bool POW2, typename IT = PT>
 __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const u64 *__restrict__ pstart, PartGeom g,
                                                              const u64 *__restrict__ bstart, const uint32_t *__restrict__ pcap,
                                                              PT *__restrict__ out, u64 *__restrict__ bend,
                                                              OvfEntry *__restrict__ ovf_list, u64 *__restrict__ ovf, u64 ovf_cap,
                                                              const uint8_t *__restrict__ heavy) {
-    constexpr int UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<PT>::PER, TILE = P2L<PT>::TILE;
+    constexpr bool NARROWS = !std::is_same<IT, PT>::value;
+    static_assert(!NARROWS || (sizeof(IT) == 8 && sizeof(PT) == 4 && POW2), "level 2 narrows 8-byte payloads to 4 bytes, power-of-two geometries");
+    constexpr int UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<IT>::PER, TILE = P2L<IT>::TILE;
+    // what a payload is kept as in the bins / arenas / overflow list: itself, or (NARROWS) the 32 bits behind its bucket digit
+    auto kept = [&](IT w) -> PT {
+        if constexpr (NARROWS) return (PT)(((u64)w << g.p2_bits) >> 32);
+        else return (PT)w;
+    };
     constexpr int HALF = PER / 2;
     constexpr uint32_t CAP = 256 / sizeof(PT);                // payloads per bin at 512 buckets (256 bytes)
     // payloads all bins hold together: 128 KiB -- 144 KiB in the 768-bucket instance (round 5), which is what the CU's 160 KiB
@@ -872,7 +885,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         __syncthreads();
         const uint32_t nchk = (uint32_t)(pb.hi - pb.lo);
         const uint32_t n = nchk * CHUNK_PAY;
-        auto load_batch = [&](uint32_t first, PT (&pay)[PER], uint32_t &have) {  // (as in part2_scatter_lines_kernel)
+        auto load_batch = [&](uint32_t first, IT (&pay)[PER], uint32_t &have) {  // (as in part2_scatter_lines_kernel)
             have = 0;
             const uint32_t myci = (first >> 8) + ((uint32_t)tid & (PER - 1)) * (NT / CHUNK_PAY) + ((uint32_t)tid >> 8);
             const uint32_t mycc = myci < nchk ? myci : nchk - 1;
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 const uint32_t chunk = __builtin_amdgcn_readlane(mychunk, j);
                 const uint32_t fillc = __builtin_amdgcn_readlane(myfill, j);
                 const bool ok = woff < fillc;
-                pay[j] = reinterpret_cast<const PT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (ok ? woff : 0u)];
+                pay[j] = reinterpret_cast<const IT *>(cs.pay)[(u64)chunk * CHUNK_PAY + (ok ? woff : 0u)];
                 have |= (uint32_t)ok << j;
             }
         };
@@ -965,17 +978,17 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
         };
         // FULL: every lane of the wave holds all its payloads of the batch -- nineteen chunks in twenty are full -- and the
         // ranks are taken without the per-payload test (and-compare-saveexec-restore around every LDS atomic: from the ISA)
-        auto batch_as = [&](auto full_tag, uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
+        auto batch_as = [&](auto full_tag, uint32_t base, IT (&pay)[PER], uint32_t have, IT (&nxt)[PER], uint32_t &have_nxt) {
             constexpr bool FULL = decltype(full_tag)::value;
             load_batch(base + TILE, nxt, have_nxt);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 uint32_t rk[HALF], dg[HALF];
                 // (a partition of the arena path has >= 32 buckets: the POW2 digit is a plain shift, no "no digit at all" case)
-                auto digit = [&](PT w) -> uint32_t {
-                    if constexpr (sizeof(PT) == 4 && POW2) return (uint32_t)w >> (32u - g.p2_bits);
-                    else if constexpr (sizeof(PT) == 4) return part_bucket32<POW2>((uint32_t)w, g);
-                    else return Pay<PT>::p2(w, g);
+                auto digit = [&](IT w) -> uint32_t {
+                    if constexpr (sizeof(IT) == 4 && POW2) return (uint32_t)w >> (32u - g.p2_bits);
+                    else if constexpr (sizeof(IT) == 4) return part_bucket32<POW2>((uint32_t)w, g);
+                    else return Pay<IT>::p2(w, g);
                 };
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
@@ -988,7 +1001,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
 #pragma unroll
                 for (int j = 0; j < HALF; ++j) {
                     const uint32_t r = rk[j];
-                    s_bin[r < capr ? dg[j] * capr + r : TOTAL] = pay[h * HALF + j];
+                    s_bin[r < capr ? dg[j] * capr + r : TOTAL] = kept(pay[h * HALF + j]);
                     omask |= (r != 0xFFFFFFFFu && r >= capr) ? (1u << j) : 0u;
                 }
                 if (kh_any(omask != 0)) {  // ranks that did not fit their bins (a heavy bucket): straight to the overflow list
@@ -1017,7 +1030,7 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                                 OvfEntry oe;
                                 oe.region = p * P2 + dg[j];
                                 oe.pad = 0;
-                                oe.pay = (u64)pay[h * HALF + j];
+                                oe.pay = (u64)kept(pay[h * HALF + j]);
                                 ovf_list[at + q++] = oe;
                             }
                     }
@@ -1036,12 +1049,12 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                 if (s_ovf_want || s_ovf_end) ovf_refill();  // (uniform; skipped entirely while nothing has overflowed)
             }
         };
-        auto batch = [&](uint32_t base, PT (&pay)[PER], uint32_t have, PT (&nxt)[PER], uint32_t &have_nxt) {
+        auto batch = [&](uint32_t base, IT (&pay)[PER], uint32_t have, IT (&nxt)[PER], uint32_t &have_nxt) {
             // (decided per wave: both forms pass the same barriers)
             if (!kh_any(have != (1u << PER) - 1u)) batch_as(std::true_type{}, base, pay, have, nxt, have_nxt);
             else batch_as(std::false_type{}, base, pay, have, nxt, have_nxt);
         };
-        PT payA[PER], payB[PER];
+        IT payA[PER], payB[PER];
         uint32_t haveA = 0, haveB = 0;
         load_batch(0, payA, haveA);
 #pragma unroll
@@ -1938,7 +1951,9 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
     // can a payload of this region equal the free marker 0xFFFFFFFF?  Only in a partition's last bucket.
     const uint32_t digit = (uint32_t)r - p1 * b2;             // the region's bucket: a real payload x has (x * b2) >> 32 == digit
     const R32Geo<POW2> rg = r32_geo<POW2>(g, digit);
-    const bool may_special = digit == b2 - 1u;                // (0xFFFFFFFF falls into the LAST bucket; b2 == 1: the only one)
+    // (0xFFFFFFFF falls into the LAST bucket; b2 == 1: the only one -- and only where all 32 bits of a payload are hash bits: in a
+    //  batch whose level 2 narrowed its payloads, g = (log2 regions, 1), a k = 25 payload has 31 and its low bit is zero)
+    const bool may_special = digit == b2 - 1u && 2 * (int)g.k - (int)g.shard_shift - (int)g.p1_bits >= 32;
     const bool no_sentinels = arena_heavy != nullptr && arena_heavy[p1] == 0;  // (uniform)
     uint32_t nreal = 0;
     uint32_t kbuf[REGION_RK];
