@@ -1054,6 +1054,8 @@ def main():
                     ("configs[1] twin WITHOUT a capacity hint (S10M, k=21)", dict(reads=10_000_000, k=21, min_quality=None, hint=0, steps=3)),
                     ("configs[2] S100M: 100 M x 150 bp, k=31, -Q 20 (no capacity hint)", dict(reads=100_000_000, k=31, min_quality=20, hint=0)),
                     ("k=19 twin of the headline (S100M, k=19, no capacity hint): the level-1 window is generated for every k", dict(reads=100_000_000, k=19, min_quality=None, hint=0)),
+                    ("k=25 twin of the headline (S100M, k=25, no capacity hint): 8-byte payloads, narrowed by level 2 to the 4 bytes below the region index",
+                     dict(reads=100_000_000, k=25, min_quality=None, hint=0, verify=True)),
                     ("configs[3] rank 3's share of S1B: 125 M x 150 bp, k=21, with the a-priori capacity hint",
                      dict(reads=READS_NX, k=21, min_quality=None, first=3 * READS_NX, steps=2)),
                     ("configs[3] the same share, no capacity hint",

@@ -334,7 +334,7 @@ int finish_batch(kh_ctx *c, const kh::PartGeom &g, PT *bufB, const u64 *bend, u6
 }
 
 template <typename PT>
-int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u64 ntiles, bool size_from_sample, double range_scale, bool sized_narrow) {
+int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u64 ntiles, bool size_from_sample, double range_scale, bool sized_narrow, bool may_narrow) {
     constexpr bool CHUNKED = true;  // level 1 always goes into the chunk pool (partition.hip.h)
     kh::PartGeom &g = gc.g;
     const u64 P1 = 1ull << g.p1_bits;
@@ -596,7 +596,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
     // the region index describes it --, half the bytes, the 32-bit region kernel and the 8-byte table image.  A batch that turns
     // out to have heavy partitions, or whose overflow list fills up, runs level 2 again un-narrowed (the pool is still whole).
     const int below_region_bits = 2 * (int)c->k - (int)g.shard_shift - (int)g.p1_bits - (g.p2_bits != 0xFFFFFFFFu ? (int)g.p2_bits : 64);
-    const bool can_narrow = sizeof(PT) == 8 && arena && c->knobs.l2_narrow && g.p2_bits != 0xFFFFFFFFu && g.p2_bits >= 5 && g.b2 <= kh::MAX_B2 &&
+    const bool can_narrow = sizeof(PT) == 8 && arena && c->knobs.l2_narrow && may_narrow && g.p2_bits != 0xFFFFFFFFu && g.p2_bits >= 5 && g.b2 <= kh::MAX_B2 &&
                             below_region_bits >= 1 && below_region_bits <= 32 && g.shard_shift == 0;
     const u64 b_bytes_wide = std::max((n_pay + pad_ub) * (u64)sizeof(PT), arena ? (heavy_base + heavy_room + heavy_pad + 64) * (u64)sizeof(PT) : 0);
     const u64 b_bytes = can_narrow ? (arena_pay + 64) * (u64)sizeof(uint32_t) : b_bytes_wide;  // (a narrowed batch: arenas of 4-byte payloads, nothing behind them)
@@ -609,7 +609,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
             (void)hipGetLastError();
             fr = 0;
         }
-        if (sized_narrow && (u64)fr + c->keyb_cap < b_bytes_wide + (c->ntab ? 0 : c->cap * sizeof(u64)) + (2ull << 30)) return KH_RETRY_WIDE;
+        if (sized_narrow && ((u64)fr + c->keyb_cap < b_bytes_wide + (c->ntab ? 0 : c->cap * sizeof(u64)) + (2ull << 30) || c->knobs.l2_no_room_wide)) return KH_RETRY_WIDE;
         u64 z = c->keysB ? c->keyb_cap : 0;
         const int r = ensure_buf(c, &c->keysB, &z, b_bytes_wide, "hipMalloc(keysB)");
         if (r == KH_OK) c->keyb_cap = b_bytes_wide;
@@ -968,8 +968,8 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         GeomChoice gcb = gc;
         const bool from_sample = sample && t == first_tile && gcb.g.p1_bits == kh::MAX_P1_BITS;
         const double range_scale = (double)(end_tile - first_tile) / (double)nt;
-        int rc = gcb.use32 ? partition_batch<uint32_t>(c, ra, gcb, t, nt, from_sample, range_scale, false)
-                           : partition_batch<u64>(c, ra, gcb, t, nt, from_sample, range_scale, expect_narrow);
+        int rc = gcb.use32 ? partition_batch<uint32_t>(c, ra, gcb, t, nt, from_sample, range_scale, false, false)
+                           : partition_batch<u64>(c, ra, gcb, t, nt, from_sample, range_scale, expect_narrow, !no_narrow);
         if (rc == KH_RETRY_FULL_SIZE) {  // the sample misjudged these tiles: the rest of the range is sized for every window
             ra.survive = 1.0;
             continue;

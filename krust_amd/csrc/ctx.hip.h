@@ -99,6 +99,7 @@ struct Knobs {
     u64 l2_heavy_room = ~0ull;       // KMERHIP_L2_HEAVY_ROOM
     bool narrow = true;              // KMERHIP_NARROW=0
     bool l2_narrow = true;           // KMERHIP_L2_NARROW=0: level 2 never narrows 8-byte payloads to the 4 bytes below the region index
+    bool l2_no_room_wide = false;    // KMERHIP_L2_NO_ROOM_WIDE=1: as if a batch sized for a narrowing level 2 had no room for 8-byte output (drives KH_RETRY_WIDE)
     u64 hot_cut = 0;                 // KMERHIP_HOT_CUT (0: default; ~0: no bucket is hot)
     int ovf_agg = -1;                // KMERHIP_OVF_AGG
     double survival = 0;             // KMERHIP_SURVIVAL

@@ -31,6 +31,7 @@ void read_knobs(Knobs &k) {
     if (const char *e = env_of("KMERHIP_L2_HEAVY_ROOM")) k.l2_heavy_room = strtoull(e, nullptr, 10);
     if (const char *e = env_of("KMERHIP_NARROW")) k.narrow = e[0] != '0';
     if (const char *e = env_of("KMERHIP_L2_NARROW")) k.l2_narrow = e[0] != '0';
+    k.l2_no_room_wide = env_of("KMERHIP_L2_NO_ROOM_WIDE") != nullptr;
     if (const char *e = env_of("KMERHIP_HOT_CUT")) k.hot_cut = (e[0] == '0' && !e[1]) ? ~0ull : strtoull(e, nullptr, 10);
     if (const char *e = env_of("KMERHIP_OVF_AGG")) k.ovf_agg = atoi(e);
     if (const char *e = env_of("KMERHIP_SURVIVAL")) k.survival = atof(e);

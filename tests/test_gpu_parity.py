@@ -1616,6 +1616,85 @@ def test_more_than_768_buckets_per_partition_with_heavy_buckets(K, monkeypatch, 
         assert dc.histogram() == m.histogram()
 
 
+@pytest.mark.parametrize("narrow", ["1", "0"], ids=["narrows", "never"])
+@pytest.mark.parametrize("k,rbits,minq", [(22, 15, None), (23, 15, 20), (24, 16, None), (25, 18, None), (26, 20, 20)])
+def test_level2_narrows_8_byte_payloads_below_the_region_index(K, monkeypatch, k, rbits, minq, narrow):
+    """Round 6: k >= 22 carries 8-byte payloads (the hash below the level-1 digit); in a power-of-two table of
+    2^rbits regions with 2k - rbits <= 32, level 2 writes the 4 bytes below the REGION index instead and the rest of the batch is a
+    32-bit batch over the virtual geometry (rbits, 1): 32-bit region kernel, 8-byte table image -- which k >= 22 never had.
+    Fresh pass, a pass over the image, results / histogram / lookups / min-count from it; then a batch with a heavy level-1
+    partition (10 % poly-A reads): its narrowed level 2 is run again wide and the image widened -- the same map.  With
+    KMERHIP_L2_NARROW=0 the 8-byte flow of rounds 1-5, for the same answers."""
+    import torch
+    monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1 << rbits))
+    monkeypatch.setenv("KMERHIP_L2_NARROW", narrow)
+    n_reads = 120_000
+    bases, qual = O.synth_reads(SEED + k, 1 << 21, 150, 0, n_reads)
+    tb, tq = torch.from_numpy(bases).cuda(), torch.from_numpy(qual).cuda()
+    torch.cuda.synchronize()
+    m = O.OracleMap()
+    m.scan_flat(bases, k, qual=qual if minq is not None else None, min_quality=minq, nthreads=NCPU)
+    half = (n_reads // 2) * 151
+    with K.DeviceCounter(k, min_quality=minq, capacity_hint=len(m), path="partition") as dc:
+        dc.push_device(tb.data_ptr(), tq.data_ptr() if minq is not None else None, half)                 # fresh
+        dc.push_device(tb.data_ptr() + half, tq.data_ptr() + half if minq is not None else None, len(bases) - half)   # over the image
+        st = dc.finish()
+        assert st["table_slots"] == 4096 << rbits and st["grows"] == 0
+        assert st["slot_bytes"] == (8 if narrow == "1" else 16), st
+        want_k, want_c = m.arrays()
+        keys, cnts = dc.result()
+        assert st["kmers"] == m.total() and np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
+        assert dc.histogram() == m.histogram()
+        probe = np.concatenate([want_k[:: max(1, len(want_k) // 4000)], np.array([0, (1 << (2 * k)) - 1], dtype=np.uint64)])
+        assert np.array_equal(dc.lookup(probe), np.array([m.get(int(x)) for x in probe], dtype=np.uint64))
+        k2, c2 = dc.result(min_count=2)
+        assert np.array_equal(k2, want_k[want_c >= 2]) and np.array_equal(c2, want_c[want_c >= 2])
+        # a heavy level-1 partition: 12 k poly-A reads among 108 k ordinary ones -> the narrowed level 2 steps aside for this batch
+        skew = bases.copy().reshape(n_reads, 151)
+        skew[::10, :150] = ord("A")
+        skew = skew.reshape(-1)
+        ts = torch.from_numpy(skew).cuda()
+        torch.cuda.synchronize()
+        dc.push_device(ts.data_ptr(), tq.data_ptr() if minq is not None else None, len(skew))
+        m.scan_flat(skew, k, qual=qual if minq is not None else None, min_quality=minq, nthreads=NCPU)
+        st = dc.finish()
+        want_k, want_c = m.arrays()
+        keys, cnts = dc.result()
+        assert st["kmers"] == m.total() and np.array_equal(keys, want_k) and np.array_equal(cnts, want_c)
+
+
+def test_a_batch_sized_for_a_narrowing_level2_that_cannot_narrow_runs_again_in_smaller_batches(K, monkeypatch):
+    """Batches of 8-byte payloads that level 2 is expected to narrow are sized at 15 bytes per window instead of 20.  Where the
+    batch cannot narrow after all -- here: heavy level-1 partitions (a fifth of the reads poly-A) -- and the 8-byte level-2 output
+    does not fit beside the pool (KMERHIP_L2_NO_ROOM_WIDE: as if), the same tiles run again in batches sized for it
+    (batch.hip KH_RETRY_WIDE).  Same map as the oracle's, more batches than the narrowing run needs."""
+    import torch
+    k, n_reads = 24, 150_000
+    monkeypatch.setenv("KMERHIP_TABLE_REGIONS", str(1 << 16))
+    bases, _ = O.synth_reads(SEED + 5, 1 << 21, 150, 0, n_reads, with_qual=False)
+    skew = bases.copy().reshape(n_reads, 151)
+    skew[::5, :150] = ord("A")
+    skew = skew.reshape(-1)
+    m = O.OracleMap()
+    m.scan_flat(skew, k, nthreads=NCPU)
+    want_k, want_c = m.arrays()
+    ts = torch.from_numpy(skew).cuda()
+    torch.cuda.synchronize()
+    got_batches = {}
+    for tag, env in (("retry", "1"), ("room", None)):
+        if env:
+            monkeypatch.setenv("KMERHIP_L2_NO_ROOM_WIDE", env)
+        else:
+            monkeypatch.delenv("KMERHIP_L2_NO_ROOM_WIDE", raising=False)
+        with K.DeviceCounter(k, capacity_hint=len(m), path="partition") as dc:
+            dc.push_device(ts.data_ptr(), None, len(skew))
+            st = dc.finish()
+            keys, cnts = dc.result()
+            assert st["kmers"] == m.total() and np.array_equal(keys, want_k) and np.array_equal(cnts, want_c), tag
+            got_batches[tag] = st["part_batches"]
+    assert got_batches["room"] == 1 and got_batches["retry"] >= 1
+
+
 @pytest.mark.parametrize("k,minq", [(21, None), (19, 20), (31, None), (25, 20)], ids=["k21", "k19q20", "k31", "k25q20"])
 @pytest.mark.parametrize("b2", [3, 40, 96, 520, 640, 1000])
 def test_tables_of_1024_x_b2_regions(K, monkeypatch, b2, k, minq):
