@@ -443,6 +443,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
             l1.pool_chunks = pool_chunks;
             l1.ctr = c->d_ctr;
             // KMERHIP_GENERIC_K=1: the C++ window where a written-out one exists; KMERHIP_P1_BINS=0: round 1's tile-sorting kernel (both for A/B)
+            l1.survive = ra.survive;
             l1.generic_k = c->knobs.generic_k;
             l1.legacy = c->knobs.p1_legacy;
             if (sizeof(PT) == 4) kh::launch_level1_32(l1, nullptr);

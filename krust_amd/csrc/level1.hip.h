@@ -569,9 +569,9 @@ __global__ __launch_bounds__(PART_NT) void part1_bins_kernel(
 // Same recipe as part1_bins_kernel, resized for 8 bytes per payload and the same 128 KiB of bins:
 //   * 1024 partitions (level 2's arena kernel takes <= 512 buckets per partition: 2^19 regions need all ten bits here),
 //     so a bin holds 16 payloads = two 64-byte SEGMENTS of 8; a flush writes whole segments and keeps <= 7 back;
-//   * to leave room for those, the bins are flushed every FW windows per lane: FW = 2 without quality masking (two
-//     arrivals per partition and flush on average: a bin overflows once in ~10^5 partition-flushes), FW = 4 with -Q
-//     (about 45 % of the windows survive the synthetic qualities: 1.8 arrivals);
+//   * to leave room for those, the bins are flushed every FW windows per lane: 4, or 8 where fewer than 0.55 of the windows
+//     survive masking -- 3.5-4 arrivals per partition and flush (round 6, level1_64.hip: rounds 3-5 flushed twice as often and
+//     paid a barrier pair and ~80 instructions per wave for every flush: k = 31 -Q 20 30.3 -> 25.8 ms, unmasked 48.6 -> 41.0);
 //   * overflow is exact, as there: the owner reserves the run's whole segments, leaves in the emptied bin where the
 //     payloads that did not fit go, and those lanes roll over their windows again and take a second rank.
 // KT: 0 = k is a run-time value, otherwise the kernel is compiled for that k (window masks, Feistel shifts and the

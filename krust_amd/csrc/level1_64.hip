@@ -9,11 +9,26 @@ namespace kh {
 namespace {
 #define KH_L1_ARGS l.abase, l.qbase, l.qaligned, l.vbeg, l.vend, l.wlo, l.tile0, l.ntiles, l.tiles_per_block, l.k, l.thr, l.g, \
                    (u64 *)l.pool, l.chunk_part, l.fill8, l.pool_next, l.pool_chunks, l.ctr
-// bins of 16 payloads are flushed every 2 windows per lane; with -Q (fewer windows survive) every 4
+// HOW OFTEN THE BINS ARE FLUSHED (round 6).  A bin holds 16 payloads, a flush keeps up to 7 back, so ~9 may arrive per partition
+// between two flushes before the slow path's extra barrier and re-roll are taken; a flush itself is a barrier pair and ~80
+// instructions in every one of the sixteen waves, whatever it finds.  Rounds 3-5 flushed every 2 windows per lane, every 4 with -Q.
+// Measured on S100M (level 1, ms), windows per lane between flushes 2 / 4 / 8 / 16:  k = 31 unmasked 48.6 / 41.0 / 47.2 / --;
+// k = 25 unmasked 49.5 / 42.6 / 48.9 / --;  k = 31 -Q 20 (0.44 of the windows survive) -- / 30.3 / 25.8 / 31.2;  k = 22 -Q 20 (0.6)
+// -- / 31.0 / 30.2 / 36.6: best where windows x survival is 3.5-4 arrivals per partition and flush.  So: every 8 windows where
+// less than 0.55 of the windows are expected to survive (the host's sample: RangeArgs::survive), else every 4.
+#ifndef KH_L1_FW_LOW
+#define KH_L1_FW_LOW 8   // (A/B builds)
+#endif
+#ifndef KH_L1_FW_HIGH
+#define KH_L1_FW_HIGH 4
+#endif
 template <int MODE, int KW>
 void launch_bins(const L1Launch &l) {
-    if (l.use_qual) hipLaunchKernelGGL((part1_bins64_kernel<true, MODE, KW, 4>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
-    else hipLaunchKernelGGL((part1_bins64_kernel<false, MODE, KW, 2>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
+    const bool low = l.survive < 0.55;
+    if (l.use_qual && low) hipLaunchKernelGGL((part1_bins64_kernel<true, MODE, KW, KH_L1_FW_LOW>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
+    else if (l.use_qual) hipLaunchKernelGGL((part1_bins64_kernel<true, MODE, KW, KH_L1_FW_HIGH>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
+    else if (low) hipLaunchKernelGGL((part1_bins64_kernel<false, MODE, KW, KH_L1_FW_LOW>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
+    else hipLaunchKernelGGL((part1_bins64_kernel<false, MODE, KW, KH_L1_FW_HIGH>), dim3(l.grid), dim3(PART_NT), 0, l.stream, KH_L1_ARGS);
 }
 #if KH_TESTING  // round 1's tile-sorting kernel: reachable through a test-build switch only, compiled into the test build only
 template <int MODE>

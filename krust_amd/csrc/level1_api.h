@@ -29,6 +29,7 @@ struct L1Launch {
     u64 *pool_next;
     u64 pool_chunks;
     Counters *ctr;
+    double survive;           // share of the windows expected to survive masking (1 = unknown / all): level1_64.hip's flush cadence
     bool generic_k;           // KMERHIP_GENERIC_K=1: the C++ window even where a written-out one exists (A/B)
     bool legacy;              // KMERHIP_P1_BINS=0: the tile-sorting kernel of round 1 (A/B)
 };
