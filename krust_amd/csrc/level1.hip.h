@@ -615,10 +615,11 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
     // for) meets no such window (0.0 % of them: a wave spans seven reads; the A/B build, KH_L1_WAVE_SKIP, is 3.5 ms SLOWER) --
     // but masked bases kill 31 windows in a row, and 47 % of the CHUNKS (a lane's sixteen windows) are dead from end to end.  So the
     // lanes whose chunk has a countable window publish it -- (chunk index, its 16-bit window mask): one word in a list, a ballot and an
-    // LDS add per wave, one more barrier per tile --, lane i takes list entry i (a chunk's code words are in LDS already), and the
-    // waves behind the list's end sit the window phases out: they only keep the barriers and flush their partitions' bins.
-    __shared__ uint32_t s_live[QUAL ? PART_NT : 1];
-    __shared__ uint32_t s_nlive;
+    // LDS add per wave --, lane i takes list entry i (a chunk's code words are in LDS already), and the waves behind the list's
+    // end sit the window phases out: they only keep the barriers and flush their partitions' bins.  The list of tile t + 1 is made
+    // DURING tile t, behind the barrier that follows its codes' staging (two lists, taken in turn): no barrier of its own.
+    __shared__ uint32_t s_live[QUAL ? 2 : 1][QUAL ? PART_NT : 1];
+    __shared__ uint32_t s_nlive[2];
     uint32_t *const s_cnt = s_mem;
     u64 *const s_bin = reinterpret_cast<u64 *>(s_mem + K64_BIN_OFF / 4);
     __attribute__((address_space(3))) char *const lds = (__attribute__((address_space(3))) char *)s_mem;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
     s_cnt[MAX_P1 + tid] = K21_WASTE0;  // the lane's own waste counter
     if (tid == 0) {
         s_flag = 0;
-        s_nlive = 0;
+        s_nlive[0] = s_nlive[1] = 0;
         s_priv_next = atomicAdd(pool_next, (u64)POOL_GRAB);
         s_priv_end = s_priv_next + POOL_GRAB;
     }
@@ -720,24 +721,42 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
         const RawChunk raw0 = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(tb, tid), vbeg, tb < te ? vend : 0);
         stage_encode<QUAL, PART_NT>(s_code, s_val, 0, true, tid, raw0, abase, qbase, qaligned, tb, vbeg, vend, thr);
     }
+#ifndef KH_L1_LIVE_LIST
+#define KH_L1_LIVE_LIST 1  // (0: A/B builds -- every lane works on its own chunk, dead or not)
+#endif
+    constexpr bool LIVE = QUAL && KH_L1_LIVE_LIST != 0;
+    // the lanes publish their live chunks of tile tt (its codes staged in s_code[cbuf], a barrier behind them) into list lb
+    auto build_list = [&](int cbuf, u64 tt, int lb) {
+        WinCtx wn;
+        wn.hi = s_code[cbuf][tid];
+        wn.lo64 = ((u64)s_code[cbuf][tid + 1] << 32) | s_code[cbuf][tid + 2];
+        wn.V = ((u64)s_val[cbuf][tid] << 32) | ((u64)s_val[cbuf][tid + 1] << 16) | (u64)s_val[cbuf][tid + 2];
+        wn.p0 = (u64)chunk_pos<PART_NT>(tt, tid);
+        const uint32_t gd = window_good(wn, k, wlo);
+        const bool live = gd != 0u;
+        const u64 m = kh_ballot(live);
+        uint32_t lbase = 0;
+        if (m) {
+            if ((int)lane_id() == __builtin_ctzll(m)) lbase = atomicAdd(&s_nlive[lb], (uint32_t)__builtin_popcountll(m));
+            lbase = (uint32_t)__shfl((int)lbase, __builtin_ctzll(m), 64);
+        }
+        if (live) s_live[lb][lbase + mbcnt(m)] = (uint32_t)tid | (gd << 16);
+    };
+    if constexpr (LIVE) {  // the first tile's list (later ones are made a tile ahead)
+        __syncthreads();
+        build_list(0, tb, 0);
+    }
     for (u64 t = tb; t < te; ++t, buf ^= 1) {
-        __syncthreads();  // B0: tile t's codes are in s_code[buf], the previous flush is over
+        __syncthreads();  // B0: tile t's codes are in s_code[buf] (and its list of live chunks whole), the previous flush is over
         // (the next tile's bases: requested here, encoded before this tile's first store -- see part1_bins_kernel)
         const RawChunk raw = load_raw<QUAL>(abase, qbase, qaligned, chunk_pos<PART_NT>(t + 1, tid), vbeg, t + 1 < te ? vend : 0);
         WinCtx w = stage_collect<PART_NT>(s_code, s_val, buf, tid, t);
-        uint32_t good = window_good(w, k, wlo);
+        uint32_t good = LIVE ? 0u : window_good(w, k, wlo);
         bool wave_busy = true;  // (uniform per wave)
-        if constexpr (QUAL) {   // the live chunks, compacted: see the banner at s_live
-            const bool live = good != 0u;
-            const u64 m = kh_ballot(live);
-            uint32_t lbase = 0;
-            if (m) {
-                if ((int)lane_id() == __builtin_ctzll(m)) lbase = atomicAdd(&s_nlive, (uint32_t)__builtin_popcountll(m));
-                lbase = (uint32_t)__shfl((int)lbase, __builtin_ctzll(m), 64);
-            }
-            if (live) s_live[lbase + mbcnt(m)] = (uint32_t)tid | (good << 16);
-            __syncthreads();  // B0': the list is whole
-            const uint32_t nlive = s_nlive;
+        const int lcur = (int)((t - tb) & 1);  // this tile's list; the other one is filled for tile t + 1 below
+        if constexpr (LIVE) {   // the live chunks, compacted: see the banner at s_live
+            const uint32_t nlive = s_nlive[lcur];
+            if (tid == 0) s_nlive[lcur ^ 1] = 0;  // (read by everybody a tile ago; added to again two barriers from here)
 #ifndef KH_L1_WAVE_ORDER
 #define KH_L1_WAVE_ORDER 0  // (1: A/B builds -- the list fills the waves in the order 0, 4, 8, 12, 1, 5, ...)
 #endif
@@ -748,7 +767,7 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
             const uint32_t wv = (uint32_t)tid >> 6, seg = KH_L1_WAVE_ORDER ? ((wv & 3u) << 2) | (wv >> 2) : wv;
             const uint32_t li = (seg << 6) | ((uint32_t)tid & 63u);
             wave_busy = (seg << 6) < nlive;
-            const uint32_t item = li < nlive ? s_live[li] : 0u;  // (a lane behind the list's end: no countable window)
+            const uint32_t item = li < nlive ? s_live[lcur][li] : 0u;  // (a lane behind the list's end: no countable window)
             const uint32_t c = item & 0xFFFFu;
             good = item >> 16;
             w.hi = s_code[buf][c];
@@ -817,7 +836,6 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
             }
             __syncthreads();  // B1
             const bool slow = s_flag != 0u;  // uniform
-            if (QUAL && h == 0 && tid == 0) s_nlive = 0;  // (everybody read it behind B0'; the next tile adds to it behind its B0)
             if (h == 0)  // tile t + 1's codes -> the other buffer (its bases were requested at B0)
                 stage_encode<QUAL, PART_NT>(s_code, s_val, buf ^ 1, false, tid, raw, abase, qbase, qaligned, t + 1, vbeg, vend, thr);
             flush(s_cnt[tid] >> 3);
@@ -850,7 +868,12 @@ __global__ __launch_bounds__(PART_NT) void part1_bins64_kernel(
                 if (tid == 0) s_flag = 0u;  // (everybody read it before B2'; it is set again after the next barrier)
             }
             if (h + 1 < NFLUSH) __syncthreads();  // B2: this flush is over (after the last one: the next tile's B0)
+            if constexpr (LIVE && h == 0 && NFLUSH > 1) build_list(buf ^ 1, t + 1, lcur ^ 1);  // (tile t + 1's codes were staged before the barrier just passed)
         });
+        if constexpr (LIVE && NFLUSH == 1) {  // (one flush per tile: the staging has no barrier behind it yet)
+            __syncthreads();
+            build_list(buf ^ 1, t + 1, lcur ^ 1);
+        }
     }
     __syncthreads();  // (the last slow path may have left carried payloads in other lanes' bins)
     const uint32_t res = s_cnt[tid] >> 3;
