@@ -763,6 +763,10 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                                                              OvfEntry *__restrict__ ovf_list, u64 *__restrict__ ovf, u64 ovf_cap,
                                                              const uint8_t *__restrict__ heavy) {
     constexpr bool NARROWS = !std::is_same<IT, PT>::value;
+#ifndef KH_ARENA_ONE_FLUSH
+#define KH_ARENA_ONE_FLUSH 1  // (0: A/B builds -- two flushes per batch whatever the payload)
+#endif
+    constexpr bool ONE_FLUSH = KH_ARENA_ONE_FLUSH != 0 && sizeof(IT) == 8 && (NARROWS || NBK != 1024);
     static_assert(!NARROWS || (sizeof(IT) == 8 && sizeof(PT) == 4 && POW2), "level 2 narrows 8-byte payloads to 4 bytes, power-of-two geometries");
     constexpr int UNIT = UNITB / (int)sizeof(PT), NT = P2L_NT, PER = P2L<IT>::PER, TILE = P2L<IT>::TILE;
     // what a payload is kept as in the bins / arenas / overflow list: itself, or (NARROWS) the 32 bits behind its bucket digit
@@ -1035,10 +1039,16 @@ __global__ __launch_bounds__(P2L_NT) void part2_arena_kernel(ChunkSrc cs, const 
                             }
                     }
                 }
+                // ONE FLUSH PER BATCH for 8-byte input (round 6): a batch of those is half as many payloads as a 4-byte one (the same
+                // registers), so a half batch brings a bin 4-8 arrivals where it has room for 17-33 beside what a flush keeps back --
+                // and a flush is a barrier pair and the whole flush code in every wave whatever it finds (level1_64.hip: the same
+                // lesson).  Both halves are ranked, then the bins are flushed once.  (Not the 1024-bucket instance of 8-byte OUTPUT:
+                // its bins hold 16.)
+                if (ONE_FLUSH && h == 0) continue;
 #if !(KH_ABL_ARENA & 2)  /* timing experiment otherwise (wrong results): no barrier between the ranks and the flush */
                 __syncthreads();  // B1
 #endif
-                if (h == 0) {  // the wait for the next batch's payloads goes HERE, before the first store (vmcnt: see part1_bins_kernel)
+                if (ONE_FLUSH || h == 0) {  // the wait for the next batch's payloads goes HERE, before the first store (vmcnt: see part1_bins_kernel)
 #pragma unroll
                     for (int j = 0; j < PER; ++j) asm volatile("" : "+v"(nxt[j]));
                 }
