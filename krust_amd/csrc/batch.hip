@@ -539,7 +539,10 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
                     }
                     const int below = 2 * (int)c->k - (int)rb;
                     size_t fr2 = 0, tot2 = 0;
-                    const bool fits = hipMemGetInfo(&fr2, &tot2) == hipSuccess && p2cap * sizeof(u64) <= ((u64)fr2 + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
+                    // (within the same third of the free memory as any other size, at 16 bytes a slot: a batch that cannot narrow after
+                    //  all -- heavy partitions -- goes through the 16-byte table)
+                    const bool fits = hipMemGetInfo(&fr2, &tot2) == hipSuccess &&
+                                      p2cap * sizeof(Slot) <= ((u64)fr2 + (c->table ? c->cap * sizeof(Slot) : 0) + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
                     if (below >= 1 && below <= 32 && rb <= kh::MAX_P1_BITS + kh::MAX_P2_BITS && fits && (!c->hinted || p2cap >= c->cap)) newcap = p2cap;
                 }
                 if (c->trace)
