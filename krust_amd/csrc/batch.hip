@@ -539,10 +539,15 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
                     }
                     const int below = 2 * (int)c->k - (int)rb;
                     size_t fr2 = 0, tot2 = 0;
-                    // (within the same third of the free memory as any other size, at 16 bytes a slot: a batch that cannot narrow after
-                    //  all -- heavy partitions -- goes through the 16-byte table)
-                    const bool fits = hipMemGetInfo(&fr2, &tot2) == hipSuccess &&
-                                      p2cap * sizeof(Slot) <= ((u64)fr2 + (c->table ? c->cap * sizeof(Slot) : 0) + (c->ntab ? c->ntab_cap * sizeof(u64) : 0)) / 3;
+                    // (its 8-byte image within a third of the free memory, and beside what this batch still has to allocate -- the arenas of
+                    //  4-byte payloads and the overflow list, ~7 bytes per payload: the partition budget was drawn when the table was half
+                    //  the size.  A batch that cannot narrow after all -- heavy partitions -- needs the 16-byte table: it comes back with
+                    //  KH_RETRY_WIDE where that does not fit, and runs again in batches that leave it room.)
+                    const u64 image_have = c->ntab ? c->ntab_cap * sizeof(u64) : 0, later = 7 * total > c->keyb_cap ? 7 * total - c->keyb_cap : 0;
+                    // (a table that HAS that size -- the context's last pass made it so -- simply keeps it: nothing to allocate)
+                    const bool fits = p2cap == c->cap ||
+                                      (hipMemGetInfo(&fr2, &tot2) == hipSuccess && p2cap * sizeof(u64) <= ((u64)fr2 + image_have) / 3 &&
+                                       (u64)fr2 + image_have >= p2cap * sizeof(u64) + later + (6ull << 30));
                     if (below >= 1 && below <= 32 && rb <= kh::MAX_P1_BITS + kh::MAX_P2_BITS && fits && (!c->hinted || p2cap >= c->cap)) newcap = p2cap;
                 }
                 if (c->trace)
@@ -613,7 +618,8 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
             (void)hipGetLastError();
             fr = 0;
         }
-        if (sized_narrow && ((u64)fr + c->keyb_cap < b_bytes_wide + (c->ntab ? 0 : c->cap * sizeof(u64)) + (2ull << 30) || c->knobs.l2_no_room_wide)) return KH_RETRY_WIDE;
+        // (8-byte payloads end in the 16-byte table: its room too, where it does not exist yet)
+        if (sized_narrow && ((u64)fr + c->keyb_cap < b_bytes_wide + (c->table ? 0 : c->cap * sizeof(Slot)) + (4ull << 30) || c->knobs.l2_no_room_wide)) return KH_RETRY_WIDE;
         u64 z = c->keysB ? c->keyb_cap : 0;
         const int r = ensure_buf(c, &c->keysB, &z, b_bytes_wide, "hipMalloc(keysB)");
         if (r == KH_OK) c->keyb_cap = b_bytes_wide;
@@ -770,6 +776,7 @@ int partition_batch(kh_ctx *c, const RangeArgs &ra, GeomChoice &gc, u64 tile0, u
         g2.b2_magic = kh::part_magic_of(1);
         g2.p2_bits = 0;
         g2.defer = 0;
+        c->narrow2_refused = false;
         if (c->trace) fprintf(stderr, "[kmerhip] level 2 narrowed the batch's payloads to the %d bits below the region index\n", below_region_bits);
         return finish_batch<uint32_t>(c, g2, reinterpret_cast<uint32_t *>(c->keysB), bend, nregions, n_all, n_ub, ovf_lim, false);
     }
@@ -959,7 +966,7 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         // that level 2 will narrow (partition_batch: a fresh table takes a power-of-two size for them; an existing one must be one):
         // 8-byte pool, 4-byte arenas.  A batch sized that way that cannot narrow after all comes back with KH_RETRY_WIDE.
         const int rb_now = (int)kh::kh_floor_log2((uint32_t)std::min<u64>(c->cap / kh::REGION_SLOTS, 1u << 20));
-        const bool expect_narrow = !gc.use32 && !no_narrow && c->knobs.l2_narrow && c->shard_shift == 0 && c->knobs.l2_arena &&
+        const bool expect_narrow = !gc.use32 && !no_narrow && !c->narrow2_refused && c->knobs.l2_narrow && c->shard_shift == 0 && c->knobs.l2_arena &&
                                    (c->table_empty ? (sample && 2 * (int)c->k - 20 <= 32) : (cap_is_pow2(c->cap) && rb_now >= 15 && 2 * (int)c->k - rb_now <= 32 && 2 * (int)c->k - rb_now >= 1));
         const u64 per_key = gc.use32 ? 11 : (expect_narrow ? 15 : 20);
         const u64 left = end_tile - t;
@@ -980,6 +987,14 @@ int count_device_range(kh_ctx *c, const uint8_t *d_bases, const uint8_t *d_qual,
         }
         if (rc == KH_RETRY_WIDE) {  // sized for a narrowing level 2 that is not to be: the same tiles again, 20 bytes per window
             no_narrow = true;
+            c->narrow2_refused = true;  // (... and this context's later ranges are sized for 8-byte output from the start, until one narrows)
+            {   // ... in batches that leave the 16-byte table its room (the budget was drawn before the table had its size)
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+                    const u64 have = (u64)fr + c->key_cap + c->keyb_cap, tab = c->table ? 0 : c->cap * sizeof(Slot);
+                    if (have > tab + (8ull << 30)) c->part_budget = std::min<u64>(c->part_budget, (u64)(0.9 * (double)(have - tab - (8ull << 30))));
+                } else (void)hipGetLastError();
+            }
             if (c->trace) fprintf(stderr, "[kmerhip] the batch was sized for 4-byte level-2 payloads and cannot have them: again in smaller batches\n");
             continue;
         }

@@ -245,6 +245,7 @@ struct kh_ctx {
     u64 est_set_cap = 0;
     u64 est_keys = 0;                // distinct keys the current fresh range is expected to bring (from that sample; 0 = no estimate)
     bool sized_by_sample = false;    // the table's size comes from such a sample (stats / trace)
+    bool narrow2_refused = false;    // a batch sized for a narrowing level 2 (15 B per window) could not narrow and had no room for 8-byte output: later ranges are sized for that
     bool estimate_on = true;         // KMERHIP_ESTIMATE=0: never (rounds 1-3's sizing: the hint, or the worst case)
     u64 part_batches = 0;
     double stage_ms[khi::ST_N] = {0};
