@@ -114,6 +114,21 @@ KH_HD uint32_t kh_feistel_f(uint32_t r, uint32_t c, uint32_t k) {
     // five instructions of a round in the extraction kernels.)
     return k < 32 ? (t >> (32 - k)) : t;
 }
+// ROUNDS 2 AND 4 (round 6 of the build: a new table hash): g(a) = bits k .. 2k-1 of the FULL product a x C -- on the device
+// v_mul_hi_u32 of the half held LEFT-aligned, (a << (32 - k)) x C >> 32 == (a x C) >> k -- where rounds 1 and 3 keep the top k
+// bits of the product's low word.  With the upper half of the hash kept left-aligned and the lower half right-aligned in the
+// written-out window (window.hip.h), a round of either kind is a multiply and ONE v_bitop3 (xor under a mask): two instructions
+// instead of multiply + shift + xor, -4 per window.  Which half gets which round matters: the level-1 digit comes from the half
+// that rounds 1 and 3 update (tools/hash_quality.py: with the roles swapped the region chi-square fails from k = 27 up).
+// Quality as the hash of rounds 1-5 and splitmix64 for k = 11 .. 32 on the tool's five key sets.
+KH_HD uint32_t kh_feistel_g(uint32_t a, uint32_t c, uint32_t k) {
+    const uint32_t mask = k < 32 ? ((1u << k) - 1u) : 0xFFFFFFFFu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a << ((32u - k) & 31u), c) & mask;  // (a < 2^k: the shift loses nothing)
+#else
+    return (uint32_t)(((uint64_t)a * c) >> k) & mask;
+#endif
+}
 #define KH_FC0 0x9E3779B1u
 #define KH_FC1 0x85EBCA77u
 #define KH_FC2 0xC2B2AE3Du
@@ -124,9 +139,9 @@ KH_HD uint64_t kh_hash_n(uint64_t key, uint32_t k) {
     const uint32_t mask = k < 32 ? ((1u << k) - 1u) : 0xFFFFFFFFu;
     uint32_t L = (uint32_t)(k < 32 ? (key >> k) : (key >> 32)) & mask, R = (uint32_t)key & mask, t;
     t = (L ^ kh_feistel_f<MODE>(R, KH_FC0, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC1, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_g(R, KH_FC1, k)) & mask; L = R; R = t;
     t = (L ^ kh_feistel_f<MODE>(R, KH_FC2, k)) & mask; L = R; R = t;
-    t = (L ^ kh_feistel_f<MODE>(R, KH_FC3, k)) & mask; L = R; R = t;
+    t = (L ^ kh_feistel_g(R, KH_FC3, k)) & mask; L = R; R = t;
     return k < 32 ? (((uint64_t)L << k) | R) : (((uint64_t)L << 32) | R);
 }
 
@@ -134,9 +149,9 @@ template <int MODE = KH_MUL_AUTO>
 KH_HD uint64_t kh_unhash_n(uint64_t h, uint32_t k) {
     const uint32_t mask = k < 32 ? ((1u << k) - 1u) : 0xFFFFFFFFu;
     uint32_t L = (uint32_t)(k < 32 ? (h >> k) : (h >> 32)) & mask, R = (uint32_t)h & mask, t;
-    t = (R ^ kh_feistel_f<MODE>(L, KH_FC3, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_g(L, KH_FC3, k)) & mask; R = L; L = t;
     t = (R ^ kh_feistel_f<MODE>(L, KH_FC2, k)) & mask; R = L; L = t;
-    t = (R ^ kh_feistel_f<MODE>(L, KH_FC1, k)) & mask; R = L; L = t;
+    t = (R ^ kh_feistel_g(L, KH_FC1, k)) & mask; R = L; L = t;
     t = (R ^ kh_feistel_f<MODE>(L, KH_FC0, k)) & mask; R = L; L = t;
     return k < 32 ? (((uint64_t)L << k) | R) : (((uint64_t)L << 32) | R);
 }

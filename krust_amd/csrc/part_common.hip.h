@@ -144,10 +144,10 @@ __device__ __forceinline__ void hash_p1_pay32(const uint32_t k, const uint32_t p
     const uint32_t mask = (1u << k) - 1u;
     uint32_t a = (uint32_t)(key >> k) & mask, b = (uint32_t)key & mask;
     a = (a ^ kh_feistel_f<MODE>(b, KH_FC0, k)) & mask;
-    b = (b ^ kh_feistel_f<MODE>(a, KH_FC1, k)) & mask;
+    b = (b ^ kh_feistel_g(a, KH_FC1, k)) & mask;
     a = (a ^ kh_feistel_f<MODE>(b, KH_FC2, k)) & mask;
 #if !KH_L1_DEFER_ROUND
-    b = (b ^ kh_feistel_f<MODE>(a, KH_FC3, k)) & mask;
+    b = (b ^ kh_feistel_g(a, KH_FC3, k)) & mask;
 #endif
     p1 = a >> (k - p1_bits);
     pay = ((a << k) | b) << (32u - (2u * k - p1_bits));  // a's top p1_bits fall off the 32-bit word
@@ -157,7 +157,7 @@ __device__ __forceinline__ uint32_t pay32_finish(uint32_t y, uint32_t p1, uint32
     const uint32_t nb = 2u * k - p1_bits;  // significant bits of the payload, left-aligned in 32
     const uint32_t alow = k > p1_bits ? y >> (32u - (k - p1_bits)) : 0u;
     const uint32_t a = (p1 << (k - p1_bits)) | alow;
-    return y ^ (kh_feistel_f<KH_MUL_AUTO>(a, KH_FC3, k) << (32u - nb));
+    return y ^ (kh_feistel_g(a, KH_FC3, k) << (32u - nb));
 }
 // ---- level-2 work unit and the two level-1 output layouts it can read -----------------------------
 struct Part2Block {

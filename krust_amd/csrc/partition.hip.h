@@ -1879,6 +1879,70 @@ __device__ __forceinline__ void region32_probe_lean(uint32_t nk, const uint32_t 
     }
 }
 
+// The same loop over a queue shared by the WAVE (round 6): `total` items, item n at word n of the wave's block of s_q.  A lane
+// that has placed its item PULLS the next unclaimed one (ballot + mbcnt over the lanes that finished in this iteration, a
+// wave-uniform cursor) instead of walking a share of its own: the loop ran until the wave's unluckiest lane -- the one whose
+// items had the longest probe sequences -- was done; now it runs for the wave's total number of probes / 64, rounded up.
+// (next4 <= 256 + 4 total <= 4 R32_QBLOCK: a lane that pulls beyond `total` reads the dummy row and stays idle.)
+// Measured (round 6, same box, twice): for the rounds that go through the loop whole -- the first round of a region that has no
+// full round, i.e. the hg-shaped input's million regions of 2.9 K payloads, nine in ten of them new keys -- 44.6 / 44.4 -> 44.0 /
+// 44.0 ms per step; behind the straight-line first probe, where a lane has two or three items left, the pulling costs what the
+// balance gains (headline 16.2 -> 16.4 ms, configs[3]'s share 19.9 -> 20.0): static shares stay there.
+#ifndef KH_REGION_PULL
+#define KH_REGION_PULL 1  // (0: A/B builds -- the lanes' own queues and region32_probe_lean for whole rounds)
+#endif
+#ifndef KH_REGION_PULL_FP
+#define KH_REGION_PULL_FP 0  // (1: A/B builds -- the pulling loop behind the straight-line first probe as well)
+#endif
+#ifndef KH_REGION_CLAIM_PARTIAL
+#define KH_REGION_CLAIM_PARTIAL 0  // (1: A/B builds -- the straight-line claims for a first round that is not full: two in flight, empty rows skipped)
+#endif
+template <bool POW2>
+__device__ __forceinline__ void region32_probe_pull(uint32_t total, const uint32_t *s_q, uint32_t *s_pay, uint32_t *s_add,
+                                                    uint32_t *s_fail, int tid, const R32Geo<POW2> &rg, uint32_t &nd) {
+    constexpr uint32_t GB = 4u * REGION_GROUP, WRAP = REGION_MASK << 2;
+    const char *const qw = reinterpret_cast<const char *>(s_q + ((uint32_t)tid >> 6) * R32_QBLOCK);  // the wave's block
+    char *const payb = reinterpret_cast<char *>(s_pay);
+    char *const addb = reinterpret_cast<char *>(s_add);
+    const uint32_t total4 = 4u * total;
+    uint32_t i4 = 4u * ((uint32_t)tid & 63u);  // the lane's item (byte offset into the block)
+    uint32_t next4 = 256u;                      // the first unclaimed item (wave-uniform)
+    uint32_t pay = *reinterpret_cast<const uint32_t *>(qw + i4);
+    uint32_t gb = rg.start_b(pay), gb0 = gb;
+    for (;;) {
+        const bool active = i4 < total4;
+        if (kh_ballot(active) == 0) break;
+        const R32Group c = r32_group_load_b(s_pay, gb);
+        uint32_t o4, f4;
+        bool hit = r32_group_find_b(c, pay, o4) && active;
+        const bool claim = r32_group_free_b(c, f4) && active && !hit;
+        bool again = false;
+        if (claim) {
+            const uint32_t old = atomicCAS(reinterpret_cast<uint32_t *>(payb + (gb | f4)), R32_FREE, pay);
+            if (old == R32_FREE) ++nd;
+            hit = old == R32_FREE || old == pay;
+            o4 = f4;
+            again = !hit;
+        }
+        if (hit) atomicAdd(reinterpret_cast<uint32_t *>(addb + (gb | o4)), 1u);
+        const bool miss = active && !hit && !again;
+        const uint32_t nb = (gb + GB) & WRAP;
+        bool done = hit;
+        if (miss && nb == gb0) {  // every group seen: region full
+            *s_fail = 1;
+            done = true;
+        }
+        gb = miss ? nb : gb;
+        const u64 dm = kh_ballot(done);
+        if (done) {
+            i4 = next4 + 4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+            pay = *reinterpret_cast<const uint32_t *>(qw + i4);
+            gb = gb0 = rg.start_b(pay);
+        }
+        next4 += 4u * (uint32_t)__builtin_popcountll(dm);
+    }
+}
+
 // uint32_t payloads: the LDS image is two 32-bit arrays, s_pay[] (0xFFFFFFFF = free) and s_add[] (count
 // added by this batch), 32 KiB per region, plus the lanes' payload queues -- nine words per lane: 36 KiB at 1024 lanes,
 // 18 at 512 (see the probing loop); the count update is a no-return ds_add_u32.  Slots that were
@@ -2039,10 +2103,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
         uint32_t pj[REGION_RK];
 #pragma unroll
         for (int j = 0; j < REGION_RK; ++j) pj[j] = kbuf[j];
+        if (rem > (u64)REGION_RK * NT) {  // (uniform; a region of one round -- most regions of a sparse table -- loads nothing here)
 #pragma unroll
-        for (int j = 0; j < REGION_RK; ++j) {  // next round's payloads in flight during the probing
-            const u64 i64 = base + (u64)(REGION_RK + j) * NT + tid;
-            kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
+            for (int j = 0; j < REGION_RK; ++j) {  // next round's payloads in flight during the probing
+                const u64 i64 = base + (u64)(REGION_RK + j) * NT + tid;
+                kbuf[j] = src[i64 < n ? (uint32_t)i64 : n - 1];
+            }
         }
 #ifndef KH_REGION_R1_LOOP
 #define KH_REGION_R1_LOOP 1  // (0: A/B builds -- the first round takes the straight-line first probe like the others)
@@ -2059,10 +2125,26 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
 #endif
         // (a FULL round only: with 2.9 K payloads in a region's one round -- the hg-shaped input -- three of a lane's eight places
         //  are empty and still swap at a dummy word, and the pass was 1.0 ms slower than through the queues: 16.5 -> 17.5 ms)
-        const bool claim_round = KH_REGION_R1_CLAIM && first_round && !hot && !may_special && rem >= (u64)REGION_RK * NT;
+        const bool claim_round = KH_REGION_R1_CLAIM && first_round && !hot && !may_special && (KH_REGION_CLAIM_PARTIAL || rem >= (u64)REGION_RK * NT);
+        const uint32_t rows = rem >= (u64)REGION_RK * NT ? (uint32_t)REGION_RK : (uint32_t)((rem + NT - 1) / NT);  // (uniform: rows of the round that hold a payload)
         if (hot || may_special || !FRESH || (first_round && !claim_round)) {
             // (the pass over a filled table keeps the old slots in registers; the straight-line first probe below
             // would push it over the 64 registers that two workgroups per CU allow)
+            if (KH_REGION_PULL && !hot && !may_special) {
+                // real payloads (sentinels dropped), compacted into the WAVE's queue: item n at word n of its block
+                const uint32_t lane = (uint32_t)tid & 63u, wq = ((uint32_t)tid >> 6) * R32_QBLOCK;
+                uint32_t wrun = 0;
+#pragma unroll
+                for (int j = 0; j < REGION_RK; ++j) {
+                    const bool valid = (uint32_t)j < nk && rg.mine(pj[j]);
+                    nreal += valid;
+                    const u64 qm = kh_ballot(valid);
+                    const uint32_t pos = wrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+                    s_q[wq + (valid ? pos : (uint32_t)REGION_RK * 64u + lane)] = pj[j];  // (row REGION_RK is a dummy row)
+                    wrun += (uint32_t)__builtin_popcountll(qm);
+                }
+                region32_probe_pull<POW2>(wrun, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
+            } else {
             uint32_t rq = 0;  // real payloads, compacted into the lane's queue (sentinels dropped)
 #pragma unroll
             for (int j = 0; j < REGION_RK; ++j)
@@ -2071,6 +2153,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             if (hot) region32_probe_round<true, POW2>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, rg, nd);
             else if (may_special) region32_probe_round<false, POW2>(rq, s_q, s_pay, s_add, &s_special, &s_fail, tid, rg, nd);
             else region32_probe_lean<POW2>(rq, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
+            }
         } else {
             // First probe of all eight payloads as straight-line code: the eight slot reads are in flight
             // together and a payload that finds its key right there (most of them: a key comes ~12 times, and at
@@ -2091,7 +2174,8 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
 #if KH_ABLR & 8  /* timing experiment: loads, LDS image and write-back only -- no probing at all */
             if (n) continue;
 #endif
-            constexpr int FP = KH_REGION_FP;
+            using FPfull = std::integral_constant<int, KH_REGION_FP>;
+            using FPpart = std::integral_constant<int, KH_REGION_CLAIM_PARTIAL ? 2 : KH_REGION_FP>;
             const uint32_t lane = (uint32_t)tid & 63u, wq = ((uint32_t)tid >> 6) * R32_QBLOCK;
             const uint32_t dummy_b = 4u * (REGION_SLOTS + (uint32_t)tid);
             // CHECK = false: a FULL round of a bucket that holds no sentinels (the arena level 2 writes none) -- every lane has
@@ -2104,11 +2188,13 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
             // 16.6 ms of an hg-shaped input's pass -- a million regions of 2.9 K payloads, nine in ten of them new keys, ALL of them
             // first-round payloads -- 11 were the loop, 27 vector + 30 scalar instructions per iteration and payload.  (That input
             // keeps the loop all the same -- see claim_round; the full first rounds of denser regions gain: 16.4 -> 16.0 ms at the headline.)
-            auto first_probe = [&](auto chk, auto clm) -> uint32_t {
+            auto first_probe = [&](auto chk, auto clm, auto fpv) -> uint32_t {
                 constexpr bool CHECK = decltype(chk)::value, CLAIM = decltype(clm)::value;
+                constexpr int FP = decltype(fpv)::value;
                 uint32_t wrun = 0;  // items queued by the wave so far (wave-uniform)
 #pragma unroll
                 for (int h = 0; h < REGION_RK; h += FP) {
+                    if (CHECK && (uint32_t)h >= rows) break;  // (uniform)
                     uint32_t oj[FP];
                     R32Group cj[FP];
                     bool vj[FP];
@@ -2161,11 +2247,12 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
 #endif
             const bool plain = KH_REGION_NOCHECK && no_sentinels && rem >= (u64)REGION_RK * NT;  // uniform
             uint32_t wrun;
-            if (claim_round) wrun = plain ? first_probe(std::false_type{}, std::true_type{}) : first_probe(std::true_type{}, std::true_type{});
-            else wrun = plain ? first_probe(std::false_type{}, std::false_type{}) : first_probe(std::true_type{}, std::false_type{});
+            if (claim_round) wrun = plain ? first_probe(std::false_type{}, std::true_type{}, FPfull{}) : first_probe(std::true_type{}, std::true_type{}, FPpart{});
+            else wrun = plain ? first_probe(std::false_type{}, std::false_type{}, FPfull{}) : first_probe(std::true_type{}, std::false_type{}, FPfull{});
             const uint32_t r = wrun > lane ? (wrun - lane + 63u) >> 6 : 0u;  // this lane's share: rows 0 .. r-1 of its column
 #if !(KH_ABLR & 1)  /* timing experiment otherwise: no probing loop behind the straight-line first probe */
-            region32_probe_lean<POW2>(r, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
+            if (KH_REGION_PULL_FP) region32_probe_pull<POW2>(wrun, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
+            else region32_probe_lean<POW2>(r, s_q, s_pay, s_add, &s_fail, tid, rg, nd);
 #endif
         }
     }

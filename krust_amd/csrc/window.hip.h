@@ -102,53 +102,47 @@ KH_HD void win_outputs_ref(uint64_t key, uint32_t &p1, uint32_t &pay32) {
 }
 
 #if defined(__HIPCC__)
-// One Feistel round on the halves held in two registers (they swap by NAME, no copies): a ^= (b * C) >> (32 - K).
-// 16 <= K <= 24: the 24-bit multiplier with the constant's low 24 bits (kh_feistel_f); otherwise v_mul_lo_u32,
-// which is VOP3 and takes no literal: the four constants come in SGPRs (%[f0] .. %[f3]).
+// The Feistel rounds on the halves held in two registers (round 6: TWO instructions per round).  A = v122 is the hash's upper half
+// LEFT-aligned (bits 32-K .. 31), B = v123 the lower half right-aligned; both stay where they are (no swaps, no copies):
+//   rounds 1, 3:  A = (A ^ (B x C)) & top-K-bits      v_mul_u32_u24 / v_mul_lo_u32 + v_bitop3 0x28  ((S0 ^ S1) & S2)
+//   rounds 2, 4:  B ^= mulhi(A, C) & low-K-bits       v_mul_hi_u32 + v_bitop3 0x78                  (S0 ^ (S1 & S2))
+// (kmer_bits.h: kh_feistel_f / kh_feistel_g -- the top K bits of the product's low word, and bits K .. 2K-1 of the full product:
+// mulhi of the left-aligned half is exactly that.)  The & of round 1 also clears what the split leaves below A's K bits (the
+// key's next bits: one v_alignbit makes A, no mask).  The two masks come in VGPRs (%[tm], %[kmv]: a v_bitop3 with an SGPR
+// operand costs 4.7 cycles instead of 2.9, tools/ubench/valu_rates.hip); 16 <= K <= 24: the 24-bit multiplier with the constant's
+// low 24 bits in rounds 1 and 3; otherwise v_mul_lo_u32, which is VOP3 and takes no literal: the constants come in SGPRs.
 #define KH_WSTR2(x) #x
 #define KH_WSTR(x) KH_WSTR2(x)
-#define KH_WIN_ROUND24(a, b, c24) "v_mul_u32_u24 v124, " c24 ", " b "\n v_lshrrev_b32 v124, %[rs], v124\n v_xor_b32 " a ", v124, " a "\n"
-#define KH_WIN_ROUND32(a, b, fc) "v_mul_lo_u32 v124, " b ", " fc "\n v_lshrrev_b32 v124, %[rs], v124\n v_xor_b32 " a ", v124, " a "\n"
-#define KH_WIN_ROUND32_K32(a, b, fc) "v_mul_lo_u32 v124, " b ", " fc "\n v_xor_b32 " a ", v124, " a "\n"
+#define KH_WIN_RA24(c24) "v_mul_u32_u24 v124, " c24 ", v123\n v_bitop3_b32 v122, v122, v124, %[tm] bitop3:0x28\n"
+#define KH_WIN_RA32(fc) "v_mul_lo_u32 v124, v123, " fc "\n v_bitop3_b32 v122, v122, v124, %[tm] bitop3:0x28\n"
+#define KH_WIN_RB(fc) "v_mul_hi_u32 v124, v122, " fc "\n v_bitop3_b32 v123, v123, v124, %[kmv] bitop3:0x78\n"
 #if KH_ABL_ROUNDS3  /* timing experiment only (wrong hash): three Feistel rounds */
-#define KH_WIN_ROUNDS24 \
-    KH_WIN_ROUND24("v122", "v123", "0x3779b1") KH_WIN_ROUND24("v123", "v122", "0xebca77") \
-    KH_WIN_ROUND24("v122", "v123", "0xb2ae3d")
+#define KH_WIN_ROUNDS24 KH_WIN_RA24("0x3779b1") KH_WIN_RB("%[f1]") KH_WIN_RA24("0xb2ae3d")
 #else
-#define KH_WIN_ROUNDS24 \
-    KH_WIN_ROUND24("v122", "v123", "0x3779b1") KH_WIN_ROUND24("v123", "v122", "0xebca77") \
-    KH_WIN_ROUND24("v122", "v123", "0xb2ae3d") KH_WIN_ROUND24("v123", "v122", "0xd4eb2f")
+#define KH_WIN_ROUNDS24 KH_WIN_RA24("0x3779b1") KH_WIN_RB("%[f1]") KH_WIN_RA24("0xb2ae3d") KH_WIN_RB("%[f3]")
 #endif
-#define KH_WIN_ROUNDS32 \
-    KH_WIN_ROUND32("v122", "v123", "%[f0]") KH_WIN_ROUND32("v123", "v122", "%[f1]") \
-    KH_WIN_ROUND32("v122", "v123", "%[f2]") KH_WIN_ROUND32("v123", "v122", "%[f3]")
-// 32-bit payloads (round 4): THREE rounds.  L = v122 -- the level-1 digit, the addresses -- is final after the third; the
-// fourth, which only changes R, is left to level 2 (part_common.hip.h hash_p1_pay32 / pay32_finish: level 1 is bound by its
+#define KH_WIN_ROUNDS32 KH_WIN_RA32("%[f0]") KH_WIN_RB("%[f1]") KH_WIN_RA32("%[f2]") KH_WIN_RB("%[f3]")
+// 32-bit payloads (round 4): THREE rounds.  A -- the level-1 digit, the addresses -- is final after the third; the
+// fourth, which only changes B, is left to level 2 (part_common.hip.h hash_p1_pay32 / pay32_finish: level 1 is bound by its
 // instruction stream, level 2 is not -- or so it seemed).  KH_L1_DEFER_ROUND=1 builds it; the default is the four-round window.
 #ifndef KH_L1_DEFER_ROUND
 #define KH_L1_DEFER_ROUND 0  // (measured: level 1 -1.0 ms, level 2 +2.0 ms -- see part_common.hip.h)
 #endif
 #if KH_L1_DEFER_ROUND
-#define KH_WIN_ROUNDS24_P32 \
-    KH_WIN_ROUND24("v122", "v123", "0x3779b1") KH_WIN_ROUND24("v123", "v122", "0xebca77") KH_WIN_ROUND24("v122", "v123", "0xb2ae3d")
-#define KH_WIN_ROUNDS32_P32 \
-    KH_WIN_ROUND32("v122", "v123", "%[f0]") KH_WIN_ROUND32("v123", "v122", "%[f1]") KH_WIN_ROUND32("v122", "v123", "%[f2]")
+#define KH_WIN_ROUNDS24_P32 KH_WIN_RA24("0x3779b1") KH_WIN_RB("%[f1]") KH_WIN_RA24("0xb2ae3d")
+#define KH_WIN_ROUNDS32_P32 KH_WIN_RA32("%[f0]") KH_WIN_RB("%[f1]") KH_WIN_RA32("%[f2]")
 #else
 #define KH_WIN_ROUNDS24_P32 KH_WIN_ROUNDS24
 #define KH_WIN_ROUNDS32_P32 KH_WIN_ROUNDS32
 #endif
-#define KH_WIN_ROUNDS32_K32 \
-    KH_WIN_ROUND32_K32("v122", "v123", "%[f0]") KH_WIN_ROUND32_K32("v123", "v122", "%[f1]") \
-    KH_WIN_ROUND32_K32("v122", "v123", "%[f2]") KH_WIN_ROUND32_K32("v123", "v122", "%[f3]")
-// After the rounds L = v122, R = v123 (two swaps per pair of rounds: back where they started).
-// Counter address and bin offset from L (K bits, the level-1 digit on top): (L >> (K - 12)) & 0xffc and
-// (L >> (K - 17)) & 0x1ff80, with a left shift where K - 12 / K - 17 is negative (the digit's low neighbours then
-// land below the mask).  A window without a key takes the lane's waste counter: sign-extended validity bit + v_bitop3.
-#define KH_WIN_ADDR(cshift_insn, bshift_insn)                                     \
-    cshift_insn " v124, %[cs], v122\n v_and_b32 v124, 0xffc, v124\n"              \
+// After the rounds A = v122 (K bits, left-aligned: the level-1 digit on top), B = v123.
+// Counter address and bin offset from A, the same shifts for every K: (A >> 20) & 0xffc and (A >> 15) & 0x1ff80.  A window
+// without a key takes the lane's waste counter: sign-extended validity bit + v_bitop3.
+#define KH_WIN_ADDR                                                               \
+    "v_lshrrev_b32 v124, 20, v122\n v_and_b32 v124, 0xffc, v124\n"                \
     "v_bfe_i32 v120, %[good], %[gb], 1\n"                                         \
     "v_bitop3_b32 %[cnta], v120, v124, %[waste] bitop3:0xca\n"                    \
-    bshift_insn " v124, %[bs], v122\n v_and_b32 %[binb], 0x1ff80, v124\n"     \
+    "v_lshrrev_b32 v124, 15, v122\n v_and_b32 %[binb], 0x1ff80, v124\n"           \
     "v_lshrrev_b32 v124, 3, %[binb]\n v_and_or_b32 %[binb], v124, %[rot], %[binb]\n"  /* | (p1 & 7) << 4: the bin's unit permutation (level1.hip.h (6)) */
 
 // 32-bit payloads, K = 11..21.  In: forward / reverse complement (hi words are zero for K <= 16), the lane's validity
@@ -160,43 +154,41 @@ __device__ __forceinline__ void win_hash32(uint32_t flo, uint32_t fhi, uint32_t 
                                            uint32_t rot, uint32_t &pay, uint32_t &cnta, uint32_t &binb) {
     static_assert(K >= 11 && K <= 21, "32-bit payloads: 2k - 10 <= 32");
     constexpr uint32_t KM = (1u << K) - 1u;
-    constexpr int RS = 32 - K;                    // the round keeps the top k bits of the product's low word
-    constexpr int PL = 42 - K, PR = 42 - 2 * K;   // payload = L << PL | R << PR (L's digit falls off the top)
-    constexpr int CS = K >= 12 ? K - 12 : 12 - K, BS = K >= 17 ? K - 17 : 17 - K;
+    constexpr int PR = 42 - 2 * K;                       // payload = A << 10 | B << PR (A's digit falls off the top)
+    constexpr int AS = K >= 17 ? 2 * K - 32 : 32 - 2 * K;  // A = key >> AS (two words) or key << AS (one word): the key's top 32 bits
     const uint32_t f0 = KH_FC0, f1 = KH_FC1, f2 = KH_FC2, f3 = KH_FC3;
+    const uint32_t tm = ~0u << (32 - K), kmv = KM;
     const uint64_t f64 = ((uint64_t)fhi << 32) | flo, r64 = ((uint64_t)rhi << 32) | rlo;
 #define KH_W32_OPERANDS                                                                                                   \
     : [pay] "=&v"(pay), [cnta] "=&v"(cnta), [binb] "=&v"(binb)                                                            \
     : [flo] "v"(flo), [fhi] "v"(fhi), [rlo] "v"(rlo), [rhi] "v"(rhi), [f] "v"(f64), [r] "v"(r64), [good] "v"(good),      \
-      [waste] "v"(waste), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3), [rot] "s"(rot),                        \
-      [k] "n"(K), [km] "n"(KM), [rs] "n"(RS), [pl] "n"(PL), [pr] "n"(PR), [cs] "n"(CS), [bs] "n"(BS), [gb] "n"(15 - J)   \
+      [waste] "v"(waste), [tm] "v"(tm), [kmv] "v"(kmv), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3),          \
+      [rot] "s"(rot), [km] "n"(KM), [as] "n"(AS), [pr] "n"(PR), [gb] "n"(15 - J)                                         \
     : "v120", "v121", "v122", "v123", "v124", "s98", "s99"
-#define KH_W32_PAY "v_lshlrev_b32 v124, %[pr], v123\n v_lshl_or_b32 %[pay], v122, %[pl], v124\n"
-#define KH_W32_PAY0 "v_lshl_or_b32 %[pay], v122, %[pl], v123\n"   /* K = 21: R needs no shift */
+#define KH_W32_PAY "v_lshlrev_b32 v124, %[pr], v123\n v_lshl_or_b32 %[pay], v122, 10, v124\n"
+#define KH_W32_PAY0 "v_lshl_or_b32 %[pay], v122, 10, v123\n"   /* K = 21: B needs no shift */
     // canonical = min(forward, reverse complement) as integers (== the reference's lexicographic choice,
     // src/kmer.rs:348-365): k >= 17 compare into an SGPR pair, two selects on it; k <= 16 one v_min_u32
 #define KH_W32_CANON64                                              \
     "v_cmp_lt_u64_e64 s[98:99], %[f], %[r]\n"                       \
     "v_cndmask_b32_e64 v120, %[rlo], %[flo], s[98:99]\n"            \
     "v_cndmask_b32_e64 v121, %[rhi], %[fhi], s[98:99]\n"            \
-    "v_alignbit_b32 v122, v121, v120, %[k]\n"      /* L */          \
-    "v_and_b32 v123, %[km], v120\n"                /* R */
+    "v_alignbit_b32 v122, v121, v120, %[as]\n"     /* A (+ the key's next bits below: round 1 clears them) */ \
+    "v_and_b32 v123, %[km], v120\n"                /* B */
 #define KH_W32_CANON32 \
-    "v_min_u32 v120, %[flo], %[rlo]\n v_lshrrev_b32 v122, %[k], v120\n v_and_b32 v123, %[km], v120\n"
+    "v_min_u32 v120, %[flo], %[rlo]\n v_lshlrev_b32 v122, %[as], v120\n v_and_b32 v123, %[km], v120\n"
 #if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the declaration)
     if constexpr (K == 21) {
-        asm(KH_W32_CANON64 KH_WIN_ROUNDS24_P32 KH_W32_PAY0 KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON64 KH_WIN_ROUNDS24_P32 KH_W32_PAY0 KH_WIN_ADDR KH_W32_OPERANDS);
     } else if constexpr (K >= 17) {
-        asm(KH_W32_CANON64 KH_WIN_ROUNDS24_P32 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON64 KH_WIN_ROUNDS24_P32 KH_W32_PAY KH_WIN_ADDR KH_W32_OPERANDS);
     } else if constexpr (K == 16) {
-        asm(KH_W32_CANON32 KH_WIN_ROUNDS24_P32 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
-    } else if constexpr (K >= 12) {
-        asm(KH_W32_CANON32 KH_WIN_ROUNDS32_P32 KH_W32_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON32 KH_WIN_ROUNDS24_P32 KH_W32_PAY KH_WIN_ADDR KH_W32_OPERANDS);
     } else {
-        asm(KH_W32_CANON32 KH_WIN_ROUNDS32_P32 KH_W32_PAY KH_WIN_ADDR("v_lshlrev_b32", "v_lshlrev_b32") KH_W32_OPERANDS);
+        asm(KH_W32_CANON32 KH_WIN_ROUNDS32_P32 KH_W32_PAY KH_WIN_ADDR KH_W32_OPERANDS);
     }
 #else
-    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)PL; (void)PR; (void)CS; (void)BS;
+    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)PR; (void)AS; (void)tm; (void)kmv;
     pay = cnta = binb = 0;
 #endif
 #undef KH_W32_CANON32
@@ -215,36 +207,35 @@ __device__ __forceinline__ void win_hash64(uint32_t flo, uint32_t fhi, uint32_t 
                                            uint32_t rot, uint32_t &klo, uint32_t &khi, uint32_t &cnta, uint32_t &binb) {
     static_assert(K >= 22 && K <= 32, "64-bit payloads");
     constexpr uint32_t KM = K < 32 ? (1u << (K & 31)) - 1u : 0xFFFFFFFFu;
-    constexpr int RS = 32 - K;
-    constexpr int CS = K - 12, BS = K - 17;
-    constexpr int PS = 74 - 2 * K, PSR = 32 - PS, PLS = 42 - K;   // the payload's shifts (above)
+    constexpr int AS = (2 * K - 32) & 31;                         // A = key >> (2K - 32): the key's top 32 bits (K = 32: its high word)
+    constexpr int PS = 74 - 2 * K, PSR = 32 - PS;                 // the payload's shifts (above)
     const uint32_t f0 = KH_FC0, f1 = KH_FC1, f2 = KH_FC2, f3 = KH_FC3;
+    const uint32_t tm = K < 32 ? ~0u << ((32 - K) & 31) : ~0u, kmv = KM;
     const uint64_t f64 = ((uint64_t)fhi << 32) | flo, r64 = ((uint64_t)rhi << 32) | rlo;
 #define KH_W64_OPERANDS                                                                                                   \
     : [klo] "=&v"(klo), [khi] "=&v"(khi), [cnta] "=&v"(cnta), [binb] "=&v"(binb)                                          \
     : [flo] "v"(flo), [fhi] "v"(fhi), [rlo] "v"(rlo), [rhi] "v"(rhi), [f] "v"(f64), [r] "v"(r64), [good] "v"(good),      \
-      [waste] "v"(waste), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3), [rot] "s"(rot),                        \
-      [k] "n"(K & 31), [km] "n"(KM), [rs] "n"(RS), [cs] "n"(CS), [bs] "n"(BS), [gb] "n"(15 - J),                         \
-      [ps] "n"(PS), [psr] "n"(PSR), [pls] "n"(PLS)                                                                       \
+      [waste] "v"(waste), [tm] "v"(tm), [kmv] "v"(kmv), [f0] "s"(f0), [f1] "s"(f1), [f2] "s"(f2), [f3] "s"(f3),          \
+      [rot] "s"(rot), [as] "n"(AS), [km] "n"(KM), [gb] "n"(15 - J), [ps] "n"(PS), [psr] "n"(PSR)                         \
     : "v120", "v122", "v123", "v124", "s98", "s99"
-    // the payload from the hashed halves (L = v122, R = v123): three instructions
-#define KH_W64_PAY "v_lshrrev_b32 v124, %[psr], v123\n v_lshl_or_b32 %[khi], v122, %[pls], v124\n v_lshlrev_b32 %[klo], %[ps], v123\n"
+    // the payload from the hashed halves (A = v122 left-aligned, B = v123): high word A << 10 | B >> (2K - 42), low word B << (74 - 2K)
+#define KH_W64_PAY "v_lshrrev_b32 v124, %[psr], v123\n v_lshl_or_b32 %[khi], v122, 10, v124\n v_lshlrev_b32 %[klo], %[ps], v123\n"
 #define KH_W64_CANON                                                \
     "v_cmp_lt_u64_e64 s[98:99], %[f], %[r]\n"                       \
     "v_cndmask_b32_e64 %[klo], %[rlo], %[flo], s[98:99]\n"          \
     "v_cndmask_b32_e64 %[khi], %[rhi], %[fhi], s[98:99]\n"
-#define KH_W64_SPLIT "v_alignbit_b32 v122, %[khi], %[klo], %[k]\n v_and_b32 v123, %[km], %[klo]\n"   /* L, R */
+#define KH_W64_SPLIT "v_alignbit_b32 v122, %[khi], %[klo], %[as]\n v_and_b32 v123, %[km], %[klo]\n"   /* A (+ next bits: round 1 clears them), B */
 #define KH_W64_SPLIT_K32 "v_mov_b32 v122, %[khi]\n v_mov_b32 v123, %[klo]\n"
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (K <= 24) {
-        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS24 KH_W64_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
+        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS24 KH_W64_PAY KH_WIN_ADDR KH_W64_OPERANDS);
     } else if constexpr (K < 32) {
-        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS32 KH_W64_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
+        asm(KH_W64_CANON KH_W64_SPLIT KH_WIN_ROUNDS32 KH_W64_PAY KH_WIN_ADDR KH_W64_OPERANDS);
     } else {
-        asm(KH_W64_CANON KH_W64_SPLIT_K32 KH_WIN_ROUNDS32_K32 KH_W64_PAY KH_WIN_ADDR("v_lshrrev_b32", "v_lshrrev_b32") KH_W64_OPERANDS);
+        asm(KH_W64_CANON KH_W64_SPLIT_K32 KH_WIN_ROUNDS32 KH_W64_PAY KH_WIN_ADDR KH_W64_OPERANDS);
     }
 #else
-    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)RS; (void)CS; (void)BS; (void)PS; (void)PSR; (void)PLS;
+    (void)f64; (void)r64; (void)rot; (void)f0; (void)f1; (void)f2; (void)f3; (void)KM; (void)AS; (void)PS; (void)PSR; (void)tm; (void)kmv;
     klo = khi = cnta = binb = 0;
 #endif
 #undef KH_W64_PAY

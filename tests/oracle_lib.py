@@ -296,11 +296,14 @@ def table_hash_np(keys, k):
     m32 = np.uint64(0xFFFFFFFF)
     L = (keys >> np.uint64(k)) & mask
     R = keys & mask
-    for c in _FC:
-        cc = np.uint64((c & 0xFFFFFF) | 1) if 16 <= k <= 24 else np.uint64(c)
-        t = (R * cc) & m32
-        if k < 32:
-            t = t >> np.uint64(32 - k)
+    for i, c in enumerate(_FC):
+        if i % 2:  # rounds 2 and 4 (kh_feistel_g): bits k .. 2k-1 of the full product (R, c < 2^32: it fits 64 bits)
+            t = ((R * np.uint64(c)) >> np.uint64(k)) & mask
+        else:
+            cc = np.uint64((c & 0xFFFFFF) | 1) if 16 <= k <= 24 else np.uint64(c)
+            t = (R * cc) & m32
+            if k < 32:
+                t = t >> np.uint64(32 - k)
         L, R = R, (L ^ t) & mask
     return (L << np.uint64(k)) | R
 

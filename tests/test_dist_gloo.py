@@ -75,20 +75,22 @@ import krust_amd
 from krust_amd.distributed import merge_across_ranks, shard_range
 
 FC = (0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F)
-def ff(r, c, k):
+def ff(r, c, k, i):
+    if i % 2:  # rounds 2 and 4 (kmer_bits.h kh_feistel_g): bits k .. 2k-1 of the full product
+        return ((r * c) >> k) & ((1 << k) - 1)
     t = (r * ((c & 0xFFFFFF) | 1)) & 0xFFFFFFFF if 16 <= k <= 24 else (r * c) & 0xFFFFFFFF
     return t >> (32 - k) if k < 32 else t
 def table_hash(key, k):
     mask = (1 << k) - 1
     L, R = (key >> k) & mask, key & mask
-    for c in FC:
-        L, R = R, (L ^ ff(R, c, k)) & mask
+    for i, c in enumerate(FC):
+        L, R = R, (L ^ ff(R, c, k, i)) & mask
     return (L << k) | R
 def table_unhash(h, k):
     mask = (1 << k) - 1
     L, R = (h >> k) & mask, h & mask
-    for c in reversed(FC):
-        L, R = (R ^ ff(L, c, k)) & mask, L
+    for i, c in reversed(list(enumerate(FC))):
+        L, R = (R ^ ff(L, c, k, i)) & mask, L
     return (L << k) | R
 
 def view(ptr, n, dtype):

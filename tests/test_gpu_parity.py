@@ -284,7 +284,9 @@ def test_many_batches_into_one_table_match_the_direct_path(K, k, minq):
 _FC = (0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F)
 
 
-def _feistel_f(r, c, k):
+def _feistel_f(r, c, k, i):
+    if i % 2:  # rounds 2 and 4 (kh_feistel_g): bits k .. 2k-1 of the full product
+        return ((r * c) >> k) & ((1 << k) - 1)
     t = (r * ((c & 0xFFFFFF) | 1)) & 0xFFFFFFFF if 16 <= k <= 24 else (r * c) & 0xFFFFFFFF
     return t >> (32 - k) if k < 32 else t
 
@@ -292,16 +294,16 @@ def _feistel_f(r, c, k):
 def _table_hash(key, k):
     mask = (1 << k) - 1
     L, R = (key >> k) & mask, key & mask
-    for c in _FC:
-        L, R = R, (L ^ _feistel_f(R, c, k)) & mask
+    for i, c in enumerate(_FC):
+        L, R = R, (L ^ _feistel_f(R, c, k, i)) & mask
     return (L << k) | R
 
 
 def _table_unhash(h, k):
     mask = (1 << k) - 1
     L, R = (h >> k) & mask, h & mask
-    for c in reversed(_FC):
-        L, R = (R ^ _feistel_f(L, c, k)) & mask, L
+    for i, c in reversed(list(enumerate(_FC))):
+        L, R = (R ^ _feistel_f(L, c, k, i)) & mask, L
     return (L << k) | R
 
 

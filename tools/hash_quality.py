@@ -12,19 +12,25 @@ FC = [0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F]
 M32 = np.uint64(0xFFFFFFFF)
 
 
-def feistel(keys, k, rounds=4, xorshift=False, mul24=None):
+def feistel(keys, k, rounds=4, xorshift=False, mul24=None, mulhi_even=False):
+    """mulhi_even=False: the hash of rounds 1-5 (every round keeps the top k bits of the product's LOW word).
+    mulhi_even=True: the shipped hash since round 6 -- rounds 2 and 4 keep bits k .. 2k-1 of the full product (v_mul_hi_u32 of
+    the left-aligned half): two instructions per round in the written-out window instead of three (window.hip.h)."""
     keys = keys.astype(np.uint64)
     mask = np.uint64((1 << k) - 1)
     if mul24 is None:
         mul24 = 16 <= k <= 24
     L = (keys >> np.uint64(k)) & mask
     R = keys & mask
-    for c in FC[:rounds]:
-        cc = np.uint64((c & 0xFFFFFF) | 1) if mul24 else np.uint64(c)
-        t = (R * cc) & M32
-        if xorshift:
-            t ^= t >> np.uint64(15)
-        t >>= np.uint64(32 - k)
+    for i, c in enumerate(FC[:rounds]):
+        if mulhi_even and i % 2 == 1:
+            t = ((R * np.uint64(c)) >> np.uint64(k)) & mask     # R < 2^32, c < 2^32: the product fits 64 bits
+        else:
+            cc = np.uint64((c & 0xFFFFFF) | 1) if mul24 else np.uint64(c)
+            t = (R * cc) & M32
+            if xorshift:
+                t ^= t >> np.uint64(15)
+            t >>= np.uint64(32 - k)
         t = (L ^ t) & mask
         L, R = R, t
     return (L << np.uint64(k)) | R
@@ -92,7 +98,8 @@ def main():
         "stride 4097": (np.arange(2_000_000, dtype=np.uint64) * np.uint64(4097)) & np.uint64((1 << (2 * k)) - 1),
     }
     variants = {
-        "feistel 4r (shipped)": lambda x: feistel(x, k),
+        "feistel 4r, mulhi in rounds 2 and 4 (shipped)": lambda x: feistel(x, k, mulhi_even=True),
+        "feistel 4r (rounds 1-5)": lambda x: feistel(x, k),
         "feistel 4r + xorshift (earlier)": lambda x: feistel(x, k, xorshift=True),
         "feistel 3r": lambda x: feistel(x, k, rounds=3),
         "feistel 3r + xorshift": lambda x: feistel(x, k, rounds=3, xorshift=True),
@@ -106,7 +113,7 @@ def main():
             hh = fn(keys)
             a, b, c = stats(hh, k, rb)
             prb, dm, dx, load = probe_stats(hh, k)
-            print(f"   {vname:34s} {a:8.3f} {b:8.3f} {c:7.3f}   probing at load {load:.2f}: mean disp {dm:6.3f}, max {dx}")
+            print(f"   {vname:46s} {a:8.3f} {b:8.3f} {c:7.3f}   probing at load {load:.2f}: mean disp {dm:6.3f}, max {dx}")
 
 
 if __name__ == "__main__":
