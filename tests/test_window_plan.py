@@ -3,7 +3,10 @@ of a lane, the bit fields the written-out window cuts out of the lane's three co
 reversed complements must be the packed k-mer of src/kmer.rs:467-471 and its reverse complement, and the level-1
 digit / 32-bit payload definition must agree with the table hash.  The extraction runs on the device as v_alignbit /
 v_bfe through builtins that are exactly the host arithmetic compiled here; the asm that follows it (canonical choice,
-Feistel rounds, addresses) is held to the same definitions by the GPU parity tests, which run every k."""
+Feistel rounds, addresses) is held to the same definitions by the GPU parity tests, which run every k.  Round 6: the same
+program checks that the table hash is a bijection of the 2k-bit keys for k = 1..32 (kh_unhash_n inverts kh_hash_n) and that the
+arithmetic of the written-out rounds -- upper half left-aligned with the key's next bits below it, masks applied by the rounds'
+own v_bitop3, v_mul_hi_u32 in rounds 2 and 4 -- modelled instruction by instruction on the host, is kh_hash_n for k = 11..32."""
 import os
 import subprocess
 

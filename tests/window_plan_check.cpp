@@ -39,6 +39,38 @@ static void check_one(const uint8_t *codes /* 48 two-bit codes, oldest first */,
     }
 }
 
+// The arithmetic of the written-out rounds (window.hip.h, round 6), instruction for instruction on the host: A = the key's top 32 bits
+// (what one v_alignbit / v_lshlrev leaves: the upper half LEFT-aligned with the key's next bits below it), B = the lower half; rounds
+// 1 and 3 are (A ^ (B x C)) & top-K-bits -- which also clears what was below A --, rounds 2 and 4 B ^= mulhi(A, C) & low-K-bits.
+// It must be kh_hash_n, the definition everything else uses, for every k the windows exist for.
+static uint64_t asm_model(uint64_t key, int K) {
+    const uint32_t km = K < 32 ? (1u << K) - 1u : 0xFFFFFFFFu, tm = K < 32 ? ~0u << (32 - K) : 0xFFFFFFFFu;
+    uint32_t A = K == 32 ? (uint32_t)(key >> 32) : 2 * K >= 32 ? (uint32_t)(key >> (2 * K - 32)) : (uint32_t)key << (32 - 2 * K);
+    uint32_t B = (uint32_t)key & km;
+    const bool m24 = K >= 16 && K <= 24;
+    const uint32_t c0 = m24 ? (KH_FC0 & 0xFFFFFFu) | 1u : KH_FC0, c2 = m24 ? (KH_FC2 & 0xFFFFFFu) | 1u : KH_FC2;
+    A = (A ^ (B * c0)) & tm;
+    B ^= (uint32_t)(((uint64_t)A * KH_FC1) >> 32) & km;
+    A = (A ^ (B * c2)) & tm;
+    B ^= (uint32_t)(((uint64_t)A * KH_FC3) >> 32) & km;
+    const uint64_t L = K < 32 ? A >> (32 - K) : A;
+    return (L << (K < 32 ? K : 32)) | B;
+}
+
+static void check_hash() {
+    for (int k = 1; k <= 32; ++k) {
+        const uint64_t kmask = kh_kmask((uint32_t)k);
+        for (int rep = 0; rep < 4000; ++rep) {
+            const uint64_t key = (rep == 0 ? 0ull : rep == 1 ? ~0ull : rep == 2 ? 1ull : rep == 3 ? 1ull << (2 * k - 1) : rnd()) & kmask;
+            const uint64_t h = kh_hash_n((uint64_t)key, (uint32_t)k);
+            bool bad = (h & ~kmask) != 0 || kh_unhash_n(h, (uint32_t)k) != key;   // a bijection of the 2k-bit keys
+            if (k >= 11) bad = bad || asm_model(key, k) != h;
+            if (bad && failures++ < 10) fprintf(stderr, "hash k=%d key %llx: h %llx back %llx model %llx\n", k, (unsigned long long)key,
+                                                (unsigned long long)h, (unsigned long long)kh_unhash_n(h, (uint32_t)k), (unsigned long long)asm_model(key, k));
+        }
+    }
+}
+
 template <int K, int... Js>
 static void check_k(std::integer_sequence<int, Js...>) {
     for (int rep = 0; rep < 200; ++rep) {
@@ -59,6 +91,7 @@ static void check_all(std::integer_sequence<int, Ks...>) {
 
 int main() {
     check_all(std::make_integer_sequence<int, 22>());  // k = 11..32
+    check_hash();
     if (failures) {
         fprintf(stderr, "%d failures\n", failures);
         return 1;
