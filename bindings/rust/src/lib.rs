@@ -130,6 +130,19 @@ pub enum HipError {
     Device(String),
 }
 
+/// `KMERHIP_ABI_VERSION` of the `include/kmerhip.h` that `mod sys` mirrors: the structs above are laid out for it.
+pub const ABI_VERSION: c_int = 2;
+
+/// Called before the first `kh_create` of every constructor: a library of another ABI version is refused, not guessed at.
+fn check_abi() -> Result<(), HipError> {
+    // SAFETY: a pure function of the library
+    let v = unsafe { sys::kh_abi_version() };
+    if v != ABI_VERSION {
+        return Err(HipError::Device(format!("libkmerhip speaks ABI version {v}, this crate {ABI_VERSION}")));
+    }
+    Ok(())
+}
+
 fn check(ctx: *const sys::KhCtx, rc: c_int) -> Result<(), HipError> {
     if rc == 0 {
         return Ok(());
@@ -221,6 +234,7 @@ impl HipKmerMap {
             input_mib: 0,
         };
         let mut ctx = std::ptr::null_mut();
+        check_abi()?;
         check(std::ptr::null(), unsafe { sys::kh_create(&mut ctx, &cfg) })?;
         Ok(Self { ctx, k, has_qual: min_quality.is_some() })
     }
@@ -362,6 +376,7 @@ impl HipKmerMapGroup {
             input_mib: 0,
         };
         let mut group = std::ptr::null_mut();
+        check_abi()?;
         check(std::ptr::null(), unsafe { sys::kh_group_create(&mut group, &cfg, devices.as_ptr(), devices.len() as u32) })?;
         Ok(Self { group, k, next: 0 })
     }

@@ -129,6 +129,7 @@ class KmerLengthError(ValueError):
 
 
 _lib = None
+ABI_VERSION = 2  # KMERHIP_ABI_VERSION of the include/kmerhip.h this file mirrors (tests/test_abi.py)
 
 
 def lib():
@@ -151,6 +152,8 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+        if L.kh_abi_version() != ABI_VERSION:  # (the structs below are laid out for this version of include/kmerhip.h)
+            raise ImportError(f"{LIB_PATH} speaks ABI version {L.kh_abi_version()}, this binding {ABI_VERSION}: rebuild the library")
         _lib = L
     return _lib
 
