@@ -2130,7 +2130,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
         if (hot || may_special || !FRESH || (first_round && !claim_round)) {
             // (the pass over a filled table keeps the old slots in registers; the straight-line first probe below
             // would push it over the 64 registers that two workgroups per CU allow)
-            if (KH_REGION_PULL && !hot && !may_special) {
+            if (KH_REGION_PULL && FRESH && !hot && !may_special) {  // (FRESH only: a pass over a filled table keeps its old slots in registers, and the 1024-lane kernel's 64 would spill)
                 // real payloads (sentinels dropped), compacted into the WAVE's queue: item n at word n of its block
                 const uint32_t lane = (uint32_t)tid & 63u, wq = ((uint32_t)tid >> 6) * R32_QBLOCK;
                 uint32_t wrun = 0;
