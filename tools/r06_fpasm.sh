@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6: the written-out first-probe step of the region pass (KH_REGION_FP_ASM) -- parity first, then same-box A/B against the C++ step
+# (the step itself is tools/region_fp_asm.patch: `git apply` it, `make -C krust_amd/csrc`, then `make -C krust_amd/csrc VARIANT=_nofpasm EXTRA=-DKH_REGION_FP_ASM=0`; measured and not kept)
 O=gpurun_out/r06fp; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_product_lib.py -x -q -m gpu > $O/parity.log 2>&1; echo "parity rc=$?" | tee -a $O/parity.log
 grep -E "passed|failed" $O/parity.log | tail -2
