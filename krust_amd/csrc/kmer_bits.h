@@ -67,7 +67,8 @@ KH_HD uint64_t kh_canonical_bits(uint64_t fwd, uint32_t k) {
 
 // ---- table hash: a BIJECTION on the 2k-bit key space, left-aligned in 64 bits -----------------
 // Four Feistel rounds over the two k-bit halves of the packed k-mer; the round function is a
-// 32-bit multiply, keeping the top k bits of the low word.  Everything is 32-bit arithmetic (a 64-bit
+// 32-bit multiply, keeping the top k bits of the low word (rounds 1 and 3: kh_feistel_f) or bits k .. 2k-1 of the
+// full product (rounds 2 and 4, since round 6: kh_feistel_g below).  Everything is 32-bit arithmetic (a 64-bit
 // multiply is four 32-bit ones, this costs four in total), and
 // being a bijection it lets the partitioned path carry 32-bit payloads instead of 64-bit keys
 // whenever 2k minus the level-1 partition bits fits in 32 (k <= 21 at the headline table size):

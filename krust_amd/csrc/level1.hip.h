@@ -246,19 +246,20 @@ constexpr uint32_t P1B_WORDS = MAX_P1 * P1B_CAP;   // 128 KiB
 //      a v_cndmask on a mask in an SGPR pair ~3.4; a v_cndmask reading a VCC that the instruction before it did not
 //      just write ~20 (the usual "v_cmp_lt_u64 vcc; v_cndmask; v_cndmask" of a 64-bit min: 27).  The compiler's code
 //      for a window adds up to ~215 such cycles, ~60 instructions (both strands rolled through registers, a second VCC
-//      read in the canonical choice, left shifts and compares for tags and addresses).  Written out it is ~27
-//      instructions, ~105 cycles, one asm statement per window (the compiler schedules the sixteen as units and
-//      allocates everything but five scratch registers):
+//      read in the canonical choice, left shifts and compares for tags and addresses).  Written out it was ~27
+//      instructions, ~105 cycles (rounds 2-5; 22 since round 6's two-instruction Feistel rounds), one asm statement per window
+//      (the compiler schedules the sixteen as units and allocates everything but five scratch registers):
 //        * no rolling state: the lane's 48 bases are three words (w2:w1:w0, first base in the top bits) and their
 //          reverse complements three more (c2:c1:c0 = 2-bit groups reversed and inverted, made once per tile); BOTH
 //          strands of window J are 42-bit fields of those at fixed offsets (forward: bit 2 (15 - J); reverse
 //          complement: bit 2 (J + 12)): v_alignbit + v_bfe each;
 //        * canonical choice: v_cmp_lt_u64 into an SGPR pair, two v_cndmask on it;
-//        * Feistel rounds of v_mul_u32_u24, v_lshrrev, v_xor: no masks (21-bit halves stay 21-bit), no copies (the
-//          halves swap by name);
-//        * outputs are what the LDS instructions need, derived from the left half L by shift-right + and: the
-//          counter's byte address (L >> 9) & 0xFFC, the bin's (L >> 4) & 0x1FF80, payload (L << 21) | R; a window
-//          without a key gets the lane's waste counter by a sign-extended v_bfe of its validity bit + v_bitop3.
+//        * Feistel rounds of a multiply and ONE v_bitop3 (round 6; window.hip.h): the upper half A stays left-aligned, the lower
+//          half B right-aligned, rounds 1 / 3 are (A ^ B x C) & top bits, rounds 2 / 4 B ^= mulhi(A, C) & low bits; no shifts,
+//          no copies (rounds 2-5: v_mul_u32_u24, v_lshrrev, v_xor with the halves swapping by name);
+//        * outputs are what the LDS instructions need, derived from A by shift-right + and: the counter's byte address
+//          (A >> 20) & 0xFFC, the bin's (A >> 15) & 0x1FF80, payload (A << 10) | B; a window without a key gets the lane's
+//          waste counter by a sign-extended v_bfe of its validity bit + v_bitop3.
 //      Other k / other geometries take the same kernel with the window in C++ (Roller + hash_p1_pay32).
 // 2-bit groups of x reversed and complemented: base m of a code word (bits 31-2m..30-2m) lands, complemented, at bits 2m..2m+1
 __device__ __forceinline__ uint32_t rev2_complement(uint32_t x) {

@@ -126,12 +126,12 @@ __device__ __forceinline__ uint32_t p1_of_hash(u64 H, const PartGeom &g) {
 __host__ __device__ inline bool p1_fast_ok(const PartGeom &g) {
     return g.shard_shift == 0 && g.p1_bits <= g.k && 2 * g.k - g.p1_bits >= 1 && 2 * g.k - g.p1_bits <= 32 && g.k < 32;
 }
-// Round 4: THE LAST FEISTEL ROUND IS LEVEL 2'S.  Written as a ^= F(b), b ^= F(a), a ^= F(b), b ^= F(a) on (a, b) = (L, R) of
+// Round 4: THE LAST FEISTEL ROUND IS LEVEL 2'S.  Written as a ^= F(b), b ^= G(a), a ^= F(b), b ^= G(a) (kh_feistel_f / _g) on (a, b) = (L, R) of
 // the key, the hash is a << k | b -- and a, which holds the level-1 digit and everything level 1's addresses are made of, is
 // final after the THIRD round; the fourth only changes b.  Level 1 is bound by its instruction stream (21 of its 26.5 ms are
 // VALU issue), level 2 by the memory system with the VALU idle half the time: so a level-1 kernel on the FAST path stores
 // y = (a_low ++ b') -- the payload with b one round short -- and whoever reads the pool (the level-2 kernels: l2_finish)
-// applies x = y ^ F(a) << ..., a = digit ++ a_low, which is the payload defined above, bit for bit.  PartGeom::defer says so.
+// applies x = y ^ G(a) << ..., a = digit ++ a_low, which is the payload defined above, bit for bit.  PartGeom::defer says so.
 // MEASURED (profiles/README.md r04, A/B builds, S100M): level 1 26.43 -> 25.42 ms at k = 21 (25.8 at k = 17, 26.9 at k = 13: one
 // round of twelve instructions fewer per window, as predicted) -- and level 2 21.8 -> 23.8 ms: the arena kernel is at its 128
 // registers with 14 spilled, and five more vector instructions per payload cost it more than level 1 gained.  Net +1 ms per
