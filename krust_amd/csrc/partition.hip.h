@@ -2235,7 +2235,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 6 : 8) void region_count_kernel32(T
                         const bool queue = valid && !hit;
                         const u64 qm = kh_ballot(queue);
                         const uint32_t pos = wrun + __builtin_amdgcn_mbcnt_hi((uint32_t)(qm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)qm, 0u));
+#if !(KH_ABLR & 16)  /* timing experiment otherwise (with & 1): no queue store in the first probe */
                         s_q[wq + (queue ? pos : (uint32_t)REGION_RK * 64u + lane)] = pay;  // (row REGION_RK is a dummy row)
+#else
+                        (void)pos;
+#endif
                         wrun += (uint32_t)__builtin_popcountll(qm);
                     }
                 }
